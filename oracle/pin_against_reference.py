@@ -1,0 +1,134 @@
+"""Pin the CPU oracle against the reference itself (build container only).
+
+Runs the reference ``model.py`` (imported through ``oracle/refshim.py``) and ``oracle/srgd_oracle.py``
+on identical seeded weights, inputs and noise, and reports max-abs differences for:
+  geometry tables, schedule scalars, one U-Net forward (with label / without), and full
+  ``tiled_sample`` runs (single tile; multi-tile with ragged minibatch and ring re-noise; CFG).
+Exit code 0 iff every comparison is within its bound.  Usage:
+    python oracle/pin_against_reference.py [--quick]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import refshim                      # noqa: E402
+from oracle import srgd_oracle as O             # noqa: E402
+from srgd_amd.synth import synth_state_dict     # noqa: E402
+
+
+def report(name, got, want, bound):
+    d = (got - want).abs().max().item() if torch.is_tensor(got) else abs(got - want)
+    ok = d <= bound
+    print(f"  {'ok ' if ok else 'BAD'} {name:58s} max|diff|={d:.3e} (bound {bound:.1e})")
+    return ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true", help="skip the dim-128 cases")
+    args = ap.parse_args()
+    ref = refshim.load_reference()
+    if ref is None:
+        print("reference not present; nothing to pin")
+        return 0
+    rm, rc = ref
+    torch.set_num_threads(8)
+    ok = True
+
+    print("[geometry] get_coord_and_pad / get_coords / get_area")
+    for (h, w) in [(256, 256), (64, 64), (1024, 1024), (8192, 8192), (300, 500), (1000, 1500), (257, 256),
+                   (512, 512), (513, 700)]:
+        ok &= rm.get_coord_and_pad(h, w) == O.canvas_box_and_pad(h, w)
+        (_, _, _, _), pad = rm.get_coord_and_pad(h, w)
+        hp, wp = h + pad[2] + pad[3], w + pad[0] + pad[1]
+        c0 = rm.get_coords(hp, wp, 256, 256, diff=0)
+        c1 = (rm.get_coords(hp, wp, 256, 256, diff=0) if (hp <= 256 and wp <= 256)
+              else rm.get_coords(hp - 256, wp - 256, 256, 256, diff=128))
+        e, o = O.sampling_grids(hp, wp)
+        ok &= (c0 == e) and (c1 == o)
+        ok &= rm.get_area(c1, hp, wp) == O.grid_bbox(o, hp, wp)
+    print("  ok" if ok else "  BAD")
+
+    print("[schedule] beta_linear_log_snr and per-step scalars (bit-exact expected)")
+    for n in (10, 50, 100, 250):
+        steps = torch.linspace(1.0, 0.0, n + 1)
+        for i in range(n):
+            a = rm.beta_linear_log_snr(steps[i])
+            b = O.log_snr_linear(steps[i])
+            ok &= bool(a == b)
+    print("  ok" if ok else "  BAD")
+
+    cases = [(16, 64)] + ([] if args.quick else [(128, 64)])
+    for dim, hw in cases:
+        print(f"[unet] dim={dim} one {hw}x{hw} tile, batch 2")
+        sampler, conf = refshim.build_reference_sampler(rm, rc, dim=dim, num_sample_steps=10)
+        schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+        sd = synth_state_dict(schema, seed=0)
+        sampler.load_state_dict(sd, strict=True)
+        usd = O.strip_model_prefix(sd)
+        cfg = O.UnetCfg(dim=dim)
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(2, 3, hw, hw, generator=g)
+        cnd = torch.rand(2, 3, hw, hw, generator=g) * 2 - 1
+        ls = torch.tensor([-3.0, 2.5])
+        lab = torch.tensor([1])
+        with torch.inference_mode():
+            for name, label, c in (("label+cond", lab, cnd), ("null-class", None, cnd), ("null-cond", lab, None)):
+                want = sampler.model(x, ls, label, c)
+                got = O.unet_forward(usd, cfg, x, ls, label, c)
+                ok &= report(f"eps {name}", got, want, 2e-5 * max(1.0, want.abs().max().item()))
+
+    def run_sampler(dim, h, w, steps, bs, ccs=1.0, cs=1.0, label=0):
+        sampler, conf = refshim.build_reference_sampler(rm, rc, dim=dim, num_sample_steps=steps)
+        schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+        sd = synth_state_dict(schema, seed=0)
+        sampler.load_state_dict(sd, strict=True)
+        usd = O.strip_model_prefix(sd)
+        cfg = O.UnetCfg(dim=dim)
+        g = torch.Generator().manual_seed(1234)
+        cond = torch.rand(1, 3, h, w, generator=g)
+        lab = torch.tensor([label]) if label is not None else None
+        t0 = time.time()
+        torch.manual_seed(71)
+        with torch.inference_mode():
+            want = sampler.tiled_sample(batch_size=bs, condition_x=cond.clone(), class_label=lab,
+                                        cond_scale=cs, class_cond_scale=ccs, num_sample_steps=steps)
+        t1 = time.time()
+        torch.manual_seed(71)
+        with torch.inference_mode():
+            got = O.tiled_sample(usd, cfg, cond.clone(), lab, batch_size=bs, num_sample_steps=steps,
+                                 cond_scale=cs, class_cond_scale=ccs)
+        t2 = time.time()
+        print(f"    reference {t1 - t0:.1f}s  oracle {t2 - t1:.1f}s")
+        return got, want
+
+    print("[sampler] dim=16, 256x256 canvas, 10 steps, CFG off")
+    got, want = run_sampler(16, 256, 256, 10, 4)
+    ok &= report("final image", got, want, 1e-4)
+    print("[sampler] dim=16, 256x256 canvas, 10 steps, class_cond_scale=2.0")
+    got, want = run_sampler(16, 256, 256, 10, 4, ccs=2.0)
+    ok &= report("final image", got, want, 1e-4)
+    print("[sampler] dim=16, 256x256 canvas, 6 steps, cond_scale=1.5, no label")
+    got, want = run_sampler(16, 256, 256, 6, 4, cs=1.5, label=None)
+    ok &= report("final image", got, want, 1e-4)
+    print("[sampler] dim=16, 300x500 image -> 768x768 canvas (9/4 tiles), 4 steps, batch_size 4 (ragged)")
+    got, want = run_sampler(16, 300, 500, 4, 4)
+    ok &= report("final image", got, want, 1e-4)
+    if not args.quick:
+        print("[sampler] dim=128, 256x256 canvas, 4 steps, CFG off")
+        got, want = run_sampler(128, 256, 256, 4, 4)
+        ok &= report("final image", got, want, 1e-4)
+    print("PINNED" if ok else "MISMATCH")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,72 @@
+"""Case definitions shared by ``make_golden.py`` (which runs the reference) and the tests
+(which rebuild the same seeded inputs and compare the oracle / the HIP path with the stored
+reference outputs).  Pure data + seeded input builders; no reference code."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+GEOMETRY_SIZES = [(256, 256), (64, 64), (1024, 1024), (8192, 8192), (300, 500), (1000, 1500),
+                  (257, 256), (512, 512), (513, 700)]
+SCHEDULE_STEPS = [10, 50, 100]
+
+UNET_CASES = [
+    dict(name="dim16_64", dim=16, hw=64, batch=2, weight_seed=0, input_seed=7,
+         log_snr=[-3.0, 2.5], label=1, modes=["label_cond", "null_class", "null_cond"]),
+    dict(name="dim128_64", dim=128, hw=64, batch=1, weight_seed=0, input_seed=8,
+         log_snr=[0.75], label=0, modes=["label_cond", "null_class"]),
+]
+
+SAMPLER_CASES = [
+    # G5: single tile canvas, CFG off / class CFG 2.0
+    dict(name="dim16_256_cfg1", dim=16, h=256, w=256, steps=10, batch_size=4, label=0,
+         cond_scale=1.0, class_cond_scale=1.0, weight_seed=0, cond="rand", cond_seed=1234, seed=71),
+    dict(name="dim16_256_cfg2", dim=16, h=256, w=256, steps=10, batch_size=4, label=0,
+         cond_scale=1.0, class_cond_scale=2.0, weight_seed=0, cond="rand", cond_seed=1234, seed=71),
+    # G6: ragged canvas -> 768x768, 9/4 tiles, ragged last minibatch, ring re-noise
+    dict(name="dim16_300x500", dim=16, h=300, w=500, steps=4, batch_size=4, label=2,
+         cond_scale=1.0, class_cond_scale=1.0, weight_seed=0, cond="rand", cond_seed=1235, seed=71),
+    # G7: BASELINE config 1 - 64x64 LR -> x4 bicubic -> 256x256, dim-128 U-Net, 10 steps, CFG off
+    dict(name="dim128_config1", dim=128, h=256, w=256, steps=10, batch_size=8, label=0,
+         cond_scale=1.0, class_cond_scale=1.0, weight_seed=0, cond="lr_bicubic", cond_seed=1234, seed=71),
+]
+
+
+def unet_inputs(case):
+    g = torch.Generator().manual_seed(case["input_seed"])
+    b, hw = case["batch"], case["hw"]
+    x = torch.randn(b, 3, hw, hw, generator=g)
+    cnd = torch.rand(b, 3, hw, hw, generator=g) * 2 - 1
+    ls = torch.tensor(case["log_snr"], dtype=torch.float32)
+    return x, cnd, ls
+
+
+def unet_mode_args(mode, case, cnd):
+    label = torch.tensor([case["label"]])
+    if mode == "label_cond":
+        return label, cnd
+    if mode == "null_class":
+        return None, cnd
+    if mode == "null_cond":
+        return label, None
+    raise KeyError(mode)
+
+
+def synthetic_lr_condition(index: int, lr_h: int, lr_w: int, scale: int = 4, seed_base: int = 1234):
+    """BASELINE.md section 4 synthetic input: uint8 LR image -> PIL bicubic x4 -> /255 float,
+    mirroring inference.py:71-73 (T.Resize on a PIL image == PIL.Image.resize(BICUBIC); ToTensor == /255)."""
+    from PIL import Image
+    g = torch.Generator().manual_seed(seed_base + index)
+    lr = torch.randint(0, 256, (lr_h, lr_w, 3), dtype=torch.uint8, generator=g).numpy()
+    hr = Image.fromarray(lr, "RGB").resize((lr_w * scale, lr_h * scale), Image.BICUBIC)
+    arr = np.asarray(hr, dtype=np.uint8)
+    return torch.from_numpy(arr.copy()).permute(2, 0, 1).float().div(255.0).unsqueeze(0).contiguous()
+
+
+def sampler_condition(case):
+    if case["cond"] == "rand":
+        g = torch.Generator().manual_seed(case["cond_seed"])
+        return torch.rand(1, 3, case["h"], case["w"], generator=g)
+    if case["cond"] == "lr_bicubic":
+        return synthetic_lr_condition(0, case["h"] // 4, case["w"] // 4, seed_base=case["cond_seed"])
+    raise KeyError(case["cond"])

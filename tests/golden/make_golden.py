@@ -1,0 +1,108 @@
+"""Generate the committed golden fixtures by running the REFERENCE itself (build container only).
+
+    python tests/golden/make_golden.py
+
+Imports ``/root/reference/model.py`` through ``oracle/refshim.py`` (stubs for its un-vendored
+imports), loads seeded synthetic weights (``srgd_amd.synth``; the published checkpoint is an LFS
+pointer), and stores inputs' checksums + the reference's outputs.  The fixtures are data only.
+Every case documents how its inputs are regenerated (seeds), so the GPU box - which has neither
+the reference nor these scripts' inputs - can rebuild identical inputs with the same torch build.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import refshim                      # noqa: E402
+from srgd_amd.synth import synth_state_dict     # noqa: E402
+from tests.golden import cases as C             # noqa: E402
+
+
+def main():
+    ref = refshim.load_reference()
+    assert ref is not None, "reference not present"
+    rm, rc = ref
+    torch.set_num_threads(8)
+
+    # ---- G1 geometry -------------------------------------------------------------------
+    geo = {}
+    for (h, w) in C.GEOMETRY_SIZES:
+        box, pad = rm.get_coord_and_pad(h, w)
+        hp, wp = h + pad[2] + pad[3], w + pad[0] + pad[1]
+        c0 = rm.get_coords(hp, wp, 256, 256, diff=0)
+        c1 = (rm.get_coords(hp, wp, 256, 256, diff=0) if (hp <= 256 and wp <= 256)
+              else rm.get_coords(hp - 256, wp - 256, 256, 256, diff=128))
+        inner, ipad = rm.get_area(c1, hp, wp)
+        big = len(c0) > 64
+        geo[f"{h}x{w}"] = dict(box=list(box), pad=list(pad), canvas=[hp, wp], n_even=len(c0), n_odd=len(c1),
+                               even=[list(c) for c in (c0[:3] + c0[-3:] if big else c0)],
+                               odd=[list(c) for c in (c1[:3] + c1[-3:] if big else c1)],
+                               truncated=big, inner=list(inner), inner_pad=list(ipad))
+    with open(os.path.join(HERE, "geometry.json"), "w") as f:
+        json.dump(geo, f, indent=1)
+
+    # ---- G2 schedule scalars (fp32, bit patterns) -------------------------------------------
+    sched = {}
+    for n in C.SCHEDULE_STEPS:
+        steps = torch.linspace(1.0, 0.0, n + 1)
+        ls = torch.stack([rm.beta_linear_log_snr(steps[i]) for i in range(n + 1)])
+        sched[f"log_snr_{n}"] = ls.numpy()
+    np.savez(os.path.join(HERE, "schedule.npz"), **sched)
+
+    # ---- schemas ---------------------------------------------------------------------------
+    for dim in (16, 128):
+        sampler, _ = refshim.build_reference_sampler(rm, rc, dim=dim)
+        schema = {k: list(v.shape) for k, v in sampler.state_dict().items()}
+        with open(os.path.join(HERE, f"schema_dim{dim}.json"), "w") as f:
+            json.dump(schema, f, indent=0)
+
+    # ---- G4 U-Net forward ----------------------------------------------------------------------
+    out = {}
+    for case in C.UNET_CASES:
+        sampler, _ = refshim.build_reference_sampler(rm, rc, dim=case["dim"])
+        schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+        sd = synth_state_dict(schema, seed=case["weight_seed"])
+        sampler.load_state_dict(sd, strict=True)
+        x, cnd, ls = C.unet_inputs(case)
+        with torch.inference_mode():
+            for mode in case["modes"]:
+                label, c = C.unet_mode_args(mode, case, cnd)
+                eps = sampler.model(x, ls, label, c)
+                out[f"{case['name']}.{mode}"] = eps.numpy()
+        out[f"{case['name']}.x_sum"] = np.float64(x.double().sum().item())
+        out[f"{case['name']}.w_sum"] = np.float64(sum(v.double().abs().sum().item() for v in sd.values()))
+    np.savez_compressed(os.path.join(HERE, "unet_eps.npz"), **out)
+
+    # ---- G5-G7 tiled_sample ---------------------------------------------------------------------
+    for case in C.SAMPLER_CASES:
+        sampler, _ = refshim.build_reference_sampler(rm, rc, dim=case["dim"], num_sample_steps=case["steps"])
+        schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+        sd = synth_state_dict(schema, seed=case["weight_seed"])
+        sampler.load_state_dict(sd, strict=True)
+        cond = C.sampler_condition(case)
+        label = torch.tensor([case["label"]]) if case["label"] is not None else None
+        torch.manual_seed(case["seed"])
+        first = torch.randn(16)
+        torch.manual_seed(case["seed"])
+        with torch.inference_mode():
+            img = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond.clone(),
+                                       class_label=label, cond_scale=case["cond_scale"],
+                                       class_cond_scale=case["class_cond_scale"],
+                                       num_sample_steps=case["steps"])
+        np.savez_compressed(os.path.join(HERE, f"sample_{case['name']}.npz"),
+                            image=img.numpy(), cond_sum=np.float64(cond.double().sum().item()),
+                            first_draw=first.numpy(),
+                            w_sum=np.float64(sum(v.double().abs().sum().item() for v in sd.values())))
+        print(case["name"], "done", tuple(img.shape), float(img.mean()))
+
+
+if __name__ == "__main__":
+    main()

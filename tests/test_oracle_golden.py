@@ -1,0 +1,115 @@
+"""CPU tests: the oracle (oracle/srgd_oracle.py) against the committed outputs of the reference
+(tests/golden/*.npz|json, produced by tests/golden/make_golden.py running /root/reference)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import srgd_oracle as O
+from srgd_amd.synth import synth_state_dict
+from tests.golden import cases as C
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _schema(dim):
+    with open(os.path.join(G, f"schema_dim{dim}.json")) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+def test_geometry_tables():
+    with open(os.path.join(G, "geometry.json")) as f:
+        geo = json.load(f)
+    for (h, w) in C.GEOMETRY_SIZES:
+        want = geo[f"{h}x{w}"]
+        box, pad = O.canvas_box_and_pad(h, w)
+        assert list(box) == want["box"] and list(pad) == want["pad"]
+        hp, wp = h + pad[2] + pad[3], w + pad[0] + pad[1]
+        assert [hp, wp] == want["canvas"]
+        even, odd = O.sampling_grids(hp, wp)
+        assert len(even) == want["n_even"] and len(odd) == want["n_odd"]
+        if want["truncated"]:
+            assert [list(c) for c in even[:3] + even[-3:]] == want["even"]
+            assert [list(c) for c in odd[:3] + odd[-3:]] == want["odd"]
+        else:
+            assert [list(c) for c in even] == want["even"]
+            assert [list(c) for c in odd] == want["odd"]
+        inner, ipad = O.grid_bbox(odd, hp, wp)
+        assert list(inner) == want["inner"] and list(ipad) == want["inner_pad"]
+
+
+def test_geometry_known_answers_survey_appendix_d():
+    # SURVEY.md Appendix D
+    assert O.canvas_box_and_pad(1024, 1024) == ((128, 128, 1152, 1152), (128, 128, 128, 128))
+    assert O.canvas_box_and_pad(300, 500) == ((134, 234, 634, 534), (134, 134, 234, 234))
+    e, o = O.sampling_grids(1280, 1280)
+    assert (len(e), len(o)) == (25, 16)
+    e, o = O.sampling_grids(8448, 8448)
+    assert (len(e), len(o)) == (1089, 1024)
+
+
+def test_schedule_bit_exact():
+    z = np.load(os.path.join(G, "schedule.npz"))
+    for n in C.SCHEDULE_STEPS:
+        steps = torch.linspace(1.0, 0.0, n + 1)
+        got = torch.stack([O.log_snr_linear(steps[i]) for i in range(n + 1)]).numpy()
+        assert np.array_equal(got.view(np.uint32), z[f"log_snr_{n}"].view(np.uint32))
+    # range -10.00005 (t=1) ... 9.21029 (t=0)
+    assert abs(float(O.log_snr_linear(torch.tensor(1.0))) + 10.00005) < 1e-4
+    assert abs(float(O.log_snr_linear(torch.tensor(0.0))) - 9.21029) < 1e-4
+
+
+@pytest.mark.parametrize("case", C.UNET_CASES, ids=lambda c: c["name"])
+def test_unet_eps_matches_reference(case):
+    z = np.load(os.path.join(G, "unet_eps.npz"))
+    sd = synth_state_dict(_schema(case["dim"]), seed=case["weight_seed"])
+    w_sum = sum(v.double().abs().sum().item() for v in sd.values())
+    assert abs(w_sum - float(z[f"{case['name']}.w_sum"])) < 1e-9 * w_sum, "synthetic weights drifted"
+    x, cnd, ls = C.unet_inputs(case)
+    assert abs(x.double().sum().item() - float(z[f"{case['name']}.x_sum"])) < 1e-6
+    usd = O.strip_model_prefix(sd)
+    cfg = O.UnetCfg(dim=case["dim"])
+    with torch.inference_mode():
+        for mode in case["modes"]:
+            label, c = C.unet_mode_args(mode, case, cnd)
+            got = O.unet_forward(usd, cfg, x, ls, label, c).numpy()
+            want = z[f"{case['name']}.{mode}"]
+            assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("case", C.SAMPLER_CASES, ids=lambda c: c["name"])
+def test_tiled_sample_matches_reference(case):
+    z = np.load(os.path.join(G, f"sample_{case['name']}.npz"))
+    sd = synth_state_dict(_schema(case["dim"]), seed=case["weight_seed"])
+    cond = C.sampler_condition(case)
+    assert abs(cond.double().sum().item() - float(z["cond_sum"])) < 1e-6
+    torch.manual_seed(case["seed"])
+    assert np.array_equal(torch.randn(16).numpy(), z["first_draw"]), "torch CPU generator stream changed"
+    label = torch.tensor([case["label"]]) if case["label"] is not None else None
+    torch.manual_seed(case["seed"])
+    with torch.inference_mode():
+        got = O.tiled_sample(O.strip_model_prefix(sd), O.UnetCfg(dim=case["dim"]), cond, label,
+                             batch_size=case["batch_size"], num_sample_steps=case["steps"],
+                             cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"])
+    want = z["image"]
+    assert got.shape == want.shape
+    assert np.abs(got.numpy() - want).max() <= 1e-4      # thread-count noise floor is ~1e-5
+
+
+def test_both_guidance_scales_raise():
+    sd = synth_state_dict(_schema(16), seed=0)
+    with pytest.raises(NotImplementedError):
+        O.tiled_sample(O.strip_model_prefix(sd), O.UnetCfg(dim=16), torch.rand(1, 3, 256, 256),
+                       torch.tensor([0]), num_sample_steps=2, cond_scale=2.0, class_cond_scale=2.0)
+
+
+def test_noise_stream_is_batch_size_independent():
+    # draws are multiples of 16 elements, so the stream seen by each tile
+    # does not depend on how tiles are grouped into minibatches.
+    torch.manual_seed(5)
+    a = torch.randn(8, 3, 256, 256)
+    torch.manual_seed(5)
+    b = torch.cat([torch.randn(3, 3, 256, 256), torch.randn(5, 3, 256, 256)])
+    assert torch.equal(a, b)
