@@ -1,0 +1,131 @@
+/* libsrgd_hip - C ABI of the MI355X (gfx950) engine for the Real-SRGD sampling hot path.
+ *
+ * The reference (yahoojapan/srgd) is pure Python/PyTorch: it has no FFI layer of its own, so
+ * this header IS the boundary a maintainer binds (ctypes stub: INTEGRATION.md).  Each entry
+ * point names the reference interface it stands behind (file:line in /root/reference).
+ *
+ * Conventions: plain C, no torch types.  Device pointers are raw HBM addresses owned by the
+ * caller (e.g. tensor.data_ptr() of PyTorch-ROCm tensors); "host" pointers are ordinary CPU
+ * memory.  Image tensors are fp32 NCHW exactly as the reference holds them.  Every call
+ * returns 0 on success, <0 on error (message: srgd_last_error()).  Calls that take a
+ * `stream` (a hipStream_t passed as void*) are asynchronous on it, never synchronise and never
+ * allocate after the first call with a given shape.  One engine per device, not thread-safe.
+ */
+#ifndef SRGD_HIP_H
+#define SRGD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srgd_engine srgd_engine;
+
+#define SRGD_MAX_STAGES 8
+#define SRGD_PRECISION_FP32 0 /* fp32 activations, exact-fp32 MFMA: parity mode (<=1e-3 vs reference) */
+#define SRGD_PRECISION_BF16 1 /* bf16 activations/weights, fp32 accumulate: throughput mode */
+
+/* Constructor arguments of ConditionalSRUnet (model.py:537-556) as get_model passes them
+ * (model.py:3504-3514).  Unsupported combinations are rejected by srgd_create. */
+typedef struct srgd_unet_config {
+  int32_t dim;                         /* unet_dim */
+  int32_t n_stages;                    /* len(dim_mults) */
+  int32_t dim_mults[SRGD_MAX_STAGES];
+  int32_t full_attn[SRGD_MAX_STAGES];  /* 0 linear attention, 1 softmax attention */
+  int32_t channels;                    /* 3 */
+  int32_t groups;                      /* resnet_block_groups = 8 */
+  int32_t heads;                       /* attn_heads = 4 */
+  int32_t dim_head;                    /* attn_dim_head = 32 */
+  int32_t sinus_dim;                   /* learned_sinusoidal_dim (even) */
+  int32_t num_classes;                 /* 0: no class embedding */
+  int32_t precision;                   /* SRGD_PRECISION_* */
+  int32_t device;                      /* HIP device ordinal */
+} srgd_unet_config;
+
+const char* srgd_last_error(void);
+const char* srgd_version(void);
+
+/* ---- lifetime -------------------------------------------------------------------------------
+ * replaces: ConditionalSRUnet.__init__ (model.py:537-675) + `.to(device)` (inference.py:155-156) */
+int srgd_create(const srgd_unet_config* cfg, srgd_engine** out);
+int srgd_destroy(srgd_engine* e);
+
+/* ---- weights --------------------------------------------------------------------------------
+ * replaces: load_state_dict(ckpt['ema_model'], strict) (model.py:3659-3662).  Names are the
+ * U-Net's state_dict keys (an optional leading "model." is accepted); data is host fp32 in the
+ * PyTorch layout (conv OIHW, linear [out,in]).  The engine packs its own device copy. */
+int srgd_num_weights(const srgd_engine* e);
+int srgd_weight_info(const srgd_engine* e, int index, char* name, size_t name_cap, int64_t shape[4], int* ndim);
+int srgd_load_weight(srgd_engine* e, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int srgd_finalize_weights(srgd_engine* e); /* fails if any tensor is missing (strict=True) */
+
+/* ---- one U-Net evaluation -------------------------------------------------------------------
+ * replaces: ConditionalSRUnet.forward(x, time, class_label, x_self_cond) (model.py:678-725).
+ * x, cond (nullable -> zeros), eps_out: device fp32 [B,3,H,W]; log_snr: host [B];
+ * class_id < 0 means class_label=None.  H, W must be divisible by 2^(n_stages-1). */
+int srgd_unet_forward(srgd_engine* e, const float* x, const float* cond, const float* log_snr_host, int class_id,
+                      float* eps_out, int B, int H, int W, void* stream);
+
+/* ---- tiled sampler --------------------------------------------------------------------------
+ * replaces: ConditionalContinuousTimeGaussianDiffusionSR.tiled_sample (model.py:3288-3413) and,
+ * per step, p_sample / p_mean_variance (model.py:3122-3188) and q_sample (model.py:3434-3447). */
+typedef struct srgd_step_scalars { /* fp32 values of model.py:3127-3134,:3168 for one step */
+  float alpha, sigma, alpha_next, c, one_minus_c;
+  float noise_scale; /* sqrt(sigma_next^2 * c) */
+  float sigma_next;  /* sqrt(sigmoid(-log_snr(t'))) for the odd-step ring (model.py:3395) */
+  float reserved;
+} srgd_step_scalars;
+
+typedef struct srgd_sampler_geometry { /* ints of get_coord_and_pad / get_coords / get_area (model.py:116-179) */
+  int32_t H, W;                 /* image size (x4 bicubic of the LR input) */
+  int32_t Hp, Wp;               /* padded canvas */
+  int32_t left, top;            /* crop box origin of the image inside the canvas */
+  int32_t inner_l, inner_t, inner_r, inner_b; /* bounding box of the shifted (odd-step) grid */
+  int32_t tile;                 /* 256 */
+  int32_t n_even, n_odd;        /* tiles per grid */
+} srgd_sampler_geometry;
+
+/* Prepares a run: cond canvas = zero outside the inner box, reflect-padded (2*cond01-1) inside
+ * (model.py:3296-3303,:3337-3342); uploads both tile grids ([n][2] = (y, x) canvas offsets) and
+ * the schedule; computes the conditioning table for every step x {label, no label}.
+ * cond01: device fp32 [3,H,W] in [0,1]; cond_canvas: device fp32 [3,Hp,Wp] (written). */
+int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const float* cond01, float* cond_canvas,
+                       const int32_t* tiles_even_host, const int32_t* tiles_odd_host, int n_steps,
+                       const srgd_step_scalars* scalars_host, const float* log_snr_host, int class_id, void* stream);
+
+/* One denoising step over every tile of grid (step % 2), `sub_batch` tiles per U-Net launch
+ * (the reference's --batch_size; results do not depend on it).
+ *   passes = 1: eps = unet(label, cond).                       (model.py:3155-3156)
+ *   passes = 2, guidance_kind 1: class guidance  (label vs None)   (model.py:3151-3154)
+ *   passes = 2, guidance_kind 2: condition guidance (cond vs zeros) (model.py:3147-3150)
+ * img / x_start (nullable): device fp32 canvases [3,Hp,Wp], updated in place.
+ * noise_tiles: device fp32 [n_tiles_of_this_grid,3,tile,tile] in reference draw order, or NULL;
+ * noise_canvas: device fp32 [3,Hp,Wp] for the odd-step ring, or NULL.  When a needed noise
+ * pointer is NULL the engine draws it on the device (Philox, `seed`).  The last step adds none. */
+int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start,
+                      const float* noise_tiles, const float* noise_canvas, int passes, int guidance_kind,
+                      float guidance_scale, int sub_batch, uint64_t seed, void* stream);
+
+/* Crop, clamp to [-1,1], map to [0,1] (model.py:3403-3405).  out01: device fp32 [3,H,W]. */
+int srgd_sampler_end(srgd_engine* e, const float* img, float* out01, void* stream);
+
+/* Fills dst[n] with N(0,1) draws of the engine's counter-based generator (initial canvas noise
+ * in throughput mode; the parity mode uploads torch's CPU stream instead). */
+int srgd_randn(srgd_engine* e, float* dst, size_t n, uint64_t seed, uint64_t stream_id, void* stream);
+
+/* ---- measurement ----------------------------------------------------------------------------
+ * Between begin and end every kernel family is bracketed by HIP events on its launch stream;
+ * end synchronises and returns accumulated milliseconds / launch counts per family and the
+ * algorithmic conv FLOPs issued (2*M*Cout*K).  Family names: srgd_profile_family_name(i). */
+int srgd_profile_begin(srgd_engine* e);
+int srgd_profile_end(srgd_engine* e, double* ms, int64_t* launches, int n_families, double* conv_flops);
+int srgd_profile_num_families(void);
+const char* srgd_profile_family_name(int i);
+int64_t srgd_device_bytes_in_use(const srgd_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRGD_HIP_H */

@@ -1,0 +1,50 @@
+/* libsrgd_hip - kernel-level C ABI: each hand-written gfx950 kernel family of the Real-SRGD hot path,
+ * callable on raw device pointers.  The engine (srgd_hip.h) is built from exactly these launchers;
+ * they are exported so that every operator can be parity-tested in isolation against the CPU oracle
+ * (tests/test_kernels_gpu.py) and bound separately by a host that wants only one of them.
+ *
+ * Layout: activations are NHWC in the activation type selected by `is_bf16` (0: fp32, 1: bf16);
+ * statistics, coefficients and weights handed in as fp32.  All pointers except `*_host` are device
+ * pointers.  Calls are asynchronous on `stream` unless stated; return 0 or <0 (srgd_last_error()).
+ */
+#ifndef SRGD_HIP_KERNELS_H
+#define SRGD_HIP_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Convolution as implicit GEMM on MFMA.  replaces: nn.Conv2d call sites of the U-Net - Block.proj
+ * (model.py:246), res_conv (:271), to_qkv/to_out (:300,:303,:341,:342), Downsample (:106-110, kind 1:
+ * pixel-unshuffle + 1x1 == 2x2/stride-2), PixelShuffleUpsample (:70-98, kind 2: 1x1 + SiLU + PixelShuffle),
+ * and torch.cat on the skip path (:713,:716,:722: two channel-concatenated sources in0|in1).
+ * weight_oihw_host / bias_host: PyTorch-layout fp32 on the HOST (packed + uploaded inside; this entry
+ * point synchronises).  gn_partial: optional device [B][groups][Hout*Wout/128][2] receiving per-tile
+ * (sum, sum of squares) of the output for a following GroupNorm. */
+int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int Hin, int Win, int KS, int stride,
+                  int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
+                  const void* residual, float* gn_partial, int groups, int is_bf16, void* stream);
+
+/* GroupNorm (from the conv's partial statistics) -> x*(scale+1)+shift -> SiLU (+ residual).
+ * replaces: Block.forward after the conv (model.py:250-259) and the ResnetBlock residual add (:285).
+ * gamma, beta: device [C]; scale_shift: device [B][2C] (scale | shift) or NULL; in place if y == x. */
+int srgd_k_groupnorm_silu(const void* x, void* y, const void* residual, const float* gn_partial, int B, int hw,
+                          int C, int groups, const float* gamma, const float* beta, const float* scale_shift,
+                          int is_bf16, void* stream);
+
+/* RMSNorm over channels * g * sqrt(C) (+ residual).  replaces: RMSNorm.forward (model.py:206-207). */
+int srgd_k_rmsnorm(const void* x, void* y, const void* residual, const float* g, int64_t npix, int C, int is_bf16,
+                   void* stream);
+
+/* qkv: [B,N,3*heads*32] -> out [B,N,heads*32].  replaces: LinearAttention.forward core (model.py:312-323)
+ * and Attention.forward core + Attend (model.py:349-354). */
+int srgd_k_linear_attention(const void* qkv, void* out, int B, int N, int heads, int is_bf16, void* stream);
+int srgd_k_full_attention(const void* qkv, void* out, int B, int N, int heads, int is_bf16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

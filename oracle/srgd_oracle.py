@@ -161,32 +161,40 @@ def resnet_block(sd, p: str, x: Tensor, t_emb: Tensor, groups: int) -> Tensor:
     return h + x
 
 
-def linear_attention(sd, p: str, x: Tensor, heads: int, dim_head: int) -> Tensor:
-    """model.py:287-324: q softmax over d, k softmax over positions, context = k v^T."""
-    b, c, hh, ww = x.shape
+def linear_attention_core(qkv: Tensor, heads: int, dim_head: int) -> Tensor:
+    """model.py:311-323 between to_qkv and to_out: qkv [b, 3*heads*dh, h, w] -> [b, heads*dh, h, w]."""
+    b, _, hh, ww = qkv.shape
     n = hh * ww
-    x = rms_norm(x, _w(sd, p + ".norm.g"))
-    qkv = F.conv2d(x, _w(sd, p + ".to_qkv.weight"))
     q, k, v = [z.reshape(b, heads, dim_head, n) for z in qkv.chunk(3, dim=1)]
     q = q.softmax(dim=2) * (dim_head ** -0.5)
     k = k.softmax(dim=3)
     ctx = torch.matmul(k, v.transpose(2, 3))            # [b,h,d,e] = sum_n k[d,n] v[e,n]
     out = torch.matmul(ctx.transpose(2, 3), q)          # [b,h,e,n] = sum_d ctx[d,e] q[d,n]
-    out = out.reshape(b, heads * dim_head, hh, ww)
+    return out.reshape(b, heads * dim_head, hh, ww)
+
+
+def full_attention_core(qkv: Tensor, heads: int, dim_head: int) -> Tensor:
+    """model.py:348-354 + Attend(flash=False): qkv [b, 3*heads*dh, h, w] -> [b, heads*dh, h, w]."""
+    b, _, hh, ww = qkv.shape
+    n = hh * ww
+    q, k, v = [z.reshape(b, heads, dim_head, n).transpose(2, 3) for z in qkv.chunk(3, dim=1)]
+    sim = torch.matmul(q, k.transpose(2, 3)) * (dim_head ** -0.5)
+    out = torch.matmul(sim.softmax(dim=-1), v)          # [b,h,n,d]
+    return out.transpose(2, 3).reshape(b, heads * dim_head, hh, ww)
+
+
+def linear_attention(sd, p: str, x: Tensor, heads: int, dim_head: int) -> Tensor:
+    """model.py:287-324: q softmax over d, k softmax over positions, context = k v^T."""
+    x = rms_norm(x, _w(sd, p + ".norm.g"))
+    out = linear_attention_core(F.conv2d(x, _w(sd, p + ".to_qkv.weight")), heads, dim_head)
     out = F.conv2d(out, _w(sd, p + ".to_out.0.weight"), _w(sd, p + ".to_out.0.bias"))
     return rms_norm(out, _w(sd, p + ".to_out.1.g"))
 
 
 def full_attention(sd, p: str, x: Tensor, heads: int, dim_head: int) -> Tensor:
     """model.py:326-355 + Attend(flash=False): softmax(q k^T / sqrt(d)) v."""
-    b, c, hh, ww = x.shape
-    n = hh * ww
     x = rms_norm(x, _w(sd, p + ".norm.g"))
-    qkv = F.conv2d(x, _w(sd, p + ".to_qkv.weight"))
-    q, k, v = [z.reshape(b, heads, dim_head, n).transpose(2, 3) for z in qkv.chunk(3, dim=1)]
-    sim = torch.matmul(q, k.transpose(2, 3)) * (dim_head ** -0.5)
-    out = torch.matmul(sim.softmax(dim=-1), v)          # [b,h,n,d]
-    out = out.transpose(2, 3).reshape(b, heads * dim_head, hh, ww)
+    out = full_attention_core(F.conv2d(x, _w(sd, p + ".to_qkv.weight")), heads, dim_head)
     return F.conv2d(out, _w(sd, p + ".to_out.weight"), _w(sd, p + ".to_out.bias"))
 
 

@@ -1,0 +1,105 @@
+"""ctypes binding of ``libsrgd_hip.so`` (C ABI: include/srgd_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call fails, the product
+path raises.  The CPU oracle under ``oracle/`` is test infrastructure and is never imported here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsrgd_hip.so")
+
+MAX_STAGES = 8
+PRECISION_FP32 = 0
+PRECISION_BF16 = 1
+
+
+class UnetConfig(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n_stages", C.c_int32),
+                ("dim_mults", C.c_int32 * MAX_STAGES), ("full_attn", C.c_int32 * MAX_STAGES),
+                ("channels", C.c_int32), ("groups", C.c_int32), ("heads", C.c_int32),
+                ("dim_head", C.c_int32), ("sinus_dim", C.c_int32), ("num_classes", C.c_int32),
+                ("precision", C.c_int32), ("device", C.c_int32)]
+
+
+class StepScalars(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("sigma", C.c_float), ("alpha_next", C.c_float), ("c", C.c_float),
+                ("one_minus_c", C.c_float), ("noise_scale", C.c_float), ("sigma_next", C.c_float),
+                ("reserved", C.c_float)]
+
+
+class SamplerGeometry(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("Hp", C.c_int32), ("Wp", C.c_int32),
+                ("left", C.c_int32), ("top", C.c_int32),
+                ("inner_l", C.c_int32), ("inner_t", C.c_int32), ("inner_r", C.c_int32), ("inner_b", C.c_int32),
+                ("tile", C.c_int32), ("n_even", C.c_int32), ("n_odd", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/srgd_hip.h declares
+PROTOTYPES = {
+    "srgd_last_error": (C.c_char_p, []),
+    "srgd_version": (C.c_char_p, []),
+    "srgd_create": (C.c_int, [C.POINTER(UnetConfig), C.POINTER(C.c_void_p)]),
+    "srgd_destroy": (C.c_int, [C.c_void_p]),
+    "srgd_num_weights": (C.c_int, [C.c_void_p]),
+    "srgd_weight_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int)]),
+    "srgd_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "srgd_finalize_weights": (C.c_int, [C.c_void_p]),
+    "srgd_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "srgd_sampler_begin": (C.c_int, [C.c_void_p, C.POINTER(SamplerGeometry), C.c_void_p, C.c_void_p,
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.POINTER(StepScalars),
+                                     C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "srgd_sampler_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_void_p]),
+    "srgd_sampler_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srgd_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "srgd_profile_begin": (C.c_int, [C.c_void_p]),
+    "srgd_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int,
+                                   C.POINTER(C.c_double)]),
+    "srgd_profile_num_families": (C.c_int, []),
+    "srgd_profile_family_name": (C.c_char_p, [C.c_int]),
+    "srgd_device_bytes_in_use": (C.c_int64, [C.c_void_p]),
+    # include/srgd_hip_kernels.h
+    "srgd_k_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int, C.c_int, C.c_void_p]),
+    "srgd_k_groupnorm_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "srgd_k_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                 C.c_void_p]),
+    "srgd_k_linear_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "srgd_k_full_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+class SrgdHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load the engine library (once).  Raises if it has not been built - no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SrgdHipError(
+                f"{LIB_PATH} is missing: build it with `python -m srgd_amd.build` (hipcc, gfx950). "
+                "The MI355X engine is the only implementation of this path; there is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)            # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().srgd_last_error().decode(errors="replace")
+        raise SrgdHipError(f"{what}: {msg}" if what else msg)

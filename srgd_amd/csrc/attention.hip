@@ -1,0 +1,333 @@
+// Attention kernels for gfx950 (fp32 arithmetic on fp32 or bf16 NHWC tensors).
+//
+// linear attention (reference model.py:312-323): q softmax over the 32 per-head channels,
+//   k softmax over ALL positions n (up to 65,536), ctx[d,e] = sum_n k[d,n] v[e,n],
+//   out[e,n] = sum_d ctx[d,e] q[d,n] * dh^-0.5.
+//   The position softmax is computed chunk-locally (max, sum, unnormalised ctx per 512
+//   positions) and merged by a fixed-order combine - no atomics, deterministic.
+// full attention (model.py:344-355 + denoising_diffusion_pytorch Attend, flash=False):
+//   softmax(q k^T dh^-0.5) v with n = 1024, flash-style (online softmax, 64-key tiles in LDS).
+#include "kernels.hpp"
+
+namespace srgd {
+namespace {
+
+constexpr int DH = 32;              // dim_head of every attention site in this model family
+constexpr int LA_CHUNK = 512;       // positions per partial
+constexpr int LA_TILE = 64;         // positions staged in LDS at a time
+
+template <typename T>
+__global__ __launch_bounds__(256) void la_partial_kernel(const T* __restrict__ qkv, int N, int heads,
+                                                          float* __restrict__ pm, float* __restrict__ pl,
+                                                          float* __restrict__ pctx) {
+  const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int nch = gridDim.x;
+  const int hid = heads * DH, C3 = 3 * hid;
+  const int tid = threadIdx.x, d = tid & 31, sub = tid >> 5;
+  const int n0 = chunk * LA_CHUNK;
+  const int cnt = min(LA_CHUNK, N - n0);
+  const T* base = qkv + (size_t)b * N * C3;
+  __shared__ float ks[LA_TILE][DH];
+  __shared__ float vs[LA_TILE][DH];
+  __shared__ float red[8][DH];
+  __shared__ float cred[8][DH][DH + 1];
+
+  // pass 1: chunk-local max of k[:, d]
+  float m = -INFINITY;
+  for (int n = sub; n < cnt; n += 8) m = fmaxf(m, to_f32<T>(base[(size_t)(n0 + n) * C3 + hid + head * DH + d]));
+  red[sub][d] = m;
+  __syncthreads();
+  m = red[0][d];
+#pragma unroll
+  for (int s = 1; s < 8; ++s) m = fmaxf(m, red[s][d]);
+  __syncthreads();
+
+  // pass 2: l[d] = sum exp(k - m), ctx[d][e] = sum exp(k - m) v[e]
+  float l = 0.f, ctx[DH];
+#pragma unroll
+  for (int e = 0; e < DH; ++e) ctx[e] = 0.f;
+  for (int t0 = 0; t0 < cnt; t0 += LA_TILE) {
+    const int tc = min(LA_TILE, cnt - t0);
+    for (int i = tid; i < LA_TILE * DH; i += 256) {
+      const int n = i >> 5, c = i & 31;
+      float kv = 0.f, vv = 0.f;
+      if (n < tc) {
+        const size_t o = (size_t)(n0 + t0 + n) * C3 + head * DH + c;
+        kv = to_f32<T>(base[o + hid]);
+        vv = to_f32<T>(base[o + 2 * hid]);
+      }
+      ks[n][c] = kv;
+      vs[n][c] = vv;
+    }
+    __syncthreads();
+    for (int n = sub; n < tc; n += 8) {
+      const float p = expf(ks[n][d] - m);
+      l += p;
+#pragma unroll
+      for (int e4 = 0; e4 < DH / 4; ++e4) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(&vs[n][e4 * 4]);
+        ctx[e4 * 4 + 0] += p * v4[0];
+        ctx[e4 * 4 + 1] += p * v4[1];
+        ctx[e4 * 4 + 2] += p * v4[2];
+        ctx[e4 * 4 + 3] += p * v4[3];
+      }
+    }
+    __syncthreads();
+  }
+  // reduce the 8 position sub-streams in fixed order
+  red[sub][d] = l;
+#pragma unroll
+  for (int e = 0; e < DH; ++e) cred[sub][d][e] = ctx[e];
+  __syncthreads();
+  const size_t pidx = ((size_t)(b * heads + head) * nch + chunk);
+  if (sub == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][d];
+    pm[pidx * DH + d] = m;
+    pl[pidx * DH + d] = s;
+  }
+  for (int e = sub; e < DH; e += 8) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += cred[k][d][e];
+    pctx[(pidx * DH + d) * DH + e] = s;
+  }
+}
+
+// one block per (b, head): merge chunk partials -> normalised, pre-scaled context [d][e]
+__global__ __launch_bounds__(256) void la_combine_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                          const float* __restrict__ pctx, int nch, float scale,
+                                                          float* __restrict__ ctxn) {
+  const int bh = blockIdx.x;
+  const int tid = threadIdx.x, d = tid >> 3, eg = tid & 7;
+  const float* m_ = pm + (size_t)bh * nch * DH;
+  const float* l_ = pl + (size_t)bh * nch * DH;
+  const float* c_ = pctx + (size_t)bh * nch * DH * DH;
+  float m = -INFINITY;
+  for (int c = 0; c < nch; ++c) m = fmaxf(m, m_[c * DH + d]);
+  float l = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < nch; ++c) {
+    const float w = expf(m_[c * DH + d] - m);
+    l += l_[c * DH + d] * w;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(c_ + ((size_t)c * DH + d) * DH + eg * 4);
+    acc[0] += v[0] * w;
+    acc[1] += v[1] * w;
+    acc[2] += v[2] * w;
+    acc[3] += v[3] * w;
+  }
+  const float inv = scale / l;
+  float* o = ctxn + ((size_t)bh * DH + d) * DH + eg * 4;
+  o[0] = acc[0] * inv;
+  o[1] = acc[1] * inv;
+  o[2] = acc[2] * inv;
+  o[3] = acc[3] * inv;
+}
+
+// one thread per (position, head): softmax over the head's 32 q channels, then a 32x32 matvec
+template <typename T>
+__global__ __launch_bounds__(256) void la_apply_kernel(const T* __restrict__ qkv, const float* __restrict__ ctxn,
+                                                        T* __restrict__ out, int N, int heads) {
+  extern __shared__ __attribute__((aligned(16))) float sctx[];   // [heads][DH*DH + 4]
+  const int b = blockIdx.y;
+  const int hid = heads * DH, C3 = 3 * hid;
+  const int HS = DH * DH + 4;
+  for (int i = threadIdx.x; i < heads * DH * DH; i += 256) {
+    const int h = i / (DH * DH), r = i - h * DH * DH;
+    sctx[h * HS + r] = ctxn[((size_t)(b * heads + h)) * DH * DH + r];
+  }
+  __syncthreads();
+  const int ppb = 256 / heads;
+  const int head = threadIdx.x % heads;
+  const int n = blockIdx.x * ppb + threadIdx.x / heads;
+  if (n >= N) return;
+  const T* qp = qkv + ((size_t)b * N + n) * C3 + head * DH;
+  float q[DH];
+  constexpr int VN = Vec16<T>::N;
+#pragma unroll
+  for (int v = 0; v < DH / VN; ++v) {
+    Vec16<T> t = reinterpret_cast<const Vec16<T>*>(qp)[v];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) q[v * VN + j] = t.get(j);
+  }
+  float mx = q[0];
+#pragma unroll
+  for (int i = 1; i < DH; ++i) mx = fmaxf(mx, q[i]);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < DH; ++i) {
+    q[i] = expf(q[i] - mx);
+    sum += q[i];
+  }
+  const float inv = 1.0f / sum;
+  float o[DH];
+#pragma unroll
+  for (int e = 0; e < DH; ++e) o[e] = 0.f;
+  const float* cx = sctx + head * HS;
+#pragma unroll 4
+  for (int dd = 0; dd < DH; ++dd) {
+    const float qs = q[dd] * inv;
+#pragma unroll
+    for (int e4 = 0; e4 < DH / 4; ++e4) {
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(cx + dd * DH + e4 * 4);
+      o[e4 * 4 + 0] += qs * c4[0];
+      o[e4 * 4 + 1] += qs * c4[1];
+      o[e4 * 4 + 2] += qs * c4[2];
+      o[e4 * 4 + 3] += qs * c4[3];
+    }
+  }
+  T* op = out + ((size_t)b * N + n) * hid + head * DH;
+#pragma unroll
+  for (int v = 0; v < DH / VN; ++v) {
+    Vec16<T> t;
+#pragma unroll
+    for (int j = 0; j < VN; ++j) t.set(j, o[v * VN + j]);
+    reinterpret_cast<Vec16<T>*>(op)[v] = t;
+  }
+}
+
+// flash-style softmax attention: one thread per query row, 64-key tiles of K and V in LDS
+constexpr int FA_TILE = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void full_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N,
+                                                         int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) float ks[FA_TILE][DH];
+  __shared__ __attribute__((aligned(16))) float vs[FA_TILE][DH];
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int hid = heads * DH, C3 = 3 * hid;
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  const bool active = qi < N;
+  const T* base = qkv + (size_t)b * N * C3;
+  constexpr int VN = Vec16<T>::N;
+  float q[DH], o[DH];
+  if (active) {
+    const T* qp = base + (size_t)qi * C3 + head * DH;
+#pragma unroll
+    for (int v = 0; v < DH / VN; ++v) {
+      Vec16<T> t = reinterpret_cast<const Vec16<T>*>(qp)[v];
+#pragma unroll
+      for (int j = 0; j < VN; ++j) q[v * VN + j] = t.get(j);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < DH; ++i) q[i] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < DH; ++i) o[i] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < N; k0 += FA_TILE) {
+    const int tc = min(FA_TILE, N - k0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < FA_TILE * DH; i += 256) {
+      const int n = i >> 5, c = i & 31;
+      float kv = 0.f, vv = 0.f;
+      if (n < tc) {
+        const size_t off = (size_t)(k0 + n) * C3 + head * DH + c;
+        kv = to_f32<T>(base[off + hid]);
+        vv = to_f32<T>(base[off + 2 * hid]);
+      }
+      ks[n][c] = kv;
+      vs[n][c] = vv;
+    }
+    __syncthreads();
+    for (int j0 = 0; j0 < tc; j0 += 16) {
+      float s[16];
+      float bm = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int e4 = 0; e4 < DH / 4; ++e4) {
+          const f32x4 k4 = *reinterpret_cast<const f32x4*>(&ks[j0 + j][e4 * 4]);
+          a += q[e4 * 4 + 0] * k4[0] + q[e4 * 4 + 1] * k4[1] + q[e4 * 4 + 2] * k4[2] + q[e4 * 4 + 3] * k4[3];
+        }
+        a *= scale;
+        if (j0 + j >= tc) a = -INFINITY;
+        s[j] = a;
+        bm = fmaxf(bm, a);
+      }
+      const float mn = fmaxf(m, bm);
+      const float corr = expf(m - mn);      // m = -inf on the first block -> 0
+      l *= corr;
+#pragma unroll
+      for (int e = 0; e < DH; ++e) o[e] *= corr;
+      m = mn;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float p = expf(s[j] - m);
+        l += p;
+#pragma unroll
+        for (int e4 = 0; e4 < DH / 4; ++e4) {
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(&vs[j0 + j][e4 * 4]);
+          o[e4 * 4 + 0] += p * v4[0];
+          o[e4 * 4 + 1] += p * v4[1];
+          o[e4 * 4 + 2] += p * v4[2];
+          o[e4 * 4 + 3] += p * v4[3];
+        }
+      }
+    }
+  }
+  if (!active) return;
+  const float inv = 1.0f / l;
+  T* op = out + ((size_t)b * N + qi) * hid + head * DH;
+#pragma unroll
+  for (int v = 0; v < DH / VN; ++v) {
+    Vec16<T> t;
+#pragma unroll
+    for (int j = 0; j < VN; ++j) t.set(j, o[v * VN + j] * inv);
+    reinterpret_cast<Vec16<T>*>(op)[v] = t;
+  }
+}
+
+}  // namespace
+
+static int la_chunks(int N) { return cdiv(N, LA_CHUNK); }
+
+size_t linear_attention_workspace(int B, int N, int heads, int dh) {
+  const size_t bh = (size_t)B * heads, nch = la_chunks(N);
+  return (bh * nch * (2 * dh + dh * dh) + bh * dh * dh) * sizeof(float);
+}
+
+int linear_attention(const void* qkv, void* out, int B, int N, int heads, int dh, float* ws, bool is_bf16,
+                     hipStream_t st) {
+  if (dh != DH) SRGD_FAIL("linear_attention: dim_head must be 32");
+  const int nch = la_chunks(N);
+  const size_t bh = (size_t)B * heads;
+  float* pm = ws;
+  float* pl = pm + bh * nch * DH;
+  float* pctx = pl + bh * nch * DH;
+  float* ctxn = pctx + bh * nch * DH * DH;
+  const float scale = 1.0f / sqrtf((float)dh);
+  dim3 g1(nch, heads, B);
+  if (is_bf16)
+    hipLaunchKernelGGL((la_partial_kernel<bf16>), g1, dim3(256), 0, st, (const bf16*)qkv, N, heads, pm, pl, pctx);
+  else
+    hipLaunchKernelGGL((la_partial_kernel<float>), g1, dim3(256), 0, st, (const float*)qkv, N, heads, pm, pl, pctx);
+  SRGD_HIP(hipGetLastError());
+  hipLaunchKernelGGL(la_combine_kernel, dim3((unsigned)bh), dim3(256), 0, st, pm, pl, pctx, nch, scale, ctxn);
+  SRGD_HIP(hipGetLastError());
+  if (256 % heads != 0) SRGD_FAIL("linear_attention: heads must divide 256");
+  const int ppb = 256 / heads;
+  dim3 g3(cdiv(N, ppb), B);
+  const size_t lds = (size_t)heads * (DH * DH + 4) * sizeof(float);
+  if (is_bf16)
+    hipLaunchKernelGGL((la_apply_kernel<bf16>), g3, dim3(256), lds, st, (const bf16*)qkv, ctxn, (bf16*)out, N, heads);
+  else
+    hipLaunchKernelGGL((la_apply_kernel<float>), g3, dim3(256), lds, st, (const float*)qkv, ctxn, (float*)out, N, heads);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int full_attention(const void* qkv, void* out, int B, int N, int heads, int dh, bool is_bf16, hipStream_t st) {
+  if (dh != DH) SRGD_FAIL("full_attention: dim_head must be 32");
+  const float scale = 1.0f / sqrtf((float)dh);
+  dim3 g(cdiv(N, 256), heads, B);
+  if (is_bf16)
+    hipLaunchKernelGGL((full_attn_kernel<bf16>), g, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, N, heads, scale);
+  else
+    hipLaunchKernelGGL((full_attn_kernel<float>), g, dim3(256), 0, st, (const float*)qkv, (float*)out, N, heads, scale);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace srgd

@@ -1,0 +1,94 @@
+// Shared device/host helpers for the gfx950 kernels of the Real-SRGD sampling path.
+// Written for MI355X (CDNA4, wave64) only - no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace srgd {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (message retrievable through srgd_last_error) ---------------------
+void set_error(const std::string& msg);
+#define SRGD_FAIL(msg)                                  \
+  do {                                                  \
+    ::srgd::set_error(std::string(msg));                \
+    return -1;                                          \
+  } while (0)
+#define SRGD_HIP(call)                                                              \
+  do {                                                                              \
+    hipError_t e__ = (call);                                                        \
+    if (e__ != hipSuccess) {                                                        \
+      ::srgd::set_error(std::string(#call) + ": " + hipGetErrorString(e__));       \
+      return -1;                                                                    \
+    }                                                                               \
+  } while (0)
+#define SRGD_TRY(call)          \
+  do {                          \
+    int r__ = (call);           \
+    if (r__ != 0) return r__;   \
+  } while (0)
+
+// ---- element conversion ---------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// A 16-byte vector of activations: 4 floats or 8 bf16.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  f32x4 v;
+  __device__ __forceinline__ float get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16> {
+  static constexpr int N = 8;
+  bf16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+
+// SiLU. PRECISE selects the accurate expf (fp32 parity mode); the bf16 mode uses the fast exp.
+template <bool PRECISE> __device__ __forceinline__ float silu(float x) {
+  if (PRECISE) return x / (1.0f + expf(-x));
+  return x * __frcp_rn(1.0f + __expf(-x));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Kernel classes for the per-class timing that bench.py reads (srgd_profile_*).
+enum KClass {
+  KC_CONV = 0,     // implicit-GEMM convolutions (3x3, 1x1, 2x2/s2)
+  KC_INIT,         // 7x7 input convolution reading the canvases
+  KC_GN,           // GroupNorm finalize + apply(+SiLU, +residual)
+  KC_RMS,          // RMSNorm
+  KC_LINATTN,      // linear attention
+  KC_FULLATTN,     // softmax attention
+  KC_FINAL,        // 1x1 output conv + CFG + DDPM update
+  KC_CANVAS,       // canvas prepare / re-noise / finish / RNG
+  KC_COND,         // conditioning MLPs
+  KC_COUNT
+};
+
+}  // namespace srgd

@@ -1,0 +1,909 @@
+// Engine behind the C ABI of include/srgd_hip.h: owns the packed weights, the activation
+// pool and the launch sequence of one ConditionalSRUnet evaluation (reference
+// model.py:678-725) and of one tiled DDPM step (model.py:3346-3396) on a single HIP stream.
+// No host synchronisation, no allocation after the first call with a given shape.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "../../include/srgd_hip.h"
+#include "kernels.hpp"
+
+namespace srgd {
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+const char* last_error() { return g_err.c_str(); }
+
+static uint16_t f32_to_bf16_host(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// OIHW fp32 -> [tap][CoutPad][Cin] in the activation type (k contiguous), see conv_igemm.hip.
+//   kind 1 (Downsample, model.py:106-110): the 1x1 conv over 'b (c p1 p2) h w' becomes a 2x2/stride-2 conv.
+//   kind 2 (PixelShuffleUpsample, model.py:70-98): output columns are permuted to (i*2+j)*Cout/4 + ch so the
+//   epilogue's pixel-shuffled stores are channel-contiguous.
+void pack_conv_weights(const float* src, const float* bias_in, int kind, int Cin, int Cout, int CoutPad, int KS,
+                       bool to_bf16, std::vector<unsigned char>& packed_out, std::vector<float>& bias_out) {
+  const int taps = KS * KS;
+  const size_t n = (size_t)taps * CoutPad * Cin;
+  std::vector<float> packed(n, 0.f);
+  bias_out.assign(Cout, 0.f);
+  for (int o = 0; o < Cout; ++o) {
+    int no = o;
+    if (kind == 2) {
+      const int ch = o >> 2, ij = o & 3;
+      no = ij * (Cout >> 2) + ch;
+    }
+    if (bias_in) bias_out[no] = bias_in[o];
+    for (int t = 0; t < taps; ++t) {
+      const int dy = t / KS, dx = t - dy * KS;
+      for (int i = 0; i < Cin; ++i) {
+        float v;
+        if (kind == 1) v = src[(size_t)o * 4 * Cin + (size_t)i * 4 + dy * 2 + dx];
+        else v = src[(((size_t)o * Cin + i) * KS + dy) * KS + dx];
+        packed[((size_t)t * CoutPad + no) * Cin + i] = v;
+      }
+    }
+  }
+  if (to_bf16) {
+    packed_out.resize(n * 2);
+    uint16_t* h = reinterpret_cast<uint16_t*>(packed_out.data());
+    for (size_t i = 0; i < n; ++i) h[i] = f32_to_bf16_host(packed[i]);
+  } else {
+    packed_out.resize(n * 4);
+    std::memcpy(packed_out.data(), packed.data(), n * 4);
+  }
+}
+
+namespace {
+
+__global__ void fill_rows_kernel(int* rows, int n, int split, int v0, int v1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) rows[i] = (i < split) ? v0 : v1;
+}
+__global__ void rows_api_kernel(int* rows, int n, int odd) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) rows[i] = 2 * i + odd;
+}
+
+
+struct HostTensor {
+  std::string name;
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool loaded = false;
+  size_t numel() const {
+    size_t n = 1;
+    for (auto s : shape) n *= (size_t)s;
+    return n;
+  }
+};
+
+enum ConvKind { CK_NORMAL = 0, CK_UNSHUFFLE = 1, CK_SHUFFLE = 2 };
+struct ConvW {
+  int Cin = 0, Cout = 0, CoutPad = 0, KS = 1, stride = 1, pad = 0, mode = CONV_PLAIN, kind = CK_NORMAL;
+  int wi = -1, bi = -1;       // indices of the host tensors
+  void* w = nullptr;
+  float* bias = nullptr;
+};
+struct Lin {
+  int in_f = 0, out_f = 0, wi = -1, bi = -1;
+  float* w = nullptr;
+  float* b = nullptr;
+};
+struct ResW {
+  int Cin = 0, Cout = 0, ss_offset = 0;
+  ConvW c1, c2, res;
+  bool has_res = false;
+  int g1i = -1, b1i = -1, g2i = -1, b2i = -1;
+  float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+  Lin mlp;
+};
+struct AttnW {
+  bool full = false;
+  int C = 0;
+  int ngi = -1, ogi = -1;
+  float *norm_g = nullptr, *out_g = nullptr;
+  ConvW qkv, out;
+};
+struct StageW {
+  ResW rb[2];
+  AttnW attn;
+  ConvW resample;
+};
+
+struct Pool {
+  struct Buf { void* p; size_t cap; bool busy; };
+  std::vector<Buf> bufs;
+  int64_t total = 0;
+  void* get(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (int i = 0; i < (int)bufs.size(); ++i)
+      if (!bufs[i].busy && bufs[i].cap >= bytes && (best < 0 || bufs[i].cap < bufs[best].cap)) best = i;
+    if (best >= 0) {
+      bufs[best].busy = true;
+      return bufs[best].p;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      set_error("activation pool: hipMalloc of " + std::to_string(bytes) + " bytes failed");
+      return nullptr;
+    }
+    total += (int64_t)bytes;
+    bufs.push_back({p, bytes, true});
+    return p;
+  }
+  void put(void* p) {
+    for (auto& b : bufs)
+      if (b.p == p) { b.busy = false; return; }
+  }
+  void release_all() {
+    for (auto& b : bufs) hipFree(b.p);
+    bufs.clear();
+    total = 0;
+  }
+};
+
+struct CondTable {
+  float* table = nullptr;   // [rows][ss_stride]
+  int rows_cap = 0;
+  float *ls = nullptr, *feat = nullptr, *h1 = nullptr, *t1 = nullptr, *trows = nullptr, *c1 = nullptr, *c2 = nullptr;
+};
+
+struct ProfRec { int kc; hipEvent_t a, b; };
+
+const char* kFamilyNames[KC_COUNT] = {"conv_igemm", "init_conv7x7", "groupnorm_silu", "rmsnorm", "linear_attention",
+                                      "full_attention", "final_conv_ddpm_step", "canvas_rng", "conditioning"};
+
+}  // namespace
+}  // namespace srgd
+
+using namespace srgd;
+
+struct srgd_engine {
+  srgd_unet_config cfg;
+  bool bf16 = false;
+  int es = 4;
+  int dim = 0, time_dim = 0, hid = 0, n_stages = 0;
+  std::vector<int> dims;
+  std::vector<HostTensor> wt;
+  std::map<std::string, int> widx;
+  bool finalized = false;
+  std::vector<void*> weight_allocs;
+  int64_t weight_bytes = 0;
+
+  float *init_w = nullptr, *init_b = nullptr, *final_w = nullptr, *final_b = nullptr, *sin_w = nullptr, *cls_emb = nullptr;
+  int init_wi = -1, init_bi = -1, final_wi = -1, final_bi = -1, sin_wi = -1, cls_emb_i = -1;
+  Lin time1, time3, cls1, cls3;
+  std::vector<StageW> downs, ups;
+  ResW mid1, mid2, final_rb;
+  AttnW mid_attn;
+  std::vector<ResW*> all_rb;
+  int ss_stride = 0;
+
+  Pool pool;
+  float* gn_partial = nullptr; size_t gn_partial_cap = 0;
+  float *coefA = nullptr, *coefB = nullptr; size_t coef_cap = 0;
+  float* la_ws = nullptr; size_t la_ws_cap = 0;
+  int* d_rows = nullptr; size_t rows_cap = 0;
+  CondTable ct_sampler, ct_api;
+
+  // sampler run state
+  srgd_sampler_geometry geo{};
+  int *d_tiles_even = nullptr, *d_tiles_odd = nullptr; size_t tiles_cap_even = 0, tiles_cap_odd = 0;
+  StepScalars* d_sc = nullptr; int sc_cap = 0;
+  int n_steps = 0, run_class = -1;
+  bool run_active = false;
+  float* rng_tiles = nullptr; size_t rng_tiles_cap = 0;
+  float* rng_canvas = nullptr; size_t rng_canvas_cap = 0;
+
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> ev_free;
+  double conv_flops = 0.0;
+
+  int reg(const std::string& name, std::vector<int64_t> shape) {
+    HostTensor t;
+    t.name = name;
+    t.shape = std::move(shape);
+    wt.push_back(std::move(t));
+    widx[name] = (int)wt.size() - 1;
+    return (int)wt.size() - 1;
+  }
+};
+
+namespace {
+
+struct Prof {
+  srgd_engine* e; int kc; hipStream_t st; hipEvent_t a{}, b{};
+  Prof(srgd_engine* e_, int kc_, hipStream_t st_) : e(e_), kc(kc_), st(st_) {
+    if (!e->prof_on) return;
+    for (hipEvent_t* ev : {&a, &b}) {
+      if (!e->ev_free.empty()) { *ev = e->ev_free.back(); e->ev_free.pop_back(); }
+      else hipEventCreate(ev);
+    }
+    hipEventRecord(a, st);
+  }
+  ~Prof() {
+    if (!e->prof_on) return;
+    hipEventRecord(b, st);
+    e->prof.push_back({kc, a, b});
+  }
+};
+
+// ----------------------------------------------------------------------- topology
+void reg_conv(srgd_engine* e, ConvW& c, const std::string& wname, const std::string& bname, int Cin, int Cout, int KS,
+              int stride, int pad, int kind) {
+  c.Cin = Cin; c.Cout = Cout; c.KS = KS; c.stride = stride; c.pad = pad; c.kind = kind;
+  c.CoutPad = cdiv(Cout, conv_tile_n()) * conv_tile_n();
+  c.mode = (kind == CK_SHUFFLE) ? CONV_PIXEL_SHUFFLE_SILU : CONV_PLAIN;
+  if (kind == CK_UNSHUFFLE) c.wi = e->reg(wname, {Cout, 4 * Cin, 1, 1});
+  else c.wi = e->reg(wname, {Cout, Cin, kind == CK_SHUFFLE ? 1 : KS, kind == CK_SHUFFLE ? 1 : KS});
+  c.bi = bname.empty() ? -1 : e->reg(bname, {Cout});
+}
+
+void reg_res(srgd_engine* e, ResW& r, const std::string& p, int Cin, int Cout, int& ss_off) {
+  r.Cin = Cin; r.Cout = Cout;
+  r.mlp.in_f = e->time_dim; r.mlp.out_f = 2 * Cout;
+  r.mlp.wi = e->reg(p + ".mlp.1.weight", {2 * Cout, e->time_dim});
+  r.mlp.bi = e->reg(p + ".mlp.1.bias", {2 * Cout});
+  reg_conv(e, r.c1, p + ".block1.proj.weight", p + ".block1.proj.bias", Cin, Cout, 3, 1, 1, CK_NORMAL);
+  r.g1i = e->reg(p + ".block1.norm.weight", {Cout});
+  r.b1i = e->reg(p + ".block1.norm.bias", {Cout});
+  reg_conv(e, r.c2, p + ".block2.proj.weight", p + ".block2.proj.bias", Cout, Cout, 3, 1, 1, CK_NORMAL);
+  r.g2i = e->reg(p + ".block2.norm.weight", {Cout});
+  r.b2i = e->reg(p + ".block2.norm.bias", {Cout});
+  r.has_res = Cin != Cout;
+  if (r.has_res) reg_conv(e, r.res, p + ".res_conv.weight", p + ".res_conv.bias", Cin, Cout, 1, 1, 0, CK_NORMAL);
+  r.ss_offset = ss_off;
+  ss_off += 2 * Cout;
+  e->all_rb.push_back(&r);
+}
+
+void reg_attn(srgd_engine* e, AttnW& a, const std::string& p, int C, bool full) {
+  a.full = full; a.C = C;
+  a.ngi = e->reg(p + ".norm.g", {1, C, 1, 1});
+  reg_conv(e, a.qkv, p + ".to_qkv.weight", "", C, 3 * e->hid, 1, 1, 0, CK_NORMAL);
+  if (full) {
+    reg_conv(e, a.out, p + ".to_out.weight", p + ".to_out.bias", e->hid, C, 1, 1, 0, CK_NORMAL);
+  } else {
+    reg_conv(e, a.out, p + ".to_out.0.weight", p + ".to_out.0.bias", e->hid, C, 1, 1, 0, CK_NORMAL);
+    a.ogi = e->reg(p + ".to_out.1.g", {1, C, 1, 1});
+  }
+}
+
+int build_topology(srgd_engine* e) {
+  const srgd_unet_config& c = e->cfg;
+  if (c.n_stages < 1 || c.n_stages > SRGD_MAX_STAGES) SRGD_FAIL("n_stages out of range");
+  if (c.channels != 3) SRGD_FAIL("only channels=3 (6-channel noisy|condition input) is supported");
+  if (c.dim_head != 32) SRGD_FAIL("only attn_dim_head=32 is supported");
+  if (c.heads < 1 || 256 % c.heads != 0) SRGD_FAIL("attn_heads must divide 256");
+  if (c.sinus_dim < 2 || c.sinus_dim % 2) SRGD_FAIL("learned_sinusoidal_dim must be even");
+  if (c.dim % 16 != 0) SRGD_FAIL("unet_dim must be a multiple of 16");
+  if (c.groups < 1 || c.dim % c.groups != 0) SRGD_FAIL("unet_dim must be divisible by resnet_block_groups");
+  e->bf16 = c.precision == SRGD_PRECISION_BF16;
+  e->es = e->bf16 ? 2 : 4;
+  e->dim = c.dim; e->time_dim = 4 * c.dim; e->hid = c.heads * c.dim_head; e->n_stages = c.n_stages;
+  e->dims.push_back(c.dim);
+  for (int s = 0; s < c.n_stages; ++s) e->dims.push_back(c.dim * c.dim_mults[s]);
+  for (int d : e->dims) {
+    if ((d / c.groups) > conv_tile_n() || conv_tile_n() % (d / c.groups) != 0)
+      SRGD_FAIL("channels per GroupNorm group must divide 128");
+  }
+  const int n = c.n_stages, td = e->time_dim;
+  e->init_wi = e->reg("init_conv.weight", {c.dim, 6, 7, 7});
+  e->init_bi = e->reg("init_conv.bias", {c.dim});
+  e->sin_wi = e->reg("time_mlp.0.weights", {c.sinus_dim / 2});
+  e->time1 = Lin{c.sinus_dim + 1, td, e->reg("time_mlp.1.weight", {td, c.sinus_dim + 1}), e->reg("time_mlp.1.bias", {td})};
+  e->time3 = Lin{td, td, e->reg("time_mlp.3.weight", {td, td}), e->reg("time_mlp.3.bias", {td})};
+  if (c.num_classes > 0) {
+    e->cls_emb_i = e->reg("class_mlp.0.weight", {c.num_classes, c.dim});
+    e->cls1 = Lin{c.dim, td, e->reg("class_mlp.1.weight", {td, c.dim}), e->reg("class_mlp.1.bias", {td})};
+    e->cls3 = Lin{td, td, e->reg("class_mlp.3.weight", {td, td}), e->reg("class_mlp.3.bias", {td})};
+  }
+  int ss = 0;
+  e->downs.resize(n);
+  e->ups.resize(n);
+  for (int s = 0; s < n; ++s) {
+    const int din = e->dims[s], dout = e->dims[s + 1];
+    const std::string p = "downs." + std::to_string(s);
+    reg_res(e, e->downs[s].rb[0], p + ".0", din, din, ss);
+    reg_res(e, e->downs[s].rb[1], p + ".1", din, din, ss);
+    reg_attn(e, e->downs[s].attn, p + ".2", din, c.full_attn[s] != 0);
+    if (s < n - 1) reg_conv(e, e->downs[s].resample, p + ".3.1.weight", p + ".3.1.bias", din, dout, 2, 2, 0, CK_UNSHUFFLE);
+    else reg_conv(e, e->downs[s].resample, p + ".3.weight", p + ".3.bias", din, dout, 3, 1, 1, CK_NORMAL);
+  }
+  const int mid = e->dims[n];
+  reg_res(e, e->mid1, "mid_block1", mid, mid, ss);
+  reg_attn(e, e->mid_attn, "mid_attn", mid, true);
+  reg_res(e, e->mid2, "mid_block2", mid, mid, ss);
+  for (int u = 0; u < n; ++u) {
+    const int s = n - 1 - u, din = e->dims[s], dout = e->dims[s + 1];
+    const std::string p = "ups." + std::to_string(u);
+    reg_res(e, e->ups[u].rb[0], p + ".0", dout + din, dout, ss);
+    reg_res(e, e->ups[u].rb[1], p + ".1", dout + din, dout, ss);
+    reg_attn(e, e->ups[u].attn, p + ".2", dout, c.full_attn[s] != 0);
+    if (u < n - 1) reg_conv(e, e->ups[u].resample, p + ".3.net.0.weight", p + ".3.net.0.bias", dout, 4 * din, 1, 1, 0, CK_SHUFFLE);
+    else reg_conv(e, e->ups[u].resample, p + ".3.weight", p + ".3.bias", dout, din, 3, 1, 1, CK_NORMAL);
+  }
+  reg_res(e, e->final_rb, "final_res_block", 2 * c.dim, c.dim, ss);
+  e->final_wi = e->reg("final_conv.weight", {3, c.dim, 1, 1});
+  e->final_bi = e->reg("final_conv.bias", {3});
+  e->ss_stride = ss;
+  return 0;
+}
+
+// ----------------------------------------------------------------------- weight packing
+int upload(srgd_engine* e, const void* host, size_t bytes, void** dev) {
+  SRGD_HIP(hipMalloc(dev, bytes));
+  e->weight_allocs.push_back(*dev);
+  e->weight_bytes += (int64_t)bytes;
+  SRGD_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+int upload_f32(srgd_engine* e, int idx, float** dev) {
+  return upload(e, e->wt[idx].data.data(), e->wt[idx].numel() * sizeof(float), (void**)dev);
+}
+
+int pack_conv(srgd_engine* e, ConvW& c) {
+  std::vector<unsigned char> packed;
+  std::vector<float> bias;
+  const float* hb = c.bi >= 0 ? e->wt[c.bi].data.data() : nullptr;
+  pack_conv_weights(e->wt[c.wi].data.data(), hb, c.kind, c.Cin, c.Cout, c.CoutPad, c.KS, e->bf16, packed, bias);
+  SRGD_TRY(upload(e, packed.data(), packed.size(), &c.w));
+  if (hb) SRGD_TRY(upload(e, bias.data(), bias.size() * 4, (void**)&c.bias));
+  return 0;
+}
+
+int pack_lin(srgd_engine* e, Lin& l) {
+  SRGD_TRY(upload_f32(e, l.wi, &l.w));
+  SRGD_TRY(upload_f32(e, l.bi, &l.b));
+  return 0;
+}
+int pack_res(srgd_engine* e, ResW& r) {
+  SRGD_TRY(pack_conv(e, r.c1));
+  SRGD_TRY(pack_conv(e, r.c2));
+  if (r.has_res) SRGD_TRY(pack_conv(e, r.res));
+  SRGD_TRY(upload_f32(e, r.g1i, &r.g1));
+  SRGD_TRY(upload_f32(e, r.b1i, &r.b1));
+  SRGD_TRY(upload_f32(e, r.g2i, &r.g2));
+  SRGD_TRY(upload_f32(e, r.b2i, &r.b2));
+  SRGD_TRY(pack_lin(e, r.mlp));
+  return 0;
+}
+int pack_attn(srgd_engine* e, AttnW& a) {
+  SRGD_TRY(upload_f32(e, a.ngi, &a.norm_g));
+  if (a.ogi >= 0) SRGD_TRY(upload_f32(e, a.ogi, &a.out_g));
+  SRGD_TRY(pack_conv(e, a.qkv));
+  SRGD_TRY(pack_conv(e, a.out));
+  return 0;
+}
+
+template <typename T> int ensure(T** p, size_t* cap, size_t need_elems) {
+  if (*cap >= need_elems) return 0;
+  if (*p) hipFree(*p);
+  *p = nullptr;
+  SRGD_HIP(hipMalloc((void**)p, need_elems * sizeof(T)));
+  *cap = need_elems;
+  return 0;
+}
+
+// ----------------------------------------------------------------------- forward pieces
+struct Ctx {
+  srgd_engine* e;
+  int nb, H, W;              // batch entries and current resolution
+  const int* rows;           // conditioning row of each entry
+  const float* table;        // conditioning table in use
+  hipStream_t st;
+};
+
+int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, int C1, int Hin, int Win, void* out,
+             const void* residual, bool stats) {
+  srgd_engine* e = x.e;
+  ConvArgs a;
+  a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
+  a.B = x.nb; a.Hin = Hin; a.Win = Win;
+  a.Hout = (Hin + 2 * c.pad - c.KS) / c.stride + 1;
+  a.Wout = (Win + 2 * c.pad - c.KS) / c.stride + 1;
+  a.KS = c.KS; a.stride = c.stride; a.pad = c.pad;
+  a.w = c.w; a.bias = c.bias; a.Cout = c.Cout; a.CoutPad = c.CoutPad;
+  a.out = out; a.residual = residual; a.mode = c.mode;
+  a.gn_partial = stats ? e->gn_partial : nullptr;
+  a.groups = e->cfg.groups;
+  if (C0 + C1 != c.Cin) SRGD_FAIL("internal: conv input channel mismatch");
+  Prof p(e, KC_CONV, x.st);
+  if (e->prof_on) e->conv_flops += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
+  return conv_igemm(a, e->bf16, x.st);
+}
+
+int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_offset /* <0: none */, void* buf,
+           const void* residual) {
+  srgd_engine* e = x.e;
+  Prof p(e, KC_GN, x.st);
+  GnFinalizeArgs f;
+  f.partial = e->gn_partial; f.nslots = hw / conv_tile_m(); f.B = x.nb; f.C = C; f.groups = e->cfg.groups; f.hw = hw;
+  f.gamma = gamma; f.beta = beta;
+  f.ss_table = ss_offset >= 0 ? x.table : nullptr; f.ss_rows = x.rows; f.step_ptr = nullptr; f.step_mul = 0;
+  f.ss_stride = e->ss_stride; f.ss_offset = ss_offset < 0 ? 0 : ss_offset; f.eps = 1e-5f;
+  f.coefA = e->coefA; f.coefB = e->coefB;
+  SRGD_TRY(gn_finalize(f, x.st));
+  return gn_apply_silu(buf, buf, residual, e->coefA, e->coefB, x.nb, hw, C, e->bf16, x.st);
+}
+
+// ResnetBlock (model.py:261-285); returns a pool buffer [nb,H,W,Cout]
+int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, int C1, void** out) {
+  srgd_engine* e = x.e;
+  const int hw = x.H * x.W;
+  const size_t bytes = (size_t)x.nb * hw * r.Cout * e->es;
+  void* u = e->pool.get(bytes);
+  void* v = e->pool.get(bytes);
+  if (!u || !v) return -1;
+  SRGD_TRY(run_conv(x, r.c1, in0, C0, in1, C1, x.H, x.W, u, nullptr, true));
+  SRGD_TRY(run_gn(x, r.g1, r.b1, r.Cout, hw, r.ss_offset, u, nullptr));
+  SRGD_TRY(run_conv(x, r.c2, u, r.Cout, nullptr, 0, x.H, x.W, v, nullptr, true));
+  if (r.has_res) {
+    SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, u, nullptr, false));   // u is free again: reuse it
+    SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, u));
+  } else {
+    if (in1) SRGD_FAIL("internal: identity residual with two sources");
+    SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, in0));
+  }
+  e->pool.put(u);
+  *out = v;
+  return 0;
+}
+
+// x + attn(x)  (model.py:703,:709,:718); returns a pool buffer [nb,H,W,C]
+int attn_block(Ctx& x, const AttnW& a, const void* in, void** out) {
+  srgd_engine* e = x.e;
+  const int hw = x.H * x.W;
+  const long npix = (long)x.nb * hw;
+  void* nrm = e->pool.get((size_t)npix * a.C * e->es);
+  void* qkv = e->pool.get((size_t)npix * 3 * e->hid * e->es);
+  void* att = e->pool.get((size_t)npix * e->hid * e->es);
+  if (!nrm || !qkv || !att) return -1;
+  { Prof p(e, KC_RMS, x.st); SRGD_TRY(rms_norm(in, nrm, nullptr, a.norm_g, npix, a.C, e->bf16, x.st)); }
+  SRGD_TRY(run_conv(x, a.qkv, nrm, a.C, nullptr, 0, x.H, x.W, qkv, nullptr, false));
+  if (a.full) {
+    Prof p(e, KC_FULLATTN, x.st);
+    SRGD_TRY(full_attention(qkv, att, x.nb, hw, e->cfg.heads, e->cfg.dim_head, e->bf16, x.st));
+  } else {
+    Prof p(e, KC_LINATTN, x.st);
+    const size_t need = linear_attention_workspace(x.nb, hw, e->cfg.heads, e->cfg.dim_head) / sizeof(float);
+    if (need > e->la_ws_cap) SRGD_FAIL("internal: linear attention workspace too small");
+    SRGD_TRY(linear_attention(qkv, att, x.nb, hw, e->cfg.heads, e->cfg.dim_head, e->la_ws, e->bf16, x.st));
+  }
+  e->pool.put(qkv);
+  if (a.full) {
+    SRGD_TRY(run_conv(x, a.out, att, e->hid, nullptr, 0, x.H, x.W, nrm, in, false));        // + bias + residual x
+  } else {
+    SRGD_TRY(run_conv(x, a.out, att, e->hid, nullptr, 0, x.H, x.W, nrm, nullptr, false));
+    Prof p(e, KC_RMS, x.st);
+    SRGD_TRY(rms_norm(nrm, nrm, in, a.out_g, npix, a.C, e->bf16, x.st));                     // RMSNorm then + x
+  }
+  e->pool.put(att);
+  *out = nrm;
+  return 0;
+}
+
+int ensure_scratch(srgd_engine* e, int nb, int H, int W) {
+  const int hw = H * W;
+  SRGD_TRY(ensure(&e->gn_partial, &e->gn_partial_cap, (size_t)nb * e->cfg.groups * (hw / conv_tile_m()) * 2));
+  const int cmax = *std::max_element(e->dims.begin(), e->dims.end());
+  size_t need = (size_t)nb * cmax;
+  if (e->coef_cap < need) {
+    if (e->coefA) hipFree(e->coefA);
+    if (e->coefB) hipFree(e->coefB);
+    e->coefA = e->coefB = nullptr;
+    SRGD_HIP(hipMalloc((void**)&e->coefA, need * 4));
+    SRGD_HIP(hipMalloc((void**)&e->coefB, need * 4));
+    e->coef_cap = need;
+  }
+  SRGD_TRY(ensure(&e->la_ws, &e->la_ws_cap, linear_attention_workspace(nb, hw, e->cfg.heads, e->cfg.dim_head) / 4));
+  SRGD_TRY(ensure(&e->d_rows, &e->rows_cap, (size_t)nb));
+  return 0;
+}
+
+// The U-Net between init_conv and final_conv.  x0: [nb,H,W,dim] (kept alive by the caller).
+int unet_body(Ctx& x, void* x0, void** out) {
+  srgd_engine* e = x.e;
+  const int n = e->n_stages;
+  const int f = 1 << (n - 1);
+  if (x.H % f || x.W % f) SRGD_FAIL("your input dimensions need to be divisible by " + std::to_string(f) + ", given the unet");
+  if (((x.H / f) * (x.W / f)) % conv_tile_m() != 0)
+    SRGD_FAIL("this build needs (H/" + std::to_string(f) + ")*(W/" + std::to_string(f) + ") to be a multiple of 128 (e.g. 128x128, 256x256 tiles)");
+  std::vector<void*> skips;
+  void* cur = x0;
+  const int H0 = x.H, W0 = x.W;
+  for (int s = 0; s < n; ++s) {
+    const StageW& sw = e->downs[s];
+    const int C = e->dims[s];
+    void *a, *b, *c;
+    SRGD_TRY(res_block(x, sw.rb[0], cur, C, nullptr, 0, &a));
+    if (cur != x0) e->pool.put(cur);
+    skips.push_back(a);
+    SRGD_TRY(res_block(x, sw.rb[1], a, C, nullptr, 0, &b));
+    SRGD_TRY(attn_block(x, sw.attn, b, &c));
+    e->pool.put(b);
+    skips.push_back(c);
+    const ConvW& rs = sw.resample;
+    const int Ho = (s < n - 1) ? x.H / 2 : x.H, Wo = (s < n - 1) ? x.W / 2 : x.W;
+    void* d = e->pool.get((size_t)x.nb * Ho * Wo * rs.Cout * e->es);
+    if (!d) return -1;
+    SRGD_TRY(run_conv(x, rs, c, C, nullptr, 0, x.H, x.W, d, nullptr, false));
+    x.H = Ho; x.W = Wo;
+    cur = d;
+  }
+  {
+    void *a, *b, *c;
+    const int C = e->dims[n];
+    SRGD_TRY(res_block(x, e->mid1, cur, C, nullptr, 0, &a));
+    e->pool.put(cur);
+    SRGD_TRY(attn_block(x, e->mid_attn, a, &b));
+    e->pool.put(a);
+    SRGD_TRY(res_block(x, e->mid2, b, C, nullptr, 0, &c));
+    e->pool.put(b);
+    cur = c;
+  }
+  for (int u = 0; u < n; ++u) {
+    const StageW& sw = e->ups[u];
+    const int s = n - 1 - u, din = e->dims[s], dout = e->dims[s + 1];
+    void *a, *b, *c;
+    void* sk = skips.back(); skips.pop_back();
+    SRGD_TRY(res_block(x, sw.rb[0], cur, dout, sk, din, &a));
+    e->pool.put(cur); e->pool.put(sk);
+    sk = skips.back(); skips.pop_back();
+    SRGD_TRY(res_block(x, sw.rb[1], a, dout, sk, din, &b));
+    e->pool.put(a); e->pool.put(sk);
+    SRGD_TRY(attn_block(x, sw.attn, b, &c));
+    e->pool.put(b);
+    const ConvW& rs = sw.resample;
+    const int Ho = (u < n - 1) ? x.H * 2 : x.H, Wo = (u < n - 1) ? x.W * 2 : x.W;
+    void* d = e->pool.get((size_t)x.nb * Ho * Wo * din * e->es);
+    if (!d) return -1;
+    SRGD_TRY(run_conv(x, rs, c, dout, nullptr, 0, x.H, x.W, d, nullptr, false));
+    e->pool.put(c);
+    x.H = Ho; x.W = Wo;
+    cur = d;
+  }
+  if (x.H != H0 || x.W != W0) SRGD_FAIL("internal: resolution bookkeeping");
+  void* fin;
+  SRGD_TRY(res_block(x, e->final_rb, cur, e->dim, x0, e->dim, &fin));
+  e->pool.put(cur);
+  *out = fin;
+  return 0;
+}
+
+// Conditioning table: rows 2i (with class embedding if class_id >= 0) and 2i+1 (without) for
+// every log-SNR value i; columns = concatenated per-ResnetBlock (scale | shift) vectors.
+int compute_conditioning(srgd_engine* e, CondTable& ct, const float* ls_host, int n, int class_id, hipStream_t st) {
+  Prof p(e, KC_COND, st);
+  const int td = e->time_dim, half = e->cfg.sinus_dim / 2, nf = e->cfg.sinus_dim + 1;
+  if (class_id >= e->cfg.num_classes) SRGD_FAIL("class label out of range");
+  if (n > ct.rows_cap) {
+    for (float** q : {&ct.table, &ct.ls, &ct.feat, &ct.h1, &ct.t1, &ct.trows, &ct.c1, &ct.c2})
+      if (*q) { hipFree(*q); *q = nullptr; }
+    SRGD_HIP(hipMalloc((void**)&ct.table, (size_t)2 * n * e->ss_stride * 4));
+    SRGD_HIP(hipMalloc((void**)&ct.ls, (size_t)n * 4));
+    SRGD_HIP(hipMalloc((void**)&ct.feat, (size_t)n * nf * 4));
+    SRGD_HIP(hipMalloc((void**)&ct.h1, (size_t)n * td * 4));
+    SRGD_HIP(hipMalloc((void**)&ct.trows, (size_t)2 * n * td * 4));
+    SRGD_HIP(hipMalloc((void**)&ct.c1, (size_t)td * 4));
+    SRGD_HIP(hipMalloc((void**)&ct.c2, (size_t)td * 4));
+    ct.rows_cap = n;
+  }
+  SRGD_HIP(hipMemcpyAsync(ct.ls, ls_host, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  SRGD_TRY(time_features(ct.ls, e->sin_w, half, n, ct.feat, st));
+  SRGD_TRY(linear_rows(ct.feat, nf, e->time1.w, e->time1.b, ct.h1, td, n, nf, td, ACT_GELU, nullptr, 0, st));
+  // rows 2i+1: t ; rows 2i: t + class embedding
+  SRGD_TRY(linear_rows(ct.h1, td, e->time3.w, e->time3.b, ct.trows + td, 2 * td, n, td, td, ACT_NONE, nullptr, 0, st));
+  if (class_id >= 0) {
+    SRGD_TRY(linear_rows(e->cls_emb + (size_t)class_id * e->dim, e->dim, e->cls1.w, e->cls1.b, ct.c1, td, 1, e->dim, td,
+                         ACT_GELU, nullptr, 0, st));
+    SRGD_TRY(linear_rows(ct.c1, td, e->cls3.w, e->cls3.b, ct.c2, td, 1, td, td, ACT_NONE, nullptr, 0, st));
+    SRGD_TRY(linear_rows(ct.h1, td, e->time3.w, e->time3.b, ct.trows, 2 * td, n, td, td, ACT_NONE, ct.c2, 0, st));
+  } else {
+    SRGD_TRY(linear_rows(ct.h1, td, e->time3.w, e->time3.b, ct.trows, 2 * td, n, td, td, ACT_NONE, nullptr, 0, st));
+  }
+  for (ResW* r : e->all_rb)
+    SRGD_TRY(linear_rows(ct.trows, td, r->mlp.w, r->mlp.b, ct.table + r->ss_offset, e->ss_stride, 2 * n, td, 2 * r->Cout,
+                         ACT_SILU_IN, nullptr, 0, st));
+  return 0;
+}
+
+}  // namespace
+
+// ======================================================================= C ABI
+extern "C" {
+
+const char* srgd_last_error(void) { return srgd::last_error(); }
+const char* srgd_version(void) { return "srgd_hip 0.1 (gfx950)"; }
+
+int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
+  if (!cfg || !out) SRGD_FAIL("srgd_create: null argument");
+  int ndev = 0;
+  SRGD_HIP(hipGetDeviceCount(&ndev));
+  if (ndev == 0) SRGD_FAIL("srgd_create: no HIP device (this library has no CPU fallback)");
+  SRGD_HIP(hipSetDevice(cfg->device));
+  std::unique_ptr<srgd_engine> e(new srgd_engine());
+  e->cfg = *cfg;
+  SRGD_TRY(build_topology(e.get()));
+  *out = e.release();
+  return 0;
+}
+
+int srgd_destroy(srgd_engine* e) {
+  if (!e) return 0;
+  hipSetDevice(e->cfg.device);
+  hipDeviceSynchronize();
+  for (void* p : e->weight_allocs) hipFree(p);
+  e->pool.release_all();
+  for (void* p : {(void*)e->gn_partial, (void*)e->coefA, (void*)e->coefB, (void*)e->la_ws, (void*)e->d_rows,
+                  (void*)e->d_tiles_even, (void*)e->d_tiles_odd, (void*)e->d_sc, (void*)e->rng_tiles, (void*)e->rng_canvas})
+    if (p) hipFree(p);
+  for (CondTable* ct : {&e->ct_sampler, &e->ct_api})
+    for (float* q : {ct->table, ct->ls, ct->feat, ct->h1, ct->t1, ct->trows, ct->c1, ct->c2})
+      if (q) hipFree(q);
+  for (auto& r : e->prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (auto ev : e->ev_free) hipEventDestroy(ev);
+  delete e;
+  return 0;
+}
+
+int srgd_num_weights(const srgd_engine* e) { return e ? (int)e->wt.size() : -1; }
+
+int srgd_weight_info(const srgd_engine* e, int index, char* name, size_t name_cap, int64_t shape[4], int* ndim) {
+  if (!e || index < 0 || index >= (int)e->wt.size()) SRGD_FAIL("srgd_weight_info: bad index");
+  const HostTensor& t = e->wt[index];
+  if (name && name_cap) {
+    std::strncpy(name, t.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (ndim) *ndim = (int)t.shape.size();
+  if (shape) for (size_t i = 0; i < t.shape.size() && i < 4; ++i) shape[i] = t.shape[i];
+  return 0;
+}
+
+int srgd_load_weight(srgd_engine* e, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+  if (!e || !name || !host_data) SRGD_FAIL("srgd_load_weight: null argument");
+  if (e->finalized) SRGD_FAIL("srgd_load_weight: weights already finalized");
+  std::string key(name);
+  if (key.rfind("model.", 0) == 0) key = key.substr(6);
+  auto it = e->widx.find(key);
+  if (it == e->widx.end()) SRGD_FAIL("Unexpected key(s) in state_dict: \"" + std::string(name) + "\"");
+  HostTensor& t = e->wt[it->second];
+  bool same = (int)t.shape.size() == ndim;
+  for (int i = 0; same && i < ndim; ++i) same = t.shape[i] == shape[i];
+  if (!same) SRGD_FAIL("size mismatch for " + key);
+  t.data.assign(host_data, host_data + t.numel());
+  t.loaded = true;
+  return 0;
+}
+
+int srgd_finalize_weights(srgd_engine* e) {
+  if (!e) SRGD_FAIL("null engine");
+  if (e->finalized) return 0;
+  std::string missing;
+  for (auto& t : e->wt)
+    if (!t.loaded) missing += (missing.empty() ? "" : ", ") + t.name;
+  if (!missing.empty()) SRGD_FAIL("Missing key(s) in state_dict: " + missing);
+  SRGD_HIP(hipSetDevice(e->cfg.device));
+  // 7x7 input conv: OIHW [dim,6,7,7] -> [ (dy*7+dx)*6 + ci ][dim]
+  {
+    const std::vector<float>& s = e->wt[e->init_wi].data;
+    std::vector<float> p((size_t)294 * e->dim);
+    for (int o = 0; o < e->dim; ++o)
+      for (int ci = 0; ci < 6; ++ci)
+        for (int dy = 0; dy < 7; ++dy)
+          for (int dx = 0; dx < 7; ++dx)
+            p[(size_t)((dy * 7 + dx) * 6 + ci) * e->dim + o] = s[(((size_t)o * 6 + ci) * 7 + dy) * 7 + dx];
+    SRGD_TRY(upload(e, p.data(), p.size() * 4, (void**)&e->init_w));
+    SRGD_TRY(upload_f32(e, e->init_bi, &e->init_b));
+  }
+  SRGD_TRY(upload_f32(e, e->final_wi, &e->final_w));
+  SRGD_TRY(upload_f32(e, e->final_bi, &e->final_b));
+  SRGD_TRY(upload_f32(e, e->sin_wi, &e->sin_w));
+  SRGD_TRY(pack_lin(e, e->time1));
+  SRGD_TRY(pack_lin(e, e->time3));
+  if (e->cfg.num_classes > 0) {
+    SRGD_TRY(upload_f32(e, e->cls_emb_i, &e->cls_emb));
+    SRGD_TRY(pack_lin(e, e->cls1));
+    SRGD_TRY(pack_lin(e, e->cls3));
+  }
+  for (auto& s : e->downs) {
+    SRGD_TRY(pack_res(e, s.rb[0])); SRGD_TRY(pack_res(e, s.rb[1]));
+    SRGD_TRY(pack_attn(e, s.attn)); SRGD_TRY(pack_conv(e, s.resample));
+  }
+  SRGD_TRY(pack_res(e, e->mid1)); SRGD_TRY(pack_attn(e, e->mid_attn)); SRGD_TRY(pack_res(e, e->mid2));
+  for (auto& s : e->ups) {
+    SRGD_TRY(pack_res(e, s.rb[0])); SRGD_TRY(pack_res(e, s.rb[1]));
+    SRGD_TRY(pack_attn(e, s.attn)); SRGD_TRY(pack_conv(e, s.resample));
+  }
+  SRGD_TRY(pack_res(e, e->final_rb));
+  for (auto& t : e->wt) { std::vector<float>().swap(t.data); }
+  e->finalized = true;
+  return 0;
+}
+
+int srgd_unet_forward(srgd_engine* e, const float* xin, const float* cond, const float* log_snr_host, int class_id,
+                      float* eps_out, int B, int H, int W, void* stream) {
+  if (!e || !e->finalized) SRGD_FAIL("srgd_unet_forward: engine has no weights");
+  if (class_id >= 0 && e->cfg.num_classes <= 0) SRGD_FAIL("class label given but the U-Net has no class embedding");
+  hipStream_t st = (hipStream_t)stream;
+  SRGD_HIP(hipSetDevice(e->cfg.device));
+  SRGD_TRY(ensure_scratch(e, B, H, W));
+  SRGD_TRY(compute_conditioning(e, e->ct_api, log_snr_host, B, class_id, st));
+  hipLaunchKernelGGL(rows_api_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, e->d_rows, B, class_id >= 0 ? 0 : 1);
+  void* x0 = e->pool.get((size_t)B * H * W * e->dim * e->es);
+  if (!x0) return -1;
+  { Prof p(e, KC_INIT, st); SRGD_TRY(init_conv_from_nchw(xin, cond, B, H, W, e->init_w, e->init_b, e->dim, x0, e->bf16, st)); }
+  Ctx x{e, B, H, W, e->d_rows, e->ct_api.table, st};
+  void* act = nullptr;
+  SRGD_TRY(unet_body(x, x0, &act));
+  { Prof p(e, KC_FINAL, st); SRGD_TRY(final_conv_to_nchw(act, B, H, W, e->dim, e->final_w, e->final_b, eps_out, e->bf16, st)); }
+  e->pool.put(act);
+  e->pool.put(x0);
+  return 0;
+}
+
+int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const float* cond01, float* cond_canvas,
+                       const int32_t* tiles_even_host, const int32_t* tiles_odd_host, int n_steps,
+                       const srgd_step_scalars* scalars_host, const float* log_snr_host, int class_id, void* stream) {
+  if (!e || !e->finalized) SRGD_FAIL("srgd_sampler_begin: engine has no weights");
+  if (!g || !cond01 || !cond_canvas || !tiles_even_host || !tiles_odd_host || !scalars_host || !log_snr_host)
+    SRGD_FAIL("srgd_sampler_begin: null argument");
+  if (class_id >= 0 && e->cfg.num_classes <= 0) SRGD_FAIL("class label given but the U-Net has no class embedding");
+  if (g->tile <= 0 || g->n_even <= 0 || g->n_odd <= 0 || n_steps <= 0) SRGD_FAIL("srgd_sampler_begin: bad geometry");
+  // F.pad(mode='reflect') requires pad < input size (model.py:3303 raises otherwise)
+  const int pl = g->left, pr = g->Wp - g->left - g->W, pt = g->top, pb = g->Hp - g->top - g->H;
+  if (pl >= g->W || pr >= g->W || pt >= g->H || pb >= g->H)
+    SRGD_FAIL("Padding size should be less than the corresponding input dimension (reflect pad)");
+  hipStream_t st = (hipStream_t)stream;
+  SRGD_HIP(hipSetDevice(e->cfg.device));
+  e->geo = *g;
+  e->n_steps = n_steps;
+  e->run_class = class_id;
+  SRGD_TRY(ensure(&e->d_tiles_even, &e->tiles_cap_even, (size_t)g->n_even * 2));
+  SRGD_TRY(ensure(&e->d_tiles_odd, &e->tiles_cap_odd, (size_t)g->n_odd * 2));
+  SRGD_HIP(hipMemcpyAsync(e->d_tiles_even, tiles_even_host, (size_t)g->n_even * 8, hipMemcpyHostToDevice, st));
+  SRGD_HIP(hipMemcpyAsync(e->d_tiles_odd, tiles_odd_host, (size_t)g->n_odd * 8, hipMemcpyHostToDevice, st));
+  if (e->sc_cap < n_steps) {
+    if (e->d_sc) hipFree(e->d_sc);
+    e->d_sc = nullptr;
+    SRGD_HIP(hipMalloc((void**)&e->d_sc, (size_t)n_steps * sizeof(StepScalars)));
+    e->sc_cap = n_steps;
+  }
+  static_assert(sizeof(StepScalars) == sizeof(srgd_step_scalars), "step scalar layout");
+  SRGD_HIP(hipMemcpyAsync(e->d_sc, scalars_host, (size_t)n_steps * sizeof(StepScalars), hipMemcpyHostToDevice, st));
+  { Prof p(e, KC_CANVAS, st);
+    SRGD_TRY(canvas_prepare_cond(cond01, g->H, g->W, g->left, g->top, g->Hp, g->Wp, g->inner_l, g->inner_t, g->inner_r,
+                                 g->inner_b, cond_canvas, st)); }
+  SRGD_TRY(compute_conditioning(e, e->ct_sampler, log_snr_host, n_steps, class_id, st));
+  // the host arrays may be reused by the caller right after this call returns
+  SRGD_HIP(hipStreamSynchronize(st));
+  e->run_active = true;
+  return 0;
+}
+
+int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start,
+                      const float* noise_tiles, const float* noise_canvas, int passes, int guidance_kind,
+                      float guidance_scale, int sub_batch, uint64_t seed, void* stream) {
+  if (!e || !e->run_active) SRGD_FAIL("srgd_sampler_step: call srgd_sampler_begin first");
+  if (step < 0 || step >= e->n_steps) SRGD_FAIL("srgd_sampler_step: step out of range");
+  if (passes != 1 && passes != 2) SRGD_FAIL("srgd_sampler_step: passes must be 1 or 2");
+  if (passes == 2 && guidance_kind != 1 && guidance_kind != 2) SRGD_FAIL("srgd_sampler_step: guidance_kind must be 1 or 2");
+  if (sub_batch < 1) SRGD_FAIL("srgd_sampler_step: sub_batch must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  SRGD_HIP(hipSetDevice(e->cfg.device));
+  const srgd_sampler_geometry& g = e->geo;
+  const int parity = step & 1;
+  const int* tiles = parity ? e->d_tiles_odd : e->d_tiles_even;
+  const int n = parity ? g.n_odd : g.n_even;
+  const bool last = step == e->n_steps - 1;
+  const size_t tile_elems = (size_t)3 * g.tile * g.tile;
+  sub_batch = std::min(sub_batch, n);
+  SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
+  const int row_label = 2 * step + (e->run_class >= 0 ? 0 : 1);
+  const int row_null = 2 * step + 1;
+  for (int first = 0; first < n; first += sub_batch) {
+    const int nt = std::min(sub_batch, n - first);
+    const int nb = nt * passes;
+    TileBatch tb{tiles, first, nt, g.Hp, g.Wp, g.tile};
+    void* x0 = e->pool.get((size_t)nb * g.tile * g.tile * e->dim * e->es);
+    if (!x0) return -1;
+    const int mask = (passes == 2 && guidance_kind == 2) ? 0x1 : 0x3;
+    { Prof p(e, KC_INIT, st);
+      SRGD_TRY(init_conv_from_canvas(img, cond_canvas, tb, passes, mask, e->init_w, e->init_b, e->dim, x0, e->bf16, st)); }
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, e->d_rows, nb, nt, row_label,
+                       (passes == 2 && guidance_kind == 1) ? row_null : row_label);
+    Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st};
+    void* act = nullptr;
+    SRGD_TRY(unet_body(x, x0, &act));
+    const float* nz = nullptr;
+    if (!last) {
+      if (noise_tiles) nz = noise_tiles + (size_t)first * tile_elems;
+      else {
+        Prof p(e, KC_CANVAS, st);
+        SRGD_TRY(ensure(&e->rng_tiles, &e->rng_tiles_cap, (size_t)sub_batch * tile_elems));
+        SRGD_TRY(philox_normal(e->rng_tiles, (size_t)nt * tile_elems, seed, ((uint64_t)(step + 1) << 32) | (uint64_t)first,
+                               nullptr, st));
+        nz = e->rng_tiles;
+      }
+    }
+    FinalStepArgs fa;
+    fa.act = act; fa.C = e->dim; fa.passes = passes; fa.guidance = guidance_scale;
+    fa.w = e->final_w; fa.bias = e->final_b; fa.img = img; fa.x_start = x_start; fa.noise = nz;
+    fa.sc = e->d_sc + step; fa.step_ptr = nullptr;
+    { Prof p(e, KC_FINAL, st); SRGD_TRY(final_step(fa, tb, e->bf16, st)); }
+    e->pool.put(act);
+    e->pool.put(x0);
+  }
+  if (parity == 1) {
+    Prof p(e, KC_CANVAS, st);
+    const float* nc = noise_canvas;
+    const size_t cn = (size_t)3 * g.Hp * g.Wp;
+    if (!nc) {
+      SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, cn));
+      SRGD_TRY(philox_normal(e->rng_canvas, cn, seed, ((uint64_t)(step + 1) << 32) | 0x80000000ull, nullptr, st));
+      nc = e->rng_canvas;
+    }
+    SRGD_TRY(canvas_ring_renoise(img, nc, g.Hp, g.Wp, g.inner_l, g.inner_t, g.inner_r, g.inner_b, e->d_sc + step, nullptr, st));
+  }
+  return 0;
+}
+
+int srgd_sampler_end(srgd_engine* e, const float* img, float* out01, void* stream) {
+  if (!e || !e->run_active) SRGD_FAIL("srgd_sampler_end: no active run");
+  hipStream_t st = (hipStream_t)stream;
+  const srgd_sampler_geometry& g = e->geo;
+  Prof p(e, KC_CANVAS, st);
+  SRGD_TRY(canvas_finish(img, g.Hp, g.Wp, g.left, g.top, g.H, g.W, out01, st));
+  e->run_active = false;
+  return 0;
+}
+
+int srgd_randn(srgd_engine* e, float* dst, size_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+  if (!e || !dst) SRGD_FAIL("srgd_randn: null argument");
+  Prof p(e, KC_CANVAS, (hipStream_t)stream);
+  return philox_normal(dst, n, seed, stream_id, nullptr, (hipStream_t)stream);
+}
+
+int srgd_profile_begin(srgd_engine* e) {
+  if (!e) SRGD_FAIL("null engine");
+  for (auto& r : e->prof) { e->ev_free.push_back(r.a); e->ev_free.push_back(r.b); }
+  e->prof.clear();
+  e->conv_flops = 0.0;
+  e->prof_on = true;
+  return 0;
+}
+
+int srgd_profile_end(srgd_engine* e, double* ms, int64_t* launches, int n_families, double* conv_flops) {
+  if (!e) SRGD_FAIL("null engine");
+  e->prof_on = false;
+  SRGD_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < n_families && i < KC_COUNT; ++i) { if (ms) ms[i] = 0.0; if (launches) launches[i] = 0; }
+  for (auto& r : e->prof) {
+    float t = 0.f;
+    SRGD_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    if (r.kc < n_families) { if (ms) ms[r.kc] += t; if (launches) launches[r.kc] += 1; }
+    e->ev_free.push_back(r.a); e->ev_free.push_back(r.b);
+  }
+  e->prof.clear();
+  if (conv_flops) *conv_flops = e->conv_flops;
+  return 0;
+}
+
+int srgd_profile_num_families(void) { return KC_COUNT; }
+const char* srgd_profile_family_name(int i) { return (i >= 0 && i < KC_COUNT) ? kFamilyNames[i] : ""; }
+int64_t srgd_device_bytes_in_use(const srgd_engine* e) { return e ? e->pool.total + e->weight_bytes : 0; }
+
+}  // extern "C"

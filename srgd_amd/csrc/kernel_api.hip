@@ -1,0 +1,91 @@
+// Kernel-level C ABI (include/srgd_hip_kernels.h): thin wrappers that let each kernel family be
+// driven - and parity-tested - in isolation.  Convenience allocations here are per call; the
+// engine itself (engine.hip) never allocates on its hot path.
+#include <vector>
+
+#include "../../include/srgd_hip_kernels.h"
+#include "kernels.hpp"
+
+using namespace srgd;
+
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t n) { SRGD_HIP(hipMalloc(&p, n)); return 0; }
+};
+__global__ void iota_rows(int* r, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) r[i] = i;
+}
+}  // namespace
+
+extern "C" {
+
+int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int Hin, int Win, int KS, int stride,
+                  int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
+                  const void* residual, float* gn_partial, int groups, int is_bf16, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int Cin = C0 + C1;
+  const int CoutPad = cdiv(Cout, conv_tile_n()) * conv_tile_n();
+  std::vector<unsigned char> packed;
+  std::vector<float> bias;
+  pack_conv_weights(weight_oihw_host, bias_host, kind, Cin, Cout, CoutPad, KS, is_bf16 != 0, packed, bias);
+  DevBuf dw, db;
+  SRGD_TRY(dw.alloc(packed.size()));
+  SRGD_HIP(hipMemcpy(dw.p, packed.data(), packed.size(), hipMemcpyHostToDevice));
+  if (bias_host) {
+    SRGD_TRY(db.alloc(bias.size() * 4));
+    SRGD_HIP(hipMemcpy(db.p, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+  }
+  ConvArgs a;
+  a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.B = B; a.Hin = Hin; a.Win = Win;
+  a.Hout = (Hin + 2 * pad - KS) / stride + 1;
+  a.Wout = (Win + 2 * pad - KS) / stride + 1;
+  a.KS = KS; a.stride = stride; a.pad = pad; a.w = dw.p; a.bias = (const float*)db.p; a.Cout = Cout; a.CoutPad = CoutPad;
+  a.out = out; a.residual = residual; a.mode = kind == 2 ? CONV_PIXEL_SHUFFLE_SILU : CONV_PLAIN;
+  a.gn_partial = gn_partial; a.groups = groups;
+  SRGD_TRY(conv_igemm(a, is_bf16 != 0, st));
+  SRGD_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int srgd_k_groupnorm_silu(const void* x, void* y, const void* residual, const float* gn_partial, int B, int hw,
+                          int C, int groups, const float* gamma, const float* beta, const float* scale_shift,
+                          int is_bf16, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (hw % conv_tile_m() != 0) SRGD_FAIL("groupnorm: hw must be a multiple of 128");
+  DevBuf cA, cB, rows;
+  SRGD_TRY(cA.alloc((size_t)B * C * 4));
+  SRGD_TRY(cB.alloc((size_t)B * C * 4));
+  SRGD_TRY(rows.alloc((size_t)B * 4));
+  hipLaunchKernelGGL(iota_rows, dim3(cdiv(B, 256)), dim3(256), 0, st, (int*)rows.p, B);
+  GnFinalizeArgs f;
+  f.partial = gn_partial; f.nslots = hw / conv_tile_m(); f.B = B; f.C = C; f.groups = groups; f.hw = hw;
+  f.gamma = gamma; f.beta = beta; f.ss_table = scale_shift; f.ss_rows = (const int*)rows.p; f.step_ptr = nullptr;
+  f.step_mul = 0; f.ss_stride = 2 * C; f.ss_offset = 0; f.eps = 1e-5f; f.coefA = (float*)cA.p; f.coefB = (float*)cB.p;
+  SRGD_TRY(gn_finalize(f, st));
+  SRGD_TRY(gn_apply_silu(x, y, residual, (const float*)cA.p, (const float*)cB.p, B, hw, C, is_bf16 != 0, st));
+  SRGD_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int srgd_k_rmsnorm(const void* x, void* y, const void* residual, const float* g, int64_t npix, int C, int is_bf16,
+                   void* stream) {
+  return rms_norm(x, y, residual, g, (long)npix, C, is_bf16 != 0, (hipStream_t)stream);
+}
+
+int srgd_k_linear_attention(const void* qkv, void* out, int B, int N, int heads, int is_bf16, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DevBuf ws;
+  SRGD_TRY(ws.alloc(linear_attention_workspace(B, N, heads, 32)));
+  SRGD_TRY(linear_attention(qkv, out, B, N, heads, 32, (float*)ws.p, is_bf16 != 0, st));
+  SRGD_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int srgd_k_full_attention(const void* qkv, void* out, int B, int N, int heads, int is_bf16, void* stream) {
+  return full_attention(qkv, out, B, N, heads, 32, is_bf16 != 0, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+// Launchers of the hand-written gfx950 kernels (one translation unit per kernel family).
+// All tensors are NHWC in the engine's activation type (fp32 or bf16, flag `is_bf16`);
+// all accumulation and normalisation arithmetic is fp32.  Every launcher is asynchronous
+// on `st`, performs no allocation and no synchronisation (hipGraph-capturable), and
+// returns 0 or -1 with the message available from srgd_last_error().
+#pragma once
+#include <vector>
+
+#include "common.hpp"
+
+namespace srgd {
+
+// ---------------------------------------------------------------- conv_igemm.hip
+enum { CONV_PLAIN = 0, CONV_PIXEL_SHUFFLE_SILU = 1 };
+struct ConvArgs {
+  const void* in0;        // NHWC [B,Hin,Win,C0]
+  const void* in1;        // NHWC [B,Hin,Win,C1] or null (channel concat (in0, in1))
+  int C0, C1;
+  int B, Hin, Win, Hout, Wout;
+  int KS, stride, pad;
+  const void* w;          // packed [KS*KS][CoutPad][C0+C1], activation type
+  const float* bias;      // [Cout] or null
+  int Cout, CoutPad;
+  void* out;              // NHWC [B,Hout,Wout,Cout]; pixel-shuffle mode: [B,2Hout,2Wout,Cout/4]
+  const void* residual;   // optional, same shape as out (plain mode)
+  int mode;
+  float* gn_partial;      // optional [B][groups][Hout*Wout/128][2]
+  int groups;
+};
+int conv_igemm(const ConvArgs& a, bool is_bf16, hipStream_t st);
+int conv_tile_m();
+int conv_tile_n();
+void pack_conv_weights(const float* src_oihw, const float* bias_in, int kind, int Cin, int Cout, int CoutPad, int KS,
+                       bool to_bf16, std::vector<unsigned char>& packed_out, std::vector<float>& bias_out);
+const char* last_error();
+
+// ---------------------------------------------------------------- norm_act.hip
+struct GnFinalizeArgs {
+  const float* partial;   // [B][groups][nslots][2]
+  int nslots;
+  int B, C, groups;
+  int hw;                 // pixels per sample
+  const float* gamma;     // [C]
+  const float* beta;      // [C]
+  const float* ss_table;  // conditioning table or null: row r holds scale at ss_offset, shift at ss_offset + C
+  const int* ss_rows;     // [B] table row of each batch entry
+  const int* step_ptr;    // optional device step counter: row += *step_ptr * step_mul
+  int step_mul;
+  int ss_stride, ss_offset;
+  float eps;
+  float* coefA;           // [B][C]   y = silu(coefA * x + coefB)
+  float* coefB;
+};
+int gn_finalize(const GnFinalizeArgs& a, hipStream_t st);
+int gn_apply_silu(const void* x, void* y, const void* residual, const float* coefA, const float* coefB,
+                  int B, int hw, int C, bool is_bf16, hipStream_t st);
+int rms_norm(const void* x, void* y, const void* residual, const float* g, long npix, int C,
+             bool is_bf16, hipStream_t st);
+
+// ---------------------------------------------------------------- attention.hip
+// qkv: [B, N, 3*heads*dh] (q | k | v, each (head, d)); out: [B, N, heads*dh]
+size_t linear_attention_workspace(int B, int N, int heads, int dh);
+int linear_attention(const void* qkv, void* out, int B, int N, int heads, int dh, float* ws,
+                     bool is_bf16, hipStream_t st);
+int full_attention(const void* qkv, void* out, int B, int N, int heads, int dh, bool is_bf16,
+                   hipStream_t st);
+
+// ---------------------------------------------------------------- cond.hip
+// feat[r] = [x, sin(2 pi x w_i), cos(2 pi x w_i)]   (reference model.py:233-238)
+int time_features(const float* log_snr, const float* w, int half, int rows, float* feat, hipStream_t st);
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU_IN = 2 };
+// y[r][o] = act_out(sum_i W[o][i] * act_in(x[r][i]) + b[o]) (+ add[r*add_stride + o])
+int linear_rows(const float* x, int x_stride, const float* W, const float* b, float* y, int y_stride,
+                int rows, int in_f, int out_f, int act, const float* add, int add_stride, hipStream_t st);
+
+// ---------------------------------------------------------------- sampler.hip
+struct StepScalars {       // fp32 values computed by the host exactly as the reference does
+  float alpha, sigma, alpha_next, c, one_minus_c, noise_scale;   // noise_scale = sqrt(sigma_next^2 * c), 0 on the last step
+  float sigma_next;        // for the ring re-noise (q_sample(0, t'))
+  float pad;
+};
+struct TileBatch {
+  const int* tile_yx;      // device [ntiles][2] canvas offsets of each tile
+  int first;               // first tile of this sub-batch in tile_yx
+  int ntiles;              // tiles in this sub-batch
+  int Hp, Wp;              // canvas size
+  int tile;                // tile edge (256)
+};
+// 7x7 input convolution (model.py:583) reading the noisy canvas and the condition canvas in
+// place (NCHW fp32 planes), writing NHWC [nb*passes, tile, tile, Cout]. use_cond[pass] selects
+// whether that pass sees the condition or zeros (LR-condition guidance, model.py:3147-3150).
+int init_conv_from_canvas(const float* img, const float* cond, const TileBatch& tb, int passes,
+                          int use_cond_mask, const float* w /*[(dy*7+dx)*6+ci][Cout] fp32*/, const float* bias,
+                          int Cout, void* out, bool is_bf16, hipStream_t st);
+// plain NCHW batch variant used by the U-Net-only entry point (x,cond: [B,3,H,W], cond may be null)
+int init_conv_from_nchw(const float* x, const float* cond, int B, int H, int W, const float* w,
+                        const float* bias, int Cout, void* out, bool is_bf16, hipStream_t st);
+// 1x1 output conv (model.py:675) -> eps; NCHW fp32 out (U-Net-only entry point)
+int final_conv_to_nchw(const void* act, int B, int H, int W, int C, const float* w /*[3][C]*/,
+                       const float* bias, float* out, bool is_bf16, hipStream_t st);
+// 1x1 output conv + guidance combine + DDPM posterior step (model.py:3147-3168, :3184-3188),
+// scattering straight into the canvases.  noise: [ntiles][3][tile][tile] fp32 or null (last step).
+struct FinalStepArgs {
+  const void* act;         // NHWC [ntiles*passes, tile, tile, C]
+  int C, passes;
+  float guidance;          // eps = null + (cond - null) * guidance when passes == 2
+  const float* w;          // [3][C]
+  const float* bias;       // [3]
+  float* img;              // canvas, updated in place
+  float* x_start;          // optional canvas
+  const float* noise;
+  const StepScalars* sc;   // device pointer
+  const int* step_ptr;     // optional device step counter indexing sc
+};
+int final_step(const FinalStepArgs& a, const TileBatch& tb, bool is_bf16, hipStream_t st);
+
+// canvas kernels (model.py:3296-3303, :3337-3342, :3392-3396, :3403-3405)
+int canvas_prepare_cond(const float* cond01 /*[3][H][W]*/, int H, int W, int pad_l, int pad_t, int Hp, int Wp,
+                        int il, int it, int ir, int ib, float* cond_canvas, hipStream_t st);
+int canvas_ring_renoise(float* img, const float* noise /*[3][Hp][Wp]*/, int Hp, int Wp, int il, int it, int ir,
+                        int ib, const StepScalars* sc, const int* step_ptr, hipStream_t st);
+int canvas_finish(const float* img, int Hp, int Wp, int left, int top, int H, int W, float* out01, hipStream_t st);
+// counter-based Gaussian noise (Philox4x32-10 + Box-Muller), throughput mode only
+int philox_normal(float* dst, size_t n, uint64_t seed, uint64_t stream_id, const int* step_ptr, hipStream_t st);
+
+}  // namespace srgd

@@ -1,0 +1,156 @@
+// GroupNorm (finalize + apply + time scale/shift + SiLU + residual) and RMSNorm for gfx950.
+// Memory-bound element-wise kernels: 16-byte vector accesses along the NHWC channel axis.
+#include "kernels.hpp"
+
+namespace srgd {
+namespace {
+
+// One wave per (sample, group): sums the per-tile partials the conv epilogue wrote (fixed
+// order, fp64) and folds GroupNorm's affine and the ResnetBlock's (scale+1, shift)
+// (reference model.py:250-257) into per-(sample, channel) coefficients y = A*x + B.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(GnFinalizeArgs a) {
+  const int b = blockIdx.x / a.groups, g = blockIdx.x - b * a.groups;
+  const int lane = threadIdx.x;
+  const float* p = a.partial + (size_t)(b * a.groups + g) * a.nslots * 2;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = lane; i < a.nslots; i += 64) {
+    s1 += (double)p[2 * i];
+    s2 += (double)p[2 * i + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  const int cpg = a.C / a.groups;
+  const double n = (double)a.hw * (double)cpg;
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float fmean = (float)mean;
+  const float* ss = nullptr;
+  if (a.ss_table) {
+    int row = a.ss_rows[b];
+    if (a.step_ptr) row += (*a.step_ptr) * a.step_mul;
+    ss = a.ss_table + (size_t)row * a.ss_stride + a.ss_offset;
+  }
+  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+    float A = rstd * a.gamma[c];
+    float B = a.beta[c] - fmean * A;
+    if (ss) {
+      const float sc = ss[c] + 1.0f, sh = ss[a.C + c];
+      A *= sc;
+      B = B * sc + sh;
+    }
+    a.coefA[(size_t)b * a.C + c] = A;
+    a.coefB[(size_t)b * a.C + c] = B;
+  }
+}
+
+template <typename T, bool PRECISE>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                        const T* __restrict__ res,
+                                                        const float* __restrict__ cA,
+                                                        const float* __restrict__ cB, long nvec, int vec_per_sample,
+                                                        int vec_per_pixel, int C) {
+  constexpr int N = Vec16<T>::N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / vec_per_sample);
+    const int c = (int)(i % vec_per_pixel) * N;
+    Vec16<T> v = reinterpret_cast<const Vec16<T>*>(x)[i];
+    Vec16<T> r;
+    if (res) r = reinterpret_cast<const Vec16<T>*>(res)[i];
+    const float* pa = cA + (size_t)b * C + c;
+    const float* pb = cB + (size_t)b * C + c;
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      float t = silu<PRECISE>(pa[j] * v.get(j) + pb[j]);
+      if (res) t += r.get(j);
+      o.set(j, t);
+    }
+    reinterpret_cast<Vec16<T>*>(y)[i] = o;
+  }
+}
+
+// RMSNorm (model.py:201-207): x / max(||x||_2, 1e-12) * g * sqrt(C)  (+ residual).
+// L lanes cooperate on one pixel (L = largest power of two <= min(64, C/vec)).
+template <typename T>
+__global__ __launch_bounds__(256) void rms_norm_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                        const T* __restrict__ res, const float* __restrict__ g,
+                                                        long npix, int C, int L, float sqrtC) {
+  constexpr int N = Vec16<T>::N;
+  const int vpp = C / N;
+  const int sub = threadIdx.x % L;
+  const int pix_per_block = 256 / L;
+  for (long p = (long)blockIdx.x * pix_per_block + threadIdx.x / L; p < npix; p += (long)gridDim.x * pix_per_block) {
+    const Vec16<T>* xp = reinterpret_cast<const Vec16<T>*>(x) + p * vpp;
+    float ss = 0.f;
+    for (int v = sub; v < vpp; v += L) {
+      Vec16<T> t = xp[v];
+#pragma unroll
+      for (int j = 0; j < N; ++j) ss += t.get(j) * t.get(j);
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = sqrtC / fmaxf(sqrtf(ss), 1e-12f);
+    for (int v = sub; v < vpp; v += L) {
+      Vec16<T> t = xp[v], o, r;
+      if (res) r = reinterpret_cast<const Vec16<T>*>(res)[p * vpp + v];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        float q = t.get(j) * inv * g[v * N + j];
+        if (res) q += r.get(j);
+        o.set(j, q);
+      }
+      reinterpret_cast<Vec16<T>*>(y)[p * vpp + v] = o;
+    }
+  }
+}
+
+}  // namespace
+
+int gn_finalize(const GnFinalizeArgs& a, hipStream_t st) {
+  if (a.C % a.groups != 0) SRGD_FAIL("gn_finalize: C % groups != 0");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B * a.groups), dim3(64), 0, st, a);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int gn_apply_silu(const void* x, void* y, const void* residual, const float* coefA, const float* coefB, int B,
+                  int hw, int C, bool is_bf16, hipStream_t st) {
+  const int N = is_bf16 ? 8 : 4;
+  if (C % N != 0) SRGD_FAIL("gn_apply: C must be a multiple of the 16-byte vector width");
+  const long nvec = (long)B * hw * C / N;
+  const int vps = (int)((long)hw * C / N), vpp = C / N;
+  const int grid = (int)std::min<long>((nvec + 255) / 256, 256L * 64);
+  if (is_bf16)
+    hipLaunchKernelGGL((gn_apply_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y,
+                       (const bf16*)residual, coefA, coefB, nvec, vps, vpp, C);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,
+                       (const float*)residual, coefA, coefB, nvec, vps, vpp, C);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int rms_norm(const void* x, void* y, const void* residual, const float* g, long npix, int C, bool is_bf16,
+             hipStream_t st) {
+  const int N = is_bf16 ? 8 : 4;
+  if (C % N != 0) SRGD_FAIL("rms_norm: C must be a multiple of the 16-byte vector width");
+  int L = 1;
+  while (L * 2 <= 64 && L * 2 <= C / N) L *= 2;
+  const long blocks = (npix + (256 / L) - 1) / (256 / L);
+  const int grid = (int)std::min<long>(blocks, 256L * 32);
+  const float sqrtC = sqrtf((float)C);
+  if (is_bf16)
+    hipLaunchKernelGGL((rms_norm_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y,
+                       (const bf16*)residual, g, npix, C, L, sqrtC);
+  else
+    hipLaunchKernelGGL((rms_norm_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,
+                       (const float*)residual, g, npix, C, L, sqrtC);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace srgd

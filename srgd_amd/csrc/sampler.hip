@@ -1,0 +1,339 @@
+// Sampler-side kernels for gfx950: the 7x7 input convolution reading tiles straight out of
+// the canvases (fuses the tile gather model.py:3368-3369 and torch.cat model.py:684), the
+// 1x1 output convolution fused with guidance + the DDPM posterior step and the tile scatter
+// (model.py:3147-3168, :3184-3188, :3379-3380), canvas preparation / ring re-noise / crop,
+// and a counter-based Gaussian generator for the throughput mode.
+#include "kernels.hpp"
+
+namespace srgd {
+namespace {
+
+// ------------------------------------------------------------------ 7x7 input conv
+constexpr int IC_T = 16;                 // output pixels per block edge
+constexpr int IC_P = IC_T + 6;           // input patch edge (halo 3)
+constexpr int IC_K = 7 * 7 * 6;          // 294
+constexpr int IC_CO = 32;                // output channels per pass over the patch
+
+struct InitSrc {
+  const float* x;          // noisy input planes
+  const float* cond;       // condition planes (may be null)
+  int canvas;              // 1: tiles of a canvas, 0: plain NCHW batch
+  const int* tile_yx;
+  int first, ntiles;       // canvas mode: entries = passes * ntiles
+  int use_cond_mask;       // bit p: pass p sees the condition
+  int H, W;                // tile / image size
+  int row_stride;          // canvas width or W
+  long plane_stride;       // canvas plane or H*W
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void init_conv_kernel(InitSrc s, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int Cout,
+                                                        T* __restrict__ out) {
+  __shared__ float patch[IC_P * IC_P][6];
+  __shared__ __attribute__((aligned(16))) float ws[IC_K][IC_CO];
+  const int entry = blockIdx.z;
+  const int bx = blockIdx.x * IC_T, by = blockIdx.y * IC_T;
+  long origin;
+  bool use_cond = s.cond != nullptr;
+  if (s.canvas) {
+    const int pass = entry / s.ntiles, t = entry - pass * s.ntiles;
+    const int ty = s.tile_yx[2 * (s.first + t)], tx = s.tile_yx[2 * (s.first + t) + 1];
+    origin = (long)ty * s.row_stride + tx;
+    use_cond = use_cond && ((s.use_cond_mask >> pass) & 1);
+  } else {
+    origin = (long)entry * 3 * s.plane_stride;
+  }
+  for (int i = threadIdx.x; i < IC_P * IC_P * 6; i += 256) {
+    const int c = i / (IC_P * IC_P), rem = i - c * IC_P * IC_P;
+    const int py = rem / IC_P, px = rem - py * IC_P;
+    const int y = by + py - 3, x = bx + px - 3;
+    float v = 0.f;
+    if (y >= 0 && y < s.H && x >= 0 && x < s.W) {
+      const long o = origin + (long)(c % 3) * s.plane_stride + (long)y * s.row_stride + x;
+      if (c < 3) v = s.x[o];
+      else if (use_cond) v = s.cond[o];
+    }
+    patch[rem][c] = v;
+  }
+  const int px = threadIdx.x & (IC_T - 1), py = threadIdx.x >> 4;
+  const int oy = by + py, ox = bx + px;
+  for (int co0 = 0; co0 < Cout; co0 += IC_CO) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < IC_K * IC_CO; i += 256) {
+      const int k = i / IC_CO, o = i - k * IC_CO;
+      ws[k][o] = (co0 + o < Cout) ? w[(size_t)k * Cout + co0 + o] : 0.f;
+    }
+    __syncthreads();
+    float acc[IC_CO];
+#pragma unroll
+    for (int o = 0; o < IC_CO; ++o) acc[o] = 0.f;
+    for (int dy = 0; dy < 7; ++dy) {
+      for (int dx = 0; dx < 7; ++dx) {
+        const float* pp = patch[(py + dy) * IC_P + px + dx];
+        const int kb = (dy * 7 + dx) * 6;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const float a = pp[c];
+#pragma unroll
+          for (int o4 = 0; o4 < IC_CO / 4; ++o4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&ws[kb + c][o4 * 4]);
+            acc[o4 * 4 + 0] += a * w4[0];
+            acc[o4 * 4 + 1] += a * w4[1];
+            acc[o4 * 4 + 2] += a * w4[2];
+            acc[o4 * 4 + 3] += a * w4[3];
+          }
+        }
+      }
+    }
+    if (oy < s.H && ox < s.W) {
+      T* op = out + (((size_t)entry * s.H + oy) * s.W + ox) * Cout + co0;
+#pragma unroll
+      for (int o = 0; o < IC_CO; ++o)
+        if (co0 + o < Cout) op[o] = from_f32<T>(acc[o] + bias[co0 + o]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ 1x1 output conv (+ DDPM step)
+template <typename T>
+__device__ __forceinline__ void out_conv3(const T* __restrict__ a, int C, const float* __restrict__ w,
+                                          const float* __restrict__ bias, float e[3]) {
+  constexpr int N = Vec16<T>::N;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int v = 0; v < C / N; ++v) {
+    Vec16<T> t = reinterpret_cast<const Vec16<T>*>(a)[v];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float x = t.get(j);
+      s0 += x * w[v * N + j];
+      s1 += x * w[C + v * N + j];
+      s2 += x * w[2 * C + v * N + j];
+    }
+  }
+  e[0] = s0 + bias[0];
+  e[1] = s1 + bias[1];
+  e[2] = s2 + bias[2];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void final_conv_nchw_kernel(const T* __restrict__ act, long npix, int hw, int C,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ out) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  float e[3];
+  out_conv3<T>(act + p * C, C, w, bias, e);
+  const long b = p / hw, r = p - b * hw;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[(b * 3 + c) * hw + r] = e[c];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void final_step_kernel(FinalStepArgs a, TileBatch tb) {
+  const int tile = tb.tile;
+  const long per_tile = (long)tile * tile;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= per_tile * tb.ntiles) return;
+  const int t = (int)(p / per_tile);
+  const int r = (int)(p - t * per_tile);
+  const int y = r / tile, x = r - y * tile;
+  float e[3];
+  out_conv3<T>(reinterpret_cast<const T*>(a.act) + p * a.C, a.C, a.w, a.bias, e);
+  if (a.passes == 2) {
+    float n[3];
+    out_conv3<T>(reinterpret_cast<const T*>(a.act) + (p + per_tile * tb.ntiles) * a.C, a.C, a.w, a.bias, n);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) e[c] = n[c] + (e[c] - n[c]) * a.guidance;     // model.py:3150 / :3154
+  }
+  const StepScalars sc = a.sc[a.step_ptr ? *a.step_ptr : 0];
+  const int ty = tb.tile_yx[2 * (tb.first + t)], tx = tb.tile_yx[2 * (tb.first + t) + 1];
+  const long plane = (long)tb.Hp * tb.Wp;
+  const long o = (long)(ty + y) * tb.Wp + tx + x;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float xt = a.img[c * plane + o];
+    float x0 = (xt - sc.sigma * e[c]) / sc.alpha;                              // model.py:3160
+    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                                        // :3163
+    float mean = sc.alpha_next * (xt * sc.one_minus_c / sc.alpha + sc.c * x0);  // :3164
+    if (a.noise) mean += sc.noise_scale * a.noise[((long)t * 3 + c) * per_tile + r];   // :3187-3188
+    a.img[c * plane + o] = mean;
+    if (a.x_start) a.x_start[c * plane + o] = x0;
+  }
+}
+
+// ------------------------------------------------------------------ canvas kernels
+__global__ void canvas_prepare_cond_kernel(const float* __restrict__ c01, int H, int W, int pad_l, int pad_t, int Hp,
+                                           int Wp, int il, int it, int ir, int ib, float* __restrict__ canvas) {
+  const long n = 3L * Hp * Wp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i / ((long)Hp * Wp));
+    const long rem = i - (long)c * Hp * Wp;
+    const int Y = (int)(rem / Wp), X = (int)(rem - (long)Y * Wp);
+    float v = 0.f;
+    if (Y >= it && Y < ib && X >= il && X < ir) {
+      int y = Y - pad_t, x = X - pad_l;
+      if (y < 0) y = -y;
+      if (y >= H) y = 2 * (H - 1) - y;
+      if (x < 0) x = -x;
+      if (x >= W) x = 2 * (W - 1) - x;
+      v = c01[((long)c * H + y) * W + x] * 2.0f - 1.0f;
+    }
+    canvas[i] = v;
+  }
+}
+
+__global__ void canvas_ring_renoise_kernel(float* __restrict__ img, const float* __restrict__ noise, int Hp, int Wp,
+                                           int il, int it, int ir, int ib, const StepScalars* __restrict__ sc,
+                                           const int* __restrict__ step_ptr) {
+  const float sigma = sc[step_ptr ? *step_ptr : 0].sigma_next;
+  const long n = 3L * Hp * Wp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long rem = i % ((long)Hp * Wp);
+    const int Y = (int)(rem / Wp), X = (int)(rem - (long)Y * Wp);
+    if (!(Y >= it && Y < ib && X >= il && X < ir)) img[i] = noise[i] * sigma;
+  }
+}
+
+__global__ void canvas_finish_kernel(const float* __restrict__ img, int Hp, int Wp, int left, int top, int H, int W,
+                                     float* __restrict__ out) {
+  const long n = 3L * H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i / ((long)H * W));
+    const long rem = i - (long)c * H * W;
+    const int y = (int)(rem / W), x = (int)(rem - (long)y * W);
+    float v = img[((long)c * Hp + top + y) * Wp + left + x];
+    v = fminf(fmaxf(v, -1.0f), 1.0f);
+    out[i] = (v + 1.0f) * 0.5f;
+  }
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
+__device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (uint32_t)p1;
+  c[3] = (uint32_t)p0;
+  c[0] = n0;
+  c[2] = n2;
+}
+
+__global__ void philox_normal_kernel(float* __restrict__ dst, size_t n, uint64_t seed, uint64_t stream_id,
+                                     const int* __restrict__ step_ptr) {
+  const uint32_t step = step_ptr ? (uint32_t)*step_ptr : 0u;
+  const size_t nq = (n + 3) / 4;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)gridDim.x * 256) {
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32) ^ (step << 8)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float u1 = ((float)c[2 * h] + 1.0f) * 2.3283064365386963e-10f;      // (0, 1]
+      const float u2 = (float)c[2 * h + 1] * 2.3283064365386963e-10f;
+      const float rad = sqrtf(-2.0f * __logf(u1));
+      float sn, cs;
+      __sincosf(6.283185307179586f * u2, &sn, &cs);
+      z[2 * h] = rad * cs;
+      z[2 * h + 1] = rad * sn;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (q * 4 + j < n) dst[q * 4 + j] = z[j];
+  }
+}
+
+template <typename T>
+int launch_init(const InitSrc& s, int entries, const float* w, const float* bias, int Cout, void* out, hipStream_t st) {
+  dim3 g(cdiv(s.W, IC_T), cdiv(s.H, IC_T), entries);
+  hipLaunchKernelGGL((init_conv_kernel<T>), g, dim3(256), 0, st, s, w, bias, Cout, (T*)out);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int grid_for(long n) { return (int)std::min<long>((n + 255) / 256, 256L * 16); }
+
+}  // namespace
+
+int init_conv_from_canvas(const float* img, const float* cond, const TileBatch& tb, int passes, int use_cond_mask,
+                          const float* w, const float* bias, int Cout, void* out, bool is_bf16, hipStream_t st) {
+  InitSrc s;
+  s.x = img; s.cond = cond; s.canvas = 1; s.tile_yx = tb.tile_yx; s.first = tb.first; s.ntiles = tb.ntiles;
+  s.use_cond_mask = use_cond_mask; s.H = tb.tile; s.W = tb.tile; s.row_stride = tb.Wp;
+  s.plane_stride = (long)tb.Hp * tb.Wp;
+  return is_bf16 ? launch_init<bf16>(s, passes * tb.ntiles, w, bias, Cout, out, st)
+                 : launch_init<float>(s, passes * tb.ntiles, w, bias, Cout, out, st);
+}
+
+int init_conv_from_nchw(const float* x, const float* cond, int B, int H, int W, const float* w, const float* bias,
+                        int Cout, void* out, bool is_bf16, hipStream_t st) {
+  InitSrc s;
+  s.x = x; s.cond = cond; s.canvas = 0; s.tile_yx = nullptr; s.first = 0; s.ntiles = B; s.use_cond_mask = 1;
+  s.H = H; s.W = W; s.row_stride = W; s.plane_stride = (long)H * W;
+  return is_bf16 ? launch_init<bf16>(s, B, w, bias, Cout, out, st) : launch_init<float>(s, B, w, bias, Cout, out, st);
+}
+
+int final_conv_to_nchw(const void* act, int B, int H, int W, int C, const float* w, const float* bias, float* out,
+                       bool is_bf16, hipStream_t st) {
+  const long npix = (long)B * H * W;
+  const int grid = (int)((npix + 255) / 256);
+  if (C % (is_bf16 ? 8 : 4) != 0) SRGD_FAIL("final_conv: C must be a multiple of the vector width");
+  if (is_bf16)
+    hipLaunchKernelGGL((final_conv_nchw_kernel<bf16>), dim3(grid), dim3(256), 0, st, (const bf16*)act, npix, H * W, C,
+                       w, bias, out);
+  else
+    hipLaunchKernelGGL((final_conv_nchw_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)act, npix, H * W,
+                       C, w, bias, out);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int final_step(const FinalStepArgs& a, const TileBatch& tb, bool is_bf16, hipStream_t st) {
+  const long n = (long)tb.ntiles * tb.tile * tb.tile;
+  const int grid = (int)((n + 255) / 256);
+  if (a.C % (is_bf16 ? 8 : 4) != 0) SRGD_FAIL("final_step: C must be a multiple of the vector width");
+  if (is_bf16) hipLaunchKernelGGL((final_step_kernel<bf16>), dim3(grid), dim3(256), 0, st, a, tb);
+  else hipLaunchKernelGGL((final_step_kernel<float>), dim3(grid), dim3(256), 0, st, a, tb);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int canvas_prepare_cond(const float* cond01, int H, int W, int pad_l, int pad_t, int Hp, int Wp, int il, int it,
+                        int ir, int ib, float* cond_canvas, hipStream_t st) {
+  hipLaunchKernelGGL(canvas_prepare_cond_kernel, dim3(grid_for(3L * Hp * Wp)), dim3(256), 0, st, cond01, H, W, pad_l,
+                     pad_t, Hp, Wp, il, it, ir, ib, cond_canvas);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int canvas_ring_renoise(float* img, const float* noise, int Hp, int Wp, int il, int it, int ir, int ib,
+                        const StepScalars* sc, const int* step_ptr, hipStream_t st) {
+  hipLaunchKernelGGL(canvas_ring_renoise_kernel, dim3(grid_for(3L * Hp * Wp)), dim3(256), 0, st, img, noise, Hp, Wp,
+                     il, it, ir, ib, sc, step_ptr);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int canvas_finish(const float* img, int Hp, int Wp, int left, int top, int H, int W, float* out01, hipStream_t st) {
+  hipLaunchKernelGGL(canvas_finish_kernel, dim3(grid_for(3L * H * W)), dim3(256), 0, st, img, Hp, Wp, left, top, H, W,
+                     out01);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int philox_normal(float* dst, size_t n, uint64_t seed, uint64_t stream_id, const int* step_ptr, hipStream_t st) {
+  hipLaunchKernelGGL(philox_normal_kernel, dim3(grid_for((long)((n + 3) / 4))), dim3(256), 0, st, dst, n, seed,
+                     stream_id, step_ptr);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace srgd

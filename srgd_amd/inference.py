@@ -1,0 +1,151 @@
+"""Batch driver with the reference ``inference.py`` surface (CLI flags, function names, file naming,
+skip-if-exists, per-image reseed) on top of the MI355X engine.
+
+Differences that are deliberate and documented: torchvision/logzero are not needed
+(PIL + numpy do the x4 bicubic resize and the uint8 conversions exactly as ``T.Resize`` on a PIL image,
+``ToTensor`` and ``ToPILImage`` do); ``--no_amp`` has a real meaning here (fp32 parity mode instead of
+bf16); ``--device_noise`` switches from the reference-compatible host noise stream to on-device Philox.
+"""
+from __future__ import annotations
+
+import glob
+import logging
+import os
+import random
+from argparse import ArgumentParser
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .config import load_config
+from .model import get_model
+
+logger = logging.getLogger("srgd_amd")
+
+
+def parse_args(argv=None):
+    p = ArgumentParser()
+    p.add_argument("-c", "--conf", required=True, help="Path to config file")
+    p.add_argument("-m", "--ckpt_path", type=str, required=True)
+    p.add_argument("--input_dir", type=str, required=True)
+    p.add_argument("--output_dir", type=str, required=True)
+    p.add_argument("--batch_size", type=int, default=8)
+    p.add_argument("--num_sample_steps", type=int, default=250)
+    p.add_argument("--interpolation", type=str, default="bicubic")
+    p.add_argument("--cond_scale", type=float, default=1.0)
+    p.add_argument("--class_cond_scale", type=float, default=1.0)
+    p.add_argument("--guidance_start_steps", type=int, default=0)
+    p.add_argument("--class_guidance_start_steps", type=int, default=0)
+    p.add_argument("--generation_start_steps", type=int, default=0)
+    p.add_argument("--start_index", type=int, default=0)
+    p.add_argument("--end_index", type=int, default=None)
+    p.add_argument("--test_label", type=int, default=None)
+    p.add_argument("--no_amp", dest="amp", action="store_false")
+    p.add_argument("--no_dpmpp_solver", dest="use_dpmpp_solver", action="store_false")
+    p.add_argument("--seed", type=int, default=71)
+    p.add_argument("--backend", type=str, default="ddp")
+    # engine-only switch (absent upstream)
+    p.add_argument("--device_noise", action="store_true",
+                   help="draw DDPM noise on the GPU (Philox) instead of replaying torch's CPU stream")
+    return p.parse_args(argv)
+
+
+def seed_everything(seed):
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+def pil_to_unit_tensor(image: Image.Image) -> torch.Tensor:
+    """ToTensor: HWC uint8 -> CHW float32 / 255."""
+    arr = np.asarray(image.convert("RGB"), dtype=np.uint8)
+    return torch.from_numpy(arr.copy()).permute(2, 0, 1).to(torch.float32).div(255.0)
+
+
+def unit_tensor_to_pil(t: torch.Tensor) -> Image.Image:
+    """ToPILImage on a float tensor: mul(255) then byte() (truncation, not rounding)."""
+    arr = t.detach().cpu().mul(255).to(torch.uint8).permute(1, 2, 0).contiguous().numpy()
+    return Image.fromarray(arr, "RGB")
+
+
+def sr_target_image(image, sr_model, scale=4, batch_size=8, test_label=2, cond_scale=1.0, guidance_start_steps=0,
+                    class_cond_scale=1.0, class_guidance_start_steps=0, generation_start_steps=0,
+                    num_sample_steps=250, enable_amp=False, interpolation="bicubic", seed=71):
+    width, height = image.size
+    # the reference maps 'lanczos' to bicubic too (inference.py:66-69)
+    resized = image.resize((width * scale, height * scale), Image.BICUBIC)
+    condition_x = pil_to_unit_tensor(resized).unsqueeze(0).to(sr_model.device)
+    label = torch.LongTensor([test_label]).to(sr_model.device) if test_label is not None else None
+    seed_everything(seed)
+    sr_model.device_noise_seed = seed
+    with torch.inference_mode():
+        output = sr_model.tiled_sample(batch_size=batch_size, condition_x=condition_x, class_label=label,
+                                       cond_scale=cond_scale, guidance_start_steps=guidance_start_steps,
+                                       class_cond_scale=class_cond_scale,
+                                       class_guidance_start_steps=class_guidance_start_steps,
+                                       generation_start_steps=generation_start_steps,
+                                       num_sample_steps=num_sample_steps, amp=enable_amp)
+    sr_img = unit_tensor_to_pil(output[0])
+    assert sr_img.size == (width * 4, height * 4)
+    return sr_img
+
+
+def try_open_image(image_path):
+    try:
+        return Image.open(image_path).convert("RGB")
+    except (IOError, SyntaxError):
+        return None
+
+
+def batch_sr_target_images(input_dir, output_dir, sr_model, scale=4, batch_size=8, test_label=2, cond_scale=1.0,
+                           guidance_start_steps=0, class_cond_scale=1.0, class_guidance_start_steps=0,
+                           generation_start_steps=0, num_sample_steps=250, start_index=0, end_index=None,
+                           enable_amp=False, interpolation="bicubic", seed=71):
+    print(f"save images at: {output_dir}")
+    os.makedirs(output_dir, exist_ok=True)
+    for filename in sorted(glob.glob(f"{input_dir}/*"))[start_index:end_index]:
+        save_path = os.path.join(output_dir, os.path.basename(filename).replace(".png", "_out.png"))
+        if os.path.exists(save_path):
+            print("skip")
+            continue
+        image = try_open_image(filename)
+        if image is None:
+            print("Invalid image or unable to open image:", filename)
+            continue
+        sr = sr_target_image(image, sr_model, scale=scale, batch_size=batch_size, test_label=test_label,
+                             cond_scale=cond_scale, guidance_start_steps=guidance_start_steps,
+                             class_cond_scale=class_cond_scale,
+                             class_guidance_start_steps=class_guidance_start_steps,
+                             generation_start_steps=generation_start_steps, num_sample_steps=num_sample_steps,
+                             enable_amp=enable_amp, interpolation=interpolation, seed=seed)
+        sr.save(save_path)
+
+
+def main(argv=None):
+    logging.basicConfig(level=logging.INFO, format="[%(levelname)s %(asctime)s] %(message)s")
+    args = parse_args(argv)
+    conf = load_config(args.conf)
+    conf.num_sample_steps = args.num_sample_steps
+    conf.ckpt_path = args.ckpt_path
+    ema_model = get_model(conf, logger)
+    if not torch.cuda.is_available():
+        raise SystemExit("srgd_amd needs an MI355X: no GPU visible and there is no CPU fallback")
+    sr_model = ema_model.module.eval().to(torch.device("cuda"))
+    sr_model.noise_source = "device" if args.device_noise else "host"
+    print(args)
+    batch_sr_target_images(args.input_dir, args.output_dir, sr_model, scale=4, batch_size=args.batch_size,
+                           test_label=args.test_label, cond_scale=args.cond_scale,
+                           guidance_start_steps=args.guidance_start_steps, class_cond_scale=args.class_cond_scale,
+                           class_guidance_start_steps=args.class_guidance_start_steps,
+                           generation_start_steps=args.generation_start_steps,
+                           num_sample_steps=args.num_sample_steps, start_index=args.start_index,
+                           end_index=args.end_index, enable_amp=args.amp, interpolation=args.interpolation,
+                           seed=args.seed)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,479 @@
+"""Host-side mirror of the reference's ``model.py`` surface for the ONE shipped sampling path
+(``model: conditional_continuous``), backed by the MI355X engine (``libsrgd_hip.so``).
+
+Kept identical to the reference so that callers and checkpoints switch over unchanged:
+  * ``get_model(conf, logger)`` (reference model.py:3500-3666) -> object with ``.module``
+  * ``ConditionalSRUnet(...)`` constructor signature (model.py:537-556) and ``state_dict`` keys/shapes
+     - the published ``.pth`` loads with ``strict=True``
+  * ``ConditionalContinuousTimeGaussianDiffusionSR.tiled_sample(...)`` signature, return value and
+    error behaviour (model.py:3288-3413)
+  * the pure-int tiling helpers ``get_coord_and_pad / get_coords / get_area`` (model.py:116-179)
+
+The modules below hold parameters only; they have no PyTorch implementation of the arithmetic.
+All compute runs in hand-written gfx950 kernels; calling this path without a GPU raises.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import SamplerGeometry, StepScalars
+from .engine import HipEngine
+
+__all__ = ["get_coord_and_pad", "get_coords", "get_area", "beta_linear_log_snr", "ConditionalSRUnet",
+           "ConditionalContinuousTimeGaussianDiffusionSR", "ModelEma", "get_model"]
+
+
+# ---------------------------------------------------------------------------------------------
+# tiling geometry (pure ints; reference model.py:116-179)
+# ---------------------------------------------------------------------------------------------
+def get_coord_and_pad(height: int, width: int, tile_size: int = 256):
+    """Canvas size and placement of an ``height x width`` image: one tile if it fits, otherwise the
+    size rounded up to whole tiles plus one extra tile (half a tile of margin per side)."""
+    fits = height <= tile_size and width <= tile_size
+    canvas_h = tile_size if fits else tile_size * (math.ceil(height / tile_size) + 1)
+    canvas_w = tile_size if fits else tile_size * (math.ceil(width / tile_size) + 1)
+    left, top = (canvas_w - width) // 2, (canvas_h - height) // 2
+    coord = (left, top, left + width, top + height)
+    pad = (left, canvas_w - width - left, top, canvas_h - height - top)
+    return coord, pad
+
+
+def _axis_starts(extent: int, tile_size: int, tile_stride: int) -> List[int]:
+    starts = list(range(0, extent - tile_size + 1, tile_stride))
+    if (extent - tile_size) % tile_stride:
+        starts.append(extent - tile_size)      # last tile is pulled back to end at the border
+    return starts
+
+
+def get_coords(h: int, w: int, tile_size: int, tile_stride: int, diff: int = 0):
+    """Row-major list of tile boxes ``(hs, he, ws, we)``, each shifted by ``diff``."""
+    return [(y + diff, y + diff + tile_size, x + diff, x + diff + tile_size)
+            for y in _axis_starts(h, tile_size, tile_stride) for x in _axis_starts(w, tile_size, tile_stride)]
+
+
+def get_area(coords, height: int, width: int):
+    """Bounding box ``(left, top, right, bottom)`` of a tile list and its margins inside the canvas."""
+    top = min([height] + [c[0] for c in coords])
+    bottom = max([0] + [c[1] for c in coords])
+    left = min([width] + [c[2] for c in coords])
+    right = max([0] + [c[3] for c in coords])
+    return (left, top, right, bottom), (left, width - right, top, height - bottom)
+
+
+# ---------------------------------------------------------------------------------------------
+# schedule scalars: host-side fp32 torch ops in the reference's own order, so the numbers handed
+# to the kernels are bit-identical to what the reference computes (model.py:2629-2633, :3127-3134)
+# ---------------------------------------------------------------------------------------------
+def beta_linear_log_snr(t: torch.Tensor) -> torch.Tensor:
+    return -torch.log(torch.special.expm1(1e-4 + 10 * (t ** 2)).clamp(min=1e-20))
+
+
+def _schedule(num_steps: int) -> Tuple[List[StepScalars], List[float]]:
+    times = torch.linspace(1.0, 0.0, num_steps + 1)
+    scalars, log_snrs = [], []
+    for i in range(num_steps):
+        ls, ls_next = beta_linear_log_snr(times[i]), beta_linear_log_snr(times[i + 1])
+        c = -torch.special.expm1(ls - ls_next)
+        alpha, sigma = ls.sigmoid().sqrt(), (-ls).sigmoid().sqrt()
+        alpha_next = ls_next.sigmoid().sqrt()
+        var = (-ls_next).sigmoid() * c
+        s = StepScalars()
+        s.alpha, s.sigma, s.alpha_next, s.c = float(alpha), float(sigma), float(alpha_next), float(c)
+        s.one_minus_c = float(1 - c)
+        s.noise_scale = float(var.sqrt())
+        s.sigma_next = float((-ls_next).sigmoid().sqrt())
+        scalars.append(s)
+        log_snrs.append(float(ls))
+    return scalars, log_snrs
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter containers (names/shapes = the reference state_dict; no forward)
+# ---------------------------------------------------------------------------------------------
+class _Params(nn.Module):
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter container: the arithmetic of this layer lives in libsrgd_hip.so")
+
+
+class _Gain(_Params):                                   # RMSNorm.g [1,C,1,1]
+    def __init__(self, c):
+        super().__init__()
+        self.g = nn.Parameter(torch.ones(1, c, 1, 1))
+
+
+class _FourierFreqs(_Params):                           # RandomOrLearnedSinusoidalPosEmb.weights [half]
+    def __init__(self, dim, frozen):
+        super().__init__()
+        self.weights = nn.Parameter(torch.randn(dim // 2), requires_grad=not frozen)
+
+
+class _ConvNormAct(_Params):                            # Block: proj + norm
+    def __init__(self, cin, cout, groups):
+        super().__init__()
+        self.proj = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm = nn.GroupNorm(groups, cout)
+
+
+class _Residual(_Params):                               # ResnetBlock
+    def __init__(self, cin, cout, time_dim, groups):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_dim, cout * 2))
+        self.block1 = _ConvNormAct(cin, cout, groups)
+        self.block2 = _ConvNormAct(cout, cout, groups)
+        self.res_conv = nn.Conv2d(cin, cout, 1) if cin != cout else nn.Identity()
+
+
+class _LinearAttn(_Params):
+    def __init__(self, c, heads, dim_head):
+        super().__init__()
+        self.norm = _Gain(c)
+        self.to_qkv = nn.Conv2d(c, heads * dim_head * 3, 1, bias=False)
+        self.to_out = nn.Sequential(nn.Conv2d(heads * dim_head, c, 1), _Gain(c))
+
+
+class _SoftmaxAttn(_Params):
+    def __init__(self, c, heads, dim_head):
+        super().__init__()
+        self.norm = _Gain(c)
+        self.to_qkv = nn.Conv2d(c, heads * dim_head * 3, 1, bias=False)
+        self.to_out = nn.Conv2d(heads * dim_head, c, 1)
+
+
+class _ShuffleUp(_Params):                              # PixelShuffleUpsample: conv1x1 -> SiLU -> PixelShuffle(2)
+    def __init__(self, cin, cout):
+        super().__init__()
+        conv = nn.Conv2d(cin, cout * 4, 1)
+        # ICNR-style start: the four sub-pixel filters of each output channel begin identical
+        base = torch.empty(cout, cin, 1, 1)
+        nn.init.kaiming_uniform_(base)
+        with torch.no_grad():
+            conv.weight.copy_(base.repeat_interleave(4, dim=0))
+            conv.bias.zero_()
+        self.net = nn.Sequential(conv, nn.SiLU(), nn.PixelShuffle(2))
+
+
+def _as_tuple(v, n):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+
+
+class ConditionalSRUnet(nn.Module):
+    """Class-conditional SR U-Net (6-channel input: noisy | LR condition; 3-channel eps output)."""
+
+    def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=3,
+                 self_condition=True, resnet_block_groups=8, learned_variance=False,
+                 learned_sinusoidal_cond=False, random_fourier_features=False, learned_sinusoidal_dim=16,
+                 attn_dim_head=32, attn_heads=4, full_attn=(False, False, False, True), flash_attn=False,
+                 pixel_shuffle_upsample=True, num_classes=None):
+        super().__init__()
+        unsupported = []
+        if init_dim not in (None, dim): unsupported.append("init_dim != dim")
+        if out_dim not in (None, channels): unsupported.append("out_dim != channels")
+        if not self_condition: unsupported.append("self_condition=False")
+        if learned_variance: unsupported.append("learned_variance=True")
+        if not (learned_sinusoidal_cond or random_fourier_features): unsupported.append("fixed sinusoidal time embedding")
+        if not pixel_shuffle_upsample: unsupported.append("pixel_shuffle_upsample=False")
+        if unsupported:
+            raise NotImplementedError("outside the shipped Real-SRGD configuration: " + ", ".join(unsupported))
+        n = len(dim_mults)
+        heads, dim_heads, full = _as_tuple(attn_heads, n), _as_tuple(attn_dim_head, n), _as_tuple(full_attn, n)
+        assert len(full) == n
+        if len(set(heads)) != 1 or len(set(dim_heads)) != 1:
+            raise NotImplementedError("per-stage attn_heads / attn_dim_head")
+        self.dim, self.dim_mults, self.channels = dim, tuple(dim_mults), channels
+        self.self_condition = self_condition
+        self.num_classes = num_classes
+        self.groups, self.heads, self.dim_head = resnet_block_groups, heads[0], dim_heads[0]
+        self.full_attn = tuple(bool(f) for f in full)
+        self.sinus_dim = learned_sinusoidal_dim
+        self.random_or_learned_sinusoidal_cond = True
+        self.out_dim = channels
+        self.flash_attn = flash_attn          # accepted; attention is a HIP kernel either way
+        self.precision = "fp32"               # precision of forward(); the sampler picks its own
+
+        time_dim = dim * 4
+        dims = [dim] + [dim * m for m in dim_mults]
+        self.init_conv = nn.Conv2d(channels * 2, dim, 7, padding=3)
+        self.time_mlp = nn.Sequential(_FourierFreqs(learned_sinusoidal_dim, random_fourier_features),
+                                      nn.Linear(learned_sinusoidal_dim + 1, time_dim), nn.GELU(),
+                                      nn.Linear(time_dim, time_dim))
+        if num_classes is not None:
+            self.class_mlp = nn.Sequential(nn.Embedding(num_classes, dim), nn.Linear(dim, time_dim), nn.GELU(),
+                                           nn.Linear(time_dim, time_dim))
+        mk_res = lambda i, o: _Residual(i, o, time_dim, resnet_block_groups)
+        mk_attn = lambda c, f: (_SoftmaxAttn if f else _LinearAttn)(c, self.heads, self.dim_head)
+        self.downs, self.ups = nn.ModuleList(), nn.ModuleList()
+        for s in range(n):
+            cin, cout = dims[s], dims[s + 1]
+            down = (nn.Sequential(nn.Identity(), nn.Conv2d(cin * 4, cout, 1)) if s < n - 1     # space-to-depth + 1x1
+                    else nn.Conv2d(cin, cout, 3, padding=1))
+            self.downs.append(nn.ModuleList([mk_res(cin, cin), mk_res(cin, cin), mk_attn(cin, self.full_attn[s]), down]))
+        self.mid_block1 = mk_res(dims[-1], dims[-1])
+        self.mid_attn = _SoftmaxAttn(dims[-1], self.heads, self.dim_head)
+        self.mid_block2 = mk_res(dims[-1], dims[-1])
+        for u in range(n):
+            s = n - 1 - u
+            cin, cout = dims[s], dims[s + 1]
+            up = _ShuffleUp(cout, cin) if u < n - 1 else nn.Conv2d(cout, cin, 3, padding=1)
+            self.ups.append(nn.ModuleList([mk_res(cout + cin, cout), mk_res(cout + cin, cout),
+                                           mk_attn(cout, self.full_attn[s]), up]))
+        self.final_res_block = mk_res(dim * 2, dim)
+        self.final_conv = nn.Conv2d(dim, channels, 1)
+
+        self._engines = {}
+        self._weights_version = 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._invalidate_engines())
+
+    # ---- engine plumbing ---------------------------------------------------------------------
+    @property
+    def downsample_factor(self) -> int:
+        return 2 ** (len(self.dim_mults) - 1)
+
+    def _invalidate_engines(self):
+        for eng in self._engines.values():
+            eng.close()
+        self._engines = {}
+        self._weights_version += 1
+
+    def _apply(self, fn, *a, **k):                  # .to()/.cuda()/.float() may move or change the parameters
+        out = super()._apply(fn, *a, **k)
+        self._invalidate_engines()
+        return out
+
+    def __deepcopy__(self, memo):
+        engines, self._engines = self._engines, {}
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        finally:
+            self._engines = engines
+        new._engines = {}
+        return new
+
+    def engine(self, precision: str = "fp32") -> HipEngine:
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _lib.SrgdHipError("ConditionalSRUnet runs on MI355X only: move the model to the GPU "
+                                    "(the CPU restatement under oracle/ is test infrastructure, not a fallback)")
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), precision)
+        if key not in self._engines:
+            eng = HipEngine(dim=self.dim, dim_mults=self.dim_mults, full_attn=self.full_attn, channels=self.channels,
+                            groups=self.groups, heads=self.heads, dim_head=self.dim_head, sinus_dim=self.sinus_dim,
+                            num_classes=self.num_classes, precision=precision, device=torch.device("cuda", key[0]))
+            eng.load_state_dict({k: v for k, v in self.state_dict().items()}, strict=True)
+            self._engines[key] = eng
+        return self._engines[key]
+
+    # ---- reference forward signature (model.py:678) ---------------------------------------------
+    def forward(self, x, time, class_label=None, x_self_cond=None):
+        f = self.downsample_factor
+        assert all(d % f == 0 for d in x.shape[-2:]), \
+            f"your input dimensions {x.shape[-2:]} need to be divisible by {f}, given the unet"
+        class_id = -1
+        if class_label is not None:
+            if class_label.numel() != 1:
+                raise NotImplementedError("per-sample class labels (the reference passes one label of shape [1])")
+            class_id = int(class_label.reshape(-1)[0])
+        time = time.reshape(-1)
+        if time.numel() == 1 and x.shape[0] > 1:
+            time = time.expand(x.shape[0])
+        return self.engine(self.precision).unet_forward(x, time, class_id, x_self_cond)
+
+
+# ---------------------------------------------------------------------------------------------
+# the sampler
+# ---------------------------------------------------------------------------------------------
+class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
+    def __init__(self, model, *, image_size, channels=3, noise_schedule="linear", num_sample_steps=500,
+                 clip_sample_denoised=True, learned_schedule_net_hidden_dim=1024,
+                 learned_noise_schedule_frac_gradient=1.0, min_snr_loss_weight=False, min_snr_gamma=5,
+                 cond_drop_prob=0.0, class_cond_drop_prob=0.0, loss_type="l2"):
+        super().__init__()
+        assert model.random_or_learned_sinusoidal_cond
+        if noise_schedule != "linear":
+            raise NotImplementedError(f"noise_schedule={noise_schedule!r}: only the shipped 'linear' log-SNR schedule is built")
+        if not clip_sample_denoised:
+            raise NotImplementedError("clip_sample_denoised=False")
+        self.model = model
+        self.channels, self.image_size = channels, image_size
+        self.log_snr = beta_linear_log_snr
+        self.num_sample_steps = num_sample_steps
+        self.clip_sample_denoised = clip_sample_denoised
+        self.min_snr_loss_weight, self.min_snr_gamma = min_snr_loss_weight, min_snr_gamma
+        self.cond_drop_prob, self.class_cond_drop_prob = cond_drop_prob, class_cond_drop_prob
+        self.loss_type = loss_type
+        # engine knobs (not part of the reference surface)
+        self.noise_source = "host"     # "host": torch CPU generator in the reference's draw order; "device": Philox
+        self.device_noise_seed = 0
+        self.max_tiles_per_launch = None   # None: use the caller's batch_size as the reference does
+
+    def set_seed(self, seed):
+        torch.cuda.manual_seed(seed)
+        self.device_noise_seed = int(seed)
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
+
+    @torch.inference_mode()
+    def tiled_sample(self, batch_size=4, tile_size=256, tile_stride=256, condition_x=None, class_label=None,
+                     cond_scale=1.0, guidance_start_steps=0, class_cond_scale=1.0, class_guidance_start_steps=0,
+                     generation_start_steps=0, num_sample_steps=None, with_images=False, with_x0_images=False,
+                     start_white_noise=True, amp=False):
+        """Tiled CFG-DDPM sampling of one image (reference model.py:3288-3413).
+
+        ``amp`` is accepted and ignored by the reference; here it selects the engine's bf16 mode
+        (False: exact-fp32 parity mode)."""
+        num_sample_steps = self.num_sample_steps if num_sample_steps is None else num_sample_steps
+        if cond_scale != 1.0 and class_cond_scale != 1.0:
+            raise NotImplementedError("Currently, you cannot specify both cond_scale and class_cond_scale at the same time.")
+        if generation_start_steps > 0 or not start_white_noise:
+            raise NotImplementedError("generation_start_steps > 0 / start_white_noise=False (q_sample start) is not built yet")
+        if tile_size != 256 or tile_stride != 256:
+            raise NotImplementedError("tile_size/tile_stride other than 256 are unusable in the reference too "
+                                      "(get_coord_and_pad is called without them, model.py:3301)")
+        dev = self.device
+        if dev.type != "cuda":
+            raise _lib.SrgdHipError("tiled_sample runs on MI355X only (no CPU fallback)")
+        batch, c, h, w = condition_x.shape
+        if batch != 1 or c != 3:
+            raise ValueError("condition_x must be [1,3,H,W] (the reference's tile gather assumes batch 1)")
+        f = self.model.downsample_factor
+        assert tile_size % f == 0, f"your input dimensions need to be divisible by {f}, given the unet"
+        eng = self.model.engine("bf16" if amp else "fp32")
+        class_id = -1 if class_label is None else int(class_label.reshape(-1)[0])
+
+        (left, top, right, bottom), pad = get_coord_and_pad(h, w)
+        hp, wp = h + pad[2] + pad[3], w + pad[0] + pad[1]
+        if max(pad[0], pad[1]) >= w or max(pad[2], pad[3]) >= h:
+            raise RuntimeError("Padding size should be less than the corresponding input dimension "
+                               f"(reflect pad {pad} of a {h}x{w} image)")
+        coords0 = get_coords(hp, wp, tile_size, tile_size, diff=0)
+        if hp <= tile_size and wp <= tile_size:
+            coords1 = get_coords(hp, wp, tile_size, tile_stride, diff=0)
+        else:
+            coords1 = get_coords(hp - tile_size, wp - tile_size, tile_size, tile_stride, diff=tile_size // 2)
+        (sl, st_, sr, sb), _ = get_area(coords1, hp, wp)
+        geo = SamplerGeometry(H=h, W=w, Hp=hp, Wp=wp, left=left, top=top, inner_l=sl, inner_t=st_, inner_r=sr,
+                              inner_b=sb, tile=tile_size, n_even=len(coords0), n_odd=len(coords1))
+        scalars, log_snrs = _schedule(num_sample_steps)
+
+        cond01 = condition_x[0].to(dev, torch.float32).contiguous()
+        cond_canvas = torch.empty(3, hp, wp, device=dev, dtype=torch.float32)
+        eng.sampler_begin(geo, cond01, cond_canvas, [(a, c_) for (a, _, c_, _) in coords0],
+                          [(a, c_) for (a, _, c_, _) in coords1], scalars, log_snrs, class_id)
+
+        host_noise = self.noise_source == "host"
+        if host_noise:
+            img = torch.randn(1, 3, hp, wp).to(dev)                      # reference draw #1 (model.py:3311)
+        else:
+            img = eng.randn_(torch.empty(1, 3, hp, wp, device=dev), self.device_noise_seed, 0)
+        x_start = img.clone() if with_x0_images else None
+        image_list = [img[:, :, top:bottom, left:right].clone().cpu()] if with_images else None
+        x0_image_list = [img[:, :, top:bottom, left:right].clone().cpu()] if with_x0_images else None
+
+        sub_batch = self.max_tiles_per_launch or batch_size
+        grids = (coords0, coords1)
+        for i in range(num_sample_steps):
+            cur_cond_scale = 1.0 if i < guidance_start_steps else cond_scale
+            cur_class_scale = 1.0 if i < class_guidance_start_steps else class_cond_scale
+            if cur_cond_scale != 1.0:
+                passes, kind, scale = 2, 2, cur_cond_scale
+            elif cur_class_scale != 1.0:
+                passes, kind, scale = 2, 1, cur_class_scale
+            else:
+                passes, kind, scale = 1, 0, 1.0
+            n_tiles = len(grids[i % 2])
+            last = i == num_sample_steps - 1
+            noise_tiles = noise_canvas = None
+            if host_noise:
+                # identical to the reference's per-minibatch randn_like draws (SURVEY Appendix D:
+                # 16-element block property makes one contiguous draw equal to the minibatch draws)
+                if not last:
+                    noise_tiles = torch.randn(n_tiles, 3, tile_size, tile_size).to(dev, non_blocking=True)
+                if i % 2 == 1:
+                    noise_canvas = torch.randn(1, 3, hp, wp).to(dev, non_blocking=True)
+            eng.sampler_step(i, img, cond_canvas, x_start, noise_tiles, noise_canvas, passes, kind, scale, sub_batch,
+                             seed=self.device_noise_seed)
+            if with_images:
+                image_list.append(img.clone().cpu())
+            if with_x0_images:
+                x0_image_list.append(x_start.clone().cpu())
+
+        out = torch.empty(1, 3, h, w, device=dev, dtype=torch.float32)
+        eng.sampler_end(img, out)
+        if with_images:
+            return (out, image_list, x0_image_list) if with_x0_images else (out, image_list)
+        return out
+
+    def sample(self, *args, **kwargs):
+        raise NotImplementedError("un-tiled p_sample_loop (model.py:3417) is not on the shipped inference path; "
+                                  "use tiled_sample")
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("training (p_losses) is not part of the inference-only release this engine mirrors")
+
+
+# ---------------------------------------------------------------------------------------------
+# factory (reference model.py:3500-3666)
+# ---------------------------------------------------------------------------------------------
+class ModelEma(nn.Module):
+    """Stand-in for ``timm.utils.ModelEmaV2`` as the reference uses it at inference: a holder whose
+    ``.module`` is an eval-mode copy that receives ``ckpt['ema_model']`` (model.py:3657-3662)."""
+
+    def __init__(self, model, decay=0.9999, device=None):
+        super().__init__()
+        self.module = copy.deepcopy(model)
+        self.module.eval()
+        self.decay, self.device = decay, device
+
+
+def _parse_bool_list(text: str) -> Tuple[bool, ...]:
+    table = {"true": True, "false": False}
+    try:
+        return tuple(table[t.strip().lower()] for t in text.split(","))
+    except KeyError as exc:
+        raise ValueError(f"full_attn must be a comma list of True/False, got {text!r}") from exc
+
+
+def get_model(conf, logger):
+    dim_mults = tuple(int(t) for t in conf.ddpm_unet_dim_mults.split(","))
+    full_attn = _parse_bool_list(conf.full_attn)
+    if conf.model != "conditional_continuous":
+        raise NotImplementedError(
+            f"model={conf.model!r}: this engine accelerates the shipped 'conditional_continuous' path only "
+            "(SURVEY.md section 8; the other wrappers have no released config or weights)")
+    unet = ConditionalSRUnet(dim=conf.unet_dim, dim_mults=dim_mults, full_attn=full_attn,
+                             learned_variance=conf.learned_variance,
+                             learned_sinusoidal_cond=conf.learned_sinusoidal_cond,
+                             learned_sinusoidal_dim=conf.learned_sinusoidal_dim, flash_attn=conf.flash_attn,
+                             pixel_shuffle_upsample=conf.pixel_shuffle_upsample, num_classes=conf.num_classes)
+    logger.info(f"ConditionalSRUnet: channels=6 dim={conf.unet_dim} dim_mults={conf.ddpm_unet_dim_mults} "
+                f"num_classes={conf.num_classes}")
+    assert conf.learned_sinusoidal_cond
+    conf.use_dpmpp_solver = False
+    model = ConditionalContinuousTimeGaussianDiffusionSR(
+        unet, image_size=conf.image_size, noise_schedule=conf.noise_schedule,
+        num_sample_steps=conf.num_sample_steps, clip_sample_denoised=conf.clip_sample_denoised,
+        learned_schedule_net_hidden_dim=conf.learned_schedule_net_hidden_dim,
+        learned_noise_schedule_frac_gradient=conf.learned_noise_schedule_frac_gradient,
+        min_snr_loss_weight=conf.min_snr_loss_weight, min_snr_gamma=conf.min_snr_gamma,
+        cond_drop_prob=conf.cond_drop_prob, class_cond_drop_prob=conf.class_cond_drop_prob,
+        loss_type=conf.loss_type)
+    logger.info(f"ConditionalContinuousTimeGaussianDiffusionSR: image_size={conf.image_size} "
+                f"num_sample_steps={conf.num_sample_steps}")
+    ema_model = ModelEma(model, decay=conf.ema_decay)
+    if conf.ckpt_path:
+        ckpt = torch.load(conf.ckpt_path, map_location="cpu", weights_only=True)
+        check = ema_model.module.load_state_dict(ckpt["ema_model"], strict=conf.load_strict)
+        logger.info(f"load ema_model weight from : {conf.ckpt_path}")
+        logger.info(f"check: {check}")
+    return ema_model

@@ -11,9 +11,9 @@ GEOMETRY_SIZES = [(256, 256), (64, 64), (1024, 1024), (8192, 8192), (300, 500), 
 SCHEDULE_STEPS = [10, 50, 100]
 
 UNET_CASES = [
-    dict(name="dim16_64", dim=16, hw=64, batch=2, weight_seed=0, input_seed=7,
+    dict(name="dim16_128", dim=16, hw=128, batch=2, weight_seed=0, input_seed=7,
          log_snr=[-3.0, 2.5], label=1, modes=["label_cond", "null_class", "null_cond"]),
-    dict(name="dim128_64", dim=128, hw=64, batch=1, weight_seed=0, input_seed=8,
+    dict(name="dim128_128", dim=128, hw=128, batch=1, weight_seed=0, input_seed=8,
          log_snr=[0.75], label=0, modes=["label_cond", "null_class"]),
 ]
 

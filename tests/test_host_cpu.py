@@ -1,0 +1,156 @@
+"""CPU tests of the host side: config/CLI surface, state_dict schema, tile geometry helpers,
+C-ABI library load + exported symbols (no compute without a GPU), loud failure off-GPU."""
+import json
+import logging
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_yaml_loads_unchanged_and_unknown_key_raises(tmp_path):
+    from srgd_amd.config import load_config
+    conf = load_config(os.path.join(ROOT, "conf", "conditional_continuous_linear_df8kost_dim128.yaml"))
+    assert conf.model == "conditional_continuous" and conf.unet_dim == 128 and conf.noise_schedule == "linear"
+    assert conf.ddpm_unet_dim_mults == "1,2,4,8" and conf.learned_sinusoidal_dim == 32 and conf.image_size == 256
+    assert conf.full_attn == "False,False,False,True" and conf.num_classes == 3 and conf.load_strict is True
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("unet_dim: 64\nnot_a_field: 1\n")
+    with pytest.raises(TypeError):
+        load_config(str(bad))
+
+
+def test_state_dict_schema_is_the_reference_schema():
+    from srgd_amd.config import load_config
+    from srgd_amd.model import get_model
+    conf = load_config(os.path.join(ROOT, "conf", "conditional_continuous_linear_df8kost_dim128.yaml"))
+    for dim in (16, 128):
+        conf.unet_dim = dim
+        ema = get_model(conf, logging.getLogger("t"))
+        sd = ema.module.state_dict()
+        with open(os.path.join(G, f"schema_dim{dim}.json")) as f:
+            ref = json.load(f)
+        assert list(sd.keys()) == list(ref.keys())
+        assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    assert sum(v.numel() for v in sd.values()) == 137_569_939
+
+
+def test_checkpoint_roundtrip_strict(tmp_path):
+    from srgd_amd.config import load_config
+    from srgd_amd.model import get_model
+    from srgd_amd.synth import synth_state_dict
+    conf = load_config(os.path.join(ROOT, "conf", "conditional_continuous_linear_df8kost_dim128.yaml"))
+    conf.unet_dim = 16
+    with open(os.path.join(G, "schema_dim16.json")) as f:
+        schema = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = synth_state_dict(schema, seed=3)
+    path = tmp_path / "ckpt.pth"
+    torch.save({"ema_model": sd}, path)
+    conf.ckpt_path = str(path)
+    ema = get_model(conf, logging.getLogger("t"))
+    got = ema.module.state_dict()
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    del sd["model.final_conv.bias"]
+    torch.save({"ema_model": sd}, path)
+    with pytest.raises(RuntimeError):
+        get_model(conf, logging.getLogger("t"))
+
+
+def test_geometry_helpers_match_golden_tables():
+    from srgd_amd.model import get_area, get_coord_and_pad, get_coords
+    from tests.golden import cases as C
+    with open(os.path.join(G, "geometry.json")) as f:
+        geo = json.load(f)
+    for (h, w) in C.GEOMETRY_SIZES:
+        want = geo[f"{h}x{w}"]
+        box, pad = get_coord_and_pad(h, w)
+        assert list(box) == want["box"] and list(pad) == want["pad"]
+        hp, wp = want["canvas"]
+        even = get_coords(hp, wp, 256, 256, diff=0)
+        odd = even if (hp <= 256 and wp <= 256) else get_coords(hp - 256, wp - 256, 256, 256, diff=128)
+        assert len(even) == want["n_even"] and len(odd) == want["n_odd"]
+        if not want["truncated"]:
+            assert [list(c) for c in even] == want["even"] and [list(c) for c in odd] == want["odd"]
+        inner, ipad = get_area(odd, hp, wp)
+        assert list(inner) == want["inner"] and list(ipad) == want["inner_pad"]
+    # ragged stride: last tile pulled back to the border
+    assert get_coords(600, 256, 256, 200) == [(0, 256, 0, 256), (200, 456, 0, 256), (344, 600, 0, 256)]
+
+
+def test_schedule_scalars_bit_identical_to_oracle():
+    from oracle import srgd_oracle as O
+    from srgd_amd.model import _schedule
+    for n in (10, 50):
+        scalars, log_snrs = _schedule(n)
+        steps = torch.linspace(1.0, 0.0, n + 1)
+        for i in range(n):
+            s = O.step_scalars(steps[i], steps[i + 1])
+            assert scalars[i].alpha == float(s["alpha"]) and scalars[i].sigma == float(s["sigma"])
+            assert scalars[i].alpha_next == float(s["alpha_next"]) and scalars[i].c == float(s["c"])
+            assert scalars[i].noise_scale == float(s["var"].sqrt()) and log_snrs[i] == float(s["log_snr"])
+            assert scalars[i].one_minus_c == float(1 - s["c"])
+
+
+def test_cli_flags_are_the_reference_flags():
+    from srgd_amd.inference import parse_args
+    a = parse_args(["-c", "x.yaml", "-m", "w.pth", "--input_dir", "i", "--output_dir", "o"])
+    assert (a.batch_size, a.num_sample_steps, a.interpolation, a.cond_scale, a.class_cond_scale) == (8, 250, "bicubic", 1.0, 1.0)
+    assert (a.guidance_start_steps, a.class_guidance_start_steps, a.generation_start_steps) == (0, 0, 0)
+    assert (a.start_index, a.end_index, a.test_label, a.amp, a.use_dpmpp_solver, a.seed, a.backend) == \
+        (0, None, None, True, True, 71, "ddp")
+    a = parse_args(["-c", "x", "-m", "w", "--input_dir", "i", "--output_dir", "o", "--no_amp", "--test_label", "0"])
+    assert a.amp is False and a.test_label == 0
+
+
+def test_image_io_conventions():
+    from PIL import Image
+    from srgd_amd.inference import pil_to_unit_tensor, unit_tensor_to_pil
+    t = torch.tensor([[[0.0, 0.999, 1.0]], [[0.5, 0.25, 0.0]], [[1.0 / 255, 254.9 / 255, 0.3]]])
+    img = unit_tensor_to_pil(t)
+    assert img.getpixel((1, 0)) == (254, 63, 254)          # truncation, like ToPILImage's mul(255).byte()
+    back = pil_to_unit_tensor(img)
+    assert back.shape == (3, 1, 3) and back.max() <= 1.0 and float(back[0, 0, 2]) == 1.0
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    from srgd_amd import _lib
+    from srgd_amd.build import build
+    build()
+    lib = _lib.lib()                                      # binds every prototype; AttributeError if one is missing
+    declared = set()
+    for header in ("srgd_hip.h", "srgd_hip_kernels.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(srgd_[a-z0-9_]+)\s*\(", text))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert b"gfx950" in lib.srgd_version()
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from srgd_amd._lib import SrgdHipError
+    from srgd_amd.config import load_config
+    from srgd_amd.model import get_model
+    conf = load_config(os.path.join(ROOT, "conf", "conditional_continuous_linear_df8kost_dim128.yaml"))
+    conf.unet_dim = 16
+    sampler = get_model(conf, logging.getLogger("t")).module.eval()
+    with pytest.raises(SrgdHipError):
+        sampler.tiled_sample(condition_x=torch.rand(1, 3, 256, 256), num_sample_steps=2)
+    with pytest.raises(SrgdHipError):
+        sampler.model(torch.zeros(1, 3, 128, 128), torch.zeros(1))
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "srgd_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

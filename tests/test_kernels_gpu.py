@@ -1,0 +1,244 @@
+"""GPU parity tests, one kernel family at a time, through the kernel-level C ABI
+(include/srgd_hip_kernels.h) against the CPU oracle / plain torch fp32 ops on the same seeded inputs.
+
+fp32 mode: exact-fp32 MFMA, tolerance = summation-order noise.  bf16 mode: inputs are rounded to
+bf16 first and the oracle runs on the rounded values, so the tolerance only covers bf16 output
+rounding + accumulation order (2^-8 relative).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import srgd_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def L():
+    from srgd_amd import _lib
+    return _lib
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def to_dev_nhwc(x_nchw, bf16):
+    """NCHW fp32 (CPU) -> NHWC contiguous on the GPU in the activation type."""
+    t = x_nchw.permute(0, 2, 3, 1).contiguous().to(DEV)
+    return t.to(torch.bfloat16) if bf16 else t
+
+
+def from_dev_nhwc(t):
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(x, bf16):
+    return x.to(torch.bfloat16).float() if bf16 else x
+
+
+def tol(bf16, ref, k=1.0):
+    scale = max(1.0, float(ref.abs().max()))
+    return (1.2e-2 if bf16 else 2e-5) * scale * k
+
+
+def run_conv(x0, x1, w, b, *, ks, stride, pad, kind, bf16, residual=None, groups=0, out_shape=None):
+    lib = L().lib()
+    B, C0, H, W = x0.shape
+    C1 = 0 if x1 is None else x1.shape[1]
+    cout = w.shape[0]
+    d0 = to_dev_nhwc(x0, bf16)
+    d1 = None if x1 is None else to_dev_nhwc(x1, bf16)
+    ho = (H + 2 * pad - ks) // stride + 1
+    wo = (W + 2 * pad - ks) // stride + 1
+    if kind == 2:
+        out = torch.empty(B, 2 * ho, 2 * wo, cout // 4, device=DEV, dtype=d0.dtype)
+    else:
+        out = torch.empty(B, ho, wo, cout, device=DEV, dtype=d0.dtype)
+    dres = None if residual is None else to_dev_nhwc(residual, bf16)
+    part = None
+    if groups:
+        part = torch.full((B, groups, ho * wo // 128, 2), float("nan"), device=DEV)
+    wh = w.contiguous().float()
+    bh = None if b is None else b.contiguous().float()
+    L().check(lib.srgd_k_conv2d(ptr(d0), ptr(d1), C0, C1, B, H, W, ks, stride, pad, kind, ptr(wh), ptr(bh), cout,
+                                ptr(out), ptr(dres), ptr(part), groups, int(bf16), stream()), "srgd_k_conv2d")
+    torch.cuda.synchronize()
+    return from_dev_nhwc(out), part
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+def test_mfma_layout_exact_small_integers(bf16):
+    # asymmetric integer data: every product and sum is exact in bf16/fp32, so the result must be
+    # bit-identical - catches any row/col/k-pairing mistake in the MFMA fragment maps.
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(-3, 4, (1, 32, 16, 16), generator=g).float()
+    w = torch.randint(-2, 3, (48, 32, 3, 3), generator=g).float()
+    b = torch.randint(-4, 5, (48,), generator=g).float()
+    got, _ = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=bf16)
+    want = F.conv2d(x, w, b, padding=1)
+    if bf16:
+        want = want.to(torch.bfloat16).float()       # outputs up to ~|2600|: bf16 output rounding only
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 32, 16), (1, 128, 128, 16, 32), (3, 64, 32, 48, 24), (1, 256, 128, 32, 32), (1, 32, 40, 10, 10)],
+                         ids=lambda s: "B%d_Cin%d_Cout%d_%dx%d" % s)
+def test_conv3x3_bias(bf16, shape):
+    B, cin, cout, H, W = shape
+    g = torch.Generator().manual_seed(1)
+    x = rnd(torch.randn(B, cin, H, W, generator=g), bf16)
+    w = rnd(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), bf16)
+    b = torch.randn(cout, generator=g)
+    got, _ = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=bf16)
+    want = F.conv2d(x, w, b, padding=1)
+    assert (got - want).abs().max() <= tol(bf16, want)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+def test_conv_two_sources_equals_concat_and_residual(bf16):
+    g = torch.Generator().manual_seed(2)
+    x0 = rnd(torch.randn(2, 64, 16, 32, generator=g), bf16)
+    x1 = rnd(torch.randn(2, 32, 16, 32, generator=g), bf16)
+    w = rnd(torch.randn(48, 96, 3, 3, generator=g) / 30, bf16)
+    b = torch.randn(48, generator=g)
+    res = rnd(torch.randn(2, 48, 16, 32, generator=g), bf16)
+    got, _ = run_conv(x0, x1, w, b, ks=3, stride=1, pad=1, kind=0, bf16=bf16, residual=res)
+    want = F.conv2d(torch.cat((x0, x1), 1), w, b, padding=1) + res
+    assert (got - want).abs().max() <= tol(bf16, want)
+    # 1x1 over a concat (res_conv of the up path), no bias
+    w1 = rnd(torch.randn(160, 96, 1, 1, generator=g) / 10, bf16)
+    got, _ = run_conv(x0, x1, w1, None, ks=1, stride=1, pad=0, kind=0, bf16=bf16)
+    want = F.conv2d(torch.cat((x0, x1), 1), w1)
+    assert (got - want).abs().max() <= tol(bf16, want)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+def test_downsample_is_unshuffle_plus_1x1(bf16):
+    g = torch.Generator().manual_seed(3)
+    x = rnd(torch.randn(2, 32, 32, 32, generator=g), bf16)
+    w = rnd(torch.randn(64, 128, 1, 1, generator=g) / 11, bf16)
+    b = torch.randn(64, generator=g)
+    got, _ = run_conv(x, None, w, b, ks=2, stride=2, pad=0, kind=1, bf16=bf16)
+    want = O.space_to_depth_conv({"d.1.weight": w, "d.1.bias": b}, "d", x)
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= tol(bf16, want)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+def test_pixel_shuffle_upsample(bf16):
+    g = torch.Generator().manual_seed(4)
+    x = rnd(torch.randn(2, 64, 16, 16, generator=g), bf16)
+    w = rnd(torch.randn(128, 64, 1, 1, generator=g) / 8, bf16)
+    b = torch.randn(128, generator=g)
+    got, _ = run_conv(x, None, w, b, ks=1, stride=1, pad=0, kind=2, bf16=bf16)
+    want = O.pixel_shuffle_up({"u.net.0.weight": w, "u.net.0.bias": b}, "u", x)
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= tol(bf16, want)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("cfg", [(2, 32, 64, 16, 16), (1, 16, 128, 32, 32), (2, 64, 16, 16, 8)],
+                         ids=lambda s: "B%d_Cin%d_Cout%d_%dx%d" % s)
+def test_conv_groupnorm_scale_shift_silu_residual(bf16, cfg):
+    # Block.forward (model.py:250-259) + the ResnetBlock residual (:285) on top of the conv's fused statistics
+    B, cin, cout, H, W = cfg
+    lib = L().lib()
+    g = torch.Generator().manual_seed(5)
+    x = rnd(torch.randn(B, cin, H, W, generator=g) * 2 + 0.5, bf16)
+    w = rnd(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), bf16)
+    b = torch.randn(cout, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
+    ss = 0.5 * torch.randn(B, 2 * cout, generator=g)
+    res = rnd(torch.randn(B, cout, H, W, generator=g), bf16)
+    conv_out, part = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=bf16, groups=8)
+    assert torch.isfinite(part).all(), "conv epilogue did not fill every GroupNorm partial slot"
+    ref_conv = F.conv2d(x, w, b, padding=1)
+    # statistics must come from the fp32 accumulators
+    s1 = part[..., 0].sum(-1).cpu()
+    want_s1 = ref_conv.reshape(B, 8, -1).sum(-1)
+    assert (s1 - want_s1).abs().max() <= 1e-3 * max(1.0, float(want_s1.abs().max()))
+    d = to_dev_nhwc(conv_out, bf16)
+    dres = to_dev_nhwc(res, bf16)
+    L().check(lib.srgd_k_groupnorm_silu(ptr(d), ptr(d), ptr(dres), ptr(part), B, H * W, cout, 8, ptr(gamma.to(DEV)),
+                                        ptr(beta.to(DEV)), ptr(ss.to(DEV)), int(bf16), stream()), "groupnorm")
+    got = from_dev_nhwc(d)
+    y = F.group_norm(conv_out if bf16 else ref_conv, 8, gamma, beta, eps=1e-5)
+    y = y * (ss[:, :cout, None, None] + 1) + ss[:, cout:, None, None]
+    want = F.silu(y) + res
+    assert (got - want).abs().max() <= tol(bf16, want, k=2.0)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("C", [16, 128, 1024])
+def test_rmsnorm(bf16, C):
+    lib = L().lib()
+    g = torch.Generator().manual_seed(6)
+    x = rnd(torch.randn(2, C, 8, 16, generator=g) * 3, bf16)
+    x[0, :, 0, 0] = 0.0                       # eps path: zero vector stays zero
+    gain = 1 + 0.1 * torch.randn(1, C, 1, 1, generator=g)
+    res = rnd(torch.randn(2, C, 8, 16, generator=g), bf16)
+    d, dres = to_dev_nhwc(x, bf16), to_dev_nhwc(res, bf16)
+    out = torch.empty_like(d)
+    L().check(lib.srgd_k_rmsnorm(ptr(d), ptr(out), ptr(dres), ptr(gain.reshape(-1).to(DEV)), 2 * 8 * 16, C, int(bf16),
+                                 stream()), "rmsnorm")
+    got = from_dev_nhwc(out)
+    want = O.rms_norm(x, gain) + res
+    assert (got - want).abs().max() <= tol(bf16, want)
+    # in place, no residual
+    L().check(lib.srgd_k_rmsnorm(ptr(d), ptr(d), ptr(None), ptr(gain.reshape(-1).to(DEV)), 2 * 8 * 16, C, int(bf16),
+                                 stream()), "rmsnorm")
+    assert (from_dev_nhwc(d) - O.rms_norm(x, gain)).abs().max() <= tol(bf16, want)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("hw", [(16, 16), (64, 64), (24, 40)], ids=lambda s: "%dx%d" % s)
+def test_linear_attention_core(bf16, hw):
+    lib = L().lib()
+    H, W = hw
+    g = torch.Generator().manual_seed(7)
+    qkv = rnd(torch.randn(2, 384, H, W, generator=g) * 2, bf16)
+    qkv[0, 128 + 5, 3, 3] = 9.0               # a spike in k: exercises the cross-chunk max merge
+    d = to_dev_nhwc(qkv, bf16)
+    out = torch.empty(2, H, W, 128, device=DEV, dtype=d.dtype)
+    L().check(lib.srgd_k_linear_attention(ptr(d), ptr(out), 2, H * W, 4, int(bf16), stream()), "linattn")
+    got = from_dev_nhwc(out)
+    want = O.linear_attention_core(qkv, 4, 32)
+    assert (got - want).abs().max() <= tol(bf16, want)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("hw", [(16, 16), (32, 32), (8, 24)], ids=lambda s: "%dx%d" % s)
+def test_full_attention_core(bf16, hw):
+    lib = L().lib()
+    H, W = hw
+    g = torch.Generator().manual_seed(8)
+    qkv = rnd(torch.randn(2, 384, H, W, generator=g) * 1.5, bf16)
+    qkv[1, :32, 2, 2] *= 6.0                  # one sharp query row: online-softmax rescale path
+    d = to_dev_nhwc(qkv, bf16)
+    out = torch.empty(2, H, W, 128, device=DEV, dtype=d.dtype)
+    L().check(lib.srgd_k_full_attention(ptr(d), ptr(out), 2, H * W, 4, int(bf16), stream()), "fullattn")
+    torch.cuda.synchronize()
+    got = from_dev_nhwc(out)
+    want = O.full_attention_core(qkv, 4, 32)
+    assert (got - want).abs().max() <= tol(bf16, want)
+
+
+def test_conv_rejects_bad_shapes():
+    lib = L().lib()
+    x = torch.zeros(1, 8, 8, 24, device=DEV)           # 24 channels: not a multiple of 16
+    w = torch.zeros(16, 24, 3, 3)
+    out = torch.zeros(1, 8, 8, 16, device=DEV)
+    rc = lib.srgd_k_conv2d(ptr(x), ptr(None), 24, 0, 1, 8, 8, 3, 1, 1, 0, ptr(w), ptr(None), 16, ptr(out), ptr(None),
+                           ptr(None), 0, 0, stream())
+    assert rc != 0 and b"multiple of 16" in lib.srgd_last_error()
