@@ -1,0 +1,199 @@
+"""Headline benchmark: HR tiles/sec of the tiled CFG-DDPM sampling path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched per rank by torch.distributed.run)
+
+One "step" = one HR tile = BASELINE.json config[1]: a 256x256 LR image -> x4 -> 1024x1024 through
+``tiled_sample`` (canvas 1280^2, 25 tiles on even / 16 on odd DDPM steps, 50 steps,
+class_cond_scale=1.0 -> 1,025 U-Net tile-forwards = 813.6 TFLOP), dim-128 U-Net, seeded synthetic
+weights with the reference state_dict schema (the published checkpoint is an LFS pointer), synthetic
+LR input already upsampled and resident in HBM when the clock starts.
+Ranks shard independent images (weak scaling, no data-path collective); weights are broadcast from
+rank 0 and the HR outputs gathered to rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is the conv implicit-GEMM family (89% of the FLOPs):
+algorithmic FLOPs / HIP-event time on the launch stream, collected in an extra profiled pass right
+after the timed region; `cpu_baseline` is the CPU oracle (oracle/srgd_oracle.py, a port of the
+reference's PyTorch path) timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TFLOP_PER_HR_TILE = 813.6          # BASELINE.md section 3 (1,025 tile-forwards x 793.8 GFLOP)
+TILE_FORWARDS_PER_HR_TILE = 1025
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="HR tiles per GPU in the timed region")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--ddpm_steps", type=int, default=50)
+    ap.add_argument("--lr_size", type=int, default=256)
+    ap.add_argument("--sub_batch", type=int, default=25, help="tiles per U-Net launch")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_profile", action="store_true")
+    ap.add_argument("--cpu_tile_forwards", type=int, default=8)
+    return ap.parse_args()
+
+
+def build_sampler(dim, device, world, rank):
+    import torch.distributed as dist
+    from srgd_amd.config import load_config
+    from srgd_amd.model import get_model
+    from srgd_amd.synth import synth_state_dict
+    conf = load_config(os.path.join(ROOT, "conf", "conditional_continuous_linear_df8kost_dim128.yaml"))
+    conf.unet_dim = dim
+    conf.num_sample_steps = 50
+    sampler = get_model(conf, logging.getLogger("bench")).module
+    schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+    if world > 1:
+        # rank 0 owns the checkpoint; everyone else receives it over RCCL/xGMI as one flat buffer
+        numel = sum(int(torch.Size(s).numel()) for s in schema.values())
+        flat = torch.empty(numel, device=device)
+        if rank == 0:
+            sd = synth_state_dict(schema, seed=0)
+            flat.copy_(torch.cat([sd[k].reshape(-1) for k in schema]))
+        dist.broadcast(flat, src=0)
+        sd, o = {}, 0
+        host = flat.cpu()
+        for k, s in schema.items():
+            n = int(torch.Size(s).numel())
+            sd[k] = host[o:o + n].reshape(s).clone()
+            o += n
+    else:
+        sd = synth_state_dict(schema, seed=0)
+    sampler.load_state_dict(sd, strict=True)
+    return sampler.eval().to(device), sd
+
+
+def cpu_baseline(sd, dim, n_tile_forwards):
+    """The CPU oracle (port of the reference PyTorch path) on a bounded sample: U-Net tile-forwards at
+    the reference's default minibatch of 8 tiles, extrapolated to HR tiles/s (1,025 tile-forwards each)."""
+    from oracle import srgd_oracle as O
+    threads = torch.get_num_threads()
+    usd = O.strip_model_prefix(sd)
+    cfg = O.UnetCfg(dim=dim)
+    b = min(8, n_tile_forwards)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(b, 3, 256, 256, generator=g)
+    c = torch.rand(b, 3, 256, 256, generator=g) * 2 - 1
+    ls = torch.full((b,), 0.5)
+    done, t0 = 0, time.perf_counter()
+    with torch.inference_mode():
+        while done < n_tile_forwards:
+            O.unet_forward(usd, cfg, x, ls, torch.tensor([0]), c)
+            done += b
+    dt = time.perf_counter() - t0
+    tf_per_s = done / dt
+    return {"value": tf_per_s / TILE_FORWARDS_PER_HR_TILE, "unit": "HR tiles/s", "cores": threads, "kind": "port",
+            "sample": f"{done} U-Net tile-forwards (256x256, dim {dim}, minibatch {b}) in {dt:.1f} s on {threads} "
+                      f"threads of {os.cpu_count()} logical CPUs = {tf_per_s:.3f} tile-forwards/s; "
+                      f"1 HR tile = {TILE_FORWARDS_PER_HR_TILE} tile-forwards"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from srgd_amd.synth import synthetic_lr_condition
+    sampler, sd = build_sampler(args.dim, device, world, rank)
+    sampler.noise_source = "device"
+    amp = args.precision == "bf16"
+    label = torch.tensor([0], device=device)
+    total = args.warmup + args.steps
+    # inputs resident in HBM before the clock starts (already x4-upsampled condition images)
+    conds = [synthetic_lr_condition(rank * total + i, args.lr_size, args.lr_size).to(device) for i in range(total)]
+
+    def run(i):
+        sampler.device_noise_seed = 71
+        return sampler.tiled_sample(batch_size=args.sub_batch, condition_x=conds[i], class_label=label,
+                                    class_cond_scale=1.0, num_sample_steps=args.ddpm_steps, amp=amp)
+
+    for i in range(args.warmup):
+        run(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [run(args.warmup + i) for i in range(args.steps)]
+    if dist:
+        stack = torch.cat(outs, 0)
+        gathered = [torch.empty_like(stack) for _ in range(world)] if rank == 0 else None
+        dist.gather(stack, gathered, dst=0)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert all(torch.isfinite(o).all() for o in outs)
+
+    if rank == 0:
+        tiles = args.steps * world
+        value = tiles / dt
+        line = {
+            "metric": "HR tiles/sec (256->1024 x4, 50 steps, CFG=1.0)", "value": value, "unit": "HR tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic (seeded LR images, seeded weights with the reference state_dict schema)",
+            "config": {"workload": f"BASELINE configs[1]: one {args.lr_size}x{args.lr_size} LR tile x4 SR per step, "
+                                   f"{args.ddpm_steps} DDPM steps, class_cond_scale=1.0, dim-{args.dim} U-Net, "
+                                   f"{args.precision}, device Philox noise",
+                       "tiles_per_unet_launch": args.sub_batch, "tile_forwards_per_step": TILE_FORWARDS_PER_HR_TILE,
+                       "parallelism": f"image-sharded x{world}"},
+            "tflops_effective": value * TFLOP_PER_HR_TILE,
+        }
+        if not args.no_profile and args.lr_size == 256 and args.ddpm_steps == 50 and args.dim == 128:
+            eng = sampler.model.engine(args.precision)
+            eng.profile_begin()
+            run(args.warmup)
+            prof = eng.profile_end()
+            conv_ms = prof["ms"]["conv_igemm"]
+            n_launch = prof["launches"]["conv_igemm"]
+            achieved = prof["conv_flops"] / (conv_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.precision]
+            line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                                "frac": achieved / peak, "traffic": None, "kernel": "conv_igemm_kernel",
+                                "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
+                                "algorithmic_gflop_per_launch": prof["conv_flops"] / max(n_launch, 1) / 1e9}
+            tot = sum(prof["ms"].values())
+            line["kernel_time_share"] = {k: round(v / tot, 4) for k, v in prof["ms"].items() if v > 0}
+            line["profiled_pass_ms"] = tot
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, args.dim, args.cpu_tile_forwards)
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

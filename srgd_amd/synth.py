@@ -44,3 +44,16 @@ def synth_tensor(key: str, shape: Sequence[int], seed: int = 0) -> torch.Tensor:
 def synth_state_dict(schema: Mapping[str, Sequence[int]], seed: int = 0) -> Dict[str, torch.Tensor]:
     """schema: key -> shape (any iteration order)."""
     return {k: synth_tensor(k, schema[k], seed) for k in schema}
+
+
+def synthetic_lr_condition(index: int, lr_h: int, lr_w: int, scale: int = 4, seed_base: int = 1234) -> torch.Tensor:
+    """BASELINE.md section 4 synthetic input: seeded uint8 LR image -> PIL bicubic x``scale`` -> /255 float
+    [1,3,H,W], i.e. what ``inference.py:71-73`` hands to ``tiled_sample`` (T.Resize on a PIL image is
+    ``Image.resize(BICUBIC)``; ToTensor is /255)."""
+    import numpy as np
+    from PIL import Image
+    g = torch.Generator().manual_seed(seed_base + index)
+    lr = torch.randint(0, 256, (lr_h, lr_w, 3), dtype=torch.uint8, generator=g).numpy()
+    hr = Image.fromarray(lr, "RGB").resize((lr_w * scale, lr_h * scale), Image.BICUBIC)
+    arr = np.asarray(hr, dtype=np.uint8)
+    return torch.from_numpy(arr.copy()).permute(2, 0, 1).float().div(255.0).unsqueeze(0).contiguous()

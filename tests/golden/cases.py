@@ -52,15 +52,7 @@ def unet_mode_args(mode, case, cnd):
     raise KeyError(mode)
 
 
-def synthetic_lr_condition(index: int, lr_h: int, lr_w: int, scale: int = 4, seed_base: int = 1234):
-    """BASELINE.md section 4 synthetic input: uint8 LR image -> PIL bicubic x4 -> /255 float,
-    mirroring inference.py:71-73 (T.Resize on a PIL image == PIL.Image.resize(BICUBIC); ToTensor == /255)."""
-    from PIL import Image
-    g = torch.Generator().manual_seed(seed_base + index)
-    lr = torch.randint(0, 256, (lr_h, lr_w, 3), dtype=torch.uint8, generator=g).numpy()
-    hr = Image.fromarray(lr, "RGB").resize((lr_w * scale, lr_h * scale), Image.BICUBIC)
-    arr = np.asarray(hr, dtype=np.uint8)
-    return torch.from_numpy(arr.copy()).permute(2, 0, 1).float().div(255.0).unsqueeze(0).contiguous()
+from srgd_amd.synth import synthetic_lr_condition  # noqa: E402,F401  (shared with bench.py)
 
 
 def sampler_condition(case):

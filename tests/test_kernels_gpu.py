@@ -170,8 +170,9 @@ def test_conv_groupnorm_scale_shift_silu_residual(bf16, cfg):
     assert (s1 - want_s1).abs().max() <= 1e-3 * max(1.0, float(want_s1.abs().max()))
     d = to_dev_nhwc(conv_out, bf16)
     dres = to_dev_nhwc(res, bf16)
-    L().check(lib.srgd_k_groupnorm_silu(ptr(d), ptr(d), ptr(dres), ptr(part), B, H * W, cout, 8, ptr(gamma.to(DEV)),
-                                        ptr(beta.to(DEV)), ptr(ss.to(DEV)), int(bf16), stream()), "groupnorm")
+    dg, db_, dss = gamma.to(DEV), beta.to(DEV), ss.to(DEV)      # keep the device copies alive across the call
+    L().check(lib.srgd_k_groupnorm_silu(ptr(d), ptr(d), ptr(dres), ptr(part), B, H * W, cout, 8, ptr(dg), ptr(db_),
+                                        ptr(dss), int(bf16), stream()), "groupnorm")
     got = from_dev_nhwc(d)
     y = F.group_norm(conv_out if bf16 else ref_conv, 8, gamma, beta, eps=1e-5)
     y = y * (ss[:, :cout, None, None] + 1) + ss[:, cout:, None, None]
@@ -190,14 +191,16 @@ def test_rmsnorm(bf16, C):
     res = rnd(torch.randn(2, C, 8, 16, generator=g), bf16)
     d, dres = to_dev_nhwc(x, bf16), to_dev_nhwc(res, bf16)
     out = torch.empty_like(d)
-    L().check(lib.srgd_k_rmsnorm(ptr(d), ptr(out), ptr(dres), ptr(gain.reshape(-1).to(DEV)), 2 * 8 * 16, C, int(bf16),
+    dgain = gain.reshape(-1).to(DEV)
+    L().check(lib.srgd_k_rmsnorm(ptr(d), ptr(out), ptr(dres), ptr(dgain), 2 * 8 * 16, C, int(bf16),
                                  stream()), "rmsnorm")
     got = from_dev_nhwc(out)
     want = O.rms_norm(x, gain) + res
     assert (got - want).abs().max() <= tol(bf16, want)
     # in place, no residual
-    L().check(lib.srgd_k_rmsnorm(ptr(d), ptr(d), ptr(None), ptr(gain.reshape(-1).to(DEV)), 2 * 8 * 16, C, int(bf16),
+    L().check(lib.srgd_k_rmsnorm(ptr(d), ptr(d), ptr(None), ptr(dgain), 2 * 8 * 16, C, int(bf16),
                                  stream()), "rmsnorm")
+    torch.cuda.synchronize()
     assert (from_dev_nhwc(d) - O.rms_norm(x, gain)).abs().max() <= tol(bf16, want)
 
 
@@ -207,8 +210,9 @@ def test_linear_attention_core(bf16, hw):
     lib = L().lib()
     H, W = hw
     g = torch.Generator().manual_seed(7)
-    qkv = rnd(torch.randn(2, 384, H, W, generator=g) * 2, bf16)
+    qkv = torch.randn(2, 384, H, W, generator=g) * 2
     qkv[0, 128 + 5, 3, 3] = 9.0               # a spike in k: exercises the cross-chunk max merge
+    qkv = rnd(qkv, bf16)
     d = to_dev_nhwc(qkv, bf16)
     out = torch.empty(2, H, W, 128, device=DEV, dtype=d.dtype)
     L().check(lib.srgd_k_linear_attention(ptr(d), ptr(out), 2, H * W, 4, int(bf16), stream()), "linattn")
@@ -223,8 +227,9 @@ def test_full_attention_core(bf16, hw):
     lib = L().lib()
     H, W = hw
     g = torch.Generator().manual_seed(8)
-    qkv = rnd(torch.randn(2, 384, H, W, generator=g) * 1.5, bf16)
+    qkv = torch.randn(2, 384, H, W, generator=g) * 1.5
     qkv[1, :32, 2, 2] *= 6.0                  # one sharp query row: online-softmax rescale path
+    qkv = rnd(qkv, bf16)
     d = to_dev_nhwc(qkv, bf16)
     out = torch.empty(2, H, W, 128, device=DEV, dtype=d.dtype)
     L().check(lib.srgd_k_full_attention(ptr(d), ptr(out), 2, H * W, 4, int(bf16), stream()), "fullattn")
