@@ -59,86 +59,87 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
   const int CC = Cin / BKC;
   const int steps = p.KS * p.KS * CC;
 
-  // per-thread staging coordinates
-  int iy0[PER], ix0[PER], ib[PER], arow[PER], aq[PER];
-  bool mval[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int cid = tid + NT * i;
-    arow[i] = cid / CPR;
-    aq[i] = cid - arow[i] * CPR;
-    const int m = m0 + arow[i];
-    mval[i] = m < M;
-    const int mm = mval[i] ? m : 0;
-    const int b = mm / HWo, rem = mm - b * HWo;
-    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-    iy0[i] = oy * p.stride - p.pad;
-    ix0[i] = ox * p.stride - p.pad;
-    ib[i] = b * p.Hin * p.Win;
+  // Per-thread staging state: PER (<= 4) 16-byte chunks of A and of B per K-step.  Everything is a NAMED
+  // scalar/vector (token-pasted), never an indexed array: hipcc keeps indexed fragment arrays in scratch,
+  // which puts a vmcnt(0) behind every global load and serialises the pipeline.
+#define SRGD_DECL(I)                                                        \
+  int iy0_##I = 0, ix0_##I = 0, ib_##I = 0, arow_##I = 0, aq_##I = 0;       \
+  bool mval_##I = false, ok_##I = false;                                    \
+  Frag<T> ra_##I, rb_##I;                                                   \
+  if (I < PER) {                                                            \
+    const int cid = tid + NT * I;                                           \
+    arow_##I = cid / CPR;                                                   \
+    aq_##I = cid - arow_##I * CPR;                                          \
+    const int m = m0 + arow_##I;                                            \
+    mval_##I = m < M;                                                       \
+    const int mm = mval_##I ? m : 0;                                        \
+    const int b = mm / HWo, rem = mm - b * HWo;                             \
+    const int oy = rem / p.Wout, ox = rem - oy * p.Wout;                    \
+    iy0_##I = oy * p.stride - p.pad;                                        \
+    ix0_##I = ox * p.stride - p.pad;                                        \
+    ib_##I = b * p.Hin * p.Win;                                             \
   }
+  SRGD_DECL(0) SRGD_DECL(1) SRGD_DECL(2) SRGD_DECL(3)
+#undef SRGD_DECL
 
-  Frag<T> ra[PER], rb[PER];
-  auto load_step = [&](int s) {
-    const int tap = s / CC, cc = s - tap * CC;
-    const int dy = tap / p.KS, dx = tap - dy * p.KS;
-    const int c = cc * BKC;
-    const char* src;
-    int Cs, coff;
-    if (c < p.C0) { src = (const char*)p.in0; Cs = p.C0; coff = c; }
-    else { src = (const char*)p.in1; Cs = p.C1; coff = c - p.C0; }
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int iy = iy0[i] + dy, ix = ix0[i] + dx;
-      const bool ok = mval[i] && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-      Frag<T> z;
-      z.v = 0;
-      if (ok) {
-        const size_t off = ((size_t)(ib[i] + iy * p.Win + ix) * Cs + coff + aq[i] * EPC) * sizeof(T);
-        z = *reinterpret_cast<const Frag<T>*>(src + off);
-      }
-      ra[i] = z;
-      const size_t woff = ((size_t)(tap * p.CoutPad + n0 + arow[i]) * Cin + c + aq[i] * EPC) * sizeof(T);
-      rb[i] = *reinterpret_cast<const Frag<T>*>((const char*)p.w + woff);
-    }
-  };
-  auto store_step = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      *reinterpret_cast<Frag<T>*>(sA(buf) + arow[i] * STRIDE + aq[i] * 16) = ra[i];
-      *reinterpret_cast<Frag<T>*>(sB(buf) + arow[i] * STRIDE + aq[i] * 16) = rb[i];
-    }
-  };
+  // branch-free zero fill: out-of-image taps read a valid dummy address and are zeroed when staged to LDS
+#define SRGD_LOAD1(I)                                                                                              \
+  if (I < PER) {                                                                                                   \
+    const int iy_ = iy0_##I + dy_, ix_ = ix0_##I + dx_;                                                            \
+    ok_##I = mval_##I && iy_ >= 0 && iy_ < p.Hin && ix_ >= 0 && ix_ < p.Win;                                       \
+    const size_t off_ =                                                                                            \
+        ok_##I ? ((size_t)(ib_##I + iy_ * p.Win + ix_) * Cs_ + coff_ + aq_##I * EPC) * sizeof(T) : (size_t)0;      \
+    ra_##I = *reinterpret_cast<const Frag<T>*>(src_ + off_);                                                       \
+    const size_t woff_ = ((size_t)(tap_ * p.CoutPad + n0 + arow_##I) * Cin + c_ + aq_##I * EPC) * sizeof(T);       \
+    rb_##I = *reinterpret_cast<const Frag<T>*>((const char*)p.w + woff_);                                          \
+  }
+#define SRGD_LOAD_STEP(S)                                                    \
+  {                                                                          \
+    const int tap_ = (S) / CC, cc_ = (S)-tap_ * CC;                          \
+    const int dy_ = tap_ / p.KS, dx_ = tap_ - dy_ * p.KS;                    \
+    const int c_ = cc_ * BKC;                                                \
+    const bool first_ = c_ < p.C0;                                           \
+    const char* src_ = first_ ? (const char*)p.in0 : (const char*)p.in1;     \
+    const int Cs_ = first_ ? p.C0 : p.C1;                                    \
+    const int coff_ = first_ ? c_ : c_ - p.C0;                               \
+    SRGD_LOAD1(0) SRGD_LOAD1(1) SRGD_LOAD1(2) SRGD_LOAD1(3)                  \
+  }
+#define SRGD_STORE1(I, BUF)                                                                   \
+  if (I < PER) {                                                                              \
+    if (!ok_##I) ra_##I.v = 0; /* masked here, not at the load: keeps the loads in flight */  \
+    *reinterpret_cast<Frag<T>*>(sA(BUF) + arow_##I * STRIDE + aq_##I * 16) = ra_##I;          \
+    *reinterpret_cast<Frag<T>*>(sB(BUF) + arow_##I * STRIDE + aq_##I * 16) = rb_##I;          \
+  }
+#define SRGD_STORE_STEP(BUF) { SRGD_STORE1(0, BUF) SRGD_STORE1(1, BUF) SRGD_STORE1(2, BUF) SRGD_STORE1(3, BUF) }
 
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = 0;
+  f32x16 acc00 = 0, acc01 = 0, acc10 = 0, acc11 = 0;
 
-  load_step(0);
-  store_step(0);
+  SRGD_LOAD_STEP(0);
+  SRGD_STORE_STEP(0);
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < steps) load_step(s + 1);
+    if (s + 1 < steps) SRGD_LOAD_STEP(s + 1);
     const char* a_base = sA(buf) + (wm * 64 + r) * STRIDE + h * 16;
     const char* b_base = sB(buf) + (wn * 64 + r) * STRIDE + h * 16;
 #pragma unroll
     for (int s2 = 0; s2 < ROWB / 32; ++s2) {
-      Frag<T> fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *reinterpret_cast<const Frag<T>*>(a_base + i * 32 * STRIDE + s2 * 32);
-        fb[i] = *reinterpret_cast<const Frag<T>*>(b_base + i * 32 * STRIDE + s2 * 32);
-      }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) mma(acc[mi][ni], fa[mi], fb[ni]);
+      const Frag<T> fa0 = *reinterpret_cast<const Frag<T>*>(a_base + s2 * 32);
+      const Frag<T> fa1 = *reinterpret_cast<const Frag<T>*>(a_base + 32 * STRIDE + s2 * 32);
+      const Frag<T> fb0 = *reinterpret_cast<const Frag<T>*>(b_base + s2 * 32);
+      const Frag<T> fb1 = *reinterpret_cast<const Frag<T>*>(b_base + 32 * STRIDE + s2 * 32);
+      mma(acc00, fa0, fb0);
+      mma(acc01, fa0, fb1);
+      mma(acc10, fa1, fb0);
+      mma(acc11, fa1, fb1);
     }
-    if (s + 1 < steps) store_step(buf ^ 1);
+    if (s + 1 < steps) SRGD_STORE_STEP(buf ^ 1);
     __syncthreads();
   }
+#undef SRGD_LOAD1
+#undef SRGD_LOAD_STEP
+#undef SRGD_STORE1
+#undef SRGD_STORE_STEP
 
   // ------------------------------- epilogue -------------------------------------------
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -157,11 +158,12 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
+      const f32x16 accv = mi == 0 ? (ni == 0 ? acc00 : acc01) : (ni == 0 ? acc10 : acc11);
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int row = wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         const int m = m0 + row;
-        float v = acc[mi][ni][reg] + bias;
+        float v = accv[reg] + bias;
         if (m < M && cval) {
           s1[ni] += v;
           s2[ni] += v * v;
