@@ -27,13 +27,22 @@ extern "C" {
 int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int Hin, int Win, int KS, int stride,
                   int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
                   const void* residual, float* gn_partial, int groups, int is_bf16, void* stream);
+/* Same, with implementation choice and timing: impl 0 = what the engine would pick, 1 = generic implicit-GEMM
+ * kernel (conv_igemm.hip), 2 = the 3x3 bf16 halo/LDS-DMA kernel (conv3x3_bf16.hip; error if not eligible).
+ * iters > 0: the launch is repeated `iters` times between two HIP events on `stream`, *avg_ms = mean duration.
+ * *stats_slots (nullable) = slots per (sample, group) written to gn_partial - pass it to srgd_k_groupnorm_silu. */
+int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B, int Hin, int Win, int KS, int stride,
+                        int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
+                        const void* residual, float* gn_partial, int groups, int is_bf16, int impl, int iters,
+                        float* avg_ms, int* stats_slots, void* stream);
 
 /* GroupNorm (from the conv's partial statistics) -> x*(scale+1)+shift -> SiLU (+ residual).
  * replaces: Block.forward after the conv (model.py:250-259) and the ResnetBlock residual add (:285).
- * gamma, beta: device [C]; scale_shift: device [B][2C] (scale | shift) or NULL; in place if y == x. */
+ * gamma, beta: device [C]; scale_shift: device [B][2C] (scale | shift) or NULL; in place if y == x.
+ * gn_partial: [B][groups][nslots][2] as written by the conv (nslots from srgd_k_conv2d_timed; generic kernel: hw/128). */
 int srgd_k_groupnorm_silu(const void* x, void* y, const void* residual, const float* gn_partial, int B, int hw,
                           int C, int groups, const float* gamma, const float* beta, const float* scale_shift,
-                          int is_bf16, void* stream);
+                          int nslots, int is_bf16, void* stream);
 
 /* RMSNorm over channels * g * sqrt(C) (+ residual).  replaces: RMSNorm.forward (model.py:206-207). */
 int srgd_k_rmsnorm(const void* x, void* y, const void* residual, const float* g, int64_t npix, int C, int is_bf16,

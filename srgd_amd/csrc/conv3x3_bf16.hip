@@ -1,0 +1,330 @@
+// 3x3 / stride 1 / pad 1 convolution, bf16 in - fp32 accumulate - bf16 out, for gfx950 (MI355X).
+// This is the kernel that carries 89 % of the FLOPs of a ConditionalSRUnet evaluation
+// (reference: Block.proj model.py:246, the last-stage 3x3 "resample" convs :647,:668).
+//
+// Implicit GEMM, M = output pixels, N = Cout, K = 9 * Cin, laid out for CDNA4:
+//   * workgroup = 512 threads = 8 waves (4 along M x 2 along N), output tile = an 8 x 32 pixel patch
+//     (M = 256) x 128 output channels; each wave owns 2 patch rows x 64 channels = 2x2 MFMA 32x32 blocks.
+//   * K is walked channel-chunk-major: for every 32-channel chunk the (8+2) x (32+2) halo patch is
+//     staged ONCE in LDS and all 9 taps are served from it by shifting the read address - global->LDS
+//     traffic for A drops 9x/1.33 versus gathering a fresh A tile per tap.
+//   * all staging is LDS-DMA (buffer_load ... lds, 16 B per lane, no VGPR round trip): the A patch
+//     (out-of-image halo pixels are zero-filled by the buffer descriptor's range check), and per K-step one
+//     8 KB weight tile, pre-swizzled on the host into its LDS image so the copy is linear and coalesced.
+//     A is double-buffered, B runs in a 3-deep ring; loads stay in flight across barriers
+//     (counted s_waitcnt vmcnt(N) + raw s_barrier, one barrier per K-step).
+//   * 64-byte LDS rows are XOR-swizzled (chunk ^= (row >> 2) & 3): ds_read_b128 is conflict-free for the
+//     MFMA operand pattern (16 consecutive rows, same chunk) at every tap shift.
+//   * epilogue: + bias, optional per-(sample, group) partial sum / sum of squares for the GroupNorm that
+//     follows (fixed-order, deterministic), bf16 store.
+//   * blockIdx is remapped so each XCD (private L2) gets a contiguous band of tiles (halo reuse in L2).
+#include "kernels.hpp"
+
+namespace srgd {
+namespace {
+
+constexpr int PH = 8, PW = 32;                 // output patch
+constexpr int HP = PH + 2, WP = PW + 2;        // halo patch: 10 x 34 = 340 pixels
+constexpr int KC = 32;                         // channels per chunk (64 B rows)
+constexpr int BN3 = 128;
+constexpr int NT3 = 512;
+constexpr int A_BYTES = 24 * 1024;             // 24 wave-instructions x 1 KiB (340 px * 64 B = 21,760 used)
+constexpr int B_BYTES = BN3 * KC * 2;          // 8 KiB
+constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 73,728
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset) {
+  // LDS destination = wave-uniform base + lane * 16
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)lds_wave_base, 16, voffset, 0, 0, 0);
+}
+
+struct Conv3Args {
+  const bf16* in0; const bf16* in1; int C0, C1;
+  int B, H, W;
+  const bf16* w;          // packed [tap][cc][ntile][128 rows][4 swizzled chunks][8]
+  const float* bias;
+  int Cout;
+  bf16* out;
+  float* gn_partial; int groups;
+};
+
+#define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+// Raw barrier (no vmcnt drain: LDS-DMA prefetches stay in flight) fenced for the instruction scheduler:
+// s_barrier is IntrNoMem to LLVM, so without sched_barrier(0) the machine scheduler hoists the next step's
+// ds_reads above it - a read of a buffer whose DMA other waves have not yet waited for.
+#define BARRIER()                        \
+  do {                                   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+
+template <bool STATS>
+__global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- tile coordinates (XCD-aware remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous band)
+  const int n_tiles = p.Cout / BN3;
+  const int tiles_x = p.W / PW, tiles_y = p.H / PH;
+  const int m_tiles = p.B * tiles_y * tiles_x;
+  const int nwg = m_tiles * n_tiles;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, rem = nwg & 7, x = wg & 7, k = wg >> 3;
+    wg = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + k;
+  }
+  const int nt = wg % n_tiles;
+  const int mt = wg / n_tiles;
+  const int b = mt / (tiles_y * tiles_x);
+  const int trem = mt - b * tiles_y * tiles_x;
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int y0 = ty * PH, x0 = tx * PW;
+  const int Cin = p.C0 + p.C1;
+  const int CC = Cin / KC;
+  const int S = CC * 9;
+
+  // ---- A staging: 24 wave-instructions per chunk; wave w issues pieces w, w+8, w+16 (pieces >= 22 are all-zero)
+  // per-lane pixel offset (y*W+x) or -1, and source chunk (0..3) of its three pieces (named scalars: see
+  // conv_igemm.hip on why staging state must not live in indexed arrays)
+#define SRGD_A_DECL(J)                                                        \
+  int a_pix##J, a_sub##J;                                                     \
+  {                                                                           \
+    const int g = (wave + 8 * J) * 64 + lane; /* 16-byte chunk in the image */ \
+    const int P = g >> 2;                                                     \
+    const int py = P / WP, px = P - py * WP;                                  \
+    const int y = y0 + py - 1, x = x0 + px - 1;                               \
+    const bool ok = P < HP * WP && y >= 0 && y < p.H && x >= 0 && x < p.W;    \
+    a_pix##J = ok ? y * p.W + x : -1;                                         \
+    a_sub##J = (g & 3) ^ ((P >> 2) & 3);                                      \
+  }
+  SRGD_A_DECL(0) SRGD_A_DECL(1) SRGD_A_DECL(2)
+#undef SRGD_A_DECL
+  const size_t img_elems0 = (size_t)p.H * p.W * p.C0, img_elems1 = (size_t)p.H * p.W * p.C1;
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (size_t)b * img_elems0), 0, (int)(img_elems0 * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.in1 ? p.in1 + (size_t)b * img_elems1 : p.in0), 0, p.in1 ? (int)(img_elems1 * 2) : 0, 0x00020000);
+  const size_t w_tile_stride = (size_t)n_tiles * B_BYTES;             // bytes between consecutive (tap, cc) tiles
+  const char* w_base = (const char*)p.w + (size_t)nt * B_BYTES;
+  const __amdgpu_buffer_rsrc_t rsw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, (int)((size_t)(9 * CC - 1) * w_tile_stride + B_BYTES), 0x00020000);
+
+  char* const sA0 = smem;
+  char* const sB0 = smem + 2 * A_BYTES;
+
+  auto issue_a = [&](int cc, int j, int a_pix, int a_sub) {
+    const int c = cc * KC;
+    const bool first = c < p.C0;
+    const int Cs = first ? p.C0 : p.C1;
+    const int coff = first ? c : c - p.C0;
+    const int voff = a_pix >= 0 ? (a_pix * Cs + coff + a_sub * 8) * 2 : 0x7ffffff0;
+    char* dst = sA0 + (cc & 1) * A_BYTES + (wave + 8 * j) * 1024;
+    if (first) dma16(rs0, dst, voff);
+    else dma16(rs1, dst, voff);
+  };
+#define issue_a_piece(CCV, J) issue_a(CCV, J, (J) == 0 ? a_pix0 : ((J) == 1 ? a_pix1 : a_pix2), (J) == 0 ? a_sub0 : ((J) == 1 ? a_sub1 : a_sub2))
+  auto issue_b = [&](int s) {               // K-step s = cc*9 + tap  ->  weight tile (tap, cc)
+    const int cc = s / 9, tap = s - cc * 9;
+    const int voff = (int)((size_t)(tap * CC + cc) * w_tile_stride) + tid * 16;
+    dma16(rsw, sB0 + (s % 3) * B_BYTES + wave * 1024, voff);
+  };
+
+  // ---- operand read addresses
+  // B: row n = wn*64 + j*32 + r, logical chunk c = 2*s2 + h  ->  byte n*64 + ((c ^ ((n>>2)&3)) << 4)
+  const int bn0 = wn * 64 + r, bn1 = bn0 + 32;
+  const int b_off0 = bn0 * 64 + ((h ^ ((bn0 >> 2) & 3)) << 4);
+  const int b_off1 = bn1 * 64 + ((h ^ ((bn1 >> 2) & 3)) << 4);
+  const int a_row0 = (2 * wm) * WP + r;         // patch pixel of (m-subtile 0, tap (0,0)); + i*WP + dy*WP + dx
+
+  f32x16 acc00 = 0, acc01 = 0, acc10 = 0, acc11 = 0;
+
+  // ---- prologue: A(0) and B[0], B[1]
+  issue_a_piece(0, 0);
+  issue_a_piece(0, 1);
+  issue_a_piece(0, 2);
+  issue_b(0);
+  if (S > 1) issue_b(1);
+  if (S > 1) WAIT_VM(1); else WAIT_VM(0);
+  BARRIER();
+
+  auto compute = [&](int cc, int tap, int s) {
+    const char* A = sA0 + (cc & 1) * A_BYTES;
+    const char* Bt = sB0 + (s % 3) * B_BYTES;
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int P0 = a_row0 + dy * WP + dx;
+    const int P1 = P0 + WP;
+    const int a0 = P0 * 64 + ((h ^ ((P0 >> 2) & 3)) << 4);
+    const int a1 = P1 * 64 + ((h ^ ((P1 >> 2) & 3)) << 4);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int x = s2 << 5;                   // k16 step toggles bit 1 of the chunk index = byte bit 5
+      const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + (a0 ^ x));
+      const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + (a1 ^ x));
+      const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(Bt + (b_off0 ^ x));
+      const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(Bt + (b_off1 ^ x));
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc11, 0, 0, 0);
+    }
+  };
+
+  // ---- main loop.  Per K-step: [issue A piece of the next chunk (taps 0..2)] [issue B[s+2]] compute(s)
+  //      wait until B[s+1] (and, implicitly, everything older) has landed, barrier.
+  for (int cc = 0; cc < CC - 1; ++cc) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int s = cc * 9 + tap;
+      if (tap < 3) issue_a_piece(cc + 1, tap);
+      issue_b(s + 2);                            // s + 2 < S always holds here (cc < CC-1)
+      compute(cc, tap, s);
+      if (tap < 3) WAIT_VM(2); else WAIT_VM(1);
+      BARRIER();
+    }
+  }
+  {
+    const int cc = CC - 1;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int s = cc * 9 + tap;
+      if (tap < 7) issue_b(s + 2);
+      compute(cc, tap, s);
+      if (tap < 7) WAIT_VM(1); else WAIT_VM(0);
+      if (tap < 8) BARRIER();
+    }
+  }
+
+#undef issue_a_piece
+  // ------------------------------- epilogue -------------------------------------------
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int col = nt * BN3 + wn * 64 + ni * 32 + r;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const f32x16 accv = mi == 0 ? (ni == 0 ? acc00 : acc01) : (ni == 0 ? acc10 : acc11);
+      const int y = y0 + 2 * wm + mi;
+      bf16* orow = p.out + ((size_t)(b * p.H + y) * p.W + x0) * p.Cout + col;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int px = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const float v = accv[reg] + bias;
+        if (STATS) {
+          s1[ni] += v;
+          s2[ni] += v * v;
+        }
+        orow[(size_t)px * p.Cout] = (bf16)v;
+      }
+    }
+  }
+  if (STATS) {
+    BARRIER();                                            // every wave is done reading LDS operands
+    float* cs = reinterpret_cast<float*>(smem);           // [4 (wm)][128][2]
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const float t1 = s1[ni] + __shfl_xor(s1[ni], 32, 64);
+      const float t2 = s2[ni] + __shfl_xor(s2[ni], 32, 64);
+      if (h == 0) {
+        const int cl = wn * 64 + ni * 32 + r;
+        cs[(wm * BN3 + cl) * 2 + 0] = t1;
+        cs[(wm * BN3 + cl) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    const int cpg = p.Cout / p.groups;                    // multiple of 16, divides or is a multiple of 128
+    const int g_in_tile = cpg >= BN3 ? 1 : BN3 / cpg;
+    if (tid < g_in_tile) {
+      const int span = cpg >= BN3 ? BN3 : cpg;
+      float a1 = 0.f, a2 = 0.f;
+      for (int c = 0; c < span; ++c) {
+        const int cl = tid * span + c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          a1 += cs[(k * BN3 + cl) * 2 + 0];
+          a2 += cs[(k * BN3 + cl) * 2 + 1];
+        }
+      }
+      // slot layout: [b][group][m-tile within image (x n-tiles per group when a group spans several)]
+      const int tiles_per_group = cpg >= BN3 ? cpg / BN3 : 1;
+      const int g = cpg >= BN3 ? (nt * BN3) / cpg : (nt * BN3) / cpg + tid;
+      const int nslots = tiles_y * tiles_x * tiles_per_group;
+      const int slot = trem * tiles_per_group + (cpg >= BN3 ? nt % tiles_per_group : 0);
+      float* dst = p.gn_partial + ((size_t)(b * p.groups + g) * nslots + slot) * 2;
+      dst[0] = a1;
+      dst[1] = a2;
+    }
+  }
+}
+
+}  // namespace
+
+bool conv3x3_bf16_eligible(const ConvArgs& a) {
+  if (a.KS != 3 || a.stride != 1 || a.pad != 1 || a.mode != CONV_PLAIN || a.residual) return false;
+  if (a.C0 % KC || a.C1 % KC || a.Cout % BN3 || a.Cout != a.CoutPad) return false;
+  if (a.Hin % PH || a.Win % PW) return false;
+  if (a.gn_partial) {
+    const int cpg = a.Cout / a.groups;
+    if (a.Cout % a.groups || cpg % 16) return false;
+    if (!(BN3 % cpg == 0 || cpg % BN3 == 0)) return false;
+  }
+  // per-image byte offsets must fit the 32-bit buffer offset
+  if ((size_t)a.Hin * a.Win * (size_t)std::max(a.C0, a.C1) * 2 >= (1ull << 31)) return false;
+  if ((size_t)9 * ((a.C0 + a.C1) / KC) * (a.Cout / BN3) * B_BYTES >= (1ull << 31)) return false;
+  return true;
+}
+
+int conv3x3_bf16_stats_slots(const ConvArgs& a) {
+  if (a.groups <= 0) return 0;
+  const int cpg = a.Cout / a.groups;
+  return (a.Hin / PH) * (a.Win / PW) * (cpg >= BN3 ? cpg / BN3 : 1);
+}
+
+// Host-side packing: OIHW fp32 -> [tap][cc][ntile][128 rows][64 B swizzled] bf16 (the LDS image of each K-step tile).
+void pack_conv3x3_bf16(const float* src_oihw, int Cin, int Cout, std::vector<unsigned short>& out,
+                       unsigned short (*to_bf16)(float)) {
+  const int CC = Cin / KC, NTL = Cout / BN3;
+  out.assign((size_t)9 * CC * NTL * BN3 * KC, 0);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int cc = 0; cc < CC; ++cc)
+      for (int nt = 0; nt < NTL; ++nt) {
+        unsigned short* tile = out.data() + ((size_t)(tap * CC + cc) * NTL + nt) * BN3 * KC;
+        for (int n = 0; n < BN3; ++n)
+          for (int c = 0; c < 4; ++c) {
+            const int cs = c ^ ((n >> 2) & 3);                       // stored chunk position
+            for (int e = 0; e < 8; ++e) {
+              const int ci = cc * KC + c * 8 + e, o = nt * BN3 + n;
+              const float v = src_oihw[(((size_t)o * Cin + ci) * 3 + tap / 3) * 3 + tap % 3];
+              tile[n * KC + cs * 8 + e] = to_bf16(v);
+            }
+          }
+      }
+}
+
+int conv3x3_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st) {
+  if (!conv3x3_bf16_eligible(a)) SRGD_FAIL("conv3x3_bf16: shape not eligible");
+  Conv3Args p;
+  p.in0 = (const bf16*)a.in0; p.in1 = (const bf16*)a.in1; p.C0 = a.C0; p.C1 = a.C1;
+  p.B = a.B; p.H = a.Hin; p.W = a.Win; p.w = (const bf16*)packed_w; p.bias = a.bias; p.Cout = a.Cout;
+  p.out = (bf16*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
+  const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set = true;
+  }
+  if (a.gn_partial) hipLaunchKernelGGL((conv3x3_bf16_kernel<true>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);
+  else hipLaunchKernelGGL((conv3x3_bf16_kernel<false>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace srgd

@@ -17,7 +17,7 @@ static thread_local std::string g_err;
 void set_error(const std::string& m) { g_err = m; }
 const char* last_error() { return g_err.c_str(); }
 
-static uint16_t f32_to_bf16_host(float f) {
+unsigned short f32_to_bf16_host(float f) {
   uint32_t u;
   std::memcpy(&u, &f, 4);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
@@ -91,6 +91,7 @@ struct ConvW {
   int Cin = 0, Cout = 0, CoutPad = 0, KS = 1, stride = 1, pad = 0, mode = CONV_PLAIN, kind = CK_NORMAL;
   int wi = -1, bi = -1;       // indices of the host tensors
   void* w = nullptr;
+  void* w3 = nullptr;         // conv3x3_bf16 fast-path packing (bf16 mode, eligible channel counts)
   float* bias = nullptr;
 };
 struct Lin {
@@ -188,6 +189,8 @@ struct srgd_engine {
   AttnW mid_attn;
   std::vector<ResW*> all_rb;
   int ss_stride = 0;
+  int stats_slots = 0;          // slots per (sample, group) the last conv wrote into gn_partial
+  bool force_generic_conv = false;
 
   Pool pool;
   float* gn_partial = nullptr; size_t gn_partial_cap = 0;
@@ -361,6 +364,11 @@ int pack_conv(srgd_engine* e, ConvW& c) {
   pack_conv_weights(e->wt[c.wi].data.data(), hb, c.kind, c.Cin, c.Cout, c.CoutPad, c.KS, e->bf16, packed, bias);
   SRGD_TRY(upload(e, packed.data(), packed.size(), &c.w));
   if (hb) SRGD_TRY(upload(e, bias.data(), bias.size() * 4, (void**)&c.bias));
+  if (e->bf16 && c.kind == CK_NORMAL && c.KS == 3 && c.Cin % 32 == 0 && c.Cout % 128 == 0) {
+    std::vector<unsigned short> p3;
+    pack_conv3x3_bf16(e->wt[c.wi].data.data(), c.Cin, c.Cout, p3, f32_to_bf16_host);
+    SRGD_TRY(upload(e, p3.data(), p3.size() * 2, &c.w3));
+  }
   return 0;
 }
 
@@ -422,6 +430,11 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
   if (C0 + C1 != c.Cin) SRGD_FAIL("internal: conv input channel mismatch");
   Prof p(e, KC_CONV, x.st);
   if (e->prof_on) e->conv_flops += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
+  if (e->bf16 && c.w3 && !e->force_generic_conv && conv3x3_bf16_eligible(a)) {
+    if (stats) e->stats_slots = conv3x3_bf16_stats_slots(a);
+    return conv3x3_bf16(a, c.w3, x.st);
+  }
+  if (stats) e->stats_slots = (a.Hout * a.Wout) / conv_tile_m();
   return conv_igemm(a, e->bf16, x.st);
 }
 
@@ -430,7 +443,7 @@ int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_
   srgd_engine* e = x.e;
   Prof p(e, KC_GN, x.st);
   GnFinalizeArgs f;
-  f.partial = e->gn_partial; f.nslots = hw / conv_tile_m(); f.B = x.nb; f.C = C; f.groups = e->cfg.groups; f.hw = hw;
+  f.partial = e->gn_partial; f.nslots = e->stats_slots; f.B = x.nb; f.C = C; f.groups = e->cfg.groups; f.hw = hw;
   f.gamma = gamma; f.beta = beta;
   f.ss_table = ss_offset >= 0 ? x.table : nullptr; f.ss_rows = x.rows; f.step_ptr = nullptr; f.step_mul = 0;
   f.ss_stride = e->ss_stride; f.ss_offset = ss_offset < 0 ? 0 : ss_offset; f.eps = 1e-5f;

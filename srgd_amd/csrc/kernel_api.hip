@@ -22,16 +22,17 @@ __global__ void iota_rows(int* r, int n) {
 
 extern "C" {
 
-int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int Hin, int Win, int KS, int stride,
-                  int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
-                  const void* residual, float* gn_partial, int groups, int is_bf16, void* stream) {
+int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B, int Hin, int Win, int KS, int stride,
+                        int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
+                        const void* residual, float* gn_partial, int groups, int is_bf16, int impl, int iters,
+                        float* avg_ms, int* stats_slots, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int Cin = C0 + C1;
   const int CoutPad = cdiv(Cout, conv_tile_n()) * conv_tile_n();
   std::vector<unsigned char> packed;
   std::vector<float> bias;
   pack_conv_weights(weight_oihw_host, bias_host, kind, Cin, Cout, CoutPad, KS, is_bf16 != 0, packed, bias);
-  DevBuf dw, db;
+  DevBuf dw, db, dw3;
   SRGD_TRY(dw.alloc(packed.size()));
   SRGD_HIP(hipMemcpy(dw.p, packed.data(), packed.size(), hipMemcpyHostToDevice));
   if (bias_host) {
@@ -45,23 +46,54 @@ int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int H
   a.KS = KS; a.stride = stride; a.pad = pad; a.w = dw.p; a.bias = (const float*)db.p; a.Cout = Cout; a.CoutPad = CoutPad;
   a.out = out; a.residual = residual; a.mode = kind == 2 ? CONV_PIXEL_SHUFFLE_SILU : CONV_PLAIN;
   a.gn_partial = gn_partial; a.groups = groups;
-  SRGD_TRY(conv_igemm(a, is_bf16 != 0, st));
+  const bool fast = impl != 1 && is_bf16 && kind == 0 && conv3x3_bf16_eligible(a);
+  if (impl == 2 && !fast) SRGD_FAIL("srgd_k_conv2d: the conv3x3_bf16 fast path does not cover this shape");
+  if (fast) {
+    std::vector<unsigned short> p3;
+    pack_conv3x3_bf16(weight_oihw_host, Cin, Cout, p3, f32_to_bf16_host);
+    SRGD_TRY(dw3.alloc(p3.size() * 2));
+    SRGD_HIP(hipMemcpy(dw3.p, p3.data(), p3.size() * 2, hipMemcpyHostToDevice));
+  }
+  if (stats_slots) *stats_slots = fast ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
+  auto run = [&]() -> int { return fast ? conv3x3_bf16(a, dw3.p, st) : conv_igemm(a, is_bf16 != 0, st); };
+  SRGD_TRY(run());
   SRGD_HIP(hipStreamSynchronize(st));
+  if (iters > 0 && avg_ms) {
+    hipEvent_t e0, e1;
+    SRGD_HIP(hipEventCreate(&e0));
+    SRGD_HIP(hipEventCreate(&e1));
+    SRGD_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) SRGD_TRY(run());
+    SRGD_HIP(hipEventRecord(e1, st));
+    SRGD_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SRGD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
   return 0;
+}
+
+int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int Hin, int Win, int KS, int stride,
+                  int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
+                  const void* residual, float* gn_partial, int groups, int is_bf16, void* stream) {
+  return srgd_k_conv2d_timed(in0, in1, C0, C1, B, Hin, Win, KS, stride, pad, kind, weight_oihw_host, bias_host, Cout,
+                             out, residual, gn_partial, groups, is_bf16, 0, 0, nullptr, nullptr, stream);
 }
 
 int srgd_k_groupnorm_silu(const void* x, void* y, const void* residual, const float* gn_partial, int B, int hw,
                           int C, int groups, const float* gamma, const float* beta, const float* scale_shift,
-                          int is_bf16, void* stream) {
+                          int nslots, int is_bf16, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (hw % conv_tile_m() != 0) SRGD_FAIL("groupnorm: hw must be a multiple of 128");
+  if (nslots <= 0) SRGD_FAIL("groupnorm: nslots must be the slot count the producing conv reported");
   DevBuf cA, cB, rows;
   SRGD_TRY(cA.alloc((size_t)B * C * 4));
   SRGD_TRY(cB.alloc((size_t)B * C * 4));
   SRGD_TRY(rows.alloc((size_t)B * 4));
   hipLaunchKernelGGL(iota_rows, dim3(cdiv(B, 256)), dim3(256), 0, st, (int*)rows.p, B);
   GnFinalizeArgs f;
-  f.partial = gn_partial; f.nslots = hw / conv_tile_m(); f.B = B; f.C = C; f.groups = groups; f.hw = hw;
+  f.partial = gn_partial; f.nslots = nslots; f.B = B; f.C = C; f.groups = groups; f.hw = hw;
   f.gamma = gamma; f.beta = beta; f.ss_table = scale_shift; f.ss_rows = (const int*)rows.p; f.step_ptr = nullptr;
   f.step_mul = 0; f.ss_stride = 2 * C; f.ss_offset = 0; f.eps = 1e-5f; f.coefA = (float*)cA.p; f.coefB = (float*)cB.p;
   SRGD_TRY(gn_finalize(f, st));

@@ -34,6 +34,16 @@ void pack_conv_weights(const float* src_oihw, const float* bias_in, int kind, in
                        bool to_bf16, std::vector<unsigned char>& packed_out, std::vector<float>& bias_out);
 const char* last_error();
 
+// ---------------------------------------------------------------- conv3x3_bf16.hip
+// Fast path for the 3x3/s1/p1 bf16 convolutions (halo patch in LDS, LDS-DMA staging).  Takes the same
+// ConvArgs (a.w is ignored) plus weights packed by pack_conv3x3_bf16.
+bool conv3x3_bf16_eligible(const ConvArgs& a);
+int conv3x3_bf16_stats_slots(const ConvArgs& a);
+void pack_conv3x3_bf16(const float* src_oihw, int Cin, int Cout, std::vector<unsigned short>& out,
+                       unsigned short (*to_bf16)(float));
+int conv3x3_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st);
+unsigned short f32_to_bf16_host(float f);
+
 // ---------------------------------------------------------------- norm_act.hip
 struct GnFinalizeArgs {
   const float* partial;   // [B][groups][nslots][2]

@@ -51,7 +51,7 @@ def tol(bf16, ref, k=1.0):
     return (1.2e-2 if bf16 else 2e-5) * scale * k
 
 
-def run_conv(x0, x1, w, b, *, ks, stride, pad, kind, bf16, residual=None, groups=0, out_shape=None):
+def run_conv(x0, x1, w, b, *, ks, stride, pad, kind, bf16, residual=None, groups=0, impl=0, want_slots=False):
     lib = L().lib()
     B, C0, H, W = x0.shape
     C1 = 0 if x1 is None else x1.shape[1]
@@ -70,9 +70,15 @@ def run_conv(x0, x1, w, b, *, ks, stride, pad, kind, bf16, residual=None, groups
         part = torch.full((B, groups, ho * wo // 128, 2), float("nan"), device=DEV)
     wh = w.contiguous().float()
     bh = None if b is None else b.contiguous().float()
-    L().check(lib.srgd_k_conv2d(ptr(d0), ptr(d1), C0, C1, B, H, W, ks, stride, pad, kind, ptr(wh), ptr(bh), cout,
-                                ptr(out), ptr(dres), ptr(part), groups, int(bf16), stream()), "srgd_k_conv2d")
+    slots = C.c_int()
+    L().check(lib.srgd_k_conv2d_timed(ptr(d0), ptr(d1), C0, C1, B, H, W, ks, stride, pad, kind, ptr(wh), ptr(bh), cout,
+                                      ptr(out), ptr(dres), ptr(part), groups, int(bf16), impl, 0, None,
+                                      C.byref(slots), stream()), "srgd_k_conv2d_timed")
     torch.cuda.synchronize()
+    if groups:
+        part = part.reshape(-1)[:B * groups * slots.value * 2].reshape(B, groups, slots.value, 2)
+    if want_slots:
+        return from_dev_nhwc(out), part, slots.value
     return from_dev_nhwc(out), part
 
 
@@ -161,7 +167,7 @@ def test_conv_groupnorm_scale_shift_silu_residual(bf16, cfg):
     gamma, beta = 1 + 0.2 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
     ss = 0.5 * torch.randn(B, 2 * cout, generator=g)
     res = rnd(torch.randn(B, cout, H, W, generator=g), bf16)
-    conv_out, part = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=bf16, groups=8)
+    conv_out, part, nslots = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=bf16, groups=8, want_slots=True)
     assert torch.isfinite(part).all(), "conv epilogue did not fill every GroupNorm partial slot"
     ref_conv = F.conv2d(x, w, b, padding=1)
     # statistics must come from the fp32 accumulators
@@ -171,8 +177,9 @@ def test_conv_groupnorm_scale_shift_silu_residual(bf16, cfg):
     d = to_dev_nhwc(conv_out, bf16)
     dres = to_dev_nhwc(res, bf16)
     dg, db_, dss = gamma.to(DEV), beta.to(DEV), ss.to(DEV)      # keep the device copies alive across the call
+    part = part.contiguous()
     L().check(lib.srgd_k_groupnorm_silu(ptr(d), ptr(d), ptr(dres), ptr(part), B, H * W, cout, 8, ptr(dg), ptr(db_),
-                                        ptr(dss), int(bf16), stream()), "groupnorm")
+                                        ptr(dss), nslots, int(bf16), stream()), "groupnorm")
     got = from_dev_nhwc(d)
     y = F.group_norm(conv_out if bf16 else ref_conv, 8, gamma, beta, eps=1e-5)
     y = y * (ss[:, :cout, None, None] + 1) + ss[:, cout:, None, None]
@@ -237,6 +244,53 @@ def test_full_attention_core(bf16, hw):
     got = from_dev_nhwc(out)
     want = O.full_attention_core(qkv, 4, 32)
     assert (got - want).abs().max() <= tol(bf16, want)
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 0, 128, 8, 32), (1, 64, 32, 256, 16, 64), (3, 128, 0, 128, 32, 32),
+                                 (1, 256, 128, 1024, 8, 32), (1, 32, 0, 2048, 8, 32)],
+                         ids=lambda s: "B%d_C%d+%d_Cout%d_%dx%d" % s)
+def test_conv3x3_bf16_fast_path_borders_sources_stats(cfg):
+    # conv3x3_bf16.hip (halo patch in LDS, LDS-DMA staging, zero fill by the buffer range check) against the
+    # oracle's conv2d on bf16-rounded operands, incl. tiles touching every image border and two sources.
+    B, c0, c1, cout, H, W = cfg
+    lib = L().lib()
+    g = torch.Generator().manual_seed(11)
+    x0 = rnd(torch.randn(B, c0, H, W, generator=g), True)
+    x1 = rnd(torch.randn(B, c1, H, W, generator=g), True) if c1 else None
+    w = rnd(torch.randn(cout, c0 + c1, 3, 3, generator=g) / (3 * (c0 + c1) ** 0.5), True)
+    b = torch.randn(cout, generator=g)
+    groups = 8 if cout <= 1024 else 0
+    got, part, nslots = run_conv(x0, x1, w, b, ks=3, stride=1, pad=1, kind=0, bf16=True, groups=groups, impl=2,
+                                 want_slots=True)
+    xin = x0 if x1 is None else torch.cat((x0, x1), 1)
+    want = F.conv2d(xin, w, b, padding=1)
+    assert (got - want).abs().max() <= tol(True, want)
+    if groups:
+        assert torch.isfinite(part).all()
+        cpg = cout // groups
+        s = part.sum(2).cpu()
+        want_s1 = want.reshape(B, groups, -1).sum(-1)
+        want_s2 = (want ** 2).reshape(B, groups, -1).sum(-1)
+        assert (s[..., 0] - want_s1).abs().max() <= 2e-3 * max(1.0, float(want_s1.abs().max()))
+        assert (s[..., 1] - want_s2).abs().max() <= 2e-3 * float(want_s2.abs().max())
+        # and the whole Block: GroupNorm + SiLU on top of those statistics
+        gamma, beta = 1 + 0.2 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
+        d = to_dev_nhwc(got, True)
+        dg, db_ = gamma.to(DEV), beta.to(DEV)
+        part = part.contiguous()
+        L().check(lib.srgd_k_groupnorm_silu(ptr(d), ptr(d), ptr(None), ptr(part), B, H * W, cout, groups, ptr(dg),
+                                            ptr(db_), ptr(None), nslots, 1, stream()), "groupnorm")
+        y = F.silu(F.group_norm(got, groups, gamma, beta, eps=1e-5))
+        assert (from_dev_nhwc(d) - y).abs().max() <= tol(True, y, k=2.0)
+
+
+def test_conv3x3_bf16_integer_exact():
+    g = torch.Generator().manual_seed(12)
+    x = torch.randint(-3, 4, (2, 64, 16, 64), generator=g).float()
+    w = torch.randint(-2, 3, (128, 64, 3, 3), generator=g).float()
+    b = torch.randint(-4, 5, (128,), generator=g).float()
+    got, _ = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=True, impl=2)
+    assert torch.equal(got, F.conv2d(x, w, b, padding=1).to(torch.bfloat16).float())
 
 
 def test_conv_rejects_bad_shapes():
