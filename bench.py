@@ -51,7 +51,6 @@ def parse():
 
 
 def build_sampler(dim, device, world, rank):
-    import torch.distributed as dist
     from srgd_amd.config import load_config
     from srgd_amd.model import get_model
     from srgd_amd.synth import synth_state_dict
@@ -62,18 +61,8 @@ def build_sampler(dim, device, world, rank):
     schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
     if world > 1:
         # rank 0 owns the checkpoint; everyone else receives it over RCCL/xGMI as one flat buffer
-        numel = sum(int(torch.Size(s).numel()) for s in schema.values())
-        flat = torch.empty(numel, device=device)
-        if rank == 0:
-            sd = synth_state_dict(schema, seed=0)
-            flat.copy_(torch.cat([sd[k].reshape(-1) for k in schema]))
-        dist.broadcast(flat, src=0)
-        sd, o = {}, 0
-        host = flat.cpu()
-        for k, s in schema.items():
-            n = int(torch.Size(s).numel())
-            sd[k] = host[o:o + n].reshape(s).clone()
-            o += n
+        from srgd_amd.parallel import broadcast_state_dict
+        sd = broadcast_state_dict(schema, synth_state_dict(schema, seed=0) if rank == 0 else None, src=0, device=device)
     else:
         sd = synth_state_dict(schema, seed=0)
     sampler.load_state_dict(sd, strict=True)
@@ -142,18 +131,16 @@ def main():
     t0 = time.perf_counter()
     outs = [run(args.warmup + i) for i in range(args.steps)]
     if dist:
-        stack = torch.cat(outs, 0)
-        gathered = [torch.empty_like(stack) for _ in range(world)] if rank == 0 else None
-        dist.gather(stack, gathered, dst=0)
+        from srgd_amd.parallel import gather_outputs
+        gathered = gather_outputs(torch.cat(outs, 0), dst=0)          # HR tiles -> rank 0 (12.6 MB each)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        from srgd_amd.parallel import max_over_ranks
+        dt = max_over_ranks(dt, device)
     assert all(torch.isfinite(o).all() for o in outs)
 
     if rank == 0:
