@@ -201,16 +201,20 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
 
 #undef issue_a_piece
   // ------------------------------- epilogue -------------------------------------------
+  // The accumulator layout (lane = output channel, register = pixel) would store 2 bytes per lane; instead the
+  // tile is transposed through LDS ([256 pixels][128 ch] bf16, rows padded to 272 B) and written out as whole
+  // 256-byte channel rows, 16 B per lane - 8 store instructions per thread instead of 64.
+  constexpr int EROW = BN3 * 2 + 16;
+  BARRIER();                                              // every wave is done reading the operand buffers
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
-    const int col = nt * BN3 + wn * 64 + ni * 32 + r;
-    const float bias = p.bias ? p.bias[col] : 0.f;
+    const int cl = wn * 64 + ni * 32 + r;                 // column inside the tile
+    const float bias = p.bias ? p.bias[nt * BN3 + cl] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const f32x16 accv = mi == 0 ? (ni == 0 ? acc00 : acc01) : (ni == 0 ? acc10 : acc11);
-      const int y = y0 + 2 * wm + mi;
-      bf16* orow = p.out + ((size_t)(b * p.H + y) * p.W + x0) * p.Cout + col;
+      char* trow = smem + ((2 * wm + mi) * PW) * EROW + cl * 2;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int px = (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -219,12 +223,24 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
           s1[ni] += v;
           s2[ni] += v * v;
         }
-        orow[(size_t)px * p.Cout] = (bf16)v;
+        *reinterpret_cast<bf16*>(trow + px * EROW) = (bf16)v;
       }
     }
   }
+  __syncthreads();
+  {
+    bf16* obase = p.out + ((size_t)(b * p.H + y0) * p.W + x0) * p.Cout + nt * BN3;
+#pragma unroll
+    for (int i = 0; i < (PH * PW * 16) / NT3; ++i) {
+      const int q = tid + NT3 * i;                        // 16-byte chunk: pixel q/16, channels (q%16)*8..+7
+      const int pix = q >> 4, c16 = q & 15;
+      const int py = pix / PW, px = pix - py * PW;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + pix * EROW + c16 * 16);
+      *reinterpret_cast<bf16x8*>(obase + ((size_t)py * p.W + px) * p.Cout + c16 * 8) = v;
+    }
+  }
   if (STATS) {
-    BARRIER();                                            // every wave is done reading LDS operands
+    __syncthreads();                                      // the staged output tile has been read back
     float* cs = reinterpret_cast<float*>(smem);           // [4 (wm)][128][2]
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {

@@ -144,38 +144,96 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
   // ------------------------------- epilogue -------------------------------------------
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
   const int CoutPS = p.Cout >> 2;
+  if constexpr (sizeof(T) == 2) {
+    // bf16: the accumulator layout (lane = output channel, register = pixel) would store 2 bytes per lane.
+    // Transpose the tile through LDS ([128 pixels][128 ch], rows padded to 272 B) and write whole channel
+    // rows, 16 B per lane: 8 store instructions per thread instead of 64 (the K loop of a 1x1 conv is only
+    // 2-16 steps long, so the store tail decides its speed).  The final __syncthreads() of the K loop has
+    // retired every operand read, so the ring buffers can be reused.
+    constexpr int EROW = BN * 2 + 16;
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int col = n0 + wn * 64 + ni * 32 + r;
-    const bool cval = col < p.Cout;
-    const float bias = (cval && p.bias) ? p.bias[col] : 0.f;
-    int ps_c = 0, ps_i = 0, ps_j = 0;
-    if (p.mode == CONV_PIXEL_SHUFFLE_SILU && cval) {
-      const int ij = col / CoutPS;
-      ps_c = col - ij * CoutPS;
-      ps_i = ij >> 1;
-      ps_j = ij & 1;
+    for (int ni = 0; ni < 2; ++ni) {
+      const int cl = wn * 64 + ni * 32 + r;
+      const int col = n0 + cl;
+      const bool cval = col < p.Cout;
+      const float bias = (cval && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const f32x16 accv = mi == 0 ? (ni == 0 ? acc00 : acc01) : (ni == 0 ? acc10 : acc11);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          float v = accv[reg] + bias;
+          if (m0 + row < M && cval) {
+            s1[ni] += v;
+            s2[ni] += v * v;
+          }
+          if (p.mode == CONV_PIXEL_SHUFFLE_SILU) v = silu<PRECISE>(v);
+          *reinterpret_cast<bf16*>(smem + row * EROW + cl * 2) = (bf16)v;
+        }
+      }
     }
+    __syncthreads();
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const f32x16 accv = mi == 0 ? (ni == 0 ? acc00 : acc01) : (ni == 0 ? acc10 : acc11);
+    for (int i = 0; i < (BM * 16) / NT; ++i) {
+      const int q = tid + NT * i;                          // 16-byte chunk: tile row q/16, columns (q%16)*8..+7
+      const int row = q >> 4, c16 = q & 15;
+      const int m = m0 + row, col = n0 + c16 * 8;
+      if (m < M && col < p.Cout) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + row * EROW + c16 * 16);
+        if (p.mode == CONV_PIXEL_SHUFFLE_SILU) {
+          const int ij = col / CoutPS, pc = col - ij * CoutPS;
+          const int b = m / HWo, rem = m - b * HWo;
+          const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+          const size_t o =
+              ((size_t)(b * 2 * p.Hout + 2 * oy + (ij >> 1)) * (2 * p.Wout) + 2 * ox + (ij & 1)) * CoutPS + pc;
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + o) = v;
+        } else {
+          const size_t o = (size_t)m * p.Cout + col;
+          if (p.residual) {
+            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.residual) + o);
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        const int m = m0 + row;
-        float v = accv[reg] + bias;
-        if (m < M && cval) {
-          s1[ni] += v;
-          s2[ni] += v * v;
-          if (p.mode == CONV_PIXEL_SHUFFLE_SILU) {
-            const int b = m / HWo, rem = m - b * HWo;
-            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            const size_t o = ((size_t)(b * 2 * p.Hout + 2 * oy + ps_i) * (2 * p.Wout) + 2 * ox + ps_j) * CoutPS + ps_c;
-            reinterpret_cast<T*>(p.out)[o] = from_f32<T>(silu<PRECISE>(v));
-          } else {
-            const size_t o = (size_t)m * p.Cout + col;
-            if (p.residual) v += to_f32<T>(reinterpret_cast<const T*>(p.residual)[o]);
-            reinterpret_cast<T*>(p.out)[o] = from_f32<T>(v);
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rr[e]);
+          }
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + o) = v;
+        }
+      }
+    }
+    if (p.gn_partial) __syncthreads();                     // staged tile consumed before the statistics reuse LDS
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = n0 + wn * 64 + ni * 32 + r;
+      const bool cval = col < p.Cout;
+      const float bias = (cval && p.bias) ? p.bias[col] : 0.f;
+      int ps_c = 0, ps_i = 0, ps_j = 0;
+      if (p.mode == CONV_PIXEL_SHUFFLE_SILU && cval) {
+        const int ij = col / CoutPS;
+        ps_c = col - ij * CoutPS;
+        ps_i = ij >> 1;
+        ps_j = ij & 1;
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const f32x16 accv = mi == 0 ? (ni == 0 ? acc00 : acc01) : (ni == 0 ? acc10 : acc11);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          const int m = m0 + row;
+          float v = accv[reg] + bias;
+          if (m < M && cval) {
+            s1[ni] += v;
+            s2[ni] += v * v;
+            if (p.mode == CONV_PIXEL_SHUFFLE_SILU) {
+              const int b = m / HWo, rem = m - b * HWo;
+              const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+              const size_t o = ((size_t)(b * 2 * p.Hout + 2 * oy + ps_i) * (2 * p.Wout) + 2 * ox + ps_j) * CoutPS + ps_c;
+              reinterpret_cast<T*>(p.out)[o] = from_f32<T>(silu<PRECISE>(v));
+            } else {
+              const size_t o = (size_t)m * p.Cout + col;
+              if (p.residual) v += to_f32<T>(reinterpret_cast<const T*>(p.residual)[o]);
+              reinterpret_cast<T*>(p.out)[o] = from_f32<T>(v);
+            }
           }
         }
       }
@@ -222,7 +280,8 @@ template <typename T, int BKC, bool PRECISE>
 int launch(const ConvArgs& a, hipStream_t st) {
   constexpr int ROWB = BKC * (int)sizeof(T);
   constexpr int STRIDE = ROWB + 16;
-  const size_t lds = (size_t)4 * BM * STRIDE;
+  size_t lds = (size_t)4 * BM * STRIDE;
+  if (sizeof(T) == 2) lds = std::max(lds, (size_t)BM * (BN * 2 + 16));     // bf16 epilogue staging tile
   const int M = a.B * a.Hout * a.Wout;
   const int grid = cdiv(M, BM) * (a.CoutPad / BN);
   static bool attr_set = false;
@@ -262,6 +321,8 @@ int conv_igemm(const ConvArgs& a, bool is_bf16, hipStream_t st) {
   }
   if (a.mode == CONV_PIXEL_SHUFFLE_SILU && (a.Cout % 4 != 0 || a.residual || a.gn_partial))
     SRGD_FAIL("conv_igemm: invalid pixel-shuffle epilogue combination");
+  if (is_bf16 && (a.Cout % 8 != 0 || (a.mode == CONV_PIXEL_SHUFFLE_SILU && (a.Cout / 4) % 8 != 0)))
+    SRGD_FAIL("conv_igemm: bf16 output channels must be a multiple of 8 (32 for the pixel-shuffle epilogue)");
   const int bkc = pick_bkc(is_bf16, a.C0, a.C1);
   if (bkc == 0) SRGD_FAIL("conv_igemm: input channels must be a multiple of 16");
   if (is_bf16) {
