@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
   const int M = p.B * HWo;
   const int Cin = p.C0 + p.C1;
   const int CC = Cin / BKC;
-  const int steps = p.KS * p.KS * CC;
+  const int steps = p.KH * p.KW * CC;
 
   // Per-thread staging state: PER (<= 4) 16-byte chunks of A and of B per K-step.  Everything is a NAMED
   // scalar/vector (token-pasted), never an indexed array: hipcc keeps indexed fragment arrays in scratch,
@@ -96,11 +96,11 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
 #define SRGD_LOAD_STEP(S)                                                    \
   {                                                                          \
     const int tap_ = (S) / CC, cc_ = (S)-tap_ * CC;                          \
-    const int dy_ = tap_ / p.KS, dx_ = tap_ - dy_ * p.KS;                    \
+    const int dy_ = tap_ / p.KW, dx_ = tap_ - dy_ * p.KW;                    \
     const int c_ = cc_ * BKC;                                                \
     const bool first_ = c_ < p.C0;                                           \
     const char* src_ = first_ ? (const char*)p.in0 : (const char*)p.in1;     \
-    const int Cs_ = first_ ? p.C0 : p.C1;                                    \
+    const int Cs_ = first_ ? p.ps0 : p.ps1;                                  \
     const int coff_ = first_ ? c_ : c_ - p.C0;                               \
     SRGD_LOAD1(0) SRGD_LOAD1(1) SRGD_LOAD1(2) SRGD_LOAD1(3)                  \
   }

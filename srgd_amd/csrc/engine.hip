@@ -181,7 +181,9 @@ struct srgd_engine {
   std::vector<void*> weight_allocs;
   int64_t weight_bytes = 0;
 
-  float *init_w = nullptr, *init_b = nullptr, *final_w = nullptr, *final_b = nullptr, *sin_w = nullptr, *cls_emb = nullptr;
+  void* init7_w = nullptr;      // 7x1 x 64-virtual-channel packing of init_conv for the MFMA route
+  int init7_coutpad = 0;
+  float *init_b = nullptr, *final_w = nullptr, *final_b = nullptr, *sin_w = nullptr, *cls_emb = nullptr;
   int init_wi = -1, init_bi = -1, final_wi = -1, final_bi = -1, sin_wi = -1, cls_emb_i = -1;
   Lin time1, time3, cls1, cls3;
   std::vector<StageW> downs, ups;
@@ -418,11 +420,11 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
              const void* residual, bool stats) {
   srgd_engine* e = x.e;
   ConvArgs a;
-  a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1;
+  a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.ps0 = C0; a.ps1 = C1;
   a.B = x.nb; a.Hin = Hin; a.Win = Win;
   a.Hout = (Hin + 2 * c.pad - c.KS) / c.stride + 1;
   a.Wout = (Win + 2 * c.pad - c.KS) / c.stride + 1;
-  a.KS = c.KS; a.stride = c.stride; a.pad = c.pad;
+  a.KH = c.KS; a.KW = c.KS; a.stride = c.stride; a.pad = c.pad;
   a.w = c.w; a.bias = c.bias; a.Cout = c.Cout; a.CoutPad = c.CoutPad;
   a.out = out; a.residual = residual; a.mode = c.mode;
   a.gn_partial = stats ? e->gn_partial : nullptr;
@@ -524,6 +526,18 @@ int ensure_scratch(srgd_engine* e, int nb, int H, int W) {
   SRGD_TRY(ensure(&e->la_ws, &e->la_ws_cap, linear_attention_workspace(nb, hw, e->cfg.heads, e->cfg.dim_head) / 4));
   SRGD_TRY(ensure(&e->d_rows, &e->rows_cap, (size_t)nb));
   return 0;
+}
+
+// 7x7 input conv on MFMA: `padded` is the gathered [entries][H+6][W+8][8] image (see kernels.hpp)
+int run_init7(srgd_engine* e, const void* padded, int entries, int H, int W, void* out, hipStream_t st) {
+  ConvArgs a;
+  a.in0 = padded; a.in1 = nullptr; a.C0 = 64; a.C1 = 0; a.ps0 = 8; a.ps1 = 0;
+  a.B = entries; a.Hin = H + 6; a.Win = W + 8; a.Hout = H; a.Wout = W;
+  a.KH = 7; a.KW = 1; a.stride = 1; a.pad = 0;
+  a.w = e->init7_w; a.bias = e->init_b; a.Cout = e->dim; a.CoutPad = e->init7_coutpad;
+  a.out = out; a.residual = nullptr; a.mode = CONV_PLAIN; a.gn_partial = nullptr; a.groups = e->cfg.groups;
+  if (e->prof_on) e->conv_flops += 0.0;   // counted under init_conv7x7, not in the conv family's FLOPs
+  return conv_igemm(a, e->bf16, st);
 }
 
 // The U-Net between init_conv and final_conv.  x0: [nb,H,W,dim] (kept alive by the caller).
@@ -710,17 +724,25 @@ int srgd_finalize_weights(srgd_engine* e) {
     if (!t.loaded) missing += (missing.empty() ? "" : ", ") + t.name;
   if (!missing.empty()) SRGD_FAIL("Missing key(s) in state_dict: " + missing);
   SRGD_HIP(hipSetDevice(e->cfg.device));
-  // 7x7 input conv: OIHW [dim,6,7,7] -> [ (dy*7+dx)*6 + ci ][dim]
+  // 7x7 input conv: OIHW [dim,6,7,7] -> 7 taps (dy) x 64 virtual channels (dx*8 + ci), see kernels.hpp
   {
     const std::vector<float>& s = e->wt[e->init_wi].data;
-    std::vector<float> p((size_t)294 * e->dim);
+    SRGD_TRY(upload_f32(e, e->init_bi, &e->init_b));
+    // MFMA route: [dy][CoutPad][dx*8 + ci] (dx = 7 and ci = 6,7 stay zero)
+    e->init7_coutpad = cdiv(e->dim, conv_tile_n()) * conv_tile_n();
+    std::vector<float> q((size_t)7 * e->init7_coutpad * 64, 0.f);
     for (int o = 0; o < e->dim; ++o)
       for (int ci = 0; ci < 6; ++ci)
         for (int dy = 0; dy < 7; ++dy)
           for (int dx = 0; dx < 7; ++dx)
-            p[(size_t)((dy * 7 + dx) * 6 + ci) * e->dim + o] = s[(((size_t)o * 6 + ci) * 7 + dy) * 7 + dx];
-    SRGD_TRY(upload(e, p.data(), p.size() * 4, (void**)&e->init_w));
-    SRGD_TRY(upload_f32(e, e->init_bi, &e->init_b));
+            q[((size_t)dy * e->init7_coutpad + o) * 64 + dx * 8 + ci] = s[(((size_t)o * 6 + ci) * 7 + dy) * 7 + dx];
+    if (e->bf16) {
+      std::vector<unsigned short> h(q.size());
+      for (size_t i = 0; i < q.size(); ++i) h[i] = f32_to_bf16_host(q[i]);
+      SRGD_TRY(upload(e, h.data(), h.size() * 2, &e->init7_w));
+    } else {
+      SRGD_TRY(upload(e, q.data(), q.size() * 4, &e->init7_w));
+    }
   }
   SRGD_TRY(upload_f32(e, e->final_wi, &e->final_w));
   SRGD_TRY(upload_f32(e, e->final_bi, &e->final_b));
@@ -758,7 +780,14 @@ int srgd_unet_forward(srgd_engine* e, const float* xin, const float* cond, const
   hipLaunchKernelGGL(rows_api_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, e->d_rows, B, class_id >= 0 ? 0 : 1);
   void* x0 = e->pool.get((size_t)B * H * W * e->dim * e->es);
   if (!x0) return -1;
-  { Prof p(e, KC_INIT, st); SRGD_TRY(init_conv_from_nchw(xin, cond, B, H, W, e->init_w, e->init_b, e->dim, x0, e->bf16, st)); }
+  {
+    Prof p(e, KC_INIT, st);
+    void* padded = e->pool.get((size_t)B * (H + 6) * (W + 8) * 8 * e->es);
+    if (!padded) return -1;
+    SRGD_TRY(init_gather_from_nchw(xin, cond, B, H, W, padded, e->bf16, st));
+    SRGD_TRY(run_init7(e, padded, B, H, W, x0, st));
+    e->pool.put(padded);
+  }
   Ctx x{e, B, H, W, e->d_rows, e->ct_api.table, st};
   void* act = nullptr;
   SRGD_TRY(unet_body(x, x0, &act));
@@ -834,8 +863,14 @@ int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_ca
     void* x0 = e->pool.get((size_t)nb * g.tile * g.tile * e->dim * e->es);
     if (!x0) return -1;
     const int mask = (passes == 2 && guidance_kind == 2) ? 0x1 : 0x3;
-    { Prof p(e, KC_INIT, st);
-      SRGD_TRY(init_conv_from_canvas(img, cond_canvas, tb, passes, mask, e->init_w, e->init_b, e->dim, x0, e->bf16, st)); }
+    {
+      Prof p(e, KC_INIT, st);
+      void* padded = e->pool.get((size_t)nb * (g.tile + 6) * (g.tile + 8) * 8 * e->es);
+      if (!padded) return -1;
+      SRGD_TRY(init_gather_from_canvas(img, cond_canvas, tb, passes, mask, padded, e->bf16, st));
+      SRGD_TRY(run_init7(e, padded, nb, g.tile, g.tile, x0, st));
+      e->pool.put(padded);
+    }
     hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, e->d_rows, nb, nt, row_label,
                        (passes == 2 && guidance_kind == 1) ? row_null : row_label);
     Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st};

@@ -40,10 +40,10 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
     SRGD_HIP(hipMemcpy(db.p, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
   }
   ConvArgs a;
-  a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.B = B; a.Hin = Hin; a.Win = Win;
+  a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.ps0 = C0; a.ps1 = C1; a.B = B; a.Hin = Hin; a.Win = Win;
   a.Hout = (Hin + 2 * pad - KS) / stride + 1;
   a.Wout = (Win + 2 * pad - KS) / stride + 1;
-  a.KS = KS; a.stride = stride; a.pad = pad; a.w = dw.p; a.bias = (const float*)db.p; a.Cout = Cout; a.CoutPad = CoutPad;
+  a.KH = KS; a.KW = KS; a.stride = stride; a.pad = pad; a.w = dw.p; a.bias = (const float*)db.p; a.Cout = Cout; a.CoutPad = CoutPad;
   a.out = out; a.residual = residual; a.mode = kind == 2 ? CONV_PIXEL_SHUFFLE_SILU : CONV_PLAIN;
   a.gn_partial = gn_partial; a.groups = groups;
   const bool fast = impl != 1 && is_bf16 && kind == 0 && conv3x3_bf16_eligible(a);

@@ -16,9 +16,11 @@ struct ConvArgs {
   const void* in0;        // NHWC [B,Hin,Win,C0]
   const void* in1;        // NHWC [B,Hin,Win,C1] or null (channel concat (in0, in1))
   int C0, C1;
+  int ps0, ps1;           // elements between consecutive input pixels of each source (normally C0 / C1; smaller for
+                          // the overlapping-window view the 7x7 input conv uses)
   int B, Hin, Win, Hout, Wout;
-  int KS, stride, pad;
-  const void* w;          // packed [KS*KS][CoutPad][C0+C1], activation type
+  int KH, KW, stride, pad;
+  const void* w;          // packed [KH*KW][CoutPad][C0+C1], activation type
   const float* bias;      // [Cout] or null
   int Cout, CoutPad;
   void* out;              // NHWC [B,Hout,Wout,Cout]; pixel-shuffle mode: [B,2Hout,2Wout,Cout/4]
@@ -96,15 +98,14 @@ struct TileBatch {
   int Hp, Wp;              // canvas size
   int tile;                // tile edge (256)
 };
-// 7x7 input convolution (model.py:583) reading the noisy canvas and the condition canvas in
-// place (NCHW fp32 planes), writing NHWC [nb*passes, tile, tile, Cout]. use_cond[pass] selects
-// whether that pass sees the condition or zeros (LR-condition guidance, model.py:3147-3150).
-int init_conv_from_canvas(const float* img, const float* cond, const TileBatch& tb, int passes,
-                          int use_cond_mask, const float* w /*[(dy*7+dx)*6+ci][Cout] fp32*/, const float* bias,
-                          int Cout, void* out, bool is_bf16, hipStream_t st);
-// plain NCHW batch variant used by the U-Net-only entry point (x,cond: [B,3,H,W], cond may be null)
-int init_conv_from_nchw(const float* x, const float* cond, int B, int H, int W, const float* w,
-                        const float* bias, int Cout, void* out, bool is_bf16, hipStream_t st);
+// 7x7 input convolution (model.py:583) on MFMA: gather the 6 input planes of every tile into a zero-haloed NHWC image
+// [entries][H+6][W+8][8 ch] (ch 6,7 = 0; position px holds input column px-3), after which output pixel (y,x), tap row
+// dy reads ONE contiguous 64-element run (8 pixels x 8 ch) -> a 7x1 implicit GEMM with 64 "channels" whose pixel
+// stride is 8 elements (conv_igemm with ps0 = 8).  The 8th pixel and channels 6,7 carry zero weights.
+int init_gather_from_canvas(const float* img, const float* cond, const TileBatch& tb, int passes, int use_cond_mask,
+                            void* padded, bool is_bf16, hipStream_t st);
+int init_gather_from_nchw(const float* x, const float* cond, int B, int H, int W, void* padded, bool is_bf16,
+                          hipStream_t st);
 // 1x1 output conv (model.py:675) -> eps; NCHW fp32 out (U-Net-only entry point)
 int final_conv_to_nchw(const void* act, int B, int H, int W, int C, const float* w /*[3][C]*/,
                        const float* bias, float* out, bool is_bf16, hipStream_t st);

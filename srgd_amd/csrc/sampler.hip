@@ -1,4 +1,4 @@
-// Sampler-side kernels for gfx950: the 7x7 input convolution reading tiles straight out of
+// Sampler-side kernels for gfx950: the gather that feeds the 7x7 input convolution straight out of
 // the canvases (fuses the tile gather model.py:3368-3369 and torch.cat model.py:684), the
 // 1x1 output convolution fused with guidance + the DDPM posterior step and the tile scatter
 // (model.py:3147-3168, :3184-3188, :3379-3380), canvas preparation / ring re-noise / crop,
@@ -9,11 +9,6 @@ namespace srgd {
 namespace {
 
 // ------------------------------------------------------------------ 7x7 input conv
-constexpr int IC_T = 16;                 // output pixels per block edge
-constexpr int IC_P = IC_T + 6;           // input patch edge (halo 3)
-constexpr int IC_K = 7 * 7 * 6;          // 294
-constexpr int IC_CO = 32;                // output channels per pass over the patch
-
 struct InitSrc {
   const float* x;          // noisy input planes
   const float* cond;       // condition planes (may be null)
@@ -26,71 +21,44 @@ struct InitSrc {
   long plane_stride;       // canvas plane or H*W
 };
 
+// Gather for the MFMA route of the 7x7 input conv (see kernels.hpp): one thread per padded position.
 template <typename T>
-__global__ __launch_bounds__(256) void init_conv_kernel(InitSrc s, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, int Cout,
-                                                        T* __restrict__ out) {
-  __shared__ float patch[IC_P * IC_P][6];
-  __shared__ __attribute__((aligned(16))) float ws[IC_K][IC_CO];
-  const int entry = blockIdx.z;
-  const int bx = blockIdx.x * IC_T, by = blockIdx.y * IC_T;
-  long origin;
-  bool use_cond = s.cond != nullptr;
-  if (s.canvas) {
-    const int pass = entry / s.ntiles, t = entry - pass * s.ntiles;
-    const int ty = s.tile_yx[2 * (s.first + t)], tx = s.tile_yx[2 * (s.first + t) + 1];
-    origin = (long)ty * s.row_stride + tx;
-    use_cond = use_cond && ((s.use_cond_mask >> pass) & 1);
-  } else {
-    origin = (long)entry * 3 * s.plane_stride;
-  }
-  for (int i = threadIdx.x; i < IC_P * IC_P * 6; i += 256) {
-    const int c = i / (IC_P * IC_P), rem = i - c * IC_P * IC_P;
-    const int py = rem / IC_P, px = rem - py * IC_P;
-    const int y = by + py - 3, x = bx + px - 3;
-    float v = 0.f;
+__global__ __launch_bounds__(256) void init_gather_kernel(InitSrc s, int entries, T* __restrict__ padded) {
+  const int Wq = s.W + 8, Hq = s.H + 6;
+  const long n = (long)entries * Hq * Wq;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int px = (int)(i % Wq);
+    const long t = i / Wq;
+    const int py = (int)(t % Hq);
+    const int entry = (int)(t / Hq);
+    const int y = py - 3, x = px - 3;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (y >= 0 && y < s.H && x >= 0 && x < s.W) {
-      const long o = origin + (long)(c % 3) * s.plane_stride + (long)y * s.row_stride + x;
-      if (c < 3) v = s.x[o];
-      else if (use_cond) v = s.cond[o];
-    }
-    patch[rem][c] = v;
-  }
-  const int px = threadIdx.x & (IC_T - 1), py = threadIdx.x >> 4;
-  const int oy = by + py, ox = bx + px;
-  for (int co0 = 0; co0 < Cout; co0 += IC_CO) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < IC_K * IC_CO; i += 256) {
-      const int k = i / IC_CO, o = i - k * IC_CO;
-      ws[k][o] = (co0 + o < Cout) ? w[(size_t)k * Cout + co0 + o] : 0.f;
-    }
-    __syncthreads();
-    float acc[IC_CO];
+      long origin;
+      bool use_cond = s.cond != nullptr;
+      if (s.canvas) {
+        const int pass = entry / s.ntiles, tt = entry - pass * s.ntiles;
+        origin = (long)s.tile_yx[2 * (s.first + tt)] * s.row_stride + s.tile_yx[2 * (s.first + tt) + 1];
+        use_cond = use_cond && ((s.use_cond_mask >> pass) & 1);
+      } else {
+        origin = (long)entry * 3 * s.plane_stride;
+      }
+      const long o = origin + (long)y * s.row_stride + x;
 #pragma unroll
-    for (int o = 0; o < IC_CO; ++o) acc[o] = 0.f;
-    for (int dy = 0; dy < 7; ++dy) {
-      for (int dx = 0; dx < 7; ++dx) {
-        const float* pp = patch[(py + dy) * IC_P + px + dx];
-        const int kb = (dy * 7 + dx) * 6;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const float a = pp[c];
-#pragma unroll
-          for (int o4 = 0; o4 < IC_CO / 4; ++o4) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&ws[kb + c][o4 * 4]);
-            acc[o4 * 4 + 0] += a * w4[0];
-            acc[o4 * 4 + 1] += a * w4[1];
-            acc[o4 * 4 + 2] += a * w4[2];
-            acc[o4 * 4 + 3] += a * w4[3];
-          }
-        }
+      for (int c = 0; c < 3; ++c) {
+        v[c] = s.x[o + c * s.plane_stride];
+        if (use_cond) v[3 + c] = s.cond[o + c * s.plane_stride];
       }
     }
-    if (oy < s.H && ox < s.W) {
-      T* op = out + (((size_t)entry * s.H + oy) * s.W + ox) * Cout + co0;
+    T* dst = padded + i * 8;
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 o8;
 #pragma unroll
-      for (int o = 0; o < IC_CO; ++o)
-        if (co0 + o < Cout) op[o] = from_f32<T>(acc[o] + bias[co0 + o]);
+      for (int c = 0; c < 8; ++c) o8[c] = (bf16)v[c];
+      *reinterpret_cast<bf16x8*>(dst) = o8;
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
     }
   }
 }
@@ -251,34 +219,34 @@ __global__ void philox_normal_kernel(float* __restrict__ dst, size_t n, uint64_t
   }
 }
 
-template <typename T>
-int launch_init(const InitSrc& s, int entries, const float* w, const float* bias, int Cout, void* out, hipStream_t st) {
-  dim3 g(cdiv(s.W, IC_T), cdiv(s.H, IC_T), entries);
-  hipLaunchKernelGGL((init_conv_kernel<T>), g, dim3(256), 0, st, s, w, bias, Cout, (T*)out);
-  SRGD_HIP(hipGetLastError());
-  return 0;
-}
-
 int grid_for(long n) { return (int)std::min<long>((n + 255) / 256, 256L * 16); }
 
 }  // namespace
 
-int init_conv_from_canvas(const float* img, const float* cond, const TileBatch& tb, int passes, int use_cond_mask,
-                          const float* w, const float* bias, int Cout, void* out, bool is_bf16, hipStream_t st) {
+int init_gather_from_canvas(const float* img, const float* cond, const TileBatch& tb, int passes, int use_cond_mask,
+                            void* padded, bool is_bf16, hipStream_t st) {
   InitSrc s;
   s.x = img; s.cond = cond; s.canvas = 1; s.tile_yx = tb.tile_yx; s.first = tb.first; s.ntiles = tb.ntiles;
   s.use_cond_mask = use_cond_mask; s.H = tb.tile; s.W = tb.tile; s.row_stride = tb.Wp;
   s.plane_stride = (long)tb.Hp * tb.Wp;
-  return is_bf16 ? launch_init<bf16>(s, passes * tb.ntiles, w, bias, Cout, out, st)
-                 : launch_init<float>(s, passes * tb.ntiles, w, bias, Cout, out, st);
+  const int entries = passes * tb.ntiles;
+  const int grid = grid_for((long)entries * (s.H + 6) * (s.W + 8));
+  if (is_bf16) hipLaunchKernelGGL((init_gather_kernel<bf16>), dim3(grid), dim3(256), 0, st, s, entries, (bf16*)padded);
+  else hipLaunchKernelGGL((init_gather_kernel<float>), dim3(grid), dim3(256), 0, st, s, entries, (float*)padded);
+  SRGD_HIP(hipGetLastError());
+  return 0;
 }
 
-int init_conv_from_nchw(const float* x, const float* cond, int B, int H, int W, const float* w, const float* bias,
-                        int Cout, void* out, bool is_bf16, hipStream_t st) {
+int init_gather_from_nchw(const float* x, const float* cond, int B, int H, int W, void* padded, bool is_bf16,
+                          hipStream_t st) {
   InitSrc s;
   s.x = x; s.cond = cond; s.canvas = 0; s.tile_yx = nullptr; s.first = 0; s.ntiles = B; s.use_cond_mask = 1;
   s.H = H; s.W = W; s.row_stride = W; s.plane_stride = (long)H * W;
-  return is_bf16 ? launch_init<bf16>(s, B, w, bias, Cout, out, st) : launch_init<float>(s, B, w, bias, Cout, out, st);
+  const int grid = grid_for((long)B * (H + 6) * (W + 8));
+  if (is_bf16) hipLaunchKernelGGL((init_gather_kernel<bf16>), dim3(grid), dim3(256), 0, st, s, B, (bf16*)padded);
+  else hipLaunchKernelGGL((init_gather_kernel<float>), dim3(grid), dim3(256), 0, st, s, B, (float*)padded);
+  SRGD_HIP(hipGetLastError());
+  return 0;
 }
 
 int final_conv_to_nchw(const void* act, int B, int H, int W, int C, const float* w, const float* bias, float* out,
