@@ -13,85 +13,54 @@ namespace srgd {
 namespace {
 
 constexpr int DH = 32;              // dim_head of every attention site in this model family
-constexpr int LA_CHUNK = 512;       // positions per partial
-constexpr int LA_TILE = 64;         // positions staged in LDS at a time
 
+// Context partials on the matrix cores.  One wave per (chunk, head): ctx[d][e] += sum_n p[n][d] v[n][e] is a
+// 32x32 tile with K = positions, fed to v_mfma_f32_32x32x2_f32 two positions at a time: lane (r, h) supplies
+// p[n+h][d=r] as the A operand and v[n+h][e=r] as the B operand, so every load is a coalesced 32-channel row
+// segment and nothing is staged through LDS.  Products are exact fp32 (p stays fp32 even in bf16 mode).
+// Pass 1 takes the chunk-local max of k (the second read of k comes from L2).
 template <typename T>
-__global__ __launch_bounds__(256) void la_partial_kernel(const T* __restrict__ qkv, int N, int heads,
+__global__ __launch_bounds__(256) void la_partial_kernel(const T* __restrict__ qkv, int N, int heads, int chunk_len,
                                                           float* __restrict__ pm, float* __restrict__ pl,
                                                           float* __restrict__ pctx) {
-  const int chunk = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int chunk = blockIdx.x, b = blockIdx.z;
   const int nch = gridDim.x;
+  const int head = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (head >= heads) return;                                  // wave-uniform
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int hid = heads * DH, C3 = 3 * hid;
-  const int tid = threadIdx.x, d = tid & 31, sub = tid >> 5;
-  const int n0 = chunk * LA_CHUNK;
-  const int cnt = min(LA_CHUNK, N - n0);
-  const T* base = qkv + (size_t)b * N * C3;
-  __shared__ float ks[LA_TILE][DH];
-  __shared__ float vs[LA_TILE][DH];
-  __shared__ float red[8][DH];
-  __shared__ float cred[8][DH][DH + 1];
+  const int n0 = chunk * chunk_len;
+  const int cnt = min(chunk_len, N - n0);
+  const T* kp = qkv + ((size_t)b * N + n0) * C3 + hid + head * DH + r;
+  const T* vp = kp + hid;
 
-  // pass 1: chunk-local max of k[:, d]
   float m = -INFINITY;
-  for (int n = sub; n < cnt; n += 8) m = fmaxf(m, to_f32<T>(base[(size_t)(n0 + n) * C3 + hid + head * DH + d]));
-  red[sub][d] = m;
-  __syncthreads();
-  m = red[0][d];
-#pragma unroll
-  for (int s = 1; s < 8; ++s) m = fmaxf(m, red[s][d]);
-  __syncthreads();
+#pragma unroll 8
+  for (int n = h; n < cnt; n += 2) m = fmaxf(m, to_f32<T>(kp[(size_t)n * C3]));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
 
-  // pass 2: l[d] = sum exp(k - m), ctx[d][e] = sum exp(k - m) v[e]
-  float l = 0.f, ctx[DH];
-#pragma unroll
-  for (int e = 0; e < DH; ++e) ctx[e] = 0.f;
-  for (int t0 = 0; t0 < cnt; t0 += LA_TILE) {
-    const int tc = min(LA_TILE, cnt - t0);
-    for (int i = tid; i < LA_TILE * DH; i += 256) {
-      const int n = i >> 5, c = i & 31;
-      float kv = 0.f, vv = 0.f;
-      if (n < tc) {
-        const size_t o = (size_t)(n0 + t0 + n) * C3 + head * DH + c;
-        kv = to_f32<T>(base[o + hid]);
-        vv = to_f32<T>(base[o + 2 * hid]);
-      }
-      ks[n][c] = kv;
-      vs[n][c] = vv;
-    }
-    __syncthreads();
-    for (int n = sub; n < tc; n += 8) {
-      const float p = expf(ks[n][d] - m);
-      l += p;
-#pragma unroll
-      for (int e4 = 0; e4 < DH / 4; ++e4) {
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(&vs[n][e4 * 4]);
-        ctx[e4 * 4 + 0] += p * v4[0];
-        ctx[e4 * 4 + 1] += p * v4[1];
-        ctx[e4 * 4 + 2] += p * v4[2];
-        ctx[e4 * 4 + 3] += p * v4[3];
-      }
-    }
-    __syncthreads();
+  f32x16 acc = 0;
+  float l = 0.f;
+#pragma unroll 4
+  for (int n = 0; n < cnt; n += 2) {
+    const bool ok = n + h < cnt;
+    const size_t o = (size_t)(ok ? n + h : 0) * C3;
+    const float kk = to_f32<T>(kp[o]);
+    const float vv = to_f32<T>(vp[o]);
+    const float pe = ok ? expf(kk - m) : 0.f;
+    l += pe;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pe, ok ? vv : 0.f, acc, 0, 0, 0);
   }
-  // reduce the 8 position sub-streams in fixed order
-  red[sub][d] = l;
-#pragma unroll
-  for (int e = 0; e < DH; ++e) cred[sub][d][e] = ctx[e];
-  __syncthreads();
+  l += __shfl_xor(l, 32, 64);
   const size_t pidx = ((size_t)(b * heads + head) * nch + chunk);
-  if (sub == 0) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += red[k][d];
-    pm[pidx * DH + d] = m;
-    pl[pidx * DH + d] = s;
+  if (h == 0) {
+    pm[pidx * DH + r] = m;
+    pl[pidx * DH + r] = l;
   }
-  for (int e = sub; e < DH; e += 8) {
-    float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += cred[k][d][e];
-    pctx[(pidx * DH + d) * DH + e] = s;
+  for (int reg = 0; reg < 16; ++reg) {
+    const int d = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    pctx[(pidx * DH + d) * DH + r] = acc[reg];
   }
 }
 
@@ -281,7 +250,9 @@ __global__ __launch_bounds__(256) void full_attn_kernel(const T* __restrict__ qk
 
 }  // namespace
 
-static int la_chunks(int N) { return cdiv(N, LA_CHUNK); }
+// positions per partial: long chunks amortise the 4.3 KB partial record; short ones keep small maps parallel
+static int la_chunk_len(int N) { return N > 16384 ? 1024 : 512; }
+static int la_chunks(int N) { return cdiv(N, la_chunk_len(N)); }
 
 size_t linear_attention_workspace(int B, int N, int heads, int dh) {
   const size_t bh = (size_t)B * heads, nch = la_chunks(N);
@@ -298,11 +269,12 @@ int linear_attention(const void* qkv, void* out, int B, int N, int heads, int dh
   float* pctx = pl + bh * nch * DH;
   float* ctxn = pctx + bh * nch * DH * DH;
   const float scale = 1.0f / sqrtf((float)dh);
-  dim3 g1(nch, heads, B);
+  dim3 g1(nch, cdiv(heads, 4), B);
+  const int clen = la_chunk_len(N);
   if (is_bf16)
-    hipLaunchKernelGGL((la_partial_kernel<bf16>), g1, dim3(256), 0, st, (const bf16*)qkv, N, heads, pm, pl, pctx);
+    hipLaunchKernelGGL((la_partial_kernel<bf16>), g1, dim3(256), 0, st, (const bf16*)qkv, N, heads, clen, pm, pl, pctx);
   else
-    hipLaunchKernelGGL((la_partial_kernel<float>), g1, dim3(256), 0, st, (const float*)qkv, N, heads, pm, pl, pctx);
+    hipLaunchKernelGGL((la_partial_kernel<float>), g1, dim3(256), 0, st, (const float*)qkv, N, heads, clen, pm, pl, pctx);
   SRGD_HIP(hipGetLastError());
   hipLaunchKernelGGL(la_combine_kernel, dim3((unsigned)bh), dim3(256), 0, st, pm, pl, pctx, nch, scale, ctxn);
   SRGD_HIP(hipGetLastError());

@@ -18,6 +18,8 @@
 //   * epilogue: + bias, optional per-(sample, group) partial sum / sum of squares for the GroupNorm that
 //     follows (fixed-order, deterministic), bf16 store.
 //   * blockIdx is remapped so each XCD (private L2) gets a contiguous band of tiles (halo reuse in L2).
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace srgd {
@@ -31,6 +33,7 @@ constexpr int NT3 = 512;
 constexpr int A_BYTES = 24 * 1024;             // 24 wave-instructions x 1 KiB (340 px * 64 B = 21,760 used)
 constexpr int B_BYTES = BN3 * KC * 2;          // 8 KiB
 constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 73,728
+constexpr int CONV3_DEFAULT_VARIANT = 0;
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -59,7 +62,7 @@ struct Conv3Args {
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 
-template <bool STATS>
+template <bool STATS, int VAR>
 __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -152,25 +155,41 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   if (S > 1) WAIT_VM(1); else WAIT_VM(0);
   BARRIER();
 
+  // A fragments of the NEXT tap (k16 step 0) can be fetched before the barrier: within a channel chunk the A
+  // patch is read-only, so only the first tap of a chunk has to wait for the barrier (VAR & 2).
+  bf16x8 nfa0, nfa1;
+  auto a_addr = [&](int tap, int i) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int P = a_row0 + (dy + i) * WP + dx;
+    return P * 64 + ((h ^ ((P >> 2) & 3)) << 4);
+  };
   auto compute = [&](int cc, int tap, int s) {
     const char* A = sA0 + (cc & 1) * A_BYTES;
     const char* Bt = sB0 + (s % 3) * B_BYTES;
-    const int dy = tap / 3, dx = tap - dy * 3;
-    const int P0 = a_row0 + dy * WP + dx;
-    const int P1 = P0 + WP;
-    const int a0 = P0 * 64 + ((h ^ ((P0 >> 2) & 3)) << 4);
-    const int a1 = P1 * 64 + ((h ^ ((P1 >> 2) & 3)) << 4);
+    const int a0 = a_addr(tap, 0), a1 = a_addr(tap, 1);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int x = s2 << 5;                   // k16 step toggles bit 1 of the chunk index = byte bit 5
-      const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + (a0 ^ x));
-      const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + (a1 ^ x));
+      bf16x8 fa0, fa1;
+      if ((VAR & 2) && s2 == 0 && tap > 0) {
+        fa0 = nfa0;
+        fa1 = nfa1;
+      } else {
+        fa0 = *reinterpret_cast<const bf16x8*>(A + (a0 ^ x));
+        fa1 = *reinterpret_cast<const bf16x8*>(A + (a1 ^ x));
+      }
       const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(Bt + (b_off0 ^ x));
       const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(Bt + (b_off1 ^ x));
+      if ((VAR & 2) && s2 == 1 && tap < 8) {
+        nfa0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap + 1, 0));
+        nfa1 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap + 1, 1));
+      }
+      if (VAR & 1) __builtin_amdgcn_s_setprio(1);
       acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc00, 0, 0, 0);
       acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc01, 0, 0, 0);
       acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc10, 0, 0, 0);
       acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc11, 0, 0, 0);
+      if (VAR & 1) __builtin_amdgcn_s_setprio(0);
     }
   };
 
@@ -330,16 +349,25 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st) {
   p.B = a.B; p.H = a.Hin; p.W = a.Win; p.w = (const bf16*)packed_w; p.bias = a.bias; p.Cout = a.Cout;
   p.out = (bf16*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
+  static int variant = -1;
+  if (variant < 0) {
+    const char* v = getenv("SRGD_CONV3_VARIANT");           // tuning knob (tools/bench_conv.py); default = shipped
+    variant = v ? atoi(v) & 3 : CONV3_DEFAULT_VARIANT;
+#define SRGD_SET(V)                                                                                               \
+  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<true, V>),                      \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));                           \
+  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<false, V>),                     \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    SRGD_SET(0) SRGD_SET(1) SRGD_SET(2) SRGD_SET(3)
+#undef SRGD_SET
   }
-  if (a.gn_partial) hipLaunchKernelGGL((conv3x3_bf16_kernel<true>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);
-  else hipLaunchKernelGGL((conv3x3_bf16_kernel<false>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);
+#define SRGD_GO(V)                                                                                                 \
+  case V:                                                                                                          \
+    if (a.gn_partial) hipLaunchKernelGGL((conv3x3_bf16_kernel<true, V>), dim3(grid), dim3(NT3), LDS_BYTES, st, p); \
+    else hipLaunchKernelGGL((conv3x3_bf16_kernel<false, V>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);             \
+    break;
+  switch (variant) { SRGD_GO(0) SRGD_GO(1) SRGD_GO(2) SRGD_GO(3) }
+#undef SRGD_GO
   SRGD_HIP(hipGetLastError());
   return 0;
 }
