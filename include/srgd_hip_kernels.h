@@ -53,6 +53,14 @@ int srgd_k_rmsnorm(const void* x, void* y, const void* residual, const float* g,
 int srgd_k_linear_attention(const void* qkv, void* out, int B, int N, int heads, int is_bf16, void* stream);
 int srgd_k_full_attention(const void* qkv, void* out, int B, int N, int heads, int is_bf16, void* stream);
 
+/* The whole LinearAttention block plus its residual, fused (bf16, C = 128, 4 heads x 32, N % 128 == 0):
+ * y = RMSNorm(to_out(linear_attention(to_qkv(RMSNorm(x))))) + x.   replaces: LinearAttention.forward
+ * (model.py:306-324) and the `attn(x) + x` at model.py:703/:718.  x, y: device bf16 [B,N,C]; weights host fp32 in
+ * PyTorch layout (to_qkv [384,C], norm.g [C], to_out.0.weight [C,128], to_out.0.bias [C], to_out.1.g [C]). */
+int srgd_k_linattn_block_fused(const void* x, void* y, int B, int N, int C, const float* to_qkv_host,
+                               const float* norm_g_host, const float* to_out_w_host, const float* to_out_b_host,
+                               const float* out_g_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

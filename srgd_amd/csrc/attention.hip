@@ -290,6 +290,13 @@ int linear_attention(const void* qkv, void* out, int B, int N, int heads, int dh
   return 0;
 }
 
+int linear_attention_combine(const float* pm, const float* pl, const float* pctx, int bh, int nch, float scale,
+                             float* ctxn, hipStream_t st) {
+  hipLaunchKernelGGL(la_combine_kernel, dim3((unsigned)bh), dim3(256), 0, st, pm, pl, pctx, nch, scale, ctxn);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
 int full_attention(const void* qkv, void* out, int B, int N, int heads, int dh, bool is_bf16, hipStream_t st) {
   if (dh != DH) SRGD_FAIL("full_attention: dim_head must be 32");
   const float scale = 1.0f / sqrtf((float)dh);

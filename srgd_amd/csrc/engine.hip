@@ -113,6 +113,9 @@ struct AttnW {
   int ngi = -1, ogi = -1;
   float *norm_g = nullptr, *out_g = nullptr;
   ConvW qkv, out;
+  // fused LinearAttention block operands (bf16, C = 128): see linattn_fused.hip
+  void *f_wkv = nullptr, *f_wq = nullptr, *f_wout = nullptr;
+  float* f_g2 = nullptr;
 };
 struct StageW {
   ResW rb[2];
@@ -193,6 +196,7 @@ struct srgd_engine {
   int ss_stride = 0;
   int stats_slots = 0;          // slots per (sample, group) the last conv wrote into gn_partial
   bool force_generic_conv = false;
+  bool force_unfused_attn = false;
 
   Pool pool;
   float* gn_partial = nullptr; size_t gn_partial_cap = 0;
@@ -395,6 +399,16 @@ int pack_attn(srgd_engine* e, AttnW& a) {
   if (a.ogi >= 0) SRGD_TRY(upload_f32(e, a.ogi, &a.out_g));
   SRGD_TRY(pack_conv(e, a.qkv));
   SRGD_TRY(pack_conv(e, a.out));
+  if (!a.full && e->bf16 && a.C == 128 && e->cfg.heads == 4 && e->cfg.dim_head == 32) {
+    std::vector<unsigned short> wkv, wq, wo;
+    linattn_fused_pack(e->wt[a.qkv.wi].data.data(), e->wt[a.ngi].data.data(), e->wt[a.out.wi].data.data(), a.C, wkv, wq, wo);
+    SRGD_TRY(upload(e, wkv.data(), wkv.size() * 2, &a.f_wkv));
+    SRGD_TRY(upload(e, wq.data(), wq.size() * 2, &a.f_wq));
+    SRGD_TRY(upload(e, wo.data(), wo.size() * 2, &a.f_wout));
+    std::vector<float> g2(a.C);
+    for (int c = 0; c < a.C; ++c) g2[c] = e->wt[a.ogi].data[c] * sqrtf((float)a.C);
+    SRGD_TRY(upload(e, g2.data(), g2.size() * 4, (void**)&a.f_g2));
+  }
   return 0;
 }
 
@@ -482,6 +496,15 @@ int attn_block(Ctx& x, const AttnW& a, const void* in, void** out) {
   srgd_engine* e = x.e;
   const int hw = x.H * x.W;
   const long npix = (long)x.nb * hw;
+  if (a.f_wkv && !e->force_unfused_attn && linattn_fused_eligible(a.C, e->cfg.heads, e->cfg.dim_head, hw, e->bf16)) {
+    Prof p(e, KC_LINATTN, x.st);
+    void* y = e->pool.get((size_t)npix * a.C * e->es);
+    if (!y) return -1;
+    if (linattn_fused_workspace(x.nb, hw) / sizeof(float) > e->la_ws_cap) SRGD_FAIL("internal: fused attention workspace too small");
+    SRGD_TRY(linattn_fused(in, y, x.nb, hw, a.f_wkv, a.f_wq, a.f_wout, a.out.bias, a.f_g2, e->la_ws, x.st));
+    *out = y;
+    return 0;
+  }
   void* nrm = e->pool.get((size_t)npix * a.C * e->es);
   void* qkv = e->pool.get((size_t)npix * 3 * e->hid * e->es);
   void* att = e->pool.get((size_t)npix * e->hid * e->es);
@@ -523,7 +546,8 @@ int ensure_scratch(srgd_engine* e, int nb, int H, int W) {
     SRGD_HIP(hipMalloc((void**)&e->coefB, need * 4));
     e->coef_cap = need;
   }
-  SRGD_TRY(ensure(&e->la_ws, &e->la_ws_cap, linear_attention_workspace(nb, hw, e->cfg.heads, e->cfg.dim_head) / 4));
+  SRGD_TRY(ensure(&e->la_ws, &e->la_ws_cap,
+                  std::max(linear_attention_workspace(nb, hw, e->cfg.heads, e->cfg.dim_head), linattn_fused_workspace(nb, hw)) / 4));
   SRGD_TRY(ensure(&e->d_rows, &e->rows_cap, (size_t)nb));
   return 0;
 }

@@ -116,6 +116,28 @@ int srgd_k_linear_attention(const void* qkv, void* out, int B, int N, int heads,
   return 0;
 }
 
+int srgd_k_linattn_block_fused(const void* x, void* y, int B, int N, int C, const float* to_qkv_host,
+                               const float* norm_g_host, const float* to_out_w_host, const float* to_out_b_host,
+                               const float* out_g_host, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!linattn_fused_eligible(C, 4, 32, N, true)) SRGD_FAIL("linattn_block_fused: needs C = 128, N % 128 == 0");
+  std::vector<unsigned short> wkv, wq, wo;
+  linattn_fused_pack(to_qkv_host, norm_g_host, to_out_w_host, C, wkv, wq, wo);
+  std::vector<float> g2(C);
+  for (int c = 0; c < C; ++c) g2[c] = out_g_host[c] * sqrtf((float)C);
+  DevBuf dkv, dq, dout, db, dg, ws;
+  SRGD_TRY(dkv.alloc(wkv.size() * 2)); SRGD_TRY(dq.alloc(wq.size() * 2)); SRGD_TRY(dout.alloc(wo.size() * 2));
+  SRGD_TRY(db.alloc(C * 4)); SRGD_TRY(dg.alloc(C * 4)); SRGD_TRY(ws.alloc(linattn_fused_workspace(B, N)));
+  SRGD_HIP(hipMemcpy(dkv.p, wkv.data(), wkv.size() * 2, hipMemcpyHostToDevice));
+  SRGD_HIP(hipMemcpy(dq.p, wq.data(), wq.size() * 2, hipMemcpyHostToDevice));
+  SRGD_HIP(hipMemcpy(dout.p, wo.data(), wo.size() * 2, hipMemcpyHostToDevice));
+  SRGD_HIP(hipMemcpy(db.p, to_out_b_host, C * 4, hipMemcpyHostToDevice));
+  SRGD_HIP(hipMemcpy(dg.p, g2.data(), C * 4, hipMemcpyHostToDevice));
+  SRGD_TRY(linattn_fused(x, y, B, N, dkv.p, dq.p, dout.p, (const float*)db.p, (const float*)dg.p, (float*)ws.p, st));
+  SRGD_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
 int srgd_k_full_attention(const void* qkv, void* out, int B, int N, int heads, int is_bf16, void* stream) {
   return full_attention(qkv, out, B, N, heads, 32, is_bf16 != 0, (hipStream_t)stream);
 }

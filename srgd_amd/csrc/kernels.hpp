@@ -76,6 +76,19 @@ int linear_attention(const void* qkv, void* out, int B, int N, int heads, int dh
                      bool is_bf16, hipStream_t st);
 int full_attention(const void* qkv, void* out, int B, int N, int heads, int dh, bool is_bf16,
                    hipStream_t st);
+// merge per-chunk (max, sum, context) partials [bh][nch][...] -> normalised context * scale, [bh][32][32]
+int linear_attention_combine(const float* pm, const float* pl, const float* pctx, int bh, int nch, float scale,
+                             float* ctxn, hipStream_t st);
+
+// ---------------------------------------------------------------- linattn_fused.hip
+// Whole LinearAttention block + residual (model.py:306-324, :703) in two kernels; bf16, C = 128, 4 heads x 32.
+bool linattn_fused_eligible(int C, int heads, int dh, int N, bool is_bf16);
+size_t linattn_fused_workspace(int B, int N);
+void linattn_fused_pack(const float* to_qkv, const float* norm_g, const float* to_out, int C,
+                        std::vector<unsigned short>& wkv_img, std::vector<unsigned short>& wq,
+                        std::vector<unsigned short>& wout);
+int linattn_fused(const void* x, void* y, int B, int N, const void* wkv_img, const void* wq, const void* wout,
+                  const float* bout, const float* g2_scaled, float* ws, hipStream_t st);
 
 // ---------------------------------------------------------------- cond.hip
 // feat[r] = [x, sin(2 pi x w_i), cos(2 pi x w_i)]   (reference model.py:233-238)

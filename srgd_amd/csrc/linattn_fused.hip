@@ -1,0 +1,456 @@
+// Fused LinearAttention block for gfx950 (bf16 mode, C = 128, 4 heads x 32): the whole of reference
+// model.py:306-324 -
+//     RMSNorm -> to_qkv (1x1) -> q softmax over d / k softmax over ALL positions -> context -> out ->
+//     to_out (1x1 + bias) -> RMSNorm -> (+ x, model.py:703)
+// in two kernels that touch HBM three times per pixel (read x, read x, write y) instead of the ten tensor
+// passes of the unfused chain (q, k, v are never materialised):
+//
+//   la1_kernel  per 128-pixel tile: x -> LDS (LDS-DMA, swizzled), row norms, [k|v] = x . Wkv'^T on MFMA with the
+//               wave tiling chosen so that ONE wave owns the k-columns and the v-columns of one head for its
+//               rows; exp(k - m) and v then feed the context product  ctx[d][e] += sum_n p[n][d] v[n][e]  straight
+//               from the accumulator registers (an accumulator tile is a valid MFMA operand for a product that sums
+//               over its row index) - no LDS round trip.  Online max/sum per column, one partial per wave.
+//   (la_combine_kernel from attention.hip merges the partials: fixed order, deterministic.)
+//   la2_kernel  per 128-pixel tile: q^T = Wq' . x^T (pixels on lanes, so the d-softmax is a per-lane register
+//               reduction), att^T = ctx^T . q' again from accumulator registers, att -> LDS, o^T = Wout . att^T
+//               + bias, RMSNorm over c (cross-wave sum of squares through LDS), * g2, + x (the x tile is still in
+//               LDS), staged and stored as whole 256-byte rows.  Wq', Wout and ctx live in registers for the
+//               lifetime of the (persistent) workgroup.
+// The RMSNorm gains g1*sqrt(C) are folded into Wkv'/Wq' on the host; 1/||x|| is applied to the GEMM result.
+#include "kernels.hpp"
+
+namespace srgd {
+namespace {
+
+constexpr int TM = 128;                 // pixels per tile
+constexpr int TILE_BYTES = TM * 256;    // [128 rows][128 bf16]
+constexpr int NTH = 512;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ int swz(int row, int chunk16) { return row * 256 + ((chunk16 ^ (row & 15)) << 4); }
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voffset, 0, 0, 0);
+}
+
+#define LA_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define LA_BARRIER()                     \
+  do {                                   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+#define LA_SYNC()                                         \
+  do {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    LA_BARRIER();                                         \
+  } while (0)
+
+// stage one 128-pixel x tile (rows px0..px0+127 of the image behind rsrc) into `buf`, XOR-swizzled
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* buf, int wave, int lane, int px0,
+                                           int npx) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = wave * 4 + j;
+    const int g = q * 64 + lane;
+    const int row = g >> 4, cs = g & 15;
+    const int c = cs ^ (row & 15);
+    const int voff = (px0 + row < npx) ? ((px0 + row) * 128 + c * 8) * 2 : 0x7ffffff0;
+    dma16(rsrc, buf + q * 1024, voff);
+  }
+}
+
+// 1 / max(||x_row||, 1e-12) for the 128 rows of a staged tile (4 threads per row)
+__device__ __forceinline__ void row_rinv(const char* tile, float* rinv, int tid) {
+  const int row = tid >> 2, part = tid & 3;
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * 256 + (part * 4 + j) * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += (float)v[e] * (float)v[e];
+  }
+  ss += __shfl_xor(ss, 1, 64);
+  ss += __shfl_xor(ss, 2, 64);
+  if (part == 0) rinv[row] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)a[8 * s + j];
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------- phase 1
+__global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x, int N, const bf16* __restrict__ wkv,
+                                                      int strip, float* __restrict__ pm, float* __restrict__ pl,
+                                                      float* __restrict__ pctx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sW = smem;                          // [256 rows][256 B] swizzled image of Wkv'
+  char* const sA = smem + 65536;                  // 2 x x tile
+  float* const sR = reinterpret_cast<float*>(smem + 65536 + 2 * TILE_BYTES);   // [2][128]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int rh = wave >> 2, head = wave & 3;
+  const int b = blockIdx.y, sidx = blockIdx.x, nstrips = gridDim.x;
+  const int px_begin = sidx * strip;
+  const int T = (min(strip, N - px_begin) + TM - 1) / TM;
+
+  const __amdgpu_buffer_rsrc_t rsx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * N * 128), 0, N * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wkv, 0, 65536, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dma16(rsw, sW + (wave * 8 + j) * 1024, (wave * 8 + j) * 1024 + lane * 16);
+  stage_tile(rsx, sA, wave, lane, px_begin, N);
+
+  float m = -INFINITY, l = 0.f;
+  f32x16 ctx = 0;
+  LA_WAIT_VM0();
+  LA_BARRIER();
+
+  for (int t = 0; t < T; ++t) {
+    const char* A = sA + (t & 1) * TILE_BYTES;
+    float* rinv = sR + (t & 1) * TM;
+    if (t + 1 < T) stage_tile(rsx, sA + ((t + 1) & 1) * TILE_BYTES, wave, lane, px_begin + (t + 1) * TM, N);
+    row_rinv(A, rinv, tid);
+    LA_SYNC();
+
+    // [k | v] of this wave's head for its 64 rows
+    f32x16 k0 = 0, k1 = 0, v0 = 0, v1 = 0;
+    const int ar0 = rh * 64 + r, ar1 = ar0 + 32;
+    const int wk = head * 32 + r, wv = 128 + head * 32 + r;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int c = 2 * s + hh;
+      const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + swz(ar0, c));
+      const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + swz(ar1, c));
+      const bf16x8 fk = *reinterpret_cast<const bf16x8*>(sW + swz(wk, c));
+      const bf16x8 fv = *reinterpret_cast<const bf16x8*>(sW + swz(wv, c));
+      k0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fk, k0, 0, 0, 0);
+      k1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fk, k1, 0, 0, 0);
+      v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fv, v0, 0, 0, 0);
+      v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fv, v1, 0, 0, 0);
+    }
+    // rows of the accumulator = pixels: apply 1/||x_n||; rows beyond the image contribute nothing
+    const int px_tile = px_begin + t * TM;
+    float bm = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 ri0 = *reinterpret_cast<const f32x4*>(rinv + rh * 64 + 8 * g + 4 * hh);
+      const f32x4 ri1 = *reinterpret_cast<const f32x4*>(rinv + rh * 64 + 32 + 8 * g + 4 * hh);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int reg = 4 * g + i;
+        const bool ok0 = px_tile + rh * 64 + 8 * g + 4 * hh + i < N;
+        const bool ok1 = px_tile + rh * 64 + 32 + 8 * g + 4 * hh + i < N;
+        k0[reg] = ok0 ? k0[reg] * ri0[i] : -INFINITY;
+        k1[reg] = ok1 ? k1[reg] * ri1[i] : -INFINITY;
+        v0[reg] = ok0 ? v0[reg] * ri0[i] : 0.f;
+        v1[reg] = ok1 ? v1[reg] * ri1[i] : 0.f;
+        bm = fmaxf(bm, fmaxf(k0[reg], k1[reg]));
+      }
+    }
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float mn = fmaxf(m, bm);
+    const float f = expf(m - mn);                 // first tile: exp(-inf) = 0
+    m = mn;
+    l *= f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      k0[i] = expf(k0[i] - mn);
+      k1[i] = expf(k1[i] - mn);
+      l += k0[i] + k1[i];
+    }
+    if (!__all(f == 1.0f)) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int d = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        ctx[reg] *= __shfl(f, d, 64);             // lane d (< 32) holds the factor of context row d
+      }
+    }
+    // ctx[d][e] += sum_n p[n][d] v[n][e]: both operands come from accumulator tiles (same row permutation)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(k0, s), pack8(v0, s), ctx, 0, 0, 0);
+      ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(k1, s), pack8(v1, s), ctx, 0, 0, 0);
+    }
+    LA_WAIT_VM0();
+    LA_BARRIER();
+  }
+  l += __shfl_xor(l, 32, 64);
+  const int nch = nstrips * 2;
+  const size_t pidx = (size_t)(b * 4 + head) * nch + sidx * 2 + rh;
+  if (hh == 0) {
+    pm[pidx * 32 + r] = m;
+    pl[pidx * 32 + r] = l;
+  }
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int d = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+    pctx[(pidx * 32 + d) * 32 + r] = ctx[reg];
+  }
+}
+
+// ------------------------------------------------------------------------------------------- phase 2
+struct La2Args {
+  const bf16* x; bf16* y; int N;
+  const bf16* wq;        // [128 d][128 c] bf16, row-major, gains folded
+  const bf16* wout;      // [128 c][128 k] bf16, row-major
+  const float* bout;     // [128]
+  const float* g2;       // [128] = to_out.1.g * sqrt(C)
+  const float* ctxn;     // [B*4][32 d][32 e] fp32: normalised context * dh^-0.5
+  int tiles_per_wg;
+};
+
+__global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sA = smem;                                   // 2 x x tile
+  char* const sT = smem + 2 * TILE_BYTES;                  // att tile, later the staged output tile
+  float* const sR = reinterpret_cast<float*>(smem + 3 * TILE_BYTES);   // [2][128] 1/||x||
+  float* const sS = sR + 2 * TM;                           // [4][128] partial sum of squares of o
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int ph = wave >> 2, hd = wave & 3;                 // pixel half; head (GEMM-q) / channel block (GEMM-out)
+  const int b = blockIdx.y;
+  const int tile0 = blockIdx.x * p.tiles_per_wg;
+  const int ntiles = (p.N + TM - 1) / TM;
+  const int T = min(p.tiles_per_wg, ntiles - tile0);
+
+  const __amdgpu_buffer_rsrc_t rsx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.N * 128), 0, p.N * 256, 0x00020000);
+  if (T > 0) stage_tile(rsx, sA, wave, lane, tile0 * TM, p.N);
+
+  // register-resident operands: rows (hd*32 + r) of Wq' and Wout as MFMA A fragments for the 8 k16 steps
+  bf16x8 wq[8], wo[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    wq[s] = *reinterpret_cast<const bf16x8*>(p.wq + (size_t)(hd * 32 + r) * 128 + (2 * s + hh) * 8);
+    wo[s] = *reinterpret_cast<const bf16x8*>(p.wout + (size_t)(hd * 32 + r) * 128 + (2 * s + hh) * 8);
+  }
+  // ctx^T of head hd as the A operand of att^T = ctx^T . q': lane (r = e, hh) element j of k-step s must be
+  // ctx[d][e] with d in the accumulator's row order: d = 16 s + 8 (j >> 2) + 4 hh + (j & 3)
+  bf16x8 cx[2];
+  {
+    const float* c = p.ctxn + (size_t)(b * 4 + hd) * 1024;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cx[s][j] = (bf16)c[(16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)) * 32 + r];
+  }
+  float bo[16], g2v[16];                                   // bias / gain of output rows c = hd*32 + row(reg, hh)
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int c = hd * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+    bo[reg] = p.bout[c];
+    g2v[reg] = p.g2[c];
+  }
+  LA_WAIT_VM0();
+  LA_BARRIER();
+
+  for (int t = 0; t < T; ++t) {
+    const char* A = sA + (t & 1) * TILE_BYTES;
+    float* rinv = sR + (t & 1) * TM;
+    const int px0 = (tile0 + t) * TM;
+    if (t + 1 < T) stage_tile(rsx, sA + ((t + 1) & 1) * TILE_BYTES, wave, lane, px0 + TM, p.N);
+    row_rinv(A, rinv, tid);
+    LA_SYNC();
+
+    // q^T (rows d of head hd, columns = this wave's 64 pixels)
+    f32x16 q0 = 0, q1 = 0;
+    const int pr0 = ph * 64 + r, pr1 = pr0 + 32;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int c = 2 * s + hh;
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(A + swz(pr0, c));
+      const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(A + swz(pr1, c));
+      q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s], x0, q0, 0, 0, 0);
+      q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s], x1, q1, 0, 0, 0);
+    }
+    // softmax over d: registers (16) x lane halves (2) of one pixel column
+    {
+      const float ri0 = rinv[pr0], ri1 = rinv[pr1];
+      float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        q0[i] *= ri0;
+        q1[i] *= ri1;
+        m0 = fmaxf(m0, q0[i]);
+        m1 = fmaxf(m1, q1[i]);
+      }
+      m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
+      m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        q0[i] = expf(q0[i] - m0);
+        q1[i] = expf(q1[i] - m1);
+        s0 += q0[i];
+        s1 += q1[i];
+      }
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      const float i0 = 1.0f / s0, i1 = 1.0f / s1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        q0[i] *= i0;
+        q1[i] *= i1;
+      }
+    }
+    // att^T[e][n] = sum_d ctx[d][e] q'[d][n]  (B operand straight from the q' accumulator registers)
+    f32x16 a0 = 0, a1 = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cx[s], pack8(q0, s), a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cx[s], pack8(q1, s), a1, 0, 0, 0);
+    }
+    // att -> LDS as [pixel][k = head*32 + e] (swizzled rows): 4 consecutive e = 8 bytes per register quad
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 w0, w1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        w0[i] = (bf16)a0[4 * g + i];
+        w1[i] = (bf16)a1[4 * g + i];
+      }
+      const int k = hd * 32 + 8 * g + 4 * hh;              // first of the 4 channels
+      *reinterpret_cast<bf16x4*>(sT + swz(pr0, k >> 3) + (k & 7) * 2) = w0;
+      *reinterpret_cast<bf16x4*>(sT + swz(pr1, k >> 3) + (k & 7) * 2) = w1;
+    }
+    LA_SYNC();
+
+    // o^T (rows c of block hd, columns = this wave's 64 pixels) = Wout . att^T + bias
+    f32x16 o0 = 0, o1 = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int c = 2 * s + hh;
+      const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(sT + swz(pr0, c));
+      const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(sT + swz(pr1, c));
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[s], t0, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[s], t1, o1, 0, 0, 0);
+    }
+    float ss0 = 0.f, ss1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      o0[i] += bo[i];
+      o1[i] += bo[i];
+      ss0 += o0[i] * o0[i];
+      ss1 += o1[i] * o1[i];
+    }
+    ss0 += __shfl_xor(ss0, 32, 64);
+    ss1 += __shfl_xor(ss1, 32, 64);
+    if (hh == 0) {
+      sS[hd * TM + pr0] = ss0;
+      sS[hd * TM + pr1] = ss1;
+    }
+    LA_SYNC();                                             // also: every wave is done reading the att tile
+    {
+      const float n0 = sS[pr0] + sS[TM + pr0] + sS[2 * TM + pr0] + sS[3 * TM + pr0];
+      const float n1 = sS[pr1] + sS[TM + pr1] + sS[2 * TM + pr1] + sS[3 * TM + pr1];
+      const float r0 = 1.0f / fmaxf(sqrtf(n0), 1e-12f), r1 = 1.0f / fmaxf(sqrtf(n1), 1e-12f);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 w0, w1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          w0[i] = (bf16)(o0[4 * g + i] * r0 * g2v[4 * g + i]);
+          w1[i] = (bf16)(o1[4 * g + i] * r1 * g2v[4 * g + i]);
+        }
+        const int c = hd * 32 + 8 * g + 4 * hh;
+        *reinterpret_cast<bf16x4*>(sT + swz(pr0, c >> 3) + (c & 7) * 2) = w0;
+        *reinterpret_cast<bf16x4*>(sT + swz(pr1, c >> 3) + (c & 7) * 2) = w1;
+      }
+    }
+    LA_SYNC();
+    // y = staged RMSNorm(o) * g2 + x, whole 256-byte rows, 16 B per lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + NTH * i;
+      const int row = q >> 4, c16 = q & 15;
+      if (px0 + row < p.N) {
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(sT + swz(row, c16));
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(A + swz(row, c16));
+        bf16x8 yv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) yv[e] = (bf16)((float)ov[e] + (float)xv[e]);
+        *reinterpret_cast<bf16x8*>(p.y + ((size_t)b * p.N + px0 + row) * 128 + c16 * 8) = yv;
+      }
+    }
+    LA_WAIT_VM0();
+    LA_SYNC();
+  }
+}
+
+}  // namespace
+
+bool linattn_fused_eligible(int C, int heads, int dh, int N, bool is_bf16) {
+  return is_bf16 && C == 128 && heads == 4 && dh == 32 && N % TM == 0 && (size_t)N * 256 < (1ull << 31);
+}
+
+static int la1_strip(int N) { return N >= 65536 ? 2048 : (N >= 16384 ? 1024 : 512); }
+
+size_t linattn_fused_workspace(int B, int N) {
+  const size_t nch = (size_t)cdiv(N, la1_strip(N)) * 2;
+  return ((size_t)B * 4 * nch * (64 + 1024) + (size_t)B * 4 * 1024) * sizeof(float);
+}
+
+// host-side operand preparation
+//   wkv_img: [256 rows = k(128) | v(128)][128 c] bf16, rows XOR-swizzled into the LDS image, gains folded
+//   wq:      [128][128] bf16 row-major, gains folded;  wout: [128][128] bf16 row-major
+void linattn_fused_pack(const float* to_qkv /*[384][C]*/, const float* norm_g /*[C]*/, const float* to_out /*[C][128]*/,
+                        int C, std::vector<unsigned short>& wkv_img, std::vector<unsigned short>& wq,
+                        std::vector<unsigned short>& wout) {
+  const float sq = sqrtf((float)C);
+  wkv_img.assign(256 * 128, 0);
+  wq.assign(128 * 128, 0);
+  wout.assign((size_t)C * 128, 0);
+  for (int row = 0; row < 256; ++row)
+    for (int c = 0; c < 128; ++c) {
+      const float v = to_qkv[(size_t)(128 + row) * C + c] * (norm_g[c] * sq);
+      const int chunk = (c >> 3) ^ (row & 15);
+      wkv_img[row * 128 + chunk * 8 + (c & 7)] = f32_to_bf16_host(v);
+    }
+  for (int d = 0; d < 128; ++d)
+    for (int c = 0; c < 128; ++c) wq[d * 128 + c] = f32_to_bf16_host(to_qkv[(size_t)d * C + c] * (norm_g[c] * sq));
+  for (int c = 0; c < C; ++c)
+    for (int k = 0; k < 128; ++k) wout[c * 128 + k] = f32_to_bf16_host(to_out[(size_t)c * 128 + k]);
+}
+
+int linattn_fused(const void* x, void* y, int B, int N, const void* wkv_img, const void* wq, const void* wout,
+                  const float* bout, const float* g2_scaled, float* ws, hipStream_t st) {
+  const int strip = la1_strip(N);
+  const int nstrips = cdiv(N, strip);
+  const int nch = nstrips * 2;
+  const size_t bh = (size_t)B * 4;
+  float* pm = ws;
+  float* pl = pm + bh * nch * 32;
+  float* pctx = pl + bh * nch * 32;
+  float* ctxn = pctx + bh * nch * 1024;
+  static bool attr = false;
+  const int lds1 = 65536 + 2 * TILE_BYTES + 2 * TM * 4;
+  const int lds2 = 3 * TILE_BYTES + 2 * TM * 4 + 4 * TM * 4;
+  if (!attr) {
+    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
+    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    attr = true;
+  }
+  hipLaunchKernelGGL(la1_kernel, dim3(nstrips, B), dim3(NTH), lds1, st, (const bf16*)x, N, (const bf16*)wkv_img, strip, pm,
+                     pl, pctx);
+  SRGD_HIP(hipGetLastError());
+  SRGD_TRY(linear_attention_combine(pm, pl, pctx, (int)bh, nch, 1.0f / sqrtf(32.0f), ctxn, st));
+  La2Args a;
+  a.x = (const bf16*)x; a.y = (bf16*)y; a.N = N; a.wq = (const bf16*)wq; a.wout = (const bf16*)wout; a.bout = bout;
+  a.g2 = g2_scaled; a.ctxn = ctxn;
+  const int ntiles = N / TM;
+  // persistent-ish: enough tiles per workgroup to amortise the register-resident operands, enough workgroups to fill 256 CUs
+  int tpw = 1;
+  while (tpw < 8 && (long)B * cdiv(ntiles, tpw * 2) >= 512) tpw *= 2;
+  a.tiles_per_wg = tpw;
+  hipLaunchKernelGGL(la2_kernel, dim3(cdiv(ntiles, tpw), B), dim3(NTH), lds2, st, a);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace srgd

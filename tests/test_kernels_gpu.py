@@ -293,6 +293,33 @@ def test_conv3x3_bf16_integer_exact():
     assert torch.equal(got, F.conv2d(x, w, b, padding=1).to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("cfg", [(1, 16, 16), (2, 32, 64), (1, 128, 128)], ids=lambda s: "B%d_%dx%d" % s)
+def test_linear_attention_block_fused(cfg):
+    # linattn_fused.hip: RMSNorm -> qkv -> linear attention -> to_out -> RMSNorm -> + x in two kernels,
+    # against the oracle's LinearAttention block on bf16-rounded inputs/weights.
+    B, H, W = cfg
+    lib = L().lib()
+    g = torch.Generator().manual_seed(21)
+    C = 128
+    x = rnd(torch.randn(B, C, H, W, generator=g) * 1.5, True)
+    sd = {"a.norm.g": 1 + 0.1 * torch.randn(1, C, 1, 1, generator=g),
+          "a.to_qkv.weight": torch.randn(384, C, 1, 1, generator=g) / C ** 0.5,
+          "a.to_out.0.weight": torch.randn(C, 128, 1, 1, generator=g) / 128 ** 0.5,
+          "a.to_out.0.bias": 0.1 * torch.randn(C, generator=g),
+          "a.to_out.1.g": 1 + 0.1 * torch.randn(1, C, 1, 1, generator=g)}
+    want = O.linear_attention(sd, "a", x, 4, 32) + x
+    d = to_dev_nhwc(x, True)
+    y = torch.empty_like(d)
+    hw = [sd["a.to_qkv.weight"].reshape(384, C).contiguous(), sd["a.norm.g"].reshape(C).contiguous(),
+          sd["a.to_out.0.weight"].reshape(C, 128).contiguous(), sd["a.to_out.0.bias"].contiguous(),
+          sd["a.to_out.1.g"].reshape(C).contiguous()]
+    L().check(lib.srgd_k_linattn_block_fused(ptr(d), ptr(y), B, H * W, C, *[ptr(t) for t in hw], stream()), "fused")
+    torch.cuda.synchronize()
+    got = from_dev_nhwc(y)
+    err = (got - want).abs().max().item()
+    assert err <= 3e-2 * max(1.0, float(want.abs().max())), err
+
+
 def test_conv_rejects_bad_shapes():
     lib = L().lib()
     x = torch.zeros(1, 8, 8, 24, device=DEV)           # 24 channels: not a multiple of 16
