@@ -248,6 +248,117 @@ __global__ __launch_bounds__(256) void full_attn_kernel(const T* __restrict__ qk
   }
 }
 
+// Softmax attention on the matrix cores (exact fp32 MFMA, so the same kernel serves both precision modes).
+// One wave = 32 query rows of one (sample, head); queries sit on the lanes, keys in the registers:
+//   S^T  = K . Q^T        A: K rows (lane r = key, k = d pair), B: Q^T (lane r = query)         16 MFMAs / 32 keys
+//   softmax over keys     = per-lane reduction over 16 registers x 2 lane halves (online max / sum)
+//   O^T += V^T . P^T      B: P^T straight from the accumulator registers (register t holds keys kappa_t and
+//                            kappa_t + 4 of the two lane halves - exactly one k pair of v_mfma_f32_32x32x2_f32),
+//                         A: V[key][e] loaded as coalesced 32-channel row segments                 16 MFMAs / 32 keys
+// No LDS in the main loop; the output tile is transposed through LDS once for row-contiguous stores.
+template <typename T>
+__global__ __launch_bounds__(256) void full_attn_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out, int N,
+                                                              int heads, float scale) {
+  __shared__ __attribute__((aligned(16))) float so[4][32][36];
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int hid = heads * DH, C3 = 3 * hid;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  if (q0 >= N) return;                                          // wave-uniform (N % 32 == 0)
+  const T* base = qkv + (size_t)b * N * C3 + head * DH;
+  constexpr int VN = Vec16<T>::N;
+
+  // this lane's share of its query row: Q[q0 + r][2t + hh] * scale, t = 0..15
+  float qv[16];
+  {
+    const T* qp = base + (size_t)(q0 + r) * C3;
+    float row[DH];
+#pragma unroll
+    for (int v = 0; v < DH / VN; ++v) {
+      Vec16<T> t = reinterpret_cast<const Vec16<T>*>(qp)[v];
+#pragma unroll
+      for (int j = 0; j < VN; ++j) row[v * VN + j] = t.get(j);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) qv[t] = (hh ? row[2 * t + 1] : row[2 * t]) * scale;
+  }
+  f32x16 o = 0;
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < N; k0 += 32) {
+    float kk[16];
+    {
+      const T* kp = base + (size_t)(k0 + r) * C3 + hid;
+      float row[DH];
+#pragma unroll
+      for (int v = 0; v < DH / VN; ++v) {
+        Vec16<T> t = reinterpret_cast<const Vec16<T>*>(kp)[v];
+#pragma unroll
+        for (int j = 0; j < VN; ++j) row[v * VN + j] = t.get(j);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) kk[t] = hh ? row[2 * t + 1] : row[2 * t];
+    }
+    // V[k0 + kappa_t + 4 hh][e = r] for the second product, issued early
+    float vv[16];
+    {
+      const T* vp = base + (size_t)k0 * C3 + 2 * hid + r;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) vv[t] = to_f32<T>(vp[(size_t)((t & 3) + 8 * (t >> 2) + 4 * hh) * C3]);
+    }
+    f32x16 st = 0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[t], qv[t], st, 0, 0, 0);
+    float bm = st[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) bm = fmaxf(bm, st[i]);
+    bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+    const float mn = fmaxf(m, bm);
+    const float corr = expf(m - mn);
+    m = mn;
+    l *= corr;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      st[i] = expf(st[i] - mn);
+      l += st[i];
+      o[i] *= corr;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[t], st[t], o, 0, 0, 0);
+  }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  // o: rows e = (reg&3) + 8 (reg>>2) + 4 hh, column = query r  ->  LDS [query][e]  ->  row-contiguous stores
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<f32x4*>(&so[wave][r][8 * g + 4 * hh]) = f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+  __builtin_amdgcn_s_waitcnt(0xC07F);                           // lgkmcnt(0): this wave's LDS writes are done
+  __builtin_amdgcn_wave_barrier();
+  {
+    // 32 queries x 32 channels per wave: lane -> (query = lane / 2 + 0/16 ..., 16 channels)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int qq = it * 16 + (lane >> 2), c0 = (lane & 3) * 8;
+      T* op = out + ((size_t)b * N + q0 + qq) * hid + head * DH + c0;
+      Vec16<T> w0;
+      if constexpr (VN == 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w0.set(j, so[wave][qq][c0 + j]);
+        *reinterpret_cast<Vec16<T>*>(op) = w0;
+      } else {
+        Vec16<T> w1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          w0.set(j, so[wave][qq][c0 + j]);
+          w1.set(j, so[wave][qq][c0 + 4 + j]);
+        }
+        reinterpret_cast<Vec16<T>*>(op)[0] = w0;
+        reinterpret_cast<Vec16<T>*>(op)[1] = w1;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // positions per partial: long chunks amortise the 4.3 KB partial record; short ones keep small maps parallel
@@ -300,6 +411,15 @@ int linear_attention_combine(const float* pm, const float* pl, const float* pctx
 int full_attention(const void* qkv, void* out, int B, int N, int heads, int dh, bool is_bf16, hipStream_t st) {
   if (dh != DH) SRGD_FAIL("full_attention: dim_head must be 32");
   const float scale = 1.0f / sqrtf((float)dh);
+  if (N % 32 == 0) {                                       // MFMA kernel (every production shape: N = 1024)
+    dim3 g(cdiv(N, 128), heads, B);
+    if (is_bf16)
+      hipLaunchKernelGGL((full_attn_mfma_kernel<bf16>), g, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, N, heads, scale);
+    else
+      hipLaunchKernelGGL((full_attn_mfma_kernel<float>), g, dim3(256), 0, st, (const float*)qkv, (float*)out, N, heads, scale);
+    SRGD_HIP(hipGetLastError());
+    return 0;
+  }
   dim3 g(cdiv(N, 256), heads, B);
   if (is_bf16)
     hipLaunchKernelGGL((full_attn_kernel<bf16>), g, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, N, heads, scale);

@@ -43,12 +43,16 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--shapes", default="all")
     ap.add_argument("--stats", type=int, default=1)
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
+    ap.add_argument("--impls", default="1,0")
     args = ap.parse_args()
     lib = _lib.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     rows = []
     for name, c0, c1, cout, hw, ks in SHAPES:
         if args.shapes == "big" and not name.startswith("3x3"):
+            continue
+        if args.only and args.only not in name:
             continue
         g = torch.Generator(device="cuda").manual_seed(0)
         B = args.batch
@@ -57,7 +61,7 @@ def main():
         w = (torch.randn(cout, c0 + c1, ks, ks) / (ks * (c0 + c1) ** 0.5)).float().contiguous()
         bias = torch.randn(cout).float()
         outs, res = [], {}
-        for impl in (1, 0):
+        for impl in [int(v) for v in args.impls.split(',')]:
             out = torch.empty(B, hw, hw, cout, device="cuda", dtype=torch.bfloat16)
             groups = 8 if (args.stats and ks == 3) else 0
             part = torch.zeros(B * 8 * (hw * hw // 128) * 2, device="cuda") if groups else None
@@ -74,6 +78,9 @@ def main():
             res[impl] = flops / (ms.value * 1e-3) / 1e12
             s1 = part[:B * 8 * slots.value * 2].view(B, 8, slots.value, 2)[..., 0].sum(-1) if groups else None
             outs.append((out.float(), s1))
+        if len(outs) < 2:
+            print(name, res, flush=True)
+            continue
         d = (outs[0][0] - outs[1][0]).abs().max().item()
         ref = outs[0][0].abs().max().item()
         ds = ((outs[0][1] - outs[1][1]).abs().max().item() / max(1.0, outs[0][1].abs().max().item())) if outs[0][1] is not None else 0.0
