@@ -18,8 +18,6 @@
 //   * epilogue: + bias, optional per-(sample, group) partial sum / sum of squares for the GroupNorm that
 //     follows (fixed-order, deterministic), bf16 store.
 //   * blockIdx is remapped so each XCD (private L2) gets a contiguous band of tiles (halo reuse in L2).
-#include <cstdlib>
-
 #include "kernels.hpp"
 
 namespace srgd {
@@ -33,7 +31,6 @@ constexpr int NT3 = 512;
 constexpr int A_BYTES = 24 * 1024;             // 24 wave-instructions x 1 KiB (340 px * 64 B = 21,760 used)
 constexpr int B_BYTES = BN3 * KC * 2;          // 8 KiB
 constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 73,728
-constexpr int CONV3_DEFAULT_VARIANT = 0;
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -50,6 +47,8 @@ struct Conv3Args {
   int Cout;
   bf16* out;
   float* gn_partial; int groups;
+  const float* gn_in_a;   // GNIN: y = silu(a[b][c] * x + b[b][c]) applied to the input while it is staged ([B][Cin] fp32)
+  int gn_in_b_off;        // byte offset of the shift array from the scale array (same allocation)
 };
 
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
@@ -62,8 +61,9 @@ struct Conv3Args {
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 
-template <bool STATS, int VAR>
+template <bool STATS, bool GNIN>
 __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
+  constexpr int VAR = 0;                         // tuning variants (s_setprio / A prefetch) measured within noise: off
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -119,6 +119,28 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
 
   char* const sA0 = smem;
   char* const sB0 = smem + 2 * A_BYTES;
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(GNIN ? p.gn_in_a + (size_t)b * Cin : (const float*)p.in0), 0, GNIN ? p.gn_in_b_off + Cin * 4 : 0, 0x00020000);
+
+  // GNIN: GroupNorm-apply + SiLU of the PRODUCER fused into this conv's staging (reference Block.forward
+  // model.py:250-259 between two convs): once a wave's own DMA pieces of a chunk have landed it rewrites them in
+  // place, y = silu(a*x + b); out-of-image halo chunks stay zero (the conv pads the activated tensor).
+  auto transform_piece = [&](int cc, int j, int a_pix, int a_sub) {
+    if (a_pix < 0) return;
+    char* q = sA0 + (cc & 1) * A_BYTES + (wave + 8 * j) * 1024 + lane * 16;
+    // the chunk's 32 scales | 32 shifts ride in the otherwise all-zero DMA piece 22 of the same A buffer
+    const float* sC = reinterpret_cast<const float*>(sA0 + (cc & 1) * A_BYTES + 22 * 1024) + a_sub * 8;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(q);
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sC), a1 = *reinterpret_cast<const f32x4*>(sC + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sC + 32), b1 = *reinterpret_cast<const f32x4*>(sC + 36);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = (bf16)silu<false>(a0[e] * (float)v[e] + b0[e]);
+      v[4 + e] = (bf16)silu<false>(a1[e] * (float)v[4 + e] + b1[e]);
+    }
+    *reinterpret_cast<bf16x8*>(q) = v;
+  };
+#define transform_a_piece(CCV, J) transform_piece(CCV, J, (J) == 0 ? a_pix0 : ((J) == 1 ? a_pix1 : a_pix2), (J) == 0 ? a_sub0 : ((J) == 1 ? a_sub1 : a_sub2))
 
   auto issue_a = [&](int cc, int j, int a_pix, int a_sub) {
     const int c = cc * KC;
@@ -127,7 +149,11 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     const int coff = first ? c : c - p.C0;
     const int voff = a_pix >= 0 ? (a_pix * Cs + coff + a_sub * 8) * 2 : 0x7ffffff0;
     char* dst = sA0 + (cc & 1) * A_BYTES + (wave + 8 * j) * 1024;
-    if (first) dma16(rs0, dst, voff);
+    if (GNIN && wave + 8 * j == 22) {
+      // lanes 0-7: scale[c..c+31], lanes 8-15: shift[c..c+31] of image b; the rest of the piece stays zero
+      const int cv = lane < 8 ? (c + lane * 4) * 4 : (lane < 16 ? p.gn_in_b_off + (c + (lane - 8) * 4) * 4 : 0x7ffffff0);
+      dma16(rsc, dst, cv);
+    } else if (first) dma16(rs0, dst, voff);
     else dma16(rs1, dst, voff);
   };
 #define issue_a_piece(CCV, J) issue_a(CCV, J, (J) == 0 ? a_pix0 : ((J) == 1 ? a_pix1 : a_pix2), (J) == 0 ? a_sub0 : ((J) == 1 ? a_sub1 : a_sub2))
@@ -153,6 +179,13 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   issue_b(0);
   if (S > 1) issue_b(1);
   if (S > 1) WAIT_VM(1); else WAIT_VM(0);
+  if (GNIN) {
+    BARRIER();                                   // coefficient piece visible; this wave's A(0) pieces have landed
+    transform_a_piece(0, 0);
+    transform_a_piece(0, 1);
+    transform_a_piece(0, 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   BARRIER();
 
   // A fragments of the NEXT tap (k16 step 0) can be fetched before the barrier: within a channel chunk the A
@@ -201,6 +234,8 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       const int s = cc * 9 + tap;
       if (tap < 3) issue_a_piece(cc + 1, tap);
       issue_b(s + 2);                            // s + 2 < S always holds here (cc < CC-1)
+      // the wait at the end of tap 3 retired this wave's three A pieces of chunk cc+1 (they are older than B[s+1])
+      if (GNIN && tap >= 4 && tap < 7) transform_a_piece(cc + 1, tap - 4);
       compute(cc, tap, s);
       if (tap < 3) WAIT_VM(2); else WAIT_VM(1);
       BARRIER();
@@ -219,6 +254,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   }
 
 #undef issue_a_piece
+#undef transform_a_piece
   // ------------------------------- epilogue -------------------------------------------
   // The accumulator layout (lane = output channel, register = pixel) would store 2 bytes per lane; instead the
   // tile is transposed through LDS ([256 pixels][128 ch] bf16, rows padded to 272 B) and written out as whole
@@ -342,32 +378,35 @@ void pack_conv3x3_bf16(const float* src_oihw, int Cin, int Cout, std::vector<uns
       }
 }
 
-int conv3x3_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st) {
+int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, const float* gn_in_b,
+                 hipStream_t st) {
   if (!conv3x3_bf16_eligible(a)) SRGD_FAIL("conv3x3_bf16: shape not eligible");
+  const bool gnin = gn_in_a != nullptr;
+  if (gnin && (a.C1 != 0 || !gn_in_b || gn_in_b < gn_in_a || (size_t)((const char*)gn_in_b - (const char*)gn_in_a) > (1u << 30)))
+    SRGD_FAIL("conv3x3_bf16: fused input GroupNorm needs one source and scale/shift arrays in one allocation");
   Conv3Args p;
   p.in0 = (const bf16*)a.in0; p.in1 = (const bf16*)a.in1; p.C0 = a.C0; p.C1 = a.C1;
   p.B = a.B; p.H = a.Hin; p.W = a.Win; p.w = (const bf16*)packed_w; p.bias = a.bias; p.Cout = a.Cout;
   p.out = (bf16*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
+  p.gn_in_a = gn_in_a;
+  p.gn_in_b_off = gnin ? (int)((const char*)gn_in_b - (const char*)gn_in_a) : 0;
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
-  static int variant = -1;
-  if (variant < 0) {
-    const char* v = getenv("SRGD_CONV3_VARIANT");           // tuning knob (tools/bench_conv.py); default = shipped
-    variant = v ? atoi(v) & 3 : CONV3_DEFAULT_VARIANT;
-#define SRGD_SET(V)                                                                                               \
-  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<true, V>),                      \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));                           \
-  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<false, V>),                     \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    SRGD_SET(0) SRGD_SET(1) SRGD_SET(2) SRGD_SET(3)
+  static bool attr_set = false;
+  constexpr int LDS_GN = LDS_BYTES;
+  if (!attr_set) {
+#define SRGD_SET(S_, G_, L_)                                                                              \
+  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_>),               \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, L_));
+    SRGD_SET(true, false, LDS_BYTES) SRGD_SET(false, false, LDS_BYTES) SRGD_SET(true, true, LDS_GN)
+    SRGD_SET(false, true, LDS_GN)
 #undef SRGD_SET
+    attr_set = true;
   }
-#define SRGD_GO(V)                                                                                                 \
-  case V:                                                                                                          \
-    if (a.gn_partial) hipLaunchKernelGGL((conv3x3_bf16_kernel<true, V>), dim3(grid), dim3(NT3), LDS_BYTES, st, p); \
-    else hipLaunchKernelGGL((conv3x3_bf16_kernel<false, V>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);             \
-    break;
-  switch (variant) { SRGD_GO(0) SRGD_GO(1) SRGD_GO(2) SRGD_GO(3) }
-#undef SRGD_GO
+  const bool stats = a.gn_partial != nullptr;
+  if (stats && gnin) hipLaunchKernelGGL((conv3x3_bf16_kernel<true, true>), dim3(grid), dim3(NT3), LDS_GN, st, p);
+  else if (stats) hipLaunchKernelGGL((conv3x3_bf16_kernel<true, false>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);
+  else if (gnin) hipLaunchKernelGGL((conv3x3_bf16_kernel<false, true>), dim3(grid), dim3(NT3), LDS_GN, st, p);
+  else hipLaunchKernelGGL((conv3x3_bf16_kernel<false, false>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);
   SRGD_HIP(hipGetLastError());
   return 0;
 }

@@ -197,6 +197,10 @@ struct srgd_engine {
   int stats_slots = 0;          // slots per (sample, group) the last conv wrote into gn_partial
   bool force_generic_conv = false;
   bool force_unfused_attn = false;
+  // conv3x3_bf16 can apply the producer's GroupNorm+SiLU while staging its input (GNIN).  Measured on MI355X it
+  // LOSES: the 16 transcendentals per 16-byte chunk sit on the barrier-paced critical path of an MFMA-bound kernel
+  // (+0.137 s of conv vs -0.055 s of gn_apply per HR tile), so it is off; kept for a staggered-schedule retry.
+  bool no_gn_fusion = true;
 
   Pool pool;
   float* gn_partial = nullptr; size_t gn_partial_cap = 0;
@@ -430,8 +434,19 @@ struct Ctx {
   hipStream_t st;
 };
 
+// gn_in: the input is a raw conv output whose GroupNorm+SiLU (coefA/coefB) the fast 3x3 kernel applies while
+// staging; *gn_in_done tells the caller whether that happened (otherwise it must run gn_apply first).
+bool conv_can_fuse_gn_in(srgd_engine* e, const ConvW& c, int nb, int H, int W) {
+  if (!e->bf16 || !c.w3 || e->force_generic_conv || e->no_gn_fusion) return false;
+  ConvArgs a{};
+  a.C0 = c.Cin; a.C1 = 0; a.ps0 = c.Cin; a.B = nb; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W;
+  a.KH = a.KW = c.KS; a.stride = c.stride; a.pad = c.pad; a.Cout = c.Cout; a.CoutPad = c.CoutPad; a.mode = c.mode;
+  a.groups = e->cfg.groups; a.gn_partial = e->gn_partial;
+  return conv3x3_bf16_eligible(a);
+}
+
 int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, int C1, int Hin, int Win, void* out,
-             const void* residual, bool stats) {
+             const void* residual, bool stats, bool gn_in = false) {
   srgd_engine* e = x.e;
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.ps0 = C0; a.ps1 = C1;
@@ -448,14 +463,15 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
   if (e->prof_on) e->conv_flops += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
   if (e->bf16 && c.w3 && !e->force_generic_conv && conv3x3_bf16_eligible(a)) {
     if (stats) e->stats_slots = conv3x3_bf16_stats_slots(a);
-    return conv3x3_bf16(a, c.w3, x.st);
+    return conv3x3_bf16(a, c.w3, gn_in ? e->coefA : nullptr, gn_in ? e->coefB : nullptr, x.st);
   }
+  if (gn_in) SRGD_FAIL("internal: fused input GroupNorm requested on the generic conv path");
   if (stats) e->stats_slots = (a.Hout * a.Wout) / conv_tile_m();
   return conv_igemm(a, e->bf16, x.st);
 }
 
 int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_offset /* <0: none */, void* buf,
-           const void* residual) {
+           const void* residual, bool finalize_only = false) {
   srgd_engine* e = x.e;
   Prof p(e, KC_GN, x.st);
   GnFinalizeArgs f;
@@ -465,6 +481,7 @@ int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_
   f.ss_stride = e->ss_stride; f.ss_offset = ss_offset < 0 ? 0 : ss_offset; f.eps = 1e-5f;
   f.coefA = e->coefA; f.coefB = e->coefB;
   SRGD_TRY(gn_finalize(f, x.st));
+  if (finalize_only) return 0;                     // the consumer conv applies y = silu(A x + B) while staging
   return gn_apply_silu(buf, buf, residual, e->coefA, e->coefB, x.nb, hw, C, e->bf16, x.st);
 }
 
@@ -477,8 +494,9 @@ int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, i
   void* v = e->pool.get(bytes);
   if (!u || !v) return -1;
   SRGD_TRY(run_conv(x, r.c1, in0, C0, in1, C1, x.H, x.W, u, nullptr, true));
-  SRGD_TRY(run_gn(x, r.g1, r.b1, r.Cout, hw, r.ss_offset, u, nullptr));
-  SRGD_TRY(run_conv(x, r.c2, u, r.Cout, nullptr, 0, x.H, x.W, v, nullptr, true));
+  const bool fuse = conv_can_fuse_gn_in(e, r.c2, x.nb, x.H, x.W);
+  SRGD_TRY(run_gn(x, r.g1, r.b1, r.Cout, hw, r.ss_offset, u, nullptr, fuse));
+  SRGD_TRY(run_conv(x, r.c2, u, r.Cout, nullptr, 0, x.H, x.W, v, nullptr, true, fuse));
   if (r.has_res) {
     SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, u, nullptr, false));   // u is free again: reuse it
     SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, u));
@@ -540,10 +558,9 @@ int ensure_scratch(srgd_engine* e, int nb, int H, int W) {
   size_t need = (size_t)nb * cmax;
   if (e->coef_cap < need) {
     if (e->coefA) hipFree(e->coefA);
-    if (e->coefB) hipFree(e->coefB);
     e->coefA = e->coefB = nullptr;
-    SRGD_HIP(hipMalloc((void**)&e->coefA, need * 4));
-    SRGD_HIP(hipMalloc((void**)&e->coefB, need * 4));
+    SRGD_HIP(hipMalloc((void**)&e->coefA, 2 * need * 4));     // one allocation: [scale | shift] (conv3x3 GNIN reads both)
+    e->coefB = e->coefA + need;
     e->coef_cap = need;
   }
   SRGD_TRY(ensure(&e->la_ws, &e->la_ws_cap,
@@ -698,7 +715,7 @@ int srgd_destroy(srgd_engine* e) {
   hipDeviceSynchronize();
   for (void* p : e->weight_allocs) hipFree(p);
   e->pool.release_all();
-  for (void* p : {(void*)e->gn_partial, (void*)e->coefA, (void*)e->coefB, (void*)e->la_ws, (void*)e->d_rows,
+  for (void* p : {(void*)e->gn_partial, (void*)e->coefA, (void*)e->la_ws, (void*)e->d_rows,
                   (void*)e->d_tiles_even, (void*)e->d_tiles_odd, (void*)e->d_sc, (void*)e->rng_tiles, (void*)e->rng_canvas})
     if (p) hipFree(p);
   for (CondTable* ct : {&e->ct_sampler, &e->ct_api})

@@ -55,7 +55,7 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
     SRGD_HIP(hipMemcpy(dw3.p, p3.data(), p3.size() * 2, hipMemcpyHostToDevice));
   }
   if (stats_slots) *stats_slots = fast ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
-  auto run = [&]() -> int { return fast ? conv3x3_bf16(a, dw3.p, st) : conv_igemm(a, is_bf16 != 0, st); };
+  auto run = [&]() -> int { return fast ? conv3x3_bf16(a, dw3.p, nullptr, nullptr, st) : conv_igemm(a, is_bf16 != 0, st); };
   SRGD_TRY(run());
   SRGD_HIP(hipStreamSynchronize(st));
   if (iters > 0 && avg_ms) {

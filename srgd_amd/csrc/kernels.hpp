@@ -43,7 +43,10 @@ bool conv3x3_bf16_eligible(const ConvArgs& a);
 int conv3x3_bf16_stats_slots(const ConvArgs& a);
 void pack_conv3x3_bf16(const float* src_oihw, int Cin, int Cout, std::vector<unsigned short>& out,
                        unsigned short (*to_bf16)(float));
-int conv3x3_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st);
+// gn_in_a/gn_in_b (nullable): [B][Cin] fp32 coefficients of y = silu(a*x + b) applied to the INPUT while it is
+// staged (the producer's GroupNorm+SiLU, fused; single source, Cin <= 1024).
+int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, const float* gn_in_b,
+                 hipStream_t st);
 unsigned short f32_to_bf16_host(float f);
 
 // ---------------------------------------------------------------- norm_act.hip

@@ -16,6 +16,7 @@
 //               + bias, RMSNorm over c (cross-wave sum of squares through LDS), * g2, + x (the x tile is still in
 //               LDS), staged and stored as whole 256-byte rows.  Wq', Wout and ctx live in registers for the
 //               lifetime of the (persistent) workgroup.
+// bf16-mode only, so exponentials use the hardware v_exp_f32 path (__expf).
 // The RMSNorm gains g1*sqrt(C) are folded into Wkv'/Wq' on the host; 1/||x|| is applied to the GEMM result.
 #include "kernels.hpp"
 
@@ -154,13 +155,13 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
     }
     bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
     const float mn = fmaxf(m, bm);
-    const float f = expf(m - mn);                 // first tile: exp(-inf) = 0
+    const float f = __expf(m - mn);                 // first tile: exp(-inf) = 0
     m = mn;
     l *= f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      k0[i] = expf(k0[i] - mn);
-      k1[i] = expf(k1[i] - mn);
+      k0[i] = __expf(k0[i] - mn);
+      k1[i] = __expf(k1[i] - mn);
       l += k0[i] + k1[i];
     }
     if (!__all(f == 1.0f)) {
@@ -285,14 +286,14 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        q0[i] = expf(q0[i] - m0);
-        q1[i] = expf(q1[i] - m1);
+        q0[i] = __expf(q0[i] - m0);
+        q1[i] = __expf(q1[i] - m1);
         s0 += q0[i];
         s1 += q1[i];
       }
       s0 += __shfl_xor(s0, 32, 64);
       s1 += __shfl_xor(s1, 32, 64);
-      const float i0 = 1.0f / s0, i1 = 1.0f / s1;
+      const float i0 = __frcp_rn(s0), i1 = __frcp_rn(s1);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         q0[i] *= i0;
