@@ -336,7 +336,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
 }  // namespace
 
 bool conv3x3_bf16_eligible(const ConvArgs& a) {
-  if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.mode != CONV_PLAIN || a.residual) return false;
+  if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.mode != CONV_PLAIN || a.residual || a.gn_res_src) return false;
   if (a.ps0 != a.C0 || (a.C1 && a.ps1 != a.C1)) return false;
   if (a.C0 % KC || a.C1 % KC || a.Cout % BN3 || a.Cout != a.CoutPad) return false;
   if (a.Hin % PH || a.Win % PW) return false;

@@ -195,6 +195,18 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rr[e]);
           }
+          if (p.gn_res_src) {
+            // h + res_conv(x) with h = SiLU(GroupNorm(block2 conv)) evaluated here from the raw conv output
+            const bf16x8 raw = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.gn_res_src) + o);
+            const size_t co = (size_t)(m / HWo) * p.Cout + col;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.gn_res_a + co), a1 = *reinterpret_cast<const f32x4*>(p.gn_res_a + co + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.gn_res_b + co), b1 = *reinterpret_cast<const f32x4*>(p.gn_res_b + co + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = (bf16)((float)v[e] + silu<PRECISE>(a0[e] * (float)raw[e] + b0[e]));
+              v[4 + e] = (bf16)((float)v[4 + e] + silu<PRECISE>(a1[e] * (float)raw[4 + e] + b1[e]));
+            }
+          }
           *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + o) = v;
         }
       }
@@ -323,6 +335,8 @@ int conv_igemm(const ConvArgs& a, bool is_bf16, hipStream_t st) {
     SRGD_FAIL("conv_igemm: invalid pixel-shuffle epilogue combination");
   if (is_bf16 && (a.Cout % 8 != 0 || (a.mode == CONV_PIXEL_SHUFFLE_SILU && (a.Cout / 4) % 8 != 0)))
     SRGD_FAIL("conv_igemm: bf16 output channels must be a multiple of 8 (32 for the pixel-shuffle epilogue)");
+  if (a.gn_res_src && (!is_bf16 || a.mode != CONV_PLAIN || !a.gn_res_a || !a.gn_res_b))
+    SRGD_FAIL("conv_igemm: the fused GroupNorm+residual tail is a bf16 plain-mode epilogue");
   const int bkc = pick_bkc(is_bf16, a.C0, a.C1);
   if (bkc == 0) SRGD_FAIL("conv_igemm: input channels must be a multiple of 16");
   if (is_bf16) {

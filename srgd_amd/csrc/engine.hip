@@ -446,7 +446,7 @@ bool conv_can_fuse_gn_in(srgd_engine* e, const ConvW& c, int nb, int H, int W) {
 }
 
 int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, int C1, int Hin, int Win, void* out,
-             const void* residual, bool stats, bool gn_in = false) {
+             const void* residual, bool stats, bool gn_in = false, const void* gn_res_src = nullptr) {
   srgd_engine* e = x.e;
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.ps0 = C0; a.ps1 = C1;
@@ -458,6 +458,7 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
   a.out = out; a.residual = residual; a.mode = c.mode;
   a.gn_partial = stats ? e->gn_partial : nullptr;
   a.groups = e->cfg.groups;
+  a.gn_res_src = gn_res_src; a.gn_res_a = gn_res_src ? e->coefA : nullptr; a.gn_res_b = gn_res_src ? e->coefB : nullptr;
   if (C0 + C1 != c.Cin) SRGD_FAIL("internal: conv input channel mismatch");
   Prof p(e, KC_CONV, x.st);
   if (e->prof_on) e->conv_flops += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
@@ -497,7 +498,11 @@ int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, i
   const bool fuse = conv_can_fuse_gn_in(e, r.c2, x.nb, x.H, x.W);
   SRGD_TRY(run_gn(x, r.g1, r.b1, r.Cout, hw, r.ss_offset, u, nullptr, fuse));
   SRGD_TRY(run_conv(x, r.c2, u, r.Cout, nullptr, 0, x.H, x.W, v, nullptr, true, fuse));
-  if (r.has_res) {
+  if (r.has_res && e->bf16) {
+    // GroupNorm2 + SiLU + (+ res_conv(x)) evaluated in the 1x1 res_conv's epilogue, in place over v
+    SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, nullptr, true));
+    SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, v, nullptr, false, false, v));
+  } else if (r.has_res) {
     SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, u, nullptr, false));   // u is free again: reuse it
     SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, u));
   } else {
@@ -577,6 +582,7 @@ int run_init7(srgd_engine* e, const void* padded, int entries, int H, int W, voi
   a.KH = 7; a.KW = 1; a.stride = 1; a.pad = 0;
   a.w = e->init7_w; a.bias = e->init_b; a.Cout = e->dim; a.CoutPad = e->init7_coutpad;
   a.out = out; a.residual = nullptr; a.mode = CONV_PLAIN; a.gn_partial = nullptr; a.groups = e->cfg.groups;
+  a.gn_res_src = nullptr; a.gn_res_a = a.gn_res_b = nullptr;
   if (e->prof_on) e->conv_flops += 0.0;   // counted under init_conv7x7, not in the conv family's FLOPs
   return conv_igemm(a, e->bf16, st);
 }

@@ -45,7 +45,7 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   a.Wout = (Win + 2 * pad - KS) / stride + 1;
   a.KH = KS; a.KW = KS; a.stride = stride; a.pad = pad; a.w = dw.p; a.bias = (const float*)db.p; a.Cout = Cout; a.CoutPad = CoutPad;
   a.out = out; a.residual = residual; a.mode = kind == 2 ? CONV_PIXEL_SHUFFLE_SILU : CONV_PLAIN;
-  a.gn_partial = gn_partial; a.groups = groups;
+  a.gn_partial = gn_partial; a.groups = groups; a.gn_res_src = nullptr; a.gn_res_a = a.gn_res_b = nullptr;
   const bool fast = impl != 1 && is_bf16 && kind == 0 && conv3x3_bf16_eligible(a);
   if (impl == 2 && !fast) SRGD_FAIL("srgd_k_conv2d: the conv3x3_bf16 fast path does not cover this shape");
   if (fast) {

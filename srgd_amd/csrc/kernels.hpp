@@ -28,6 +28,11 @@ struct ConvArgs {
   int mode;
   float* gn_partial;      // optional [B][groups][Hout*Wout/128][2]
   int groups;
+  // optional fused tail of a ResnetBlock (model.py:283-285) for the 1x1 res_conv, bf16 only:
+  //   out = (acc + bias) + silu(gn_res_a[b][c] * gn_res_src + gn_res_b[b][c])      (out may alias gn_res_src)
+  const void* gn_res_src;
+  const float* gn_res_a;
+  const float* gn_res_b;
 };
 int conv_igemm(const ConvArgs& a, bool is_bf16, hipStream_t st);
 int conv_tile_m();
