@@ -163,14 +163,27 @@ def main():
             eng.profile_begin()
             run(args.warmup)
             prof = eng.profile_end()
-            conv_ms = prof["ms"]["conv_igemm"]
-            n_launch = prof["launches"]["conv_igemm"]
-            achieved = prof["conv_flops"] / (conv_ms * 1e-3) / 1e12
+            # the dominant kernel: conv3x3_bf16_kernel in bf16 mode, the generic implicit GEMM in fp32 mode
+            fam = "conv3x3_bf16" if prof["ms"].get("conv3x3_bf16", 0.0) > prof["ms"]["conv_igemm"] else "conv_igemm"
+            conv_ms, n_launch, fl = prof["ms"][fam], prof["launches"][fam], prof["flops"][fam]
+            achieved = fl / (conv_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[args.precision]
+            kname = "conv3x3_bf16_kernel" if fam == "conv3x3_bf16" else "conv_igemm_kernel"
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+            if os.path.exists(pmc) and args.precision == "bf16":
+                t = json.load(open(pmc)).get(kname)
+                if t:   # gfx950: FETCH_SIZE counts half of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> x2
+                    traffic = (2.0 * t["FETCH_SIZE"]["avg_kb"] + t["WRITE_SIZE"]["avg_kb"]) * 1024.0
+                    traffic_src = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             line["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                                "frac": achieved / peak, "traffic": None, "kernel": "conv_igemm_kernel",
-                                "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
-                                "algorithmic_gflop_per_launch": prof["conv_flops"] / max(n_launch, 1) / 1e9}
+                                "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
+                                "traffic_source": traffic_src, "kernel": kname, "launches": n_launch,
+                                "avg_launch_ms": conv_ms / max(n_launch, 1),
+                                "algorithmic_gflop_per_launch": fl / max(n_launch, 1) / 1e9,
+                                "family_time_share": conv_ms / sum(prof["ms"].values())}
+            all_conv_ms = prof["ms"]["conv_igemm"] + prof["ms"].get("conv3x3_bf16", 0.0)
+            line["conv_all_tflops"] = (prof["flops"]["conv_igemm"] + prof["flops"].get("conv3x3_bf16", 0.0)) / (all_conv_ms * 1e-3) / 1e12
             tot = sum(prof["ms"].values())
             line["kernel_time_share"] = {k: round(v / tot, 4) for k, v in prof["ms"].items() if v > 0}
             line["profiled_pass_ms"] = tot

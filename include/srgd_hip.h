@@ -117,10 +117,10 @@ int srgd_randn(srgd_engine* e, float* dst, size_t n, uint64_t seed, uint64_t str
 
 /* ---- measurement ----------------------------------------------------------------------------
  * Between begin and end every kernel family is bracketed by HIP events on its launch stream;
- * end synchronises and returns accumulated milliseconds / launch counts per family and the
- * algorithmic conv FLOPs issued (2*M*Cout*K).  Family names: srgd_profile_family_name(i). */
+ * end synchronises and returns, per family, accumulated milliseconds, launch counts and (for the two
+ * convolution families) the algorithmic FLOPs issued (2*M*Cout*K).  Family names: srgd_profile_family_name(i). */
 int srgd_profile_begin(srgd_engine* e);
-int srgd_profile_end(srgd_engine* e, double* ms, int64_t* launches, int n_families, double* conv_flops);
+int srgd_profile_end(srgd_engine* e, double* ms, int64_t* launches, double* flops, int n_families);
 int srgd_profile_num_families(void);
 const char* srgd_profile_family_name(int i);
 int64_t srgd_device_bytes_in_use(const srgd_engine* e);

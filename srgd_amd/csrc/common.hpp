@@ -79,7 +79,8 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Kernel classes for the per-class timing that bench.py reads (srgd_profile_*).
 enum KClass {
-  KC_CONV = 0,     // implicit-GEMM convolutions (3x3, 1x1, 2x2/s2)
+  KC_CONV = 0,     // generic implicit-GEMM convolutions (1x1, 2x2/s2, pixel-shuffle, fp32 mode, odd shapes)
+  KC_CONV3,        // conv3x3_bf16_kernel: the 3x3 bf16 fast path (dominant kernel)
   KC_INIT,         // 7x7 input convolution reading the canvases
   KC_GN,           // GroupNorm finalize + apply(+SiLU, +residual)
   KC_RMS,          // RMSNorm

@@ -164,7 +164,7 @@ struct CondTable {
 
 struct ProfRec { int kc; hipEvent_t a, b; };
 
-const char* kFamilyNames[KC_COUNT] = {"conv_igemm", "init_conv7x7", "groupnorm_silu", "rmsnorm", "linear_attention",
+const char* kFamilyNames[KC_COUNT] = {"conv_igemm", "conv3x3_bf16", "init_conv7x7", "groupnorm_silu", "rmsnorm", "linear_attention",
                                       "full_attention", "final_conv_ddpm_step", "canvas_rng", "conditioning"};
 
 }  // namespace
@@ -222,7 +222,7 @@ struct srgd_engine {
   bool prof_on = false;
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_free;
-  double conv_flops = 0.0;
+  double fam_flops[KC_COUNT] = {};   // algorithmic FLOPs issued per family while profiling (conv families only)
 
   int reg(const std::string& name, std::vector<int64_t> shape) {
     HostTensor t;
@@ -460,9 +460,11 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
   a.groups = e->cfg.groups;
   a.gn_res_src = gn_res_src; a.gn_res_a = gn_res_src ? e->coefA : nullptr; a.gn_res_b = gn_res_src ? e->coefB : nullptr;
   if (C0 + C1 != c.Cin) SRGD_FAIL("internal: conv input channel mismatch");
-  Prof p(e, KC_CONV, x.st);
-  if (e->prof_on) e->conv_flops += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
-  if (e->bf16 && c.w3 && !e->force_generic_conv && conv3x3_bf16_eligible(a)) {
+  const bool fast = e->bf16 && c.w3 && !e->force_generic_conv && conv3x3_bf16_eligible(a);
+  Prof p(e, fast ? KC_CONV3 : KC_CONV, x.st);
+  if (e->prof_on)
+    e->fam_flops[fast ? KC_CONV3 : KC_CONV] += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
+  if (fast) {
     if (stats) e->stats_slots = conv3x3_bf16_stats_slots(a);
     return conv3x3_bf16(a, c.w3, gn_in ? e->coefA : nullptr, gn_in ? e->coefB : nullptr, x.st);
   }
@@ -583,7 +585,6 @@ int run_init7(srgd_engine* e, const void* padded, int entries, int H, int W, voi
   a.w = e->init7_w; a.bias = e->init_b; a.Cout = e->dim; a.CoutPad = e->init7_coutpad;
   a.out = out; a.residual = nullptr; a.mode = CONV_PLAIN; a.gn_partial = nullptr; a.groups = e->cfg.groups;
   a.gn_res_src = nullptr; a.gn_res_a = a.gn_res_b = nullptr;
-  if (e->prof_on) e->conv_flops += 0.0;   // counted under init_conv7x7, not in the conv family's FLOPs
   return conv_igemm(a, e->bf16, st);
 }
 
@@ -976,16 +977,20 @@ int srgd_profile_begin(srgd_engine* e) {
   if (!e) SRGD_FAIL("null engine");
   for (auto& r : e->prof) { e->ev_free.push_back(r.a); e->ev_free.push_back(r.b); }
   e->prof.clear();
-  e->conv_flops = 0.0;
+  for (double& f : e->fam_flops) f = 0.0;
   e->prof_on = true;
   return 0;
 }
 
-int srgd_profile_end(srgd_engine* e, double* ms, int64_t* launches, int n_families, double* conv_flops) {
+int srgd_profile_end(srgd_engine* e, double* ms, int64_t* launches, double* flops, int n_families) {
   if (!e) SRGD_FAIL("null engine");
   e->prof_on = false;
   SRGD_HIP(hipDeviceSynchronize());
-  for (int i = 0; i < n_families && i < KC_COUNT; ++i) { if (ms) ms[i] = 0.0; if (launches) launches[i] = 0; }
+  for (int i = 0; i < n_families && i < KC_COUNT; ++i) {
+    if (ms) ms[i] = 0.0;
+    if (launches) launches[i] = 0;
+    if (flops) flops[i] = e->fam_flops[i];
+  }
   for (auto& r : e->prof) {
     float t = 0.f;
     SRGD_HIP(hipEventElapsedTime(&t, r.a, r.b));
@@ -993,7 +998,6 @@ int srgd_profile_end(srgd_engine* e, double* ms, int64_t* launches, int n_famili
     e->ev_free.push_back(r.a); e->ev_free.push_back(r.b);
   }
   e->prof.clear();
-  if (conv_flops) *conv_flops = e->conv_flops;
   return 0;
 }
 

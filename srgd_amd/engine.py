@@ -151,11 +151,11 @@ class HipEngine:
         n = self._L.srgd_profile_num_families()
         ms = (C.c_double * n)()
         cnt = (C.c_int64 * n)()
-        fl = C.c_double()
-        check(self._L.srgd_profile_end(self._h, ms, cnt, n, C.byref(fl)), "srgd_profile_end")
+        fl = (C.c_double * n)()
+        check(self._L.srgd_profile_end(self._h, ms, cnt, fl, n), "srgd_profile_end")
         names = [self._L.srgd_profile_family_name(i).decode() for i in range(n)]
         return {"ms": {names[i]: ms[i] for i in range(n)}, "launches": {names[i]: int(cnt[i]) for i in range(n)},
-                "conv_flops": fl.value}
+                "flops": {names[i]: fl[i] for i in range(n)}}
 
     def bytes_in_use(self) -> int:
         return int(self._L.srgd_device_bytes_in_use(self._h))
