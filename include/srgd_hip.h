@@ -108,6 +108,12 @@ int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_ca
                       const float* noise_tiles, const float* noise_canvas, int passes, int guidance_kind,
                       float guidance_scale, int sub_batch, uint64_t seed, void* stream);
 
+/* Optional start from the forward-diffused condition instead of white noise (generation_start_steps > 0 or
+ * start_white_noise=False): img = reflect_pad(2*cond01-1) * alpha + noise * sigma over the whole canvas
+ * (q_sample, model.py:3305-3308, :3312-3315, :3434-3442).  noise_canvas: device [3,Hp,Wp] or NULL (device RNG). */
+int srgd_sampler_q_start(srgd_engine* e, const float* cond01, const float* noise_canvas, float alpha, float sigma,
+                         float* img, uint64_t seed, void* stream);
+
 /* Crop, clamp to [-1,1], map to [0,1] (model.py:3403-3405).  out01: device fp32 [3,H,W]. */
 int srgd_sampler_end(srgd_engine* e, const float* img, float* out01, void* stream);
 

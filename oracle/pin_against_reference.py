@@ -86,7 +86,7 @@ def main():
                 got = O.unet_forward(usd, cfg, x, ls, label, c)
                 ok &= report(f"eps {name}", got, want, 2e-5 * max(1.0, want.abs().max().item()))
 
-    def run_sampler(dim, h, w, steps, bs, ccs=1.0, cs=1.0, label=0):
+    def run_sampler(dim, h, w, steps, bs, ccs=1.0, cs=1.0, label=0, **extra):
         sampler, conf = refshim.build_reference_sampler(rm, rc, dim=dim, num_sample_steps=steps)
         schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
         sd = synth_state_dict(schema, seed=0)
@@ -100,12 +100,12 @@ def main():
         torch.manual_seed(71)
         with torch.inference_mode():
             want = sampler.tiled_sample(batch_size=bs, condition_x=cond.clone(), class_label=lab,
-                                        cond_scale=cs, class_cond_scale=ccs, num_sample_steps=steps)
+                                        cond_scale=cs, class_cond_scale=ccs, num_sample_steps=steps, **extra)
         t1 = time.time()
         torch.manual_seed(71)
         with torch.inference_mode():
             got = O.tiled_sample(usd, cfg, cond.clone(), lab, batch_size=bs, num_sample_steps=steps,
-                                 cond_scale=cs, class_cond_scale=ccs)
+                                 cond_scale=cs, class_cond_scale=ccs, **extra)
         t2 = time.time()
         print(f"    reference {t1 - t0:.1f}s  oracle {t2 - t1:.1f}s")
         return got, want
@@ -121,6 +121,12 @@ def main():
     ok &= report("final image", got, want, 1e-4)
     print("[sampler] dim=16, 300x500 image -> 768x768 canvas (9/4 tiles), 4 steps, batch_size 4 (ragged)")
     got, want = run_sampler(16, 300, 500, 4, 4)
+    ok &= report("final image", got, want, 1e-4)
+    print("[sampler] dim=16, 256x256, 8 steps, generation_start_steps=3, class guidance 1.5 from step 5")
+    got, want = run_sampler(16, 256, 256, 8, 4, ccs=1.5, generation_start_steps=3, class_guidance_start_steps=5)
+    ok &= report("final image", got, want, 1e-4)
+    print("[sampler] dim=16, 300x300 -> 768x768 canvas, 3 steps, start_white_noise=False")
+    got, want = run_sampler(16, 300, 300, 3, 8, start_white_noise=False)
     ok &= report("final image", got, want, 1e-4)
     if not args.quick:
         print("[sampler] dim=128, 256x256 canvas, 4 steps, CFG off")

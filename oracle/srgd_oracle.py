@@ -337,9 +337,10 @@ def predict_and_step(sd, cfg: UnetCfg, x: Tensor, t: Tensor, t_next: Tensor, con
 def tiled_sample(sd, cfg: UnetCfg, condition_x: Tensor, class_label: Optional[Tensor] = None, *,
                  batch_size: int = 4, num_sample_steps: int = 50, cond_scale: float = 1.0,
                  guidance_start_steps: int = 0, class_cond_scale: float = 1.0,
-                 class_guidance_start_steps: int = 0, tile: int = 256,
+                 class_guidance_start_steps: int = 0, tile: int = 256, generation_start_steps: int = 0,
+                 start_white_noise: bool = True,
                  noise: Optional["NoiseSource"] = None, trace: Optional[dict] = None) -> Tensor:
-    """model.py:3288-3413 tiled_sample (generation_start_steps=0, start_white_noise=True).
+    """model.py:3288-3413 tiled_sample.
 
     condition_x: [1,3,H,W] in [0,1].  Returns [1,3,H,W] in [0,1].
     """
@@ -348,7 +349,13 @@ def tiled_sample(sd, cfg: UnetCfg, condition_x: Tensor, class_label: Optional[Te
     _, _, h, w = cond.shape
     (left, top, right, bottom), pad = canvas_box_and_pad(h, w)            # :3301 (tile fixed at 256)
     cond = F.pad(cond, pad, mode="reflect")                              # :3303
-    img = noise.randn(cond.shape)                                        # :3311
+    if generation_start_steps > 0 or not start_white_noise:              # :3305-3308 / :3312-3315 q_sample start
+        t0 = (1.0 - torch.tensor(generation_start_steps / num_sample_steps)) if generation_start_steps > 0 \
+            else torch.tensor(1.0)
+        ls0 = log_snr_linear(t0)
+        img = cond * ls0.sigmoid().sqrt() + noise.randn(cond.shape) * (-ls0).sigmoid().sqrt()   # :3434-3442
+    else:
+        img = noise.randn(cond.shape)                                    # :3311
     steps = torch.linspace(1.0, 0.0, num_sample_steps + 1)               # :3325
     hp, wp = cond.shape[-2:]
     grids = sampling_grids(hp, wp, tile, tile)
@@ -356,6 +363,8 @@ def tiled_sample(sd, cfg: UnetCfg, condition_x: Tensor, class_label: Optional[Te
     cond = F.pad(cond[:, :, it:ib, il:ir], ipad, mode="constant", value=0.0)   # :3341-3342
     x_start = img.clone()
     for i in range(num_sample_steps):
+        if i < generation_start_steps:                                   # :3347-3348
+            continue
         cs = cond_scale if i >= guidance_start_steps else 1.0            # :3349-3356
         ccs = class_cond_scale if i >= class_guidance_start_steps else 1.0
         t, t_next = steps[i], steps[i + 1]

@@ -957,6 +957,23 @@ int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_ca
   return 0;
 }
 
+int srgd_sampler_q_start(srgd_engine* e, const float* cond01, const float* noise_canvas, float alpha, float sigma,
+                         float* img, uint64_t seed, void* stream) {
+  if (!e || !e->run_active) SRGD_FAIL("srgd_sampler_q_start: call srgd_sampler_begin first");
+  if (!cond01 || !img) SRGD_FAIL("srgd_sampler_q_start: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const srgd_sampler_geometry& g = e->geo;
+  Prof p(e, KC_CANVAS, st);
+  const float* nz = noise_canvas;
+  if (!nz) {
+    const size_t cn = (size_t)3 * g.Hp * g.Wp;
+    SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, cn));
+    SRGD_TRY(philox_normal(e->rng_canvas, cn, seed, 0, nullptr, st));
+    nz = e->rng_canvas;
+  }
+  return canvas_q_start(cond01, g.H, g.W, g.left, g.top, g.Hp, g.Wp, nz, alpha, sigma, img, st);
+}
+
 int srgd_sampler_end(srgd_engine* e, const float* img, float* out01, void* stream) {
   if (!e || !e->run_active) SRGD_FAIL("srgd_sampler_end: no active run");
   hipStream_t st = (hipStream_t)stream;

@@ -149,6 +149,8 @@ int final_step(const FinalStepArgs& a, const TileBatch& tb, bool is_bf16, hipStr
 // canvas kernels (model.py:3296-3303, :3337-3342, :3392-3396, :3403-3405)
 int canvas_prepare_cond(const float* cond01 /*[3][H][W]*/, int H, int W, int pad_l, int pad_t, int Hp, int Wp,
                         int il, int it, int ir, int ib, float* cond_canvas, hipStream_t st);
+int canvas_q_start(const float* cond01, int H, int W, int pad_l, int pad_t, int Hp, int Wp, const float* noise,
+                   float alpha, float sigma, float* img, hipStream_t st);
 int canvas_ring_renoise(float* img, const float* noise /*[3][Hp][Wp]*/, int Hp, int Wp, int il, int it, int ir,
                         int ib, const StepScalars* sc, const int* step_ptr, hipStream_t st);
 int canvas_finish(const float* img, int Hp, int Wp, int left, int top, int H, int W, float* out01, hipStream_t st);

@@ -152,6 +152,26 @@ __global__ void canvas_prepare_cond_kernel(const float* __restrict__ c01, int H,
   }
 }
 
+// q_sample start of a run (model.py:3305-3308, :3312-3315): img = reflect_pad(2*cond-1) * alpha + noise * sigma over
+// the WHOLE canvas (the condition is not yet zeroed outside the inner box at that point of the reference).
+__global__ void canvas_q_start_kernel(const float* __restrict__ c01, int H, int W, int pad_l, int pad_t, int Hp, int Wp,
+                                      const float* __restrict__ noise, float alpha, float sigma,
+                                      float* __restrict__ img) {
+  const long n = 3L * Hp * Wp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i / ((long)Hp * Wp));
+    const long rem = i - (long)c * Hp * Wp;
+    const int Y = (int)(rem / Wp), X = (int)(rem - (long)Y * Wp);
+    int y = Y - pad_t, x = X - pad_l;
+    if (y < 0) y = -y;
+    if (y >= H) y = 2 * (H - 1) - y;
+    if (x < 0) x = -x;
+    if (x >= W) x = 2 * (W - 1) - x;
+    const float v = c01[((long)c * H + y) * W + x] * 2.0f - 1.0f;
+    img[i] = v * alpha + noise[i] * sigma;
+  }
+}
+
 __global__ void canvas_ring_renoise_kernel(float* __restrict__ img, const float* __restrict__ noise, int Hp, int Wp,
                                            int il, int it, int ir, int ib, const StepScalars* __restrict__ sc,
                                            const int* __restrict__ step_ptr) {
@@ -278,6 +298,14 @@ int canvas_prepare_cond(const float* cond01, int H, int W, int pad_l, int pad_t,
                         int ir, int ib, float* cond_canvas, hipStream_t st) {
   hipLaunchKernelGGL(canvas_prepare_cond_kernel, dim3(grid_for(3L * Hp * Wp)), dim3(256), 0, st, cond01, H, W, pad_l,
                      pad_t, Hp, Wp, il, it, ir, ib, cond_canvas);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int canvas_q_start(const float* cond01, int H, int W, int pad_l, int pad_t, int Hp, int Wp, const float* noise,
+                   float alpha, float sigma, float* img, hipStream_t st) {
+  hipLaunchKernelGGL(canvas_q_start_kernel, dim3(grid_for(3L * Hp * Wp)), dim3(256), 0, st, cond01, H, W, pad_l, pad_t, Hp,
+                     Wp, noise, alpha, sigma, img);
   SRGD_HIP(hipGetLastError());
   return 0;
 }

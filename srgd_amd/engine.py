@@ -132,6 +132,13 @@ class HipEngine:
                                             float(guidance_scale), int(sub_batch), int(seed) & (2 ** 64 - 1),
                                             _stream_ptr(self.device)), "srgd_sampler_step")
 
+    def sampler_q_start(self, cond01: torch.Tensor, noise_canvas: Optional[torch.Tensor], alpha: float, sigma: float,
+                        img: torch.Tensor, seed: int = 0) -> None:
+        with torch.cuda.device(self.device):
+            check(self._L.srgd_sampler_q_start(self._h, _dev_ptr(cond01), _dev_ptr(noise_canvas), float(alpha), float(sigma),
+                                               _dev_ptr(img), int(seed) & (2 ** 64 - 1), _stream_ptr(self.device)),
+                  "srgd_sampler_q_start")
+
     def sampler_end(self, img: torch.Tensor, out01: torch.Tensor) -> None:
         with torch.cuda.device(self.device):
             check(self._L.srgd_sampler_end(self._h, _dev_ptr(img), _dev_ptr(out01), _stream_ptr(self.device)),

@@ -335,8 +335,6 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
         num_sample_steps = self.num_sample_steps if num_sample_steps is None else num_sample_steps
         if cond_scale != 1.0 and class_cond_scale != 1.0:
             raise NotImplementedError("Currently, you cannot specify both cond_scale and class_cond_scale at the same time.")
-        if generation_start_steps > 0 or not start_white_noise:
-            raise NotImplementedError("generation_start_steps > 0 / start_white_noise=False (q_sample start) is not built yet")
         if tile_size != 256 or tile_stride != 256:
             raise NotImplementedError("tile_size/tile_stride other than 256 are unusable in the reference too "
                                       "(get_coord_and_pad is called without them, model.py:3301)")
@@ -372,7 +370,15 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
                           [(a, c_) for (a, _, c_, _) in coords1], scalars, log_snrs, class_id)
 
         host_noise = self.noise_source == "host"
-        if host_noise:
+        if generation_start_steps > 0 or not start_white_noise:
+            # start from the forward-diffused condition (model.py:3305-3308 / :3312-3315); same single draw
+            t0 = (1.0 - torch.tensor(generation_start_steps / num_sample_steps)) if generation_start_steps > 0 \
+                else torch.tensor(1.0)
+            ls0 = beta_linear_log_snr(t0)
+            img = torch.empty(1, 3, hp, wp, device=dev)
+            eng.sampler_q_start(cond01, torch.randn(1, 3, hp, wp).to(dev) if host_noise else None,
+                                float(ls0.sigmoid().sqrt()), float((-ls0).sigmoid().sqrt()), img, self.device_noise_seed)
+        elif host_noise:
             img = torch.randn(1, 3, hp, wp).to(dev)                      # reference draw #1 (model.py:3311)
         else:
             img = eng.randn_(torch.empty(1, 3, hp, wp, device=dev), self.device_noise_seed, 0)
@@ -383,6 +389,8 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
         sub_batch = self.max_tiles_per_launch or batch_size
         grids = (coords0, coords1)
         for i in range(num_sample_steps):
+            if i < generation_start_steps:
+                continue
             cur_cond_scale = 1.0 if i < guidance_start_steps else cond_scale
             cur_class_scale = 1.0 if i < class_guidance_start_steps else class_cond_scale
             if cur_cond_scale != 1.0:

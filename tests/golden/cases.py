@@ -26,6 +26,13 @@ SAMPLER_CASES = [
     # G6: ragged canvas -> 768x768, 9/4 tiles, ragged last minibatch, ring re-noise
     dict(name="dim16_300x500", dim=16, h=300, w=500, steps=4, batch_size=4, label=2,
          cond_scale=1.0, class_cond_scale=1.0, weight_seed=0, cond="rand", cond_seed=1235, seed=71),
+    # q_sample start (generation_start_steps > 0 / start_white_noise=False) and delayed class guidance
+    dict(name="dim16_256_genstart", dim=16, h=256, w=256, steps=8, batch_size=4, label=1,
+         cond_scale=1.0, class_cond_scale=1.5, weight_seed=0, cond="rand", cond_seed=1236, seed=71,
+         generation_start_steps=3, class_guidance_start_steps=5),
+    dict(name="dim16_300x300_nowhite", dim=16, h=300, w=300, steps=3, batch_size=8, label=0,
+         cond_scale=1.0, class_cond_scale=1.0, weight_seed=0, cond="rand", cond_seed=1237, seed=71,
+         start_white_noise=False),
     # G7: BASELINE config 1 - 64x64 LR -> x4 bicubic -> 256x256, dim-128 U-Net, 10 steps, CFG off
     dict(name="dim128_config1", dim=128, h=256, w=256, steps=10, batch_size=8, label=0,
          cond_scale=1.0, class_cond_scale=1.0, weight_seed=0, cond="lr_bicubic", cond_seed=1234, seed=71),
@@ -62,3 +69,9 @@ def sampler_condition(case):
     if case["cond"] == "lr_bicubic":
         return synthetic_lr_condition(0, case["h"] // 4, case["w"] // 4, seed_base=case["cond_seed"])
     raise KeyError(case["cond"])
+
+
+def extra_kwargs(case):
+    """Optional tiled_sample knobs a case may carry (same names in the reference, the oracle and the product)."""
+    keys = ("generation_start_steps", "class_guidance_start_steps", "guidance_start_steps", "start_white_noise")
+    return {k: case[k] for k in keys if k in case}

@@ -96,7 +96,7 @@ def main():
             img = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond.clone(),
                                        class_label=label, cond_scale=case["cond_scale"],
                                        class_cond_scale=case["class_cond_scale"],
-                                       num_sample_steps=case["steps"])
+                                       num_sample_steps=case["steps"], **C.extra_kwargs(case))
         np.savez_compressed(os.path.join(HERE, f"sample_{case['name']}.npz"),
                             image=img.numpy(), cond_sum=np.float64(cond.double().sum().item()),
                             first_draw=first.numpy(),

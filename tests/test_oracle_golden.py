@@ -92,7 +92,8 @@ def test_tiled_sample_matches_reference(case):
     with torch.inference_mode():
         got = O.tiled_sample(O.strip_model_prefix(sd), O.UnetCfg(dim=case["dim"]), cond, label,
                              batch_size=case["batch_size"], num_sample_steps=case["steps"],
-                             cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"])
+                             cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
+                             **C.extra_kwargs(case))
     want = z["image"]
     assert got.shape == want.shape
     assert np.abs(got.numpy() - want).max() <= 1e-4      # thread-count noise floor is ~1e-5
