@@ -12,12 +12,14 @@
 //     (out-of-image halo pixels are zero-filled by the buffer descriptor's range check), and per K-step one
 //     8 KB weight tile, pre-swizzled on the host into its LDS image so the copy is linear and coalesced.
 //     A is double-buffered, B runs in a 3-deep ring; loads stay in flight across barriers
-//     (counted s_waitcnt vmcnt(N) + raw s_barrier, one barrier per K-step).
+//     (counted s_waitcnt vmcnt(N) + raw s_barrier, one barrier per K-step).  A 4-deep ring measured the same.
 //   * 64-byte LDS rows are XOR-swizzled (chunk ^= (row >> 2) & 3): ds_read_b128 is conflict-free for the
 //     MFMA operand pattern (16 consecutive rows, same chunk) at every tap shift.
 //   * epilogue: + bias, optional per-(sample, group) partial sum / sum of squares for the GroupNorm that
 //     follows (fixed-order, deterministic), bf16 store.
 //   * blockIdx is remapped so each XCD (private L2) gets a contiguous band of tiles (halo reuse in L2).
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace srgd {
@@ -30,7 +32,8 @@ constexpr int BN3 = 128;
 constexpr int NT3 = 512;
 constexpr int A_BYTES = 24 * 1024;             // 24 wave-instructions x 1 KiB (340 px * 64 B = 21,760 used)
 constexpr int B_BYTES = BN3 * KC * 2;          // 8 KiB
-constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 73,728
+constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 73,728: two workgroups per CU
+constexpr int CONV3_M16_DEFAULT = 1;     // 16x16x32 measured +1..2 % over 32x32x16 on the production shapes
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -61,15 +64,23 @@ struct Conv3Args {
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 
-template <bool STATS, bool GNIN>
+// M16 selects the MFMA shape: false = v_mfma_f32_32x32x16_bf16 (2x2 blocks per wave, two k16 steps per chunk),
+// true = v_mfma_f32_16x16x32_bf16 (4x4 blocks, one k32 step).  Same LDS bytes read per FLOP and the same
+// accumulator count; the 16x16 shape sustains a higher clock on MI355X (MI355X_MICROARCH.md, DVFS item 7).
+// Row swizzle: chunk ^= (row >> 2) & 3 for the 32x32 operand pattern (32 rows x 1 chunk per lane half),
+//              chunk ^= (row >> 1) & 3 for the 16x16 pattern (16 rows x 4 chunks) - each conflict-free for its
+//              ds_read_b128 lane groups at every tap shift (checked exhaustively on the bank model).
+template <bool M16> __device__ __forceinline__ int row_swz(int row) { return M16 ? (row >> 1) & 3 : (row >> 2) & 3; }
+
+template <bool STATS, bool GNIN, bool M16>
 __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
-  constexpr int VAR = 0;                         // tuning variants (s_setprio / A prefetch) measured within noise: off
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
+  const int r = lane & 31, h = lane >> 5;            // 32x32 shape: row / k half
+  const int r16 = lane & 15, q16 = lane >> 4;        // 16x16 shape: row / 8-channel chunk
 
   // ---- tile coordinates (XCD-aware remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous band)
   const int n_tiles = p.Cout / BN3;
@@ -91,9 +102,9 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   const int CC = Cin / KC;
   const int S = CC * 9;
 
-  // ---- A staging: 24 wave-instructions per chunk; wave w issues pieces w, w+8, w+16 (pieces >= 22 are all-zero)
-  // per-lane pixel offset (y*W+x) or -1, and source chunk (0..3) of its three pieces (named scalars: see
-  // conv_igemm.hip on why staging state must not live in indexed arrays)
+  // ---- A staging: 24 wave-instructions per chunk; wave w issues pieces w, w+8, w+16 (pieces >= 22 are all-zero).
+  // Per-lane pixel offset (y*W+x) or -1 and source chunk (0..3) of its three pieces, as NAMED scalars (indexed
+  // arrays of staging state end up in scratch: see conv_igemm.hip).
 #define SRGD_A_DECL(J)                                                        \
   int a_pix##J, a_sub##J;                                                     \
   {                                                                           \
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     const int y = y0 + py - 1, x = x0 + px - 1;                               \
     const bool ok = P < HP * WP && y >= 0 && y < p.H && x >= 0 && x < p.W;    \
     a_pix##J = ok ? y * p.W + x : -1;                                         \
-    a_sub##J = (g & 3) ^ ((P >> 2) & 3);                                      \
+    a_sub##J = (g & 3) ^ row_swz<M16>(P);                                     \
   }
   SRGD_A_DECL(0) SRGD_A_DECL(1) SRGD_A_DECL(2)
 #undef SRGD_A_DECL
@@ -130,15 +141,16 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     char* q = sA0 + (cc & 1) * A_BYTES + (wave + 8 * j) * 1024 + lane * 16;
     // the chunk's 32 scales | 32 shifts ride in the otherwise all-zero DMA piece 22 of the same A buffer
     const float* sC = reinterpret_cast<const float*>(sA0 + (cc & 1) * A_BYTES + 22 * 1024) + a_sub * 8;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(q);
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sC), a1 = *reinterpret_cast<const f32x4*>(sC + 4);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(sC + 32), b1 = *reinterpret_cast<const f32x4*>(sC + 36);
+    // two 8-byte halves: keeps the live temporaries small (the kernel sits at the 128-VGPR cap of 2 workgroups/CU)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = (bf16)silu<false>(a0[e] * (float)v[e] + b0[e]);
-      v[4 + e] = (bf16)silu<false>(a1[e] * (float)v[4 + e] + b1[e]);
+    for (int hf = 0; hf < 2; ++hf) {
+      bf16x4 v = *reinterpret_cast<const bf16x4*>(q + hf * 8);
+      const f32x4 ca = *reinterpret_cast<const f32x4*>(sC + hf * 4);
+      const f32x4 cb = *reinterpret_cast<const f32x4*>(sC + 32 + hf * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (bf16)silu<false>(ca[e] * (float)v[e] + cb[e]);
+      *reinterpret_cast<bf16x4*>(q + hf * 8) = v;
     }
-    *reinterpret_cast<bf16x8*>(q) = v;
   };
 #define transform_a_piece(CCV, J) transform_piece(CCV, J, (J) == 0 ? a_pix0 : ((J) == 1 ? a_pix1 : a_pix2), (J) == 0 ? a_sub0 : ((J) == 1 ? a_sub1 : a_sub2))
 
@@ -163,22 +175,68 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     dma16(rsw, sB0 + (s % 3) * B_BYTES + wave * 1024, voff);
   };
 
-  // ---- operand read addresses
-  // B: row n = wn*64 + j*32 + r, logical chunk c = 2*s2 + h  ->  byte n*64 + ((c ^ ((n>>2)&3)) << 4)
-  const int bn0 = wn * 64 + r, bn1 = bn0 + 32;
-  const int b_off0 = bn0 * 64 + ((h ^ ((bn0 >> 2) & 3)) << 4);
-  const int b_off1 = bn1 * 64 + ((h ^ ((bn1 >> 2) & 3)) << 4);
-  const int a_row0 = (2 * wm) * WP + r;         // patch pixel of (m-subtile 0, tap (0,0)); + i*WP + dy*WP + dx
+  // ---- accumulators: 64 fp32 per lane in both shapes
+  f32x16 acc00 = 0, acc01 = 0, acc10 = 0, acc11 = 0;                                     // 32x32: [mi][ni]
+  f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c10 = 0, c11 = 0, c12 = 0, c13 = 0,          // 16x16: [mi][ni]
+        c20 = 0, c21 = 0, c22 = 0, c23 = 0, c30 = 0, c31 = 0, c32 = 0, c33 = 0;
 
-  f32x16 acc00 = 0, acc01 = 0, acc10 = 0, acc11 = 0;
+  // ---- operand read addresses.  `opq` is an opaque zero refreshed once per channel chunk: it stops the compiler
+  // from hoisting the per-tap A addresses out of the K loop into ~18 long-lived VGPRs (the kernel lives at the
+  // 128-VGPR cap of 2 workgroups per CU); recomputing one costs ~5 VALU ops.
+  int opq = 0;
+  // 32x32: B row n = wn*64 + j*32 + r, logical chunk 2*s2 + h;  16x16: B row n = wn*64 + j*16 + r16, chunk q16
+  auto b_addr = [&](int j) {
+    const int n = M16 ? wn * 64 + j * 16 + r16 : wn * 64 + j * 32 + r;
+    return n * 64 + (((M16 ? q16 : h) ^ row_swz<M16>(n)) << 4);
+  };
+  auto a_addr = [&](int tap, int i) {        // 32x32: i = patch row of the wave (0/1); 16x16: i = 16-pixel block (0..3)
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int P = M16 ? (2 * wm + (i >> 1) + dy) * WP + (i & 1) * 16 + r16 + dx + opq
+                      : (2 * wm + i + dy) * WP + r + dx + opq;
+    return P * 64 + (((M16 ? q16 : h) ^ row_swz<M16>(P)) << 4);
+  };
+  auto compute = [&](int cc, int tap, int s) {
+    const char* A = sA0 + (cc & 1) * A_BYTES;
+    const char* Bt = sB0 + (s % 3) * B_BYTES;
+    if constexpr (M16) {
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 0));
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 1));
+      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 2));
+      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 3));
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(0));
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(1));
+      const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(2));
+      const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(3));
+#define MM(C_, A_, B_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, C_, 0, 0, 0)
+      MM(c00, a0, b0); MM(c01, a0, b1); MM(c02, a0, b2); MM(c03, a0, b3);
+      MM(c10, a1, b0); MM(c11, a1, b1); MM(c12, a1, b2); MM(c13, a1, b3);
+      MM(c20, a2, b0); MM(c21, a2, b1); MM(c22, a2, b2); MM(c23, a2, b3);
+      MM(c30, a3, b0); MM(c31, a3, b1); MM(c32, a3, b2); MM(c33, a3, b3);
+#undef MM
+    } else {
+      const int a0 = a_addr(tap, 0), a1 = a_addr(tap, 1), b0 = b_addr(0), b1 = b_addr(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int x = s2 << 5;                 // k16 step toggles bit 1 of the chunk index = byte bit 5
+        const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + (a0 ^ x));
+        const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + (a1 ^ x));
+        const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(Bt + (b0 ^ x));
+        const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(Bt + (b1 ^ x));
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc11, 0, 0, 0);
+      }
+    }
+  };
 
   // ---- prologue: A(0) and B[0], B[1]
   issue_a_piece(0, 0);
   issue_a_piece(0, 1);
   issue_a_piece(0, 2);
   issue_b(0);
-  if (S > 1) issue_b(1);
-  if (S > 1) WAIT_VM(1); else WAIT_VM(0);
+  issue_b(1);                                    // S >= 9 always
+  WAIT_VM(1);
   if (GNIN) {
     BARRIER();                                   // coefficient piece visible; this wave's A(0) pieces have landed
     transform_a_piece(0, 0);
@@ -188,52 +246,15 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   }
   BARRIER();
 
-  // A fragments of the NEXT tap (k16 step 0) can be fetched before the barrier: within a channel chunk the A
-  // patch is read-only, so only the first tap of a chunk has to wait for the barrier (VAR & 2).
-  bf16x8 nfa0, nfa1;
-  auto a_addr = [&](int tap, int i) {
-    const int dy = tap / 3, dx = tap - dy * 3;
-    const int P = a_row0 + (dy + i) * WP + dx;
-    return P * 64 + ((h ^ ((P >> 2) & 3)) << 4);
-  };
-  auto compute = [&](int cc, int tap, int s) {
-    const char* A = sA0 + (cc & 1) * A_BYTES;
-    const char* Bt = sB0 + (s % 3) * B_BYTES;
-    const int a0 = a_addr(tap, 0), a1 = a_addr(tap, 1);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int x = s2 << 5;                   // k16 step toggles bit 1 of the chunk index = byte bit 5
-      bf16x8 fa0, fa1;
-      if ((VAR & 2) && s2 == 0 && tap > 0) {
-        fa0 = nfa0;
-        fa1 = nfa1;
-      } else {
-        fa0 = *reinterpret_cast<const bf16x8*>(A + (a0 ^ x));
-        fa1 = *reinterpret_cast<const bf16x8*>(A + (a1 ^ x));
-      }
-      const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(Bt + (b_off0 ^ x));
-      const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(Bt + (b_off1 ^ x));
-      if ((VAR & 2) && s2 == 1 && tap < 8) {
-        nfa0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap + 1, 0));
-        nfa1 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap + 1, 1));
-      }
-      if (VAR & 1) __builtin_amdgcn_s_setprio(1);
-      acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc00, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc01, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc10, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc11, 0, 0, 0);
-      if (VAR & 1) __builtin_amdgcn_s_setprio(0);
-    }
-  };
-
   // ---- main loop.  Per K-step: [issue A piece of the next chunk (taps 0..2)] [issue B[s+2]] compute(s)
-  //      wait until B[s+1] (and, implicitly, everything older) has landed, barrier.
+  //      wait until B[s+1] (and, in order, everything older) has landed, barrier.
   for (int cc = 0; cc < CC - 1; ++cc) {
+    asm volatile("" : "+v"(opq));
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int s = cc * 9 + tap;
       if (tap < 3) issue_a_piece(cc + 1, tap);
-      issue_b(s + 2);                            // s + 2 < S always holds here (cc < CC-1)
+      issue_b(s + 2);                            // always < S here (cc < CC-1)
       // the wait at the end of tap 3 retired this wave's three A pieces of chunk cc+1 (they are older than B[s+1])
       if (GNIN && tap >= 4 && tap < 7) transform_a_piece(cc + 1, tap - 4);
       compute(cc, tap, s);
@@ -243,6 +264,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   }
   {
     const int cc = CC - 1;
+    asm volatile("" : "+v"(opq));
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int s = cc * 9 + tap;
@@ -252,33 +274,57 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       if (tap < 8) BARRIER();
     }
   }
-
 #undef issue_a_piece
 #undef transform_a_piece
+
   // ------------------------------- epilogue -------------------------------------------
   // The accumulator layout (lane = output channel, register = pixel) would store 2 bytes per lane; instead the
   // tile is transposed through LDS ([256 pixels][128 ch] bf16, rows padded to 272 B) and written out as whole
   // 256-byte channel rows, 16 B per lane - 8 store instructions per thread instead of 64.
   constexpr int EROW = BN3 * 2 + 16;
   BARRIER();                                              // every wave is done reading the operand buffers
-  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  constexpr int NI = M16 ? 4 : 2;                         // column blocks per wave (16 or 32 wide)
+  float s1[NI], s2[NI];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int cl = wn * 64 + ni * 32 + r;                 // column inside the tile
+  for (int ni = 0; ni < NI; ++ni) {
+    s1[ni] = 0.f;
+    s2[ni] = 0.f;
+    const int cl = M16 ? wn * 64 + ni * 16 + r16 : wn * 64 + ni * 32 + r;       // column inside the tile
     const float bias = p.bias ? p.bias[nt * BN3 + cl] : 0.f;
+    if constexpr (M16) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const f32x16 accv = mi == 0 ? (ni == 0 ? acc00 : acc01) : (ni == 0 ? acc10 : acc11);
-      char* trow = smem + ((2 * wm + mi) * PW) * EROW + cl * 2;
+      for (int mi = 0; mi < 4; ++mi) {
+        const f32x4 av = mi == 0 ? (ni == 0 ? c00 : ni == 1 ? c01 : ni == 2 ? c02 : c03)
+                       : mi == 1 ? (ni == 0 ? c10 : ni == 1 ? c11 : ni == 2 ? c12 : c13)
+                       : mi == 2 ? (ni == 0 ? c20 : ni == 1 ? c21 : ni == 2 ? c22 : c23)
+                                 : (ni == 0 ? c30 : ni == 1 ? c31 : ni == 2 ? c32 : c33);
+        // C layout of 16x16: column = lane & 15, row = (lane >> 4) * 4 + reg  ->  pixel (mi & 1) * 16 + row of patch row
+        char* trow = smem + ((2 * wm + (mi >> 1)) * PW + (mi & 1) * 16 + q16 * 4) * EROW + cl * 2;
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int px = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        const float v = accv[reg] + bias;
-        if (STATS) {
-          s1[ni] += v;
-          s2[ni] += v * v;
+        for (int reg = 0; reg < 4; ++reg) {
+          const float v = av[reg] + bias;
+          if (STATS) {
+            s1[ni] += v;
+            s2[ni] += v * v;
+          }
+          *reinterpret_cast<bf16*>(trow + reg * EROW) = (bf16)v;
         }
-        *reinterpret_cast<bf16*>(trow + px * EROW) = (bf16)v;
+      }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const f32x16 accv = mi == 0 ? (ni == 0 ? acc00 : acc01) : (ni == 0 ? acc10 : acc11);
+        char* trow = smem + ((2 * wm + mi) * PW) * EROW + cl * 2;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int px = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          const float v = accv[reg] + bias;
+          if (STATS) {
+            s1[ni] += v;
+            s2[ni] += v * v;
+          }
+          *reinterpret_cast<bf16*>(trow + px * EROW) = (bf16)v;
+        }
       }
     }
   }
@@ -298,11 +344,16 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     __syncthreads();                                      // the staged output tile has been read back
     float* cs = reinterpret_cast<float*>(smem);           // [4 (wm)][128][2]
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const float t1 = s1[ni] + __shfl_xor(s1[ni], 32, 64);
-      const float t2 = s2[ni] + __shfl_xor(s2[ni], 32, 64);
-      if (h == 0) {
-        const int cl = wn * 64 + ni * 32 + r;
+    for (int ni = 0; ni < NI; ++ni) {
+      float t1 = s1[ni], t2 = s2[ni];
+      t1 += __shfl_xor(t1, 32, 64);
+      t2 += __shfl_xor(t2, 32, 64);
+      if (M16) {
+        t1 += __shfl_xor(t1, 16, 64);
+        t2 += __shfl_xor(t2, 16, 64);
+      }
+      if (M16 ? lane < 16 : h == 0) {
+        const int cl = M16 ? wn * 64 + ni * 16 + r16 : wn * 64 + ni * 32 + r;
         cs[(wm * BN3 + cl) * 2 + 0] = t1;
         cs[(wm * BN3 + cl) * 2 + 1] = t2;
       }
@@ -358,8 +409,18 @@ int conv3x3_bf16_stats_slots(const ConvArgs& a) {
 }
 
 // Host-side packing: OIHW fp32 -> [tap][cc][ntile][128 rows][64 B swizzled] bf16 (the LDS image of each K-step tile).
+bool conv3x3_bf16_m16() {
+  static int m16 = -1;
+  if (m16 < 0) {
+    const char* v = getenv("SRGD_CONV3_M16");               // tuning knob; the shipped default is CONV3_M16_DEFAULT
+    m16 = v ? (atoi(v) != 0) : CONV3_M16_DEFAULT;
+  }
+  return m16 != 0;
+}
+
 void pack_conv3x3_bf16(const float* src_oihw, int Cin, int Cout, std::vector<unsigned short>& out,
                        unsigned short (*to_bf16)(float)) {
+  const bool m16 = conv3x3_bf16_m16();
   const int CC = Cin / KC, NTL = Cout / BN3;
   out.assign((size_t)9 * CC * NTL * BN3 * KC, 0);
   for (int tap = 0; tap < 9; ++tap)
@@ -368,7 +429,7 @@ void pack_conv3x3_bf16(const float* src_oihw, int Cin, int Cout, std::vector<uns
         unsigned short* tile = out.data() + ((size_t)(tap * CC + cc) * NTL + nt) * BN3 * KC;
         for (int n = 0; n < BN3; ++n)
           for (int c = 0; c < 4; ++c) {
-            const int cs = c ^ ((n >> 2) & 3);                       // stored chunk position
+            const int cs = c ^ (m16 ? (n >> 1) & 3 : (n >> 2) & 3);  // stored chunk position (row_swz of the kernel)
             for (int e = 0; e < 8; ++e) {
               const int ci = cc * KC + c * 8 + e, o = nt * BN3 + n;
               const float v = src_oihw[(((size_t)o * Cin + ci) * 3 + tap / 3) * 3 + tap % 3];
@@ -392,21 +453,25 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   p.gn_in_b_off = gnin ? (int)((const char*)gn_in_b - (const char*)gn_in_a) : 0;
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
   static bool attr_set = false;
-  constexpr int LDS_GN = LDS_BYTES;
   if (!attr_set) {
-#define SRGD_SET(S_, G_, L_)                                                                              \
-  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_>),               \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, L_));
-    SRGD_SET(true, false, LDS_BYTES) SRGD_SET(false, false, LDS_BYTES) SRGD_SET(true, true, LDS_GN)
-    SRGD_SET(false, true, LDS_GN)
+#define SRGD_SET(S_, G_, M_)                                                                              \
+  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_, M_>),           \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    SRGD_SET(true, false, false) SRGD_SET(false, false, false) SRGD_SET(true, true, false) SRGD_SET(false, true, false)
+    SRGD_SET(true, false, true) SRGD_SET(false, false, true) SRGD_SET(true, true, true) SRGD_SET(false, true, true)
 #undef SRGD_SET
     attr_set = true;
   }
   const bool stats = a.gn_partial != nullptr;
-  if (stats && gnin) hipLaunchKernelGGL((conv3x3_bf16_kernel<true, true>), dim3(grid), dim3(NT3), LDS_GN, st, p);
-  else if (stats) hipLaunchKernelGGL((conv3x3_bf16_kernel<true, false>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);
-  else if (gnin) hipLaunchKernelGGL((conv3x3_bf16_kernel<false, true>), dim3(grid), dim3(NT3), LDS_GN, st, p);
-  else hipLaunchKernelGGL((conv3x3_bf16_kernel<false, false>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);
+#define SRGD_GO(S_, G_, M_) hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_, M_>), dim3(grid), dim3(NT3), LDS_BYTES, st, p)
+  if (conv3x3_bf16_m16()) {
+    if (stats && gnin) SRGD_GO(true, true, true); else if (stats) SRGD_GO(true, false, true);
+    else if (gnin) SRGD_GO(false, true, true); else SRGD_GO(false, false, true);
+  } else {
+    if (stats && gnin) SRGD_GO(true, true, false); else if (stats) SRGD_GO(true, false, false);
+    else if (gnin) SRGD_GO(false, true, false); else SRGD_GO(false, false, false);
+  }
+#undef SRGD_GO
   SRGD_HIP(hipGetLastError());
   return 0;
 }

@@ -4,6 +4,7 @@
 // No host synchronisation, no allocation after the first call with a given shape.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -712,6 +713,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   std::unique_ptr<srgd_engine> e(new srgd_engine());
   e->cfg = *cfg;
   SRGD_TRY(build_topology(e.get()));
+  if (const char* v = getenv("SRGD_GN_FUSION")) e->no_gn_fusion = atoi(v) == 0;   // experiment switch (see no_gn_fusion)
   *out = e.release();
   return 0;
 }
