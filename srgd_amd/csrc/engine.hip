@@ -69,6 +69,7 @@ __global__ void fill_rows_kernel(int* rows, int n, int split, int v0, int v1) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) rows[i] = (i < split) ? v0 : v1;
 }
+__global__ void set_step_kernel(int* step, int v) { *step = v; }
 __global__ void rows_api_kernel(int* rows, int n, int odd) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) rows[i] = 2 * i + odd;
@@ -128,6 +129,7 @@ struct Pool {
   struct Buf { void* p; size_t cap; bool busy; };
   std::vector<Buf> bufs;
   int64_t total = 0;
+  bool no_alloc = false;
   void* get(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
     int best = -1;
@@ -138,6 +140,10 @@ struct Pool {
       return bufs[best].p;
     }
     void* p = nullptr;
+    if (no_alloc) {
+      set_error("activation pool: allocation requested while a hipGraph is being captured (pool not warm)");
+      return nullptr;
+    }
     if (hipMalloc(&p, bytes) != hipSuccess) {
       set_error("activation pool: hipMalloc of " + std::to_string(bytes) + " bytes failed");
       return nullptr;
@@ -218,6 +224,19 @@ struct srgd_engine {
   bool run_active = false;
   float* rng_tiles = nullptr; size_t rng_tiles_cap = 0;
   float* rng_canvas = nullptr; size_t rng_canvas_cap = 0;
+
+  // device-side step counter + per-run hipGraph cache: a DDPM step is one graph per (grid parity, guidance mode);
+  // step-dependent values (conditioning row, schedule scalars, RNG stream) are read through d_step, so one captured
+  // graph serves every step of that parity.
+  int* d_step = nullptr;
+  hipStream_t cap_stream = nullptr;
+  bool use_graphs = true;
+  bool capturing = false;
+  struct StepGraph {
+    int parity, passes, kind, sub_batch; float scale; const void *img, *cond, *xs; uint64_t seed; bool last;
+    int seen; hipGraphExec_t exec; hipGraph_t graph;
+  };
+  std::vector<StepGraph> graphs;
 
   // profiling
   bool prof_on = false;
@@ -433,6 +452,7 @@ struct Ctx {
   const int* rows;           // conditioning row of each entry
   const float* table;        // conditioning table in use
   hipStream_t st;
+  const int* step_ptr = nullptr;   // sampler: device step counter (row += *step_ptr * 2)
 };
 
 // gn_in: the input is a raw conv output whose GroupNorm+SiLU (coefA/coefB) the fast 3x3 kernel applies while
@@ -481,7 +501,7 @@ int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_
   GnFinalizeArgs f;
   f.partial = e->gn_partial; f.nslots = e->stats_slots; f.B = x.nb; f.C = C; f.groups = e->cfg.groups; f.hw = hw;
   f.gamma = gamma; f.beta = beta;
-  f.ss_table = ss_offset >= 0 ? x.table : nullptr; f.ss_rows = x.rows; f.step_ptr = nullptr; f.step_mul = 0;
+  f.ss_table = ss_offset >= 0 ? x.table : nullptr; f.ss_rows = x.rows; f.step_ptr = x.step_ptr; f.step_mul = 2;
   f.ss_stride = e->ss_stride; f.ss_offset = ss_offset < 0 ? 0 : ss_offset; f.eps = 1e-5f;
   f.coefA = e->coefA; f.coefB = e->coefB;
   SRGD_TRY(gn_finalize(f, x.st));
@@ -698,6 +718,8 @@ int compute_conditioning(srgd_engine* e, CondTable& ct, const float* ls_host, in
 
 }  // namespace
 
+static void drop_step_graphs(srgd_engine* e);
+
 // ======================================================================= C ABI
 extern "C" {
 
@@ -714,6 +736,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   e->cfg = *cfg;
   SRGD_TRY(build_topology(e.get()));
   if (const char* v = getenv("SRGD_GN_FUSION")) e->no_gn_fusion = atoi(v) == 0;   // experiment switch (see no_gn_fusion)
+  if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   *out = e.release();
   return 0;
 }
@@ -722,6 +745,9 @@ int srgd_destroy(srgd_engine* e) {
   if (!e) return 0;
   hipSetDevice(e->cfg.device);
   hipDeviceSynchronize();
+  drop_step_graphs(e);
+  if (e->cap_stream) hipStreamDestroy(e->cap_stream);
+  if (e->d_step) hipFree(e->d_step);
   for (void* p : e->weight_allocs) hipFree(p);
   e->pool.release_all();
   for (void* p : {(void*)e->gn_partial, (void*)e->coefA, (void*)e->la_ws, (void*)e->d_rows,
@@ -861,6 +887,7 @@ int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const flo
     SRGD_FAIL("Padding size should be less than the corresponding input dimension (reflect pad)");
   hipStream_t st = (hipStream_t)stream;
   SRGD_HIP(hipSetDevice(e->cfg.device));
+  drop_step_graphs(e);                       // graphs bake in canvas / table / tile-list pointers of one run
   e->geo = *g;
   e->n_steps = n_steps;
   e->run_class = class_id;
@@ -886,26 +913,16 @@ int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const flo
   return 0;
 }
 
-int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start,
-                      const float* noise_tiles, const float* noise_canvas, int passes, int guidance_kind,
-                      float guidance_scale, int sub_batch, uint64_t seed, void* stream) {
-  if (!e || !e->run_active) SRGD_FAIL("srgd_sampler_step: call srgd_sampler_begin first");
-  if (step < 0 || step >= e->n_steps) SRGD_FAIL("srgd_sampler_step: step out of range");
-  if (passes != 1 && passes != 2) SRGD_FAIL("srgd_sampler_step: passes must be 1 or 2");
-  if (passes == 2 && guidance_kind != 1 && guidance_kind != 2) SRGD_FAIL("srgd_sampler_step: guidance_kind must be 1 or 2");
-  if (sub_batch < 1) SRGD_FAIL("srgd_sampler_step: sub_batch must be >= 1");
-  hipStream_t st = (hipStream_t)stream;
-  SRGD_HIP(hipSetDevice(e->cfg.device));
+// all launches of one DDPM step; step-dependent values come through e->d_step (set by the caller on the stream)
+static int sampler_step_launch(srgd_engine* e, bool last, int parity, float* img, const float* cond_canvas, float* x_start,
+                               const float* noise_tiles, const float* noise_canvas, int passes, int guidance_kind,
+                               float guidance_scale, int sub_batch, uint64_t seed, hipStream_t st) {
   const srgd_sampler_geometry& g = e->geo;
-  const int parity = step & 1;
   const int* tiles = parity ? e->d_tiles_odd : e->d_tiles_even;
   const int n = parity ? g.n_odd : g.n_even;
-  const bool last = step == e->n_steps - 1;
   const size_t tile_elems = (size_t)3 * g.tile * g.tile;
-  sub_batch = std::min(sub_batch, n);
-  SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
-  const int row_label = 2 * step + (e->run_class >= 0 ? 0 : 1);
-  const int row_null = 2 * step + 1;
+  const int row_label = e->run_class >= 0 ? 0 : 1;       // + 2 * step inside gn_finalize
+  const int row_null = 1;
   for (int first = 0; first < n; first += sub_batch) {
     const int nt = std::min(sub_batch, n - first);
     const int nb = nt * passes;
@@ -923,7 +940,7 @@ int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_ca
     }
     hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, e->d_rows, nb, nt, row_label,
                        (passes == 2 && guidance_kind == 1) ? row_null : row_label);
-    Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st};
+    Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st, e->d_step};
     void* act = nullptr;
     SRGD_TRY(unet_body(x, x0, &act));
     const float* nz = nullptr;
@@ -931,16 +948,14 @@ int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_ca
       if (noise_tiles) nz = noise_tiles + (size_t)first * tile_elems;
       else {
         Prof p(e, KC_CANVAS, st);
-        SRGD_TRY(ensure(&e->rng_tiles, &e->rng_tiles_cap, (size_t)sub_batch * tile_elems));
-        SRGD_TRY(philox_normal(e->rng_tiles, (size_t)nt * tile_elems, seed, ((uint64_t)(step + 1) << 32) | (uint64_t)first,
-                               nullptr, st));
+        SRGD_TRY(philox_normal(e->rng_tiles, (size_t)nt * tile_elems, seed, (1ull << 32) | (uint64_t)first, e->d_step, st));
         nz = e->rng_tiles;
       }
     }
     FinalStepArgs fa;
     fa.act = act; fa.C = e->dim; fa.passes = passes; fa.guidance = guidance_scale;
     fa.w = e->final_w; fa.bias = e->final_b; fa.img = img; fa.x_start = x_start; fa.noise = nz;
-    fa.sc = e->d_sc + step; fa.step_ptr = nullptr;
+    fa.sc = e->d_sc; fa.step_ptr = e->d_step;
     { Prof p(e, KC_FINAL, st); SRGD_TRY(final_step(fa, tb, e->bf16, st)); }
     e->pool.put(act);
     e->pool.put(x0);
@@ -948,14 +963,81 @@ int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_ca
   if (parity == 1) {
     Prof p(e, KC_CANVAS, st);
     const float* nc = noise_canvas;
-    const size_t cn = (size_t)3 * g.Hp * g.Wp;
     if (!nc) {
-      SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, cn));
-      SRGD_TRY(philox_normal(e->rng_canvas, cn, seed, ((uint64_t)(step + 1) << 32) | 0x80000000ull, nullptr, st));
+      SRGD_TRY(philox_normal(e->rng_canvas, (size_t)3 * g.Hp * g.Wp, seed, (1ull << 32) | 0x80000000ull, e->d_step, st));
       nc = e->rng_canvas;
     }
-    SRGD_TRY(canvas_ring_renoise(img, nc, g.Hp, g.Wp, g.inner_l, g.inner_t, g.inner_r, g.inner_b, e->d_sc + step, nullptr, st));
+    SRGD_TRY(canvas_ring_renoise(img, nc, g.Hp, g.Wp, g.inner_l, g.inner_t, g.inner_r, g.inner_b, e->d_sc, e->d_step, st));
   }
+  return 0;
+}
+
+static void drop_step_graphs(srgd_engine* e) {
+  for (auto& sg : e->graphs) {
+    if (sg.exec) (void)hipGraphExecDestroy(sg.exec);
+    if (sg.graph) (void)hipGraphDestroy(sg.graph);
+  }
+  e->graphs.clear();
+}
+
+int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start,
+                      const float* noise_tiles, const float* noise_canvas, int passes, int guidance_kind,
+                      float guidance_scale, int sub_batch, uint64_t seed, void* stream) {
+  if (!e || !e->run_active) SRGD_FAIL("srgd_sampler_step: call srgd_sampler_begin first");
+  if (step < 0 || step >= e->n_steps) SRGD_FAIL("srgd_sampler_step: step out of range");
+  if (passes != 1 && passes != 2) SRGD_FAIL("srgd_sampler_step: passes must be 1 or 2");
+  if (passes == 2 && guidance_kind != 1 && guidance_kind != 2) SRGD_FAIL("srgd_sampler_step: guidance_kind must be 1 or 2");
+  if (sub_batch < 1) SRGD_FAIL("srgd_sampler_step: sub_batch must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  SRGD_HIP(hipSetDevice(e->cfg.device));
+  const srgd_sampler_geometry& g = e->geo;
+  const int parity = step & 1;
+  const int n = parity ? g.n_odd : g.n_even;
+  const bool last = step == e->n_steps - 1;
+  sub_batch = std::min(sub_batch, n);
+  // every allocation happens here, before any capture
+  SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
+  if (!noise_tiles) SRGD_TRY(ensure(&e->rng_tiles, &e->rng_tiles_cap, (size_t)sub_batch * 3 * g.tile * g.tile));
+  if (!noise_canvas) SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, (size_t)3 * g.Hp * g.Wp));
+  if (!e->d_step) SRGD_HIP(hipMalloc((void**)&e->d_step, sizeof(int)));
+  hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, e->d_step, step);
+
+  const bool graphable = e->use_graphs && !e->prof_on && !noise_tiles && !noise_canvas;
+  if (!graphable)
+    return sampler_step_launch(e, last, parity, img, cond_canvas, x_start, noise_tiles, noise_canvas, passes, guidance_kind,
+                               guidance_scale, sub_batch, seed, st);
+  srgd_engine::StepGraph* sg = nullptr;
+  for (auto& c : e->graphs)
+    if (c.parity == parity && c.passes == passes && c.kind == guidance_kind && c.sub_batch == sub_batch &&
+        c.scale == guidance_scale && c.img == img && c.cond == cond_canvas && c.xs == x_start && c.seed == seed &&
+        c.last == last)
+      sg = &c;
+  if (!sg) {   // first time: run eagerly (warms the activation pool and every lazily-set kernel attribute)
+    e->graphs.push_back({parity, passes, guidance_kind, sub_batch, guidance_scale, img, cond_canvas, x_start, seed, last, 1,
+                         nullptr, nullptr});
+    return sampler_step_launch(e, last, parity, img, cond_canvas, x_start, nullptr, nullptr, passes, guidance_kind,
+                               guidance_scale, sub_batch, seed, st);
+  }
+  if (!sg->exec) {   // second time: capture the identical launch sequence
+    // capture on a private stream (the caller's may be the legacy default stream, which cannot capture); nothing
+    // executes during capture, the graph is then launched on the caller's stream
+    if (!e->cap_stream) SRGD_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    SRGD_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+    e->pool.no_alloc = true;
+    const int rc = sampler_step_launch(e, last, parity, img, cond_canvas, x_start, nullptr, nullptr, passes, guidance_kind,
+                                       guidance_scale, sub_batch, seed, e->cap_stream);
+    e->pool.no_alloc = false;
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(e->cap_stream, &graph);
+    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess || !graph) SRGD_FAIL(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ie != hipSuccess) { (void)hipGraphDestroy(graph); SRGD_FAIL(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+    sg->graph = graph;
+    sg->exec = exec;
+  }
+  SRGD_HIP(hipGraphLaunch(sg->exec, st));
   return 0;
 }
 
