@@ -37,12 +37,14 @@ PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md: dense MFM
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2, help="HR tiles per GPU in the timed region")
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5, help="HR tiles per GPU in the timed region")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--images", type=int, default=5,
+                    help="HR tiles sampled in lock-step per tiled_sample call (their 256^2 U-Net tiles share launches)")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--ddpm_steps", type=int, default=50)
     ap.add_argument("--lr_size", type=int, default=256)
-    ap.add_argument("--sub_batch", type=int, default=25, help="tiles per U-Net launch")
+    ap.add_argument("--sub_batch", type=int, default=0, help="tiles per U-Net launch (0: all tiles of a lock-step group)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
@@ -116,20 +118,26 @@ def main():
     total = args.warmup + args.steps
     # inputs resident in HBM before the clock starts (already x4-upsampled condition images)
     conds = [synthetic_lr_condition(rank * total + i, args.lr_size, args.lr_size).to(device) for i in range(total)]
+    n_even = ((4 * args.lr_size + 255) // 256 + 1) ** 2 if args.lr_size * 4 > 256 else 1
 
-    def run(i):
-        sampler.device_noise_seed = 71
-        return sampler.tiled_sample(batch_size=args.sub_batch, condition_x=conds[i], class_label=label,
-                                    class_cond_scale=1.0, num_sample_steps=args.ddpm_steps, amp=amp)
+    def run(lo, hi):
+        """HR tiles [lo, hi) in lock-step groups of --images (each image sampled exactly as it would be alone)."""
+        res = []
+        for a in range(lo, hi, args.images):
+            b = min(a + args.images, hi)
+            sampler.device_noise_seed = 71
+            res.append(sampler.tiled_sample(batch_size=args.sub_batch or n_even * (b - a),
+                                            condition_x=torch.cat(conds[a:b], 0), class_label=label,
+                                            class_cond_scale=1.0, num_sample_steps=args.ddpm_steps, amp=amp))
+        return res
 
-    for i in range(args.warmup):
-        run(i)
+    run(0, args.warmup)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs = [run(args.warmup + i) for i in range(args.steps)]
+    outs = run(args.warmup, total)
     if dist:
         from srgd_amd.parallel import gather_outputs
         gathered = gather_outputs(torch.cat(outs, 0), dst=0)          # HR tiles -> rank 0 (12.6 MB each)
@@ -153,15 +161,18 @@ def main():
             "data": "synthetic (seeded LR images, seeded weights with the reference state_dict schema)",
             "config": {"workload": f"BASELINE configs[1]: one {args.lr_size}x{args.lr_size} LR tile x4 SR per step, "
                                    f"{args.ddpm_steps} DDPM steps, class_cond_scale=1.0, dim-{args.dim} U-Net, "
-                                   f"{args.precision}, device Philox noise",
-                       "tiles_per_unet_launch": args.sub_batch, "tile_forwards_per_step": TILE_FORWARDS_PER_HR_TILE,
+                                   f"{args.precision}, device Philox noise; {min(args.images, args.steps)} steps "
+                                   f"(HR tiles) advance in lock-step so their U-Net tiles share launches",
+                       "images_in_lockstep": min(args.images, args.steps),
+                       "tiles_per_unet_launch": args.sub_batch or n_even * min(args.images, args.steps),
+                       "tile_forwards_per_step": TILE_FORWARDS_PER_HR_TILE,
                        "parallelism": f"image-sharded x{world}"},
             "tflops_effective": value * TFLOP_PER_HR_TILE,
         }
         if not args.no_profile and args.lr_size == 256 and args.ddpm_steps == 50 and args.dim == 128:
             eng = sampler.model.engine(args.precision)
             eng.profile_begin()
-            run(args.warmup)
+            run(args.warmup, args.warmup + min(args.images, args.steps))
             prof = eng.profile_end()
             # the dominant kernel: conv3x3_bf16_kernel in bf16 mode, the generic implicit GEMM in fp32 mode
             fam = "conv3x3_bf16" if prof["ms"].get("conv3x3_bf16", 0.0) > prof["ms"]["conv_igemm"] else "conv_igemm"

@@ -84,13 +84,15 @@ typedef struct srgd_sampler_geometry { /* ints of get_coord_and_pad / get_coords
   int32_t left, top;            /* crop box origin of the image inside the canvas */
   int32_t inner_l, inner_t, inner_r, inner_b; /* bounding box of the shifted (odd-step) grid */
   int32_t tile;                 /* 256 */
-  int32_t n_even, n_odd;        /* tiles per grid */
+  int32_t n_even, n_odd;        /* tiles per grid (of ONE image) */
+  int32_t n_images;             /* >= 1: same-sized images sampled in lock-step (one U-Net batch spans all of them);
+                                 * every image sees the noise stream the reference gives it after its own reseed */
 } srgd_sampler_geometry;
 
 /* Prepares a run: cond canvas = zero outside the inner box, reflect-padded (2*cond01-1) inside
  * (model.py:3296-3303,:3337-3342); uploads both tile grids ([n][2] = (y, x) canvas offsets) and
  * the schedule; computes the conditioning table for every step x {label, no label}.
- * cond01: device fp32 [3,H,W] in [0,1]; cond_canvas: device fp32 [3,Hp,Wp] (written). */
+ * cond01: device fp32 [n_images,3,H,W] in [0,1]; cond_canvas: device fp32 [n_images,3,Hp,Wp] (written). */
 int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const float* cond01, float* cond_canvas,
                        const int32_t* tiles_even_host, const int32_t* tiles_odd_host, int n_steps,
                        const srgd_step_scalars* scalars_host, const float* log_snr_host, int class_id, void* stream);
@@ -100,10 +102,13 @@ int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const flo
  *   passes = 1: eps = unet(label, cond).                       (model.py:3155-3156)
  *   passes = 2, guidance_kind 1: class guidance  (label vs None)   (model.py:3151-3154)
  *   passes = 2, guidance_kind 2: condition guidance (cond vs zeros) (model.py:3147-3150)
- * img / x_start (nullable): device fp32 canvases [3,Hp,Wp], updated in place.
+ * img / x_start (nullable): device fp32 canvases [n_images,3,Hp,Wp], updated in place; sub_batch counts tiles over
+ * all images (image-major order).
  * noise_tiles: device fp32 [n_tiles_of_this_grid,3,tile,tile] in reference draw order, or NULL;
  * noise_canvas: device fp32 [3,Hp,Wp] for the odd-step ring, or NULL.  When a needed noise
- * pointer is NULL the engine draws it on the device (Philox, `seed`).  The last step adds none. */
+ * pointer is NULL the engine draws it on the device (Philox, `seed`).  The last step adds none.  The noise of
+ * one image is shared by all n_images (each image of the reference is sampled after reseeding with the same seed,
+ * inference.py:73, so same-sized images see identical draws). */
 int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start,
                       const float* noise_tiles, const float* noise_canvas, int passes, int guidance_kind,
                       float guidance_scale, int sub_batch, uint64_t seed, void* stream);

@@ -34,7 +34,7 @@ class SamplerGeometry(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("Hp", C.c_int32), ("Wp", C.c_int32),
                 ("left", C.c_int32), ("top", C.c_int32),
                 ("inner_l", C.c_int32), ("inner_t", C.c_int32), ("inner_r", C.c_int32), ("inner_b", C.c_int32),
-                ("tile", C.c_int32), ("n_even", C.c_int32), ("n_odd", C.c_int32)]
+                ("tile", C.c_int32), ("n_even", C.c_int32), ("n_odd", C.c_int32), ("n_images", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/srgd_hip.h declares

@@ -880,7 +880,8 @@ int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const flo
   if (!g || !cond01 || !cond_canvas || !tiles_even_host || !tiles_odd_host || !scalars_host || !log_snr_host)
     SRGD_FAIL("srgd_sampler_begin: null argument");
   if (class_id >= 0 && e->cfg.num_classes <= 0) SRGD_FAIL("class label given but the U-Net has no class embedding");
-  if (g->tile <= 0 || g->n_even <= 0 || g->n_odd <= 0 || n_steps <= 0) SRGD_FAIL("srgd_sampler_begin: bad geometry");
+  if (g->tile <= 0 || g->n_even <= 0 || g->n_odd <= 0 || n_steps <= 0 || g->n_images < 1)
+    SRGD_FAIL("srgd_sampler_begin: bad geometry");
   // F.pad(mode='reflect') requires pad < input size (model.py:3303 raises otherwise)
   const int pl = g->left, pr = g->Wp - g->left - g->W, pt = g->top, pb = g->Hp - g->top - g->H;
   if (pl >= g->W || pr >= g->W || pt >= g->H || pb >= g->H)
@@ -891,10 +892,23 @@ int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const flo
   e->geo = *g;
   e->n_steps = n_steps;
   e->run_class = class_id;
-  SRGD_TRY(ensure(&e->d_tiles_even, &e->tiles_cap_even, (size_t)g->n_even * 2));
-  SRGD_TRY(ensure(&e->d_tiles_odd, &e->tiles_cap_odd, (size_t)g->n_odd * 2));
-  SRGD_HIP(hipMemcpyAsync(e->d_tiles_even, tiles_even_host, (size_t)g->n_even * 8, hipMemcpyHostToDevice, st));
-  SRGD_HIP(hipMemcpyAsync(e->d_tiles_odd, tiles_odd_host, (size_t)g->n_odd * 8, hipMemcpyHostToDevice, st));
+  // device tile lists are image-major [(y, x, image)]: one U-Net batch may span several images
+  std::vector<int32_t> tl_even, tl_odd;
+  for (int im = 0; im < g->n_images; ++im) {
+    for (int t = 0; t < g->n_even; ++t)
+      tl_even.insert(tl_even.end(), {tiles_even_host[2 * t], tiles_even_host[2 * t + 1], im});
+    for (int t = 0; t < g->n_odd; ++t) tl_odd.insert(tl_odd.end(), {tiles_odd_host[2 * t], tiles_odd_host[2 * t + 1], im});
+  }
+  for (size_t t = 0; t < tl_even.size(); t += 3)
+    if (tl_even[t] < 0 || tl_even[t + 1] < 0 || tl_even[t] + g->tile > g->Hp || tl_even[t + 1] + g->tile > g->Wp)
+      SRGD_FAIL("srgd_sampler_begin: even-grid tile outside the canvas");
+  for (size_t t = 0; t < tl_odd.size(); t += 3)
+    if (tl_odd[t] < 0 || tl_odd[t + 1] < 0 || tl_odd[t] + g->tile > g->Hp || tl_odd[t + 1] + g->tile > g->Wp)
+      SRGD_FAIL("srgd_sampler_begin: odd-grid tile outside the canvas");
+  SRGD_TRY(ensure(&e->d_tiles_even, &e->tiles_cap_even, tl_even.size()));
+  SRGD_TRY(ensure(&e->d_tiles_odd, &e->tiles_cap_odd, tl_odd.size()));
+  SRGD_HIP(hipMemcpyAsync(e->d_tiles_even, tl_even.data(), tl_even.size() * 4, hipMemcpyHostToDevice, st));
+  SRGD_HIP(hipMemcpyAsync(e->d_tiles_odd, tl_odd.data(), tl_odd.size() * 4, hipMemcpyHostToDevice, st));
   if (e->sc_cap < n_steps) {
     if (e->d_sc) hipFree(e->d_sc);
     e->d_sc = nullptr;
@@ -904,7 +918,7 @@ int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const flo
   static_assert(sizeof(StepScalars) == sizeof(srgd_step_scalars), "step scalar layout");
   SRGD_HIP(hipMemcpyAsync(e->d_sc, scalars_host, (size_t)n_steps * sizeof(StepScalars), hipMemcpyHostToDevice, st));
   { Prof p(e, KC_CANVAS, st);
-    SRGD_TRY(canvas_prepare_cond(cond01, g->H, g->W, g->left, g->top, g->Hp, g->Wp, g->inner_l, g->inner_t, g->inner_r,
+    SRGD_TRY(canvas_prepare_cond(cond01, 3 * g->n_images, g->H, g->W, g->left, g->top, g->Hp, g->Wp, g->inner_l, g->inner_t, g->inner_r,
                                  g->inner_b, cond_canvas, st)); }
   SRGD_TRY(compute_conditioning(e, e->ct_sampler, log_snr_host, n_steps, class_id, st));
   // the host arrays may be reused by the caller right after this call returns
@@ -919,14 +933,24 @@ static int sampler_step_launch(srgd_engine* e, bool last, int parity, float* img
                                float guidance_scale, int sub_batch, uint64_t seed, hipStream_t st) {
   const srgd_sampler_geometry& g = e->geo;
   const int* tiles = parity ? e->d_tiles_odd : e->d_tiles_even;
-  const int n = parity ? g.n_odd : g.n_even;
+  const int n_local = parity ? g.n_odd : g.n_even;
+  const int n = n_local * g.n_images;
   const size_t tile_elems = (size_t)3 * g.tile * g.tile;
+  const float* nz = nullptr;
+  if (!last) {
+    nz = noise_tiles;
+    if (!nz) {   // one image's worth of tile noise, shared by every image and independent of sub_batch
+      Prof p(e, KC_CANVAS, st);
+      SRGD_TRY(philox_normal(e->rng_tiles, (size_t)n_local * tile_elems, seed, 1ull << 32, e->d_step, st));
+      nz = e->rng_tiles;
+    }
+  }
   const int row_label = e->run_class >= 0 ? 0 : 1;       // + 2 * step inside gn_finalize
   const int row_null = 1;
   for (int first = 0; first < n; first += sub_batch) {
     const int nt = std::min(sub_batch, n - first);
     const int nb = nt * passes;
-    TileBatch tb{tiles, first, nt, g.Hp, g.Wp, g.tile};
+    TileBatch tb{tiles, first, nt, g.Hp, g.Wp, g.tile, n_local};
     void* x0 = e->pool.get((size_t)nb * g.tile * g.tile * e->dim * e->es);
     if (!x0) return -1;
     const int mask = (passes == 2 && guidance_kind == 2) ? 0x1 : 0x3;
@@ -943,15 +967,6 @@ static int sampler_step_launch(srgd_engine* e, bool last, int parity, float* img
     Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st, e->d_step};
     void* act = nullptr;
     SRGD_TRY(unet_body(x, x0, &act));
-    const float* nz = nullptr;
-    if (!last) {
-      if (noise_tiles) nz = noise_tiles + (size_t)first * tile_elems;
-      else {
-        Prof p(e, KC_CANVAS, st);
-        SRGD_TRY(philox_normal(e->rng_tiles, (size_t)nt * tile_elems, seed, (1ull << 32) | (uint64_t)first, e->d_step, st));
-        nz = e->rng_tiles;
-      }
-    }
     FinalStepArgs fa;
     fa.act = act; fa.C = e->dim; fa.passes = passes; fa.guidance = guidance_scale;
     fa.w = e->final_w; fa.bias = e->final_b; fa.img = img; fa.x_start = x_start; fa.noise = nz;
@@ -967,7 +982,7 @@ static int sampler_step_launch(srgd_engine* e, bool last, int parity, float* img
       SRGD_TRY(philox_normal(e->rng_canvas, (size_t)3 * g.Hp * g.Wp, seed, (1ull << 32) | 0x80000000ull, e->d_step, st));
       nc = e->rng_canvas;
     }
-    SRGD_TRY(canvas_ring_renoise(img, nc, g.Hp, g.Wp, g.inner_l, g.inner_t, g.inner_r, g.inner_b, e->d_sc, e->d_step, st));
+    SRGD_TRY(canvas_ring_renoise(img, 3 * g.n_images, nc, g.Hp, g.Wp, g.inner_l, g.inner_t, g.inner_r, g.inner_b, e->d_sc, e->d_step, st));
   }
   return 0;
 }
@@ -992,12 +1007,13 @@ int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_ca
   SRGD_HIP(hipSetDevice(e->cfg.device));
   const srgd_sampler_geometry& g = e->geo;
   const int parity = step & 1;
-  const int n = parity ? g.n_odd : g.n_even;
+  const int n_local = parity ? g.n_odd : g.n_even;
+  const int n = n_local * g.n_images;
   const bool last = step == e->n_steps - 1;
   sub_batch = std::min(sub_batch, n);
   // every allocation happens here, before any capture
   SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
-  if (!noise_tiles) SRGD_TRY(ensure(&e->rng_tiles, &e->rng_tiles_cap, (size_t)sub_batch * 3 * g.tile * g.tile));
+  if (!noise_tiles) SRGD_TRY(ensure(&e->rng_tiles, &e->rng_tiles_cap, (size_t)n_local * 3 * g.tile * g.tile));
   if (!noise_canvas) SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, (size_t)3 * g.Hp * g.Wp));
   if (!e->d_step) SRGD_HIP(hipMalloc((void**)&e->d_step, sizeof(int)));
   hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, e->d_step, step);
@@ -1055,7 +1071,7 @@ int srgd_sampler_q_start(srgd_engine* e, const float* cond01, const float* noise
     SRGD_TRY(philox_normal(e->rng_canvas, cn, seed, 0, nullptr, st));
     nz = e->rng_canvas;
   }
-  return canvas_q_start(cond01, g.H, g.W, g.left, g.top, g.Hp, g.Wp, nz, alpha, sigma, img, st);
+  return canvas_q_start(cond01, 3 * g.n_images, g.H, g.W, g.left, g.top, g.Hp, g.Wp, nz, alpha, sigma, img, st);
 }
 
 int srgd_sampler_end(srgd_engine* e, const float* img, float* out01, void* stream) {
@@ -1063,7 +1079,7 @@ int srgd_sampler_end(srgd_engine* e, const float* img, float* out01, void* strea
   hipStream_t st = (hipStream_t)stream;
   const srgd_sampler_geometry& g = e->geo;
   Prof p(e, KC_CANVAS, st);
-  SRGD_TRY(canvas_finish(img, g.Hp, g.Wp, g.left, g.top, g.H, g.W, out01, st));
+  SRGD_TRY(canvas_finish(img, 3 * g.n_images, g.Hp, g.Wp, g.left, g.top, g.H, g.W, out01, st));
   e->run_active = false;
   return 0;
 }

@@ -113,11 +113,12 @@ struct StepScalars {       // fp32 values computed by the host exactly as the re
   float pad;
 };
 struct TileBatch {
-  const int* tile_yx;      // device [ntiles][2] canvas offsets of each tile
+  const int* tile_yx;      // device [n_images * n_local][3] = (y, x, image) of each tile, image-major
   int first;               // first tile of this sub-batch in tile_yx
   int ntiles;              // tiles in this sub-batch
   int Hp, Wp;              // canvas size
   int tile;                // tile edge (256)
+  int n_local;             // tiles per image (noise is indexed by the tile's position inside its image)
 };
 // 7x7 input convolution (model.py:583) on MFMA: gather the 6 input planes of every tile into a zero-haloed NHWC image
 // [entries][H+6][W+8][8 ch] (ch 6,7 = 0; position px holds input column px-3), after which output pixel (y,x), tap row
@@ -147,13 +148,15 @@ struct FinalStepArgs {
 int final_step(const FinalStepArgs& a, const TileBatch& tb, bool is_bf16, hipStream_t st);
 
 // canvas kernels (model.py:3296-3303, :3337-3342, :3392-3396, :3403-3405)
-int canvas_prepare_cond(const float* cond01 /*[3][H][W]*/, int H, int W, int pad_l, int pad_t, int Hp, int Wp,
-                        int il, int it, int ir, int ib, float* cond_canvas, hipStream_t st);
-int canvas_q_start(const float* cond01, int H, int W, int pad_l, int pad_t, int Hp, int Wp, const float* noise,
-                   float alpha, float sigma, float* img, hipStream_t st);
-int canvas_ring_renoise(float* img, const float* noise /*[3][Hp][Wp]*/, int Hp, int Wp, int il, int it, int ir,
-                        int ib, const StepScalars* sc, const int* step_ptr, hipStream_t st);
-int canvas_finish(const float* img, int Hp, int Wp, int left, int top, int H, int W, float* out01, hipStream_t st);
+// `planes` = 3 * n_images; the noise canvas [3][Hp][Wp] is shared by every image (index taken modulo 3*Hp*Wp)
+int canvas_prepare_cond(const float* cond01 /*[planes][H][W]*/, int planes, int H, int W, int pad_l, int pad_t, int Hp,
+                        int Wp, int il, int it, int ir, int ib, float* cond_canvas, hipStream_t st);
+int canvas_q_start(const float* cond01, int planes, int H, int W, int pad_l, int pad_t, int Hp, int Wp,
+                   const float* noise, float alpha, float sigma, float* img, hipStream_t st);
+int canvas_ring_renoise(float* img, int planes, const float* noise /*[3][Hp][Wp]*/, int Hp, int Wp, int il, int it,
+                        int ir, int ib, const StepScalars* sc, const int* step_ptr, hipStream_t st);
+int canvas_finish(const float* img, int planes, int Hp, int Wp, int left, int top, int H, int W, float* out01,
+                  hipStream_t st);
 // counter-based Gaussian noise (Philox4x32-10 + Box-Muller), throughput mode only
 int philox_normal(float* dst, size_t n, uint64_t seed, uint64_t stream_id, const int* step_ptr, hipStream_t st);
 

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void init_gather_kernel(InitSrc s, int entries
       bool use_cond = s.cond != nullptr;
       if (s.canvas) {
         const int pass = entry / s.ntiles, tt = entry - pass * s.ntiles;
-        origin = (long)s.tile_yx[2 * (s.first + tt)] * s.row_stride + s.tile_yx[2 * (s.first + tt) + 1];
+        const int* tyx = s.tile_yx + 3 * (s.first + tt);
+        origin = (long)tyx[2] * 3 * s.plane_stride + (long)tyx[0] * s.row_stride + tyx[1];
         use_cond = use_cond && ((s.use_cond_mask >> pass) & 1);
       } else {
         origin = (long)entry * 3 * s.plane_stride;
@@ -116,25 +117,28 @@ __global__ __launch_bounds__(256) void final_step_kernel(FinalStepArgs a, TileBa
     for (int c = 0; c < 3; ++c) e[c] = n[c] + (e[c] - n[c]) * a.guidance;     // model.py:3150 / :3154
   }
   const StepScalars sc = a.sc[a.step_ptr ? *a.step_ptr : 0];
-  const int ty = tb.tile_yx[2 * (tb.first + t)], tx = tb.tile_yx[2 * (tb.first + t) + 1];
+  const int* tyx = tb.tile_yx + 3 * (tb.first + t);
+  const int ty = tyx[0], tx = tyx[1];
   const long plane = (long)tb.Hp * tb.Wp;
-  const long o = (long)(ty + y) * tb.Wp + tx + x;
+  const long o = (long)tyx[2] * 3 * plane + (long)(ty + y) * tb.Wp + tx + x;
+  const int tl = (tb.first + t) % tb.n_local;       // tile index inside its image: selects the noise tile
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float xt = a.img[c * plane + o];
     float x0 = (xt - sc.sigma * e[c]) / sc.alpha;                              // model.py:3160
     x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                                        // :3163
     float mean = sc.alpha_next * (xt * sc.one_minus_c / sc.alpha + sc.c * x0);  // :3164
-    if (a.noise) mean += sc.noise_scale * a.noise[((long)t * 3 + c) * per_tile + r];   // :3187-3188
+    if (a.noise) mean += sc.noise_scale * a.noise[((long)tl * 3 + c) * per_tile + r];   // :3187-3188
     a.img[c * plane + o] = mean;
     if (a.x_start) a.x_start[c * plane + o] = x0;
   }
 }
 
 // ------------------------------------------------------------------ canvas kernels
-__global__ void canvas_prepare_cond_kernel(const float* __restrict__ c01, int H, int W, int pad_l, int pad_t, int Hp,
-                                           int Wp, int il, int it, int ir, int ib, float* __restrict__ canvas) {
-  const long n = 3L * Hp * Wp;
+__global__ void canvas_prepare_cond_kernel(const float* __restrict__ c01, int planes, int H, int W, int pad_l, int pad_t,
+                                           int Hp, int Wp, int il, int it, int ir, int ib,
+                                           float* __restrict__ canvas) {
+  const long n = (long)planes * Hp * Wp;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int c = (int)(i / ((long)Hp * Wp));
     const long rem = i - (long)c * Hp * Wp;
@@ -154,10 +158,11 @@ __global__ void canvas_prepare_cond_kernel(const float* __restrict__ c01, int H,
 
 // q_sample start of a run (model.py:3305-3308, :3312-3315): img = reflect_pad(2*cond-1) * alpha + noise * sigma over
 // the WHOLE canvas (the condition is not yet zeroed outside the inner box at that point of the reference).
-__global__ void canvas_q_start_kernel(const float* __restrict__ c01, int H, int W, int pad_l, int pad_t, int Hp, int Wp,
-                                      const float* __restrict__ noise, float alpha, float sigma,
+__global__ void canvas_q_start_kernel(const float* __restrict__ c01, int planes, int H, int W, int pad_l, int pad_t,
+                                      int Hp, int Wp, const float* __restrict__ noise, float alpha, float sigma,
                                       float* __restrict__ img) {
-  const long n = 3L * Hp * Wp;
+  const long n = (long)planes * Hp * Wp;
+  const long nmod = 3L * Hp * Wp;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int c = (int)(i / ((long)Hp * Wp));
     const long rem = i - (long)c * Hp * Wp;
@@ -168,25 +173,26 @@ __global__ void canvas_q_start_kernel(const float* __restrict__ c01, int H, int 
     if (x < 0) x = -x;
     if (x >= W) x = 2 * (W - 1) - x;
     const float v = c01[((long)c * H + y) * W + x] * 2.0f - 1.0f;
-    img[i] = v * alpha + noise[i] * sigma;
+    img[i] = v * alpha + noise[i % nmod] * sigma;
   }
 }
 
-__global__ void canvas_ring_renoise_kernel(float* __restrict__ img, const float* __restrict__ noise, int Hp, int Wp,
-                                           int il, int it, int ir, int ib, const StepScalars* __restrict__ sc,
-                                           const int* __restrict__ step_ptr) {
+__global__ void canvas_ring_renoise_kernel(float* __restrict__ img, int planes, const float* __restrict__ noise, int Hp,
+                                           int Wp, int il, int it, int ir, int ib,
+                                           const StepScalars* __restrict__ sc, const int* __restrict__ step_ptr) {
   const float sigma = sc[step_ptr ? *step_ptr : 0].sigma_next;
-  const long n = 3L * Hp * Wp;
+  const long n = (long)planes * Hp * Wp;
+  const long nmod = 3L * Hp * Wp;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const long rem = i % ((long)Hp * Wp);
     const int Y = (int)(rem / Wp), X = (int)(rem - (long)Y * Wp);
-    if (!(Y >= it && Y < ib && X >= il && X < ir)) img[i] = noise[i] * sigma;
+    if (!(Y >= it && Y < ib && X >= il && X < ir)) img[i] = noise[i % nmod] * sigma;
   }
 }
 
-__global__ void canvas_finish_kernel(const float* __restrict__ img, int Hp, int Wp, int left, int top, int H, int W,
-                                     float* __restrict__ out) {
-  const long n = 3L * H * W;
+__global__ void canvas_finish_kernel(const float* __restrict__ img, int planes, int Hp, int Wp, int left, int top, int H,
+                                     int W, float* __restrict__ out) {
+  const long n = (long)planes * H * W;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int c = (int)(i / ((long)H * W));
     const long rem = i - (long)c * H * W;
@@ -294,33 +300,34 @@ int final_step(const FinalStepArgs& a, const TileBatch& tb, bool is_bf16, hipStr
   return 0;
 }
 
-int canvas_prepare_cond(const float* cond01, int H, int W, int pad_l, int pad_t, int Hp, int Wp, int il, int it,
-                        int ir, int ib, float* cond_canvas, hipStream_t st) {
-  hipLaunchKernelGGL(canvas_prepare_cond_kernel, dim3(grid_for(3L * Hp * Wp)), dim3(256), 0, st, cond01, H, W, pad_l,
-                     pad_t, Hp, Wp, il, it, ir, ib, cond_canvas);
+int canvas_prepare_cond(const float* cond01, int planes, int H, int W, int pad_l, int pad_t, int Hp, int Wp, int il,
+                        int it, int ir, int ib, float* cond_canvas, hipStream_t st) {
+  hipLaunchKernelGGL(canvas_prepare_cond_kernel, dim3(grid_for((long)planes * Hp * Wp)), dim3(256), 0, st, cond01, planes,
+                     H, W, pad_l, pad_t, Hp, Wp, il, it, ir, ib, cond_canvas);
   SRGD_HIP(hipGetLastError());
   return 0;
 }
 
-int canvas_q_start(const float* cond01, int H, int W, int pad_l, int pad_t, int Hp, int Wp, const float* noise,
-                   float alpha, float sigma, float* img, hipStream_t st) {
-  hipLaunchKernelGGL(canvas_q_start_kernel, dim3(grid_for(3L * Hp * Wp)), dim3(256), 0, st, cond01, H, W, pad_l, pad_t, Hp,
-                     Wp, noise, alpha, sigma, img);
+int canvas_q_start(const float* cond01, int planes, int H, int W, int pad_l, int pad_t, int Hp, int Wp,
+                   const float* noise, float alpha, float sigma, float* img, hipStream_t st) {
+  hipLaunchKernelGGL(canvas_q_start_kernel, dim3(grid_for((long)planes * Hp * Wp)), dim3(256), 0, st, cond01, planes, H, W,
+                     pad_l, pad_t, Hp, Wp, noise, alpha, sigma, img);
   SRGD_HIP(hipGetLastError());
   return 0;
 }
 
-int canvas_ring_renoise(float* img, const float* noise, int Hp, int Wp, int il, int it, int ir, int ib,
+int canvas_ring_renoise(float* img, int planes, const float* noise, int Hp, int Wp, int il, int it, int ir, int ib,
                         const StepScalars* sc, const int* step_ptr, hipStream_t st) {
-  hipLaunchKernelGGL(canvas_ring_renoise_kernel, dim3(grid_for(3L * Hp * Wp)), dim3(256), 0, st, img, noise, Hp, Wp,
-                     il, it, ir, ib, sc, step_ptr);
+  hipLaunchKernelGGL(canvas_ring_renoise_kernel, dim3(grid_for((long)planes * Hp * Wp)), dim3(256), 0, st, img, planes,
+                     noise, Hp, Wp, il, it, ir, ib, sc, step_ptr);
   SRGD_HIP(hipGetLastError());
   return 0;
 }
 
-int canvas_finish(const float* img, int Hp, int Wp, int left, int top, int H, int W, float* out01, hipStream_t st) {
-  hipLaunchKernelGGL(canvas_finish_kernel, dim3(grid_for(3L * H * W)), dim3(256), 0, st, img, Hp, Wp, left, top, H, W,
-                     out01);
+int canvas_finish(const float* img, int planes, int Hp, int Wp, int left, int top, int H, int W, float* out01,
+                  hipStream_t st) {
+  hipLaunchKernelGGL(canvas_finish_kernel, dim3(grid_for((long)planes * H * W)), dim3(256), 0, st, img, planes, Hp, Wp,
+                     left, top, H, W, out01);
   SRGD_HIP(hipGetLastError());
   return 0;
 }

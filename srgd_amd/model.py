@@ -328,10 +328,14 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
                      cond_scale=1.0, guidance_start_steps=0, class_cond_scale=1.0, class_guidance_start_steps=0,
                      generation_start_steps=0, num_sample_steps=None, with_images=False, with_x0_images=False,
                      start_white_noise=True, amp=False):
-        """Tiled CFG-DDPM sampling of one image (reference model.py:3288-3413).
+        """Tiled CFG-DDPM sampling (reference model.py:3288-3413).
 
         ``amp`` is accepted and ignored by the reference; here it selects the engine's bf16 mode
-        (False: exact-fp32 parity mode)."""
+        (False: exact-fp32 parity mode).  ``condition_x`` is ``[1,3,H,W]`` as in the reference, or
+        ``[B,3,H,W]``: B same-sized images sampled in lock-step, each exactly as the reference would
+        sample it on its own after ``seed_everything(seed)`` (inference.py:73) - i.e. all B see the
+        same noise stream - with every U-Net launch spanning tiles of all images (fills the GPU
+        better than 25/16 tiles of one image do).  ``batch_size`` counts tiles across all images."""
         num_sample_steps = self.num_sample_steps if num_sample_steps is None else num_sample_steps
         if cond_scale != 1.0 and class_cond_scale != 1.0:
             raise NotImplementedError("Currently, you cannot specify both cond_scale and class_cond_scale at the same time.")
@@ -342,8 +346,8 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
         if dev.type != "cuda":
             raise _lib.SrgdHipError("tiled_sample runs on MI355X only (no CPU fallback)")
         batch, c, h, w = condition_x.shape
-        if batch != 1 or c != 3:
-            raise ValueError("condition_x must be [1,3,H,W] (the reference's tile gather assumes batch 1)")
+        if batch < 1 or c != 3:
+            raise ValueError("condition_x must be [B,3,H,W] (B=1 in the reference, whose tile gather assumes batch 1)")
         f = self.model.downsample_factor
         assert tile_size % f == 0, f"your input dimensions need to be divisible by {f}, given the unet"
         eng = self.model.engine("bf16" if amp else "fp32")
@@ -361,11 +365,11 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
             coords1 = get_coords(hp - tile_size, wp - tile_size, tile_size, tile_stride, diff=tile_size // 2)
         (sl, st_, sr, sb), _ = get_area(coords1, hp, wp)
         geo = SamplerGeometry(H=h, W=w, Hp=hp, Wp=wp, left=left, top=top, inner_l=sl, inner_t=st_, inner_r=sr,
-                              inner_b=sb, tile=tile_size, n_even=len(coords0), n_odd=len(coords1))
+                              inner_b=sb, tile=tile_size, n_even=len(coords0), n_odd=len(coords1), n_images=batch)
         scalars, log_snrs = _schedule(num_sample_steps)
 
-        cond01 = condition_x[0].to(dev, torch.float32).contiguous()
-        cond_canvas = torch.empty(3, hp, wp, device=dev, dtype=torch.float32)
+        cond01 = condition_x.to(dev, torch.float32).contiguous()
+        cond_canvas = torch.empty(batch, 3, hp, wp, device=dev, dtype=torch.float32)
         eng.sampler_begin(geo, cond01, cond_canvas, [(a, c_) for (a, _, c_, _) in coords0],
                           [(a, c_) for (a, _, c_, _) in coords1], scalars, log_snrs, class_id)
 
@@ -375,13 +379,13 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
             t0 = (1.0 - torch.tensor(generation_start_steps / num_sample_steps)) if generation_start_steps > 0 \
                 else torch.tensor(1.0)
             ls0 = beta_linear_log_snr(t0)
-            img = torch.empty(1, 3, hp, wp, device=dev)
+            img = torch.empty(batch, 3, hp, wp, device=dev)
             eng.sampler_q_start(cond01, torch.randn(1, 3, hp, wp).to(dev) if host_noise else None,
                                 float(ls0.sigmoid().sqrt()), float((-ls0).sigmoid().sqrt()), img, self.device_noise_seed)
         elif host_noise:
-            img = torch.randn(1, 3, hp, wp).to(dev)                      # reference draw #1 (model.py:3311)
+            img = torch.randn(1, 3, hp, wp).to(dev).repeat(batch, 1, 1, 1)   # reference draw #1 (model.py:3311)
         else:
-            img = eng.randn_(torch.empty(1, 3, hp, wp, device=dev), self.device_noise_seed, 0)
+            img = eng.randn_(torch.empty(1, 3, hp, wp, device=dev), self.device_noise_seed, 0).repeat(batch, 1, 1, 1)
         x_start = img.clone() if with_x0_images else None
         image_list = [img[:, :, top:bottom, left:right].clone().cpu()] if with_images else None
         x0_image_list = [img[:, :, top:bottom, left:right].clone().cpu()] if with_x0_images else None
@@ -416,7 +420,7 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
             if with_x0_images:
                 x0_image_list.append(x_start.clone().cpu())
 
-        out = torch.empty(1, 3, h, w, device=dev, dtype=torch.float32)
+        out = torch.empty(batch, 3, h, w, device=dev, dtype=torch.float32)
         eng.sampler_end(img, out)
         if with_images:
             return (out, image_list, x0_image_list) if with_x0_images else (out, image_list)

@@ -222,3 +222,48 @@ def test_hipgraph_replay_is_bitwise_identical_to_eager_launches():
         sampler.noise_source = "host"
     assert torch.isfinite(outs["1"]).all()
     assert torch.equal(outs["1"], outs["0"])
+
+
+@pytest.mark.parametrize("noise,amp", [("host", False), ("device", True)])
+def test_lockstep_images_equal_their_solo_runs(noise, amp):
+    # [B,3,H,W] condition: B same-sized images advance together, every U-Net launch spanning tiles of all of them.
+    # Each must come out bit-identical to sampling it alone with the same seed (what the reference's per-image
+    # seed_everything gives, inference.py:73), for a sub-batch that straddles image boundaries too.
+    sampler = build_sampler(16)
+    conds = torch.cat([C.synthetic_lr_condition(s, 96, 96) for s in (0, 1, 2)]).cuda()     # 3 x (384^2 -> canvas 768^2)
+    label = torch.tensor([1]).cuda()
+    sampler.noise_source = noise
+    sampler.device_noise_seed = 11
+    try:
+        solo = []
+        for i in range(3):
+            torch.manual_seed(9)
+            solo.append(sampler.tiled_sample(batch_size=9, condition_x=conds[i:i + 1], class_label=label,
+                                             num_sample_steps=5, class_cond_scale=1.3, amp=amp).cpu())
+        for bs in (27, 7):
+            torch.manual_seed(9)
+            both = sampler.tiled_sample(batch_size=bs, condition_x=conds, class_label=label, num_sample_steps=5,
+                                        class_cond_scale=1.3, amp=amp).cpu()
+            assert both.shape == (3, 3, 384, 384)
+            for i in range(3):
+                assert torch.equal(both[i:i + 1], solo[i]), (bs, i)
+    finally:
+        sampler.noise_source = "host"
+
+
+def test_lockstep_full_size_batch_of_five():
+    # the bench shape: 5 x (256^2 LR -> 1024^2) in one run = 125 / 80 tiles per U-Net launch at dim 128, bf16
+    # (activation buffers of ~2 GB: exercises 64-bit indexing); image 3 must equal its solo run.
+    sampler = build_sampler(128)
+    conds = torch.cat([C.synthetic_lr_condition(s, 256, 256) for s in range(5)]).cuda()
+    label = torch.tensor([0]).cuda()
+    sampler.noise_source = "device"
+    sampler.device_noise_seed = 71
+    try:
+        five = sampler.tiled_sample(batch_size=125, condition_x=conds, class_label=label, num_sample_steps=3, amp=True).cpu()
+        solo = sampler.tiled_sample(batch_size=25, condition_x=conds[3:4], class_label=label, num_sample_steps=3, amp=True).cpu()
+    finally:
+        sampler.noise_source = "host"
+    assert torch.isfinite(five).all()
+    assert torch.equal(five[3:4], solo)
+    assert not torch.equal(five[0], five[1])
