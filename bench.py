@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--images", type=int, default=5,
                     help="HR tiles sampled in lock-step per tiled_sample call (their 256^2 U-Net tiles share launches)")
+    ap.add_argument("--workload", choices=["tiles", "canvas"], default="tiles",
+                    help="tiles: BASELINE configs[1] units, images sharded over ranks (weak scaling, the headline); "
+                         "canvas: ONE --lr_size^2 image per step whose tiles are sharded over all ranks with a per-step "
+                         "tile all-gather (configs[3] with --lr_size 2048; strong scaling, secondary)")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--ddpm_steps", type=int, default=50)
     ap.add_argument("--lr_size", type=int, default=256)
@@ -117,7 +121,15 @@ def main():
     label = torch.tensor([0], device=device)
     total = args.warmup + args.steps
     # inputs resident in HBM before the clock starts (already x4-upsampled condition images)
-    conds = [synthetic_lr_condition(rank * total + i, args.lr_size, args.lr_size).to(device) for i in range(total)]
+    canvas_mode = args.workload == "canvas"
+    if canvas_mode:
+        args.images = 1
+        if world > 1:
+            from srgd_amd.parallel import shard_canvas
+            shard_canvas(sampler)
+    # canvas mode: every rank works on the SAME image; tiles mode: every rank has its own images
+    conds = [synthetic_lr_condition((0 if canvas_mode else rank * total) + i, args.lr_size, args.lr_size).to(device)
+             for i in range(total)]
     n_even = ((4 * args.lr_size + 255) // 256 + 1) ** 2 if args.lr_size * 4 > 256 else 1
 
     def run(lo, hi):
@@ -126,7 +138,7 @@ def main():
         for a in range(lo, hi, args.images):
             b = min(a + args.images, hi)
             sampler.device_noise_seed = 71
-            res.append(sampler.tiled_sample(batch_size=args.sub_batch or n_even * (b - a),
+            res.append(sampler.tiled_sample(batch_size=args.sub_batch or min(125, n_even * (b - a)),
                                             condition_x=torch.cat(conds[a:b], 0), class_label=label,
                                             class_cond_scale=1.0, num_sample_steps=args.ddpm_steps, amp=amp))
         return res
@@ -138,7 +150,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     outs = run(args.warmup, total)
-    if dist:
+    if dist and not canvas_mode:
         from srgd_amd.parallel import gather_outputs
         gathered = gather_outputs(torch.cat(outs, 0), dst=0)          # HR tiles -> rank 0 (12.6 MB each)
     torch.cuda.synchronize()
@@ -151,7 +163,25 @@ def main():
         dt = max_over_ranks(dt, device)
     assert all(torch.isfinite(o).all() for o in outs)
 
-    if rank == 0:
+    if rank == 0 and canvas_mode:
+        from srgd_amd.model import get_coord_and_pad, get_coords
+        h = 4 * args.lr_size
+        _, pad = get_coord_and_pad(h, h)
+        hp = h + pad[2] + pad[3]
+        ne = len(get_coords(hp, hp, 256, 256))
+        no = ne if hp <= 256 else len(get_coords(hp - 256, hp - 256, 256, 256, diff=128))
+        tf = sum(ne if i % 2 == 0 else no for i in range(args.ddpm_steps))
+        print(json.dumps({
+            "metric": f"U-Net tile-forwards/sec on one {h}x{h} image ({args.ddpm_steps} steps, CFG=1.0)",
+            "value": args.steps * tf / dt, "unit": "tile-forwards/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic (seeded LR image, seeded weights)",
+            "config": {"workload": f"one {args.lr_size}x{args.lr_size} LR image x4, canvas {hp}x{hp}, {ne}/{no} tiles per "
+                                   f"even/odd step, tiles sharded over {world} rank(s), per-step tile all-gather",
+                       "tile_forwards_per_step": tf, "parallelism": f"canvas-sharded x{world}"},
+            "hr_tile_equivalents_per_s": args.steps * tf / dt / TILE_FORWARDS_PER_HR_TILE,
+            "tflops_effective": args.steps * tf / dt * 0.7938}), flush=True)
+    elif rank == 0:
         tiles = args.steps * world
         value = tiles / dt
         line = {

@@ -113,6 +113,21 @@ int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_ca
                       const float* noise_tiles, const float* noise_canvas, int passes, int guidance_kind,
                       float guidance_scale, int sub_batch, uint64_t seed, void* stream);
 
+/* Same as srgd_sampler_step restricted to tiles [tile_first, tile_first+tile_count) of the step's grid (image-major
+ * index; tile_count < 0 = to the end); the odd-step ring re-noise runs only when do_ring != 0.  This is the
+ * per-rank unit when ONE canvas is sharded over several GPUs: every rank holds
+ * the whole canvas, updates its own tiles, then the tiles are exchanged (srgd_sampler_exchange_tiles + an
+ * all-gather).  noise_tiles still points at the noise of the WHOLE grid (indexed by the global tile number). */
+int srgd_sampler_step_tiles(srgd_engine* e, int step, int tile_first, int tile_count, int do_ring, float* img,
+                            const float* cond_canvas, float* x_start, const float* noise_tiles,
+                            const float* noise_canvas, int passes, int guidance_kind, float guidance_scale,
+                            int sub_batch, uint64_t seed, void* stream);
+
+/* Copies tiles [tile_first, tile_first+tile_count) of grid `parity` between a canvas [n_images,3,Hp,Wp] and a
+ * packed device buffer [tile_count,3,tile,tile]: to_canvas = 0 packs (canvas -> tiles), 1 unpacks. */
+int srgd_sampler_exchange_tiles(srgd_engine* e, int parity, int tile_first, int tile_count, float* canvas, float* tiles,
+                                int to_canvas, void* stream);
+
 /* Optional start from the forward-diffused condition instead of white noise (generation_start_steps > 0 or
  * start_white_noise=False): img = reflect_pad(2*cond01-1) * alpha + noise * sigma over the whole canvas
  * (q_sample, model.py:3305-3308, :3312-3315, :3434-3442).  noise_canvas: device [3,Hp,Wp] or NULL (device RNG). */

@@ -234,6 +234,7 @@ struct srgd_engine {
   bool capturing = false;
   struct StepGraph {
     int parity, passes, kind, sub_batch; float scale; const void *img, *cond, *xs; uint64_t seed; bool last;
+    int tile_first, tile_count; bool ring;
     int seen; hipGraphExec_t exec; hipGraph_t graph;
   };
   std::vector<StepGraph> graphs;
@@ -928,13 +929,14 @@ int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const flo
 }
 
 // all launches of one DDPM step; step-dependent values come through e->d_step (set by the caller on the stream)
-static int sampler_step_launch(srgd_engine* e, bool last, int parity, float* img, const float* cond_canvas, float* x_start,
-                               const float* noise_tiles, const float* noise_canvas, int passes, int guidance_kind,
-                               float guidance_scale, int sub_batch, uint64_t seed, hipStream_t st) {
+static int sampler_step_launch(srgd_engine* e, bool last, int parity, int tile_first, int tile_count, bool ring, float* img,
+                               const float* cond_canvas, float* x_start, const float* noise_tiles,
+                               const float* noise_canvas, int passes, int guidance_kind, float guidance_scale,
+                               int sub_batch, uint64_t seed, hipStream_t st) {
   const srgd_sampler_geometry& g = e->geo;
   const int* tiles = parity ? e->d_tiles_odd : e->d_tiles_even;
   const int n_local = parity ? g.n_odd : g.n_even;
-  const int n = n_local * g.n_images;
+  const int n = tile_first + tile_count;               // this call covers tiles [tile_first, n) of the image-major list
   const size_t tile_elems = (size_t)3 * g.tile * g.tile;
   const float* nz = nullptr;
   if (!last) {
@@ -947,7 +949,7 @@ static int sampler_step_launch(srgd_engine* e, bool last, int parity, float* img
   }
   const int row_label = e->run_class >= 0 ? 0 : 1;       // + 2 * step inside gn_finalize
   const int row_null = 1;
-  for (int first = 0; first < n; first += sub_batch) {
+  for (int first = tile_first; first < n; first += sub_batch) {
     const int nt = std::min(sub_batch, n - first);
     const int nb = nt * passes;
     TileBatch tb{tiles, first, nt, g.Hp, g.Wp, g.tile, n_local};
@@ -975,7 +977,7 @@ static int sampler_step_launch(srgd_engine* e, bool last, int parity, float* img
     e->pool.put(act);
     e->pool.put(x0);
   }
-  if (parity == 1) {
+  if (parity == 1 && ring) {
     Prof p(e, KC_CANVAS, st);
     const float* nc = noise_canvas;
     if (!nc) {
@@ -998,6 +1000,14 @@ static void drop_step_graphs(srgd_engine* e) {
 int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start,
                       const float* noise_tiles, const float* noise_canvas, int passes, int guidance_kind,
                       float guidance_scale, int sub_batch, uint64_t seed, void* stream) {
+  return srgd_sampler_step_tiles(e, step, 0, -1, 1, img, cond_canvas, x_start, noise_tiles, noise_canvas, passes,
+                                 guidance_kind, guidance_scale, sub_batch, seed, stream);
+}
+
+int srgd_sampler_step_tiles(srgd_engine* e, int step, int tile_first, int tile_count, int do_ring, float* img,
+                            const float* cond_canvas, float* x_start, const float* noise_tiles,
+                            const float* noise_canvas, int passes, int guidance_kind, float guidance_scale,
+                            int sub_batch, uint64_t seed, void* stream) {
   if (!e || !e->run_active) SRGD_FAIL("srgd_sampler_step: call srgd_sampler_begin first");
   if (step < 0 || step >= e->n_steps) SRGD_FAIL("srgd_sampler_step: step out of range");
   if (passes != 1 && passes != 2) SRGD_FAIL("srgd_sampler_step: passes must be 1 or 2");
@@ -1010,29 +1020,32 @@ int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_ca
   const int n_local = parity ? g.n_odd : g.n_even;
   const int n = n_local * g.n_images;
   const bool last = step == e->n_steps - 1;
-  sub_batch = std::min(sub_batch, n);
+  if (tile_count < 0) tile_count = n - tile_first;
+  if (tile_first < 0 || tile_count < 0 || tile_first + tile_count > n) SRGD_FAIL("srgd_sampler_step_tiles: tile range outside the grid");
+  const bool ring = do_ring != 0;
+  sub_batch = std::max(1, std::min(sub_batch, std::max(tile_count, 1)));
   // every allocation happens here, before any capture
   SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
   if (!noise_tiles) SRGD_TRY(ensure(&e->rng_tiles, &e->rng_tiles_cap, (size_t)n_local * 3 * g.tile * g.tile));
-  if (!noise_canvas) SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, (size_t)3 * g.Hp * g.Wp));
+  if (!noise_canvas && ring) SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, (size_t)3 * g.Hp * g.Wp));
   if (!e->d_step) SRGD_HIP(hipMalloc((void**)&e->d_step, sizeof(int)));
   hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, e->d_step, step);
 
   const bool graphable = e->use_graphs && !e->prof_on && !noise_tiles && !noise_canvas;
   if (!graphable)
-    return sampler_step_launch(e, last, parity, img, cond_canvas, x_start, noise_tiles, noise_canvas, passes, guidance_kind,
-                               guidance_scale, sub_batch, seed, st);
+    return sampler_step_launch(e, last, parity, tile_first, tile_count, ring, img, cond_canvas, x_start, noise_tiles,
+                               noise_canvas, passes, guidance_kind, guidance_scale, sub_batch, seed, st);
   srgd_engine::StepGraph* sg = nullptr;
   for (auto& c : e->graphs)
     if (c.parity == parity && c.passes == passes && c.kind == guidance_kind && c.sub_batch == sub_batch &&
         c.scale == guidance_scale && c.img == img && c.cond == cond_canvas && c.xs == x_start && c.seed == seed &&
-        c.last == last)
+        c.last == last && c.tile_first == tile_first && c.tile_count == tile_count && c.ring == ring)
       sg = &c;
   if (!sg) {   // first time: run eagerly (warms the activation pool and every lazily-set kernel attribute)
-    e->graphs.push_back({parity, passes, guidance_kind, sub_batch, guidance_scale, img, cond_canvas, x_start, seed, last, 1,
-                         nullptr, nullptr});
-    return sampler_step_launch(e, last, parity, img, cond_canvas, x_start, nullptr, nullptr, passes, guidance_kind,
-                               guidance_scale, sub_batch, seed, st);
+    e->graphs.push_back({parity, passes, guidance_kind, sub_batch, guidance_scale, img, cond_canvas, x_start, seed, last,
+                         tile_first, tile_count, ring, 1, nullptr, nullptr});
+    return sampler_step_launch(e, last, parity, tile_first, tile_count, ring, img, cond_canvas, x_start, nullptr, nullptr,
+                               passes, guidance_kind, guidance_scale, sub_batch, seed, st);
   }
   if (!sg->exec) {   // second time: capture the identical launch sequence
     // capture on a private stream (the caller's may be the legacy default stream, which cannot capture); nothing
@@ -1040,8 +1053,8 @@ int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_ca
     if (!e->cap_stream) SRGD_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
     SRGD_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
     e->pool.no_alloc = true;
-    const int rc = sampler_step_launch(e, last, parity, img, cond_canvas, x_start, nullptr, nullptr, passes, guidance_kind,
-                                       guidance_scale, sub_batch, seed, e->cap_stream);
+    const int rc = sampler_step_launch(e, last, parity, tile_first, tile_count, ring, img, cond_canvas, x_start, nullptr,
+                                       nullptr, passes, guidance_kind, guidance_scale, sub_batch, seed, e->cap_stream);
     e->pool.no_alloc = false;
     hipGraph_t graph = nullptr;
     const hipError_t ce = hipStreamEndCapture(e->cap_stream, &graph);
@@ -1055,6 +1068,21 @@ int srgd_sampler_step(srgd_engine* e, int step, float* img, const float* cond_ca
   }
   SRGD_HIP(hipGraphLaunch(sg->exec, st));
   return 0;
+}
+
+int srgd_sampler_exchange_tiles(srgd_engine* e, int parity, int tile_first, int tile_count, float* canvas, float* tiles,
+                                int to_canvas, void* stream) {
+  if (!e || !e->run_active) SRGD_FAIL("srgd_sampler_exchange_tiles: call srgd_sampler_begin first");
+  if (!canvas || !tiles) SRGD_FAIL("srgd_sampler_exchange_tiles: null argument");
+  const srgd_sampler_geometry& g = e->geo;
+  const int n = (parity & 1 ? g.n_odd : g.n_even) * g.n_images;
+  if (tile_first < 0 || tile_count < 0 || tile_first + tile_count > n)
+    SRGD_FAIL("srgd_sampler_exchange_tiles: tile range outside the grid");
+  if (tile_count == 0) return 0;
+  Prof p(e, KC_CANVAS, (hipStream_t)stream);
+  TileBatch tb{parity & 1 ? e->d_tiles_odd : e->d_tiles_even, tile_first, tile_count, g.Hp, g.Wp, g.tile,
+               parity & 1 ? g.n_odd : g.n_even};
+  return canvas_exchange_tiles(canvas, tiles, tb, to_canvas != 0, (hipStream_t)stream);
 }
 
 int srgd_sampler_q_start(srgd_engine* e, const float* cond01, const float* noise_canvas, float alpha, float sigma,

@@ -203,6 +203,30 @@ __global__ void canvas_finish_kernel(const float* __restrict__ img, int planes, 
   }
 }
 
+// tile <-> packed buffer copy, one float4 per thread
+__global__ __launch_bounds__(256) void canvas_exchange_tiles_kernel(float* __restrict__ canvas, float* __restrict__ packed,
+                                                                    TileBatch tb, int to_canvas) {
+  const int q4 = tb.tile / 4;
+  const long n = (long)tb.ntiles * 3 * tb.tile * q4;
+  const long plane = (long)tb.Hp * tb.Wp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int xq = (int)(i % q4);
+    long r = i / q4;
+    const int y = (int)(r % tb.tile);
+    r /= tb.tile;
+    const int c = (int)(r % 3), t = (int)(r / 3);
+    const int* tyx = tb.tile_yx + 3 * (tb.first + t);
+    float* cp = canvas + ((long)tyx[2] * 3 + c) * plane + (long)(tyx[0] + y) * tb.Wp + tyx[1] + xq * 4;
+    float* pp = packed + i * 4;
+    if (to_canvas) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pp);
+      cp[0] = v[0]; cp[1] = v[1]; cp[2] = v[2]; cp[3] = v[3];
+    } else {
+      *reinterpret_cast<f32x4*>(pp) = f32x4{cp[0], cp[1], cp[2], cp[3]};
+    }
+  }
+}
+
 // ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
 __device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
   const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
@@ -328,6 +352,14 @@ int canvas_finish(const float* img, int planes, int Hp, int Wp, int left, int to
                   hipStream_t st) {
   hipLaunchKernelGGL(canvas_finish_kernel, dim3(grid_for((long)planes * H * W)), dim3(256), 0, st, img, planes, Hp, Wp,
                      left, top, H, W, out01);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int canvas_exchange_tiles(float* canvas, float* tiles, const TileBatch& tb, bool to_canvas, hipStream_t st) {
+  if (tb.tile % 4 != 0) SRGD_FAIL("canvas_exchange_tiles: tile edge must be a multiple of 4");
+  const long n = (long)tb.ntiles * 3 * tb.tile * (tb.tile / 4);
+  hipLaunchKernelGGL(canvas_exchange_tiles_kernel, dim3(grid_for(n)), dim3(256), 0, st, canvas, tiles, tb, to_canvas ? 1 : 0);
   SRGD_HIP(hipGetLastError());
   return 0;
 }

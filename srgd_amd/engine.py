@@ -132,6 +132,26 @@ class HipEngine:
                                             float(guidance_scale), int(sub_batch), int(seed) & (2 ** 64 - 1),
                                             _stream_ptr(self.device)), "srgd_sampler_step")
 
+    def sampler_step_tiles(self, step: int, tile_first: int, tile_count: int, do_ring: bool, img: torch.Tensor,
+                           cond_canvas: torch.Tensor, x_start: Optional[torch.Tensor],
+                           noise_tiles: Optional[torch.Tensor], noise_canvas: Optional[torch.Tensor], passes: int,
+                           guidance_kind: int, guidance_scale: float, sub_batch: int, seed: int = 0) -> None:
+        with torch.cuda.device(self.device):
+            check(self._L.srgd_sampler_step_tiles(self._h, step, int(tile_first), int(tile_count), int(bool(do_ring)),
+                                                  _dev_ptr(img), _dev_ptr(cond_canvas), _dev_ptr(x_start),
+                                                  _dev_ptr(noise_tiles), _dev_ptr(noise_canvas), passes, guidance_kind,
+                                                  float(guidance_scale), int(sub_batch), int(seed) & (2 ** 64 - 1),
+                                                  _stream_ptr(self.device)), "srgd_sampler_step_tiles")
+
+    def sampler_exchange_tiles(self, parity: int, tile_first: int, tile_count: int, canvas: torch.Tensor,
+                               tiles: torch.Tensor, to_canvas: bool) -> None:
+        """Pack (canvas -> tiles) or unpack (tiles -> canvas) tiles [tile_first, tile_first+tile_count) of a grid."""
+        assert tiles.is_contiguous() and tiles.dtype == torch.float32 and tiles.numel() >= tile_count * 3 * 256 * 256
+        with torch.cuda.device(self.device):
+            check(self._L.srgd_sampler_exchange_tiles(self._h, int(parity), int(tile_first), int(tile_count),
+                                                      _dev_ptr(canvas), _dev_ptr(tiles), int(bool(to_canvas)),
+                                                      _stream_ptr(self.device)), "srgd_sampler_exchange_tiles")
+
     def sampler_q_start(self, cond01: torch.Tensor, noise_canvas: Optional[torch.Tensor], alpha: float, sigma: float,
                         img: torch.Tensor, seed: int = 0) -> None:
         with torch.cuda.device(self.device):

@@ -1,6 +1,9 @@
 """Multi-GPU plumbing: one process per GPU, ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on
 ROCm; ``gloo`` in the CPU tests).  The path shards by independent images: there
 is no data-path collective - only a one-time weight broadcast and a final gather of the HR outputs.
+One huge image (config 4: 8192^2, 1089/1024 tiles per step) shards differently: every rank keeps the whole
+canvas, runs a contiguous slice of each step's tiles, and the updated tiles are all-gathered after the step
+(856 MB fp32 per step at 8448^2, ~3 ms over 7 xGMI links against ~130 ms of compute per rank and step).
 """
 from __future__ import annotations
 
@@ -46,3 +49,52 @@ def max_over_ranks(seconds: float, device: torch.device) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------
+# one canvas over several GPUs
+# ---------------------------------------------------------------------------------------------
+def tile_slices(n_tiles: int, world: int) -> List[range]:
+    """Contiguous equal-width slices (the last ones may be short or empty): rank r owns tiles
+    ``[r*w, min(n, (r+1)*w))`` with ``w = ceil(n / world)``, so that the all-gathered buffer
+    ``[world, w, ...]`` flattened holds tiles 0..n-1 in grid order in its first n entries."""
+    w = -(-n_tiles // world)
+    return [range(min(n_tiles, r * w), min(n_tiles, (r + 1) * w)) for r in range(world)]
+
+
+def shard_canvas(sampler, group=None):
+    """Make ``sampler.tiled_sample`` split every step's tile list over the ranks of ``group`` (default: WORLD).
+    All ranks must call tiled_sample with identical arguments (and, in host-noise mode, identical torch seeds);
+    all of them return the full image.  Results are bit-identical to the single-GPU run: tiles are independent
+    within a step (model.py:3361-3380) and the noise of a tile depends only on its index in the grid."""
+    sampler.canvas_group = group if group is not None else dist.group.WORLD
+    return sampler
+
+
+def _all_gather_tiles(mine: torch.Tensor, group) -> torch.Tensor:
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, mine, group=group)       # one RCCL all-gather, no staging copies
+    else:
+        dist.all_gather(list(out.unbind(0)), mine, group=group)
+    return out
+
+
+def sharded_step(eng, group, step: int, n_tiles: int, img, cond_canvas, x_start, noise_tiles, noise_canvas,
+                 passes: int, kind: int, scale: float, sub_batch: int, seed: int) -> None:
+    """One DDPM step of a canvas shared by the ranks of ``group``: my slice of the tiles, then exchange."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    sl = tile_slices(n_tiles, world)
+    mine, width = sl[rank], len(sl[0])
+    eng.sampler_step_tiles(step, mine.start, len(mine), True, img, cond_canvas, x_start, noise_tiles, noise_canvas,
+                           passes, kind, scale, sub_batch, seed)
+    if world == 1:
+        return
+    for canvas in (img, x_start):
+        if canvas is None:
+            continue
+        packed = torch.zeros(width, 3, 256, 256, device=img.device, dtype=torch.float32)
+        eng.sampler_exchange_tiles(step & 1, mine.start, len(mine), canvas, packed, to_canvas=False)
+        everyone = _all_gather_tiles(packed, group).reshape(world * width, 3, 256, 256)
+        eng.sampler_exchange_tiles(step & 1, 0, n_tiles, canvas, everyone, to_canvas=True)
