@@ -28,13 +28,18 @@ int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int H
                   int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
                   const void* residual, float* gn_partial, int groups, int is_bf16, void* stream);
 /* Same, with implementation choice and timing: impl 0 = what the engine would pick, 1 = generic implicit-GEMM
- * kernel (conv_igemm.hip), 2 = the 3x3 bf16 halo/LDS-DMA kernel (conv3x3_bf16.hip; error if not eligible).
+ * kernel (conv_igemm.hip), 2 = the 3x3 bf16 halo/LDS-DMA kernel (conv3x3_bf16.hip; error if not eligible),
+ * 3 = the pointwise bf16 streaming GEMM (conv1x1_bf16.hip; error if not eligible).
+ * gn_tail_src (nullable, NHWC like out): out = silu(gn_tail_a[b][c] * gn_tail_src + gn_tail_b[b][c]) + conv(in) -
+ * the second GroupNorm+SiLU of a ResnetBlock and its residual add folded into the 1x1 res_conv (model.py:250-259,:285);
+ * gn_tail_a / gn_tail_b: device fp32 [B][Cout].  May alias out.
  * iters > 0: the launch is repeated `iters` times between two HIP events on `stream`, *avg_ms = mean duration.
  * *stats_slots (nullable) = slots per (sample, group) written to gn_partial - pass it to srgd_k_groupnorm_silu. */
 int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B, int Hin, int Win, int KS, int stride,
                         int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
                         const void* residual, float* gn_partial, int groups, int is_bf16, int impl, int iters,
-                        float* avg_ms, int* stats_slots, void* stream);
+                        float* avg_ms, int* stats_slots, const void* gn_tail_src, const float* gn_tail_a,
+                        const float* gn_tail_b, void* stream);
 
 /* GroupNorm (from the conv's partial statistics) -> x*(scale+1)+shift -> SiLU (+ residual).
  * replaces: Block.forward after the conv (model.py:250-259) and the ResnetBlock residual add (:285).

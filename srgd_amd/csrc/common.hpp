@@ -81,6 +81,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 enum KClass {
   KC_CONV = 0,     // generic implicit-GEMM convolutions (1x1, 2x2/s2, pixel-shuffle, fp32 mode, odd shapes)
   KC_CONV3,        // conv3x3_bf16_kernel: the 3x3 bf16 fast path (dominant kernel)
+  KC_CONV1,        // conv1x1_bf16_kernel: pointwise bf16 streaming GEMM (res_conv + GN tail, to_qkv/to_out, resamplers)
   KC_INIT,         // 7x7 input convolution reading the canvases
   KC_GN,           // GroupNorm finalize + apply(+SiLU, +residual)
   KC_RMS,          // RMSNorm

@@ -51,7 +51,13 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int n_tiles = p.CoutPad / BN;
-  const int mt = blockIdx.x / n_tiles, nt = blockIdx.x - mt * n_tiles;
+  // XCD-aware order: hardware deals consecutive workgroup ids round-robin to the 8 XCDs (one L2 each); renumber so
+  // that each XCD walks a contiguous run of logical tiles - the n-tiles of one m-tile (same A rows) and the
+  // neighbouring m-tiles (shared 3x3 halo rows) then hit the same L2 instead of 8 different ones
+  const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7;
+  const int xcd = blockIdx.x & 7, xloc = blockIdx.x >> 3;
+  const int bid = xcd * xq + (xcd < xr ? xcd : xr) + xloc;
+  const int mt = bid / n_tiles, nt = bid - mt * n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
   const int HWo = p.Hout * p.Wout;
   const int M = p.B * HWo;

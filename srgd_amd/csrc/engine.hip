@@ -94,6 +94,7 @@ struct ConvW {
   int wi = -1, bi = -1;       // indices of the host tensors
   void* w = nullptr;
   void* w3 = nullptr;         // conv3x3_bf16 fast-path packing (bf16 mode, eligible channel counts)
+  void* w1 = nullptr;         // conv1x1_bf16 packing (bf16 mode: 1x1 / pixel-shuffle / space-to-depth layers)
   float* bias = nullptr;
 };
 struct Lin {
@@ -171,7 +172,7 @@ struct CondTable {
 
 struct ProfRec { int kc; hipEvent_t a, b; };
 
-const char* kFamilyNames[KC_COUNT] = {"conv_igemm", "conv3x3_bf16", "init_conv7x7", "groupnorm_silu", "rmsnorm", "linear_attention",
+const char* kFamilyNames[KC_COUNT] = {"conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "init_conv7x7", "groupnorm_silu", "rmsnorm", "linear_attention",
                                       "full_attention", "final_conv_ddpm_step", "canvas_rng", "conditioning"};
 
 }  // namespace
@@ -208,6 +209,7 @@ struct srgd_engine {
   // LOSES: the 16 transcendentals per 16-byte chunk sit on the barrier-paced critical path of an MFMA-bound kernel
   // (+0.137 s of conv vs -0.055 s of gn_apply per HR tile), so it is off; kept for a staggered-schedule retry.
   bool no_gn_fusion = true;
+  bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
 
   Pool pool;
   float* gn_partial = nullptr; size_t gn_partial_cap = 0;
@@ -400,6 +402,14 @@ int pack_conv(srgd_engine* e, ConvW& c) {
     pack_conv3x3_bf16(e->wt[c.wi].data.data(), c.Cin, c.Cout, p3, f32_to_bf16_host);
     SRGD_TRY(upload(e, p3.data(), p3.size() * 2, &c.w3));
   }
+  if (e->bf16 && (c.KS == 1 || c.kind == CK_UNSHUFFLE) && c.Cin % 32 == 0 && c.Cout % 128 == 0 && c.CoutPad == c.Cout) {
+    std::vector<unsigned char> f32p;
+    std::vector<float> unused;
+    pack_conv_weights(e->wt[c.wi].data.data(), hb, c.kind, c.Cin, c.Cout, c.CoutPad, c.KS, false, f32p, unused);
+    std::vector<unsigned short> p1;
+    pack_conv1x1_bf16(reinterpret_cast<const float*>(f32p.data()), c.KS * c.KS, c.Cin, c.Cout, p1, f32_to_bf16_host);
+    SRGD_TRY(upload(e, p1.data(), p1.size() * 2, &c.w1));
+  }
   return 0;
 }
 
@@ -483,9 +493,12 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
   a.gn_res_src = gn_res_src; a.gn_res_a = gn_res_src ? e->coefA : nullptr; a.gn_res_b = gn_res_src ? e->coefB : nullptr;
   if (C0 + C1 != c.Cin) SRGD_FAIL("internal: conv input channel mismatch");
   const bool fast = e->bf16 && c.w3 && !e->force_generic_conv && conv3x3_bf16_eligible(a);
-  Prof p(e, fast ? KC_CONV3 : KC_CONV, x.st);
+  const bool fast1 = !fast && e->bf16 && c.w1 && !e->force_generic_conv && !e->no_conv1x1 && !stats && conv1x1_bf16_eligible(a);
+  const int fam = fast ? KC_CONV3 : fast1 ? KC_CONV1 : KC_CONV;
+  Prof p(e, fam, x.st);
   if (e->prof_on)
-    e->fam_flops[fast ? KC_CONV3 : KC_CONV] += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
+    e->fam_flops[fam] += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
+  if (fast1) return conv1x1_bf16(a, c.w1, x.st);
   if (fast) {
     if (stats) e->stats_slots = conv3x3_bf16_stats_slots(a);
     return conv3x3_bf16(a, c.w3, gn_in ? e->coefA : nullptr, gn_in ? e->coefB : nullptr, x.st);
@@ -738,6 +751,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   SRGD_TRY(build_topology(e.get()));
   if (const char* v = getenv("SRGD_GN_FUSION")) e->no_gn_fusion = atoi(v) == 0;   // experiment switch (see no_gn_fusion)
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
+  if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
   *out = e.release();
   return 0;
 }

@@ -25,14 +25,15 @@ extern "C" {
 int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B, int Hin, int Win, int KS, int stride,
                         int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
                         const void* residual, float* gn_partial, int groups, int is_bf16, int impl, int iters,
-                        float* avg_ms, int* stats_slots, void* stream) {
+                        float* avg_ms, int* stats_slots, const void* gn_tail_src, const float* gn_tail_a,
+                        const float* gn_tail_b, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int Cin = C0 + C1;
   const int CoutPad = cdiv(Cout, conv_tile_n()) * conv_tile_n();
   std::vector<unsigned char> packed;
   std::vector<float> bias;
   pack_conv_weights(weight_oihw_host, bias_host, kind, Cin, Cout, CoutPad, KS, is_bf16 != 0, packed, bias);
-  DevBuf dw, db, dw3;
+  DevBuf dw, db, dw3, dw1;
   SRGD_TRY(dw.alloc(packed.size()));
   SRGD_HIP(hipMemcpy(dw.p, packed.data(), packed.size(), hipMemcpyHostToDevice));
   if (bias_host) {
@@ -45,9 +46,22 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   a.Wout = (Win + 2 * pad - KS) / stride + 1;
   a.KH = KS; a.KW = KS; a.stride = stride; a.pad = pad; a.w = dw.p; a.bias = (const float*)db.p; a.Cout = Cout; a.CoutPad = CoutPad;
   a.out = out; a.residual = residual; a.mode = kind == 2 ? CONV_PIXEL_SHUFFLE_SILU : CONV_PLAIN;
-  a.gn_partial = gn_partial; a.groups = groups; a.gn_res_src = nullptr; a.gn_res_a = a.gn_res_b = nullptr;
-  const bool fast = impl != 1 && is_bf16 && kind == 0 && conv3x3_bf16_eligible(a);
+  a.gn_partial = gn_partial; a.groups = groups;
+  a.gn_res_src = gn_tail_src; a.gn_res_a = gn_tail_src ? gn_tail_a : nullptr; a.gn_res_b = gn_tail_src ? gn_tail_b : nullptr;
+  if (gn_tail_src && (!gn_tail_a || !gn_tail_b)) SRGD_FAIL("srgd_k_conv2d: gn_tail_src needs gn_tail_a and gn_tail_b");
+  const bool fast = (impl == 0 || impl == 2) && is_bf16 && kind == 0 && conv3x3_bf16_eligible(a);
   if (impl == 2 && !fast) SRGD_FAIL("srgd_k_conv2d: the conv3x3_bf16 fast path does not cover this shape");
+  const bool fast1 = !fast && (impl == 0 || impl == 3) && is_bf16 && conv1x1_bf16_eligible(a);
+  if (impl == 3 && !fast1) SRGD_FAIL("srgd_k_conv2d: the conv1x1_bf16 fast path does not cover this shape");
+  if (fast1) {
+    std::vector<unsigned char> f32p;
+    std::vector<float> unused;
+    pack_conv_weights(weight_oihw_host, bias_host, kind, Cin, Cout, CoutPad, KS, false, f32p, unused);
+    std::vector<unsigned short> p1;
+    pack_conv1x1_bf16(reinterpret_cast<const float*>(f32p.data()), KS * KS, Cin, Cout, p1, f32_to_bf16_host);
+    SRGD_TRY(dw1.alloc(p1.size() * 2));
+    SRGD_HIP(hipMemcpy(dw1.p, p1.data(), p1.size() * 2, hipMemcpyHostToDevice));
+  }
   if (fast) {
     std::vector<unsigned short> p3;
     pack_conv3x3_bf16(weight_oihw_host, Cin, Cout, p3, f32_to_bf16_host);
@@ -55,7 +69,9 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
     SRGD_HIP(hipMemcpy(dw3.p, p3.data(), p3.size() * 2, hipMemcpyHostToDevice));
   }
   if (stats_slots) *stats_slots = fast ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
-  auto run = [&]() -> int { return fast ? conv3x3_bf16(a, dw3.p, nullptr, nullptr, st) : conv_igemm(a, is_bf16 != 0, st); };
+  auto run = [&]() -> int {
+    return fast ? conv3x3_bf16(a, dw3.p, nullptr, nullptr, st) : fast1 ? conv1x1_bf16(a, dw1.p, st) : conv_igemm(a, is_bf16 != 0, st);
+  };
   SRGD_TRY(run());
   SRGD_HIP(hipStreamSynchronize(st));
   if (iters > 0 && avg_ms) {
@@ -79,7 +95,8 @@ int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int H
                   int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
                   const void* residual, float* gn_partial, int groups, int is_bf16, void* stream) {
   return srgd_k_conv2d_timed(in0, in1, C0, C1, B, Hin, Win, KS, stride, pad, kind, weight_oihw_host, bias_host, Cout,
-                             out, residual, gn_partial, groups, is_bf16, 0, 0, nullptr, nullptr, stream);
+                             out, residual, gn_partial, groups, is_bf16, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             stream);
 }
 
 int srgd_k_groupnorm_silu(const void* x, void* y, const void* residual, const float* gn_partial, int B, int hw,

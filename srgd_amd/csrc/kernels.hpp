@@ -41,6 +41,15 @@ void pack_conv_weights(const float* src_oihw, const float* bias_in, int kind, in
                        bool to_bf16, std::vector<unsigned char>& packed_out, std::vector<float>& bias_out);
 const char* last_error();
 
+// ---------------------------------------------------------------- conv1x1_bf16.hip
+// bf16 streaming GEMM for the pointwise layers (1x1 incl. two-source K, residual add, fused GroupNorm tail,
+// pixel-shuffle + SiLU; 2x2/stride-2 space-to-depth gather).  Same ConvArgs (a.w ignored); weights from pack_conv1x1_bf16
+// which takes the generic path's fp32 [tap][Cout][Cin] order (pack_conv_weights with to_bf16 = false).
+bool conv1x1_bf16_eligible(const ConvArgs& a);
+void pack_conv1x1_bf16(const float* src_tap_o_i, int taps, int Cin, int Cout, std::vector<unsigned short>& out,
+                       unsigned short (*to_bf16)(float));
+int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st);
+
 // ---------------------------------------------------------------- conv3x3_bf16.hip
 // Fast path for the 3x3/s1/p1 bf16 convolutions (halo patch in LDS, LDS-DMA staging).  Takes the same
 // ConvArgs (a.w is ignored) plus weights packed by pack_conv3x3_bf16.

@@ -29,10 +29,11 @@ def _sample(sampler, case, noise, amp, **kw):
 
 
 def _worker(rank, world, port, out_dir):
+    import datetime
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from srgd_amd.parallel import shard_canvas
     from tests.test_engine_gpu import build_sampler
     case = next(c for c in C.SAMPLER_CASES if c["name"] == "dim16_300x500")
@@ -56,7 +57,19 @@ def test_two_ranks_sharing_a_canvas_equal_the_single_process_run(tmp_path):
     o, imgs, x0s = _sample(sampler, case, "host", False, with_images=True, with_x0_images=True)
     want["x0_last"] = x0s[-1]
     sampler.noise_source = "host"
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    # bounded wait: a rendezvous or collective that never completes must fail this test, not stall the suite
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(timeout=300)
+    hung = [pr for pr in procs if pr.is_alive()]
+    for pr in hung:
+        pr.terminate()
+    assert not hung, "a rank did not finish within 300 s"
+    assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
     for r in range(2):
         got = torch.load(tmp_path / f"r{r}.pt")
         for k in want:

@@ -51,7 +51,8 @@ def tol(bf16, ref, k=1.0):
     return (1.2e-2 if bf16 else 2e-5) * scale * k
 
 
-def run_conv(x0, x1, w, b, *, ks, stride, pad, kind, bf16, residual=None, groups=0, impl=0, want_slots=False):
+def run_conv(x0, x1, w, b, *, ks, stride, pad, kind, bf16, residual=None, groups=0, impl=0, want_slots=False,
+             gn_tail=None):
     lib = L().lib()
     B, C0, H, W = x0.shape
     C1 = 0 if x1 is None else x1.shape[1]
@@ -71,9 +72,14 @@ def run_conv(x0, x1, w, b, *, ks, stride, pad, kind, bf16, residual=None, groups
     wh = w.contiguous().float()
     bh = None if b is None else b.contiguous().float()
     slots = C.c_int()
+    tail_src = tail_a = tail_b = None
+    if gn_tail is not None:                 # (h [B,C,H,W], a [B,C], b [B,C]): out = silu(a*h + b) + conv(x)
+        tail_src = to_dev_nhwc(gn_tail[0], bf16)
+        tail_a, tail_b = gn_tail[1].float().contiguous().to(DEV), gn_tail[2].float().contiguous().to(DEV)
     L().check(lib.srgd_k_conv2d_timed(ptr(d0), ptr(d1), C0, C1, B, H, W, ks, stride, pad, kind, ptr(wh), ptr(bh), cout,
                                       ptr(out), ptr(dres), ptr(part), groups, int(bf16), impl, 0, None,
-                                      C.byref(slots), stream()), "srgd_k_conv2d_timed")
+                                      C.byref(slots), ptr(tail_src), ptr(tail_a), ptr(tail_b), stream()),
+              "srgd_k_conv2d_timed")
     torch.cuda.synchronize()
     if groups:
         part = part.reshape(-1)[:B * groups * slots.value * 2].reshape(B, groups, slots.value, 2)
@@ -328,3 +334,71 @@ def test_conv_rejects_bad_shapes():
     rc = lib.srgd_k_conv2d(ptr(x), ptr(None), 24, 0, 1, 8, 8, 3, 1, 1, 0, ptr(w), ptr(None), 16, ptr(out), ptr(None),
                            ptr(None), 0, 0, stream())
     assert rc != 0 and b"multiple of 16" in lib.srgd_last_error()
+
+
+# ------------------------------------------------------------------ conv1x1_bf16 (pointwise streaming GEMM)
+def test_conv1x1_fast_path_exact_small_integers():
+    # integer data: exact in bf16 -> bit-identical to torch; catches A/B swizzle, K-walk (two sources) and
+    # transposed-epilogue mistakes.  M = 2*16*32 = 1024 rows (4 tiles), Cout 256 (2 n-tiles), K = 64 + 32.
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randint(-3, 4, (2, 64, 16, 32), generator=g).float()
+    x1 = torch.randint(-3, 4, (2, 32, 16, 32), generator=g).float()
+    w = torch.randint(-2, 3, (256, 96, 1, 1), generator=g).float()
+    b = torch.randint(-4, 5, (256,), generator=g).float()
+    got, _ = run_conv(x0, x1, w, b, ks=1, stride=1, pad=0, kind=0, bf16=True, impl=3)
+    want = F.conv2d(torch.cat((x0, x1), 1), w, b).to(torch.bfloat16).float()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("variant", ["plain", "residual", "gn_tail", "pixel_shuffle", "unshuffle"])
+def test_conv1x1_fast_path_matches_torch_and_generic(variant):
+    g = torch.Generator().manual_seed(12)
+    B, H, W = 2, 16, 32
+    kw = dict(ks=1, stride=1, pad=0, kind=0, bf16=True)
+    if variant == "pixel_shuffle":
+        x0, x1 = rnd(torch.randn(B, 64, H, W, generator=g), True), None
+        w = rnd(torch.randn(512, 64, 1, 1, generator=g) / 8, True)
+        b = torch.randn(512, generator=g)
+        kw["kind"] = 2
+        want = O.pixel_shuffle_up({"u.net.0.weight": w, "u.net.0.bias": b}, "u", x0)
+    elif variant == "unshuffle":
+        x0, x1 = rnd(torch.randn(B, 32, 2 * H, 2 * W, generator=g), True), None
+        w = rnd(torch.randn(128, 128, 1, 1, generator=g) / 11, True)
+        b = torch.randn(128, generator=g)
+        kw.update(ks=2, stride=2, kind=1)
+        want = O.space_to_depth_conv({"d.1.weight": w, "d.1.bias": b}, "d", x0)
+    else:
+        x0 = rnd(torch.randn(B, 64, H, W, generator=g), True)
+        x1 = rnd(torch.randn(B, 32, H, W, generator=g), True)
+        w = rnd(torch.randn(128, 96, 1, 1, generator=g) / 10, True)
+        b = torch.randn(128, generator=g)
+        want = F.conv2d(torch.cat((x0, x1), 1), w, b)
+        if variant == "residual":
+            kw["residual"] = rnd(torch.randn(B, 128, H, W, generator=g), True)
+            want = want + kw["residual"]
+        if variant == "gn_tail":
+            h = rnd(torch.randn(B, 128, H, W, generator=g), True)
+            ca, cb = 1 + 0.3 * torch.randn(B, 128, generator=g), 0.5 * torch.randn(B, 128, generator=g)
+            kw["gn_tail"] = (h, ca, cb)
+            want = F.silu(ca[:, :, None, None] * h + cb[:, :, None, None]) + want
+    fast, _ = run_conv(x0, x1, w, b, impl=3, **kw)
+    generic, _ = run_conv(x0, x1, w, b, impl=1, **kw)
+    assert fast.shape == want.shape
+    assert (fast - want).abs().max() <= tol(True, want, k=2.0)
+    assert (fast - generic).abs().max() <= tol(True, want, k=2.0)
+
+
+def test_conv1x1_production_shape_agrees_with_generic():
+    # res_conv of the last up stage: 128+128 -> 128 at 256^2 with the GroupNorm tail, in place (out aliases the tail source
+    # in the engine; here separate buffers), batch 3
+    g = torch.Generator().manual_seed(13)
+    x0 = rnd(torch.randn(3, 128, 256, 256, generator=g), True)
+    x1 = rnd(torch.randn(3, 128, 256, 256, generator=g), True)
+    w = rnd(torch.randn(128, 256, 1, 1, generator=g) / 16, True)
+    b = torch.randn(128, generator=g)
+    h = rnd(torch.randn(3, 128, 256, 256, generator=g), True)
+    ca, cb = 1 + 0.3 * torch.randn(3, 128, generator=g), 0.5 * torch.randn(3, 128, generator=g)
+    kw = dict(ks=1, stride=1, pad=0, kind=0, bf16=True, gn_tail=(h, ca, cb))
+    fast, _ = run_conv(x0, x1, w, b, impl=3, **kw)
+    generic, _ = run_conv(x0, x1, w, b, impl=1, **kw)
+    assert (fast - generic).abs().max() <= tol(True, generic, k=2.0)

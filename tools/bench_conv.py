@@ -34,6 +34,10 @@ SHAPES = [
     ("1x1 128+128->128 @256", 128, 128, 128, 256, 1),
     ("1x1 128->128 @256", 128, 0, 128, 256, 1),
     ("1x1 1024->2048 @32", 1024, 0, 2048, 32, 1),
+    ("1x1 256+128->256 @128", 256, 128, 256, 128, 1),
+    ("1x1 256->384 @128", 256, 0, 384, 128, 1),
+    ("1x1 128->256 @128", 128, 0, 256, 128, 1),
+    ("1x1 512+256->512 @64", 512, 256, 512, 64, 1),
 ]
 
 
@@ -71,7 +75,7 @@ def main():
                                          ks, 1, ks // 2, 0, C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), cout,
                                          C.c_void_p(out.data_ptr()), C.c_void_p(0),
                                          C.c_void_p(part.data_ptr() if groups else 0), groups, 1, impl, args.iters,
-                                         C.byref(ms), C.byref(slots), st)
+                                         C.byref(ms), C.byref(slots), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), st)
             _lib.check(rc, name)
             torch.cuda.synchronize()
             flops = 2.0 * B * hw * hw * cout * ks * ks * (c0 + c1)
