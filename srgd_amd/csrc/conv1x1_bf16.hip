@@ -43,7 +43,9 @@ struct Conv1Args {
   const bf16* in0; const bf16* in1; int C0, C1;
   int B, Hin, Win;        // input image grid
   int Hout, Wout;         // conv output grid (== input grid for taps 1, half of it for taps 4)
-  int taps;               // 1, or 4 = 2x2 / stride-2 gather (space-to-depth folded into the K walk)
+  int KH, KW, stride;     // gather taps: 1x1; 2x2 / stride 2 (space-to-depth folded into the K walk); 7x1 (input conv)
+  int ps0, ps1;           // pixel stride of each source in elements (== C0 / C1 except for the input conv's
+                          // overlapping 64-element rows over an 8-channel image, see kernels.hpp)
   const bf16* w;          // packed [tap][cc][ntile][128 rows][64 B swizzled]
   const float* bias;
   int Cout;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
   const int p0 = (int)(m0 - (long)b * HWo);        // pixel offset inside the image
   const int Cin = p.C0 + p.C1;
   const int CC = Cin / KC1;
-  const int S = p.taps * CC;
+  const int S = p.KH * p.KW * CC;
 
   // ---- A staging: 16 wave-instructions per stage, wave w issues pieces w and w+8.  Per-lane input pixel (inside the
   // image, tap (0,0)) and source chunk of its two pieces.
@@ -87,16 +89,15 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
     const int g = (wave + 8 * J) * 64 + lane;                                \
     const int P = g >> 2;                                                    \
     const int op = p0 + P;                                                   \
-    if (p.taps == 1) a_pix##J = op;                                          \
-    else {                                                                   \
+    {                                                                        \
       const int oy = op / p.Wout, ox = op - oy * p.Wout;                     \
-      a_pix##J = 2 * oy * p.Win + 2 * ox;                                    \
+      a_pix##J = oy * p.stride * p.Win + ox * p.stride;                      \
     }                                                                        \
     a_sub##J = (g & 3) ^ row_swz1(P);                                        \
   }
   SRGD_A1_DECL(0) SRGD_A1_DECL(1)
 #undef SRGD_A1_DECL
-  const size_t img0 = (size_t)p.Hin * p.Win * p.C0, img1 = (size_t)p.Hin * p.Win * p.C1;
+  const size_t img0 = (size_t)p.Hin * p.Win * p.ps0, img1 = (size_t)p.Hin * p.Win * p.ps1;
   const __amdgpu_buffer_rsrc_t rs0 =
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (size_t)b * img0), 0, (int)(img0 * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
@@ -109,9 +110,10 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
     const int tap = s / CC, cc = s - tap * CC;
     const int c = cc * KC1;
     const bool first = c < p.C0;
-    const int Cs = first ? p.C0 : p.C1;
+    const int Cs = first ? p.ps0 : p.ps1;
     const int coff = first ? c : c - p.C0;
-    const int toff = (tap >> 1) * p.Win + (tap & 1);
+    const int tdy = tap / p.KW;
+    const int toff = tdy * p.Win + (tap - tdy * p.KW);
     char* st = smem + (s % RING1) * STAGE1;
     const int v0 = ((a_pix0 + toff) * Cs + coff + a_sub0 * 8) * 2;
     const int v1 = ((a_pix1 + toff) * Cs + coff + a_sub1 * 8) * 2;
@@ -237,17 +239,18 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
 
 // Which generic-conv calls this kernel takes over (bf16 activations only).
 bool conv1x1_bf16_eligible(const ConvArgs& a) {
-  const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
-  const bool unshuffle = a.KH == 2 && a.KW == 2 && a.stride == 2 && a.pad == 0 && a.C1 == 0;
-  if (!pointwise && !unshuffle) return false;
-  if (a.ps0 != a.C0 || (a.C1 && a.ps1 != a.C1)) return false;
+  if (a.pad != 0 || a.stride < 1 || a.KH < 1 || a.KW < 1) return false;
+  if ((a.Hout - 1) * a.stride + a.KH > a.Hin || (a.Wout - 1) * a.stride + a.KW > a.Win) return false;   // gather stays inside
+  if (a.ps0 % 8 || (a.C1 && (a.ps1 % 8 || a.ps1 < a.C1))) return false;                              // 16-byte aligned rows
+  if (a.ps0 != a.C0 && (a.C1 || (long)(a.Win - (a.Wout - 1) * a.stride - a.KW) * a.ps0 + a.ps0 < a.C0)) return false;
+  if (a.C1 && (a.KH != 1 || a.KW != 1)) return false;
   if (a.C0 % KC1 || a.C1 % KC1 || a.Cout % BN1 || a.Cout != a.CoutPad) return false;
   if (((long)a.Hout * a.Wout) % BM1) return false;
   if (a.gn_partial) return false;
   if (a.mode == CONV_PIXEL_SHUFFLE_SILU && ((a.Cout / 4) % BN1 || a.residual || a.gn_res_src)) return false;
   if (a.mode != CONV_PLAIN && a.mode != CONV_PIXEL_SHUFFLE_SILU) return false;
   if (a.residual && a.gn_res_src) return false;
-  if ((size_t)a.Hin * a.Win * (size_t)std::max(a.C0, a.C1) * 2 >= (1ull << 31)) return false;
+  if ((size_t)a.Hin * a.Win * (size_t)std::max(a.ps0, a.ps1) * 2 >= (1ull << 31)) return false;
   if ((size_t)a.KH * a.KW * ((a.C0 + a.C1) / KC1) * (a.Cout / BN1) * B1_BYTES >= (1ull << 31)) return false;
   return true;
 }
@@ -277,7 +280,8 @@ int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st) {
   if (!conv1x1_bf16_eligible(a)) SRGD_FAIL("conv1x1_bf16: shape not eligible");
   Conv1Args p;
   p.in0 = (const bf16*)a.in0; p.in1 = (const bf16*)a.in1; p.C0 = a.C0; p.C1 = a.C1;
-  p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Hout = a.Hout; p.Wout = a.Wout; p.taps = a.KH * a.KW;
+  p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Hout = a.Hout; p.Wout = a.Wout;
+  p.KH = a.KH; p.KW = a.KW; p.stride = a.stride; p.ps0 = a.ps0; p.ps1 = a.C1 ? a.ps1 : 0;
   p.w = (const bf16*)packed_w; p.bias = a.bias; p.Cout = a.Cout; p.out = (bf16*)a.out;
   p.aux = a.gn_res_src ? (const bf16*)a.gn_res_src : (const bf16*)a.residual;
   p.gn_a = a.gn_res_a; p.gn_b = a.gn_res_b;

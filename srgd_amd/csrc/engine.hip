@@ -194,6 +194,7 @@ struct srgd_engine {
 
   void* init7_w = nullptr;      // 7x1 x 64-virtual-channel packing of init_conv for the MFMA route
   int init7_coutpad = 0;
+  void* init7_w1 = nullptr;     // same weights in the conv1x1_bf16 tile order
   float *init_b = nullptr, *final_w = nullptr, *final_b = nullptr, *sin_w = nullptr, *cls_emb = nullptr;
   int init_wi = -1, init_bi = -1, final_wi = -1, final_bi = -1, sin_wi = -1, cls_emb_i = -1;
   Lin time1, time3, cls1, cls3;
@@ -620,6 +621,8 @@ int run_init7(srgd_engine* e, const void* padded, int entries, int H, int W, voi
   a.w = e->init7_w; a.bias = e->init_b; a.Cout = e->dim; a.CoutPad = e->init7_coutpad;
   a.out = out; a.residual = nullptr; a.mode = CONV_PLAIN; a.gn_partial = nullptr; a.groups = e->cfg.groups;
   a.gn_res_src = nullptr; a.gn_res_a = a.gn_res_b = nullptr;
+  if (e->bf16 && e->init7_w1 && !e->no_conv1x1 && !e->force_generic_conv && conv1x1_bf16_eligible(a))
+    return conv1x1_bf16(a, e->init7_w1, st);
   return conv_igemm(a, e->bf16, st);
 }
 
@@ -831,6 +834,11 @@ int srgd_finalize_weights(srgd_engine* e) {
       std::vector<unsigned short> h(q.size());
       for (size_t i = 0; i < q.size(); ++i) h[i] = f32_to_bf16_host(q[i]);
       SRGD_TRY(upload(e, h.data(), h.size() * 2, &e->init7_w));
+      if (e->init7_coutpad == e->dim) {          // streaming-GEMM route (conv1x1_bf16.hip, 7x1 gather)
+        std::vector<unsigned short> p1;
+        pack_conv1x1_bf16(q.data(), 7, 64, e->dim, p1, f32_to_bf16_host);
+        SRGD_TRY(upload(e, p1.data(), p1.size() * 2, &e->init7_w1));
+      }
     } else {
       SRGD_TRY(upload(e, q.data(), q.size() * 4, &e->init7_w));
     }

@@ -267,3 +267,29 @@ def test_lockstep_full_size_batch_of_five():
     assert torch.isfinite(five).all()
     assert torch.equal(five[3:4], solo)
     assert not torch.equal(five[0], five[1])
+
+
+def test_streaming_pointwise_path_equals_generic_path_bitwise():
+    # bf16 engine, dim 128: every pointwise layer (res_conv + GroupNorm tail, to_qkv / to_out, both resamplers, the 7x1
+    # route of the input conv) runs on conv1x1_bf16.hip; SRGD_CONV1X1=0 sends them through the generic implicit GEMM.
+    # Same MFMA shape, same K order, same rounding points -> the eps prediction must not change by a single bit.
+    import os
+    case = next(c for c in C.UNET_CASES if c["dim"] == 128)
+    sampler = build_sampler(128, weight_seed=case["weight_seed"])
+    unet = sampler.model
+    x, cnd, ls = C.unet_inputs(case)
+    label, c = C.unet_mode_args(case["modes"][0], case, cnd)
+    outs = {}
+    unet.precision = "bf16"
+    try:
+        for mode in ("1", "0"):
+            os.environ["SRGD_CONV1X1"] = mode
+            unet._invalidate_engines()
+            outs[mode] = unet(x.cuda(), ls.cuda(), None if label is None else label.cuda(),
+                              None if c is None else c.cuda()).cpu()
+    finally:
+        os.environ.pop("SRGD_CONV1X1", None)
+        unet._invalidate_engines()
+        unet.precision = "fp32"
+    assert torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["1"], outs["0"])
