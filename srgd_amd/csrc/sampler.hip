@@ -99,23 +99,63 @@ __global__ __launch_bounds__(256) void final_conv_nchw_kernel(const T* __restric
   for (int c = 0; c < 3; ++c) out[(b * 3 + c) * hw + r] = e[c];
 }
 
+// 16 lanes share one pixel's channel vector (one 16-byte load each, a wave reads 4 pixels = a contiguous run), partial
+// dot products are combined with xor-shuffles inside the 16-lane group; returns the 3 outputs in every lane of the group.
+template <typename T>
+__device__ __forceinline__ void out_conv3_coop(const T* __restrict__ a, int C, const float* __restrict__ w,
+                                               const float* __restrict__ bias, int lane16, float e[3]) {
+  constexpr int N = Vec16<T>::N;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int v = lane16; v < C / N; v += 16) {
+    Vec16<T> t = reinterpret_cast<const Vec16<T>*>(a)[v];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const float x = t.get(j);
+      s0 += x * w[v * N + j];
+      s1 += x * w[C + v * N + j];
+      s2 += x * w[2 * C + v * N + j];
+    }
+  }
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {
+    s0 += __shfl_xor(s0, m, 64);
+    s1 += __shfl_xor(s1, m, 64);
+    s2 += __shfl_xor(s2, m, 64);
+  }
+  e[0] = s0 + bias[0];
+  e[1] = s1 + bias[1];
+  e[2] = s2 + bias[2];
+}
+
+// One block = 256 consecutive pixels of one tile.  Phase 1: 16 groups of 16 lanes walk the pixels (coalesced reads of
+// the activation rows), eps (after the guidance combine) goes to LDS; phase 2: one thread per pixel does the DDPM
+// update on the three canvas planes (coalesced along x).
 template <typename T>
 __global__ __launch_bounds__(256) void final_step_kernel(FinalStepArgs a, TileBatch tb) {
+  __shared__ float eps[3][256];
   const int tile = tb.tile;
   const long per_tile = (long)tile * tile;
-  const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  if (p >= per_tile * tb.ntiles) return;
+  const long p0 = (long)blockIdx.x * 256;                 // per_tile % 256 == 0: the block stays inside one tile
+  const int lane16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const T* act = reinterpret_cast<const T*>(a.act);
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int q = i * 16 + grp;
+    float e[3];
+    out_conv3_coop<T>(act + (p0 + q) * a.C, a.C, a.w, a.bias, lane16, e);
+    if (a.passes == 2) {
+      float n[3];
+      out_conv3_coop<T>(act + (p0 + q + per_tile * tb.ntiles) * a.C, a.C, a.w, a.bias, lane16, n);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) e[c] = n[c] + (e[c] - n[c]) * a.guidance;     // model.py:3150 / :3154
+    }
+    if (lane16 < 3) eps[lane16][q] = lane16 == 0 ? e[0] : (lane16 == 1 ? e[1] : e[2]);
+  }
+  __syncthreads();
+  const long p = p0 + threadIdx.x;
   const int t = (int)(p / per_tile);
   const int r = (int)(p - t * per_tile);
   const int y = r / tile, x = r - y * tile;
-  float e[3];
-  out_conv3<T>(reinterpret_cast<const T*>(a.act) + p * a.C, a.C, a.w, a.bias, e);
-  if (a.passes == 2) {
-    float n[3];
-    out_conv3<T>(reinterpret_cast<const T*>(a.act) + (p + per_tile * tb.ntiles) * a.C, a.C, a.w, a.bias, n);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) e[c] = n[c] + (e[c] - n[c]) * a.guidance;     // model.py:3150 / :3154
-  }
   const StepScalars sc = a.sc[a.step_ptr ? *a.step_ptr : 0];
   const int* tyx = tb.tile_yx + 3 * (tb.first + t);
   const int ty = tyx[0], tx = tyx[1];
@@ -125,7 +165,7 @@ __global__ __launch_bounds__(256) void final_step_kernel(FinalStepArgs a, TileBa
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float xt = a.img[c * plane + o];
-    float x0 = (xt - sc.sigma * e[c]) / sc.alpha;                              // model.py:3160
+    float x0 = (xt - sc.sigma * eps[c][threadIdx.x]) / sc.alpha;                // model.py:3160
     x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                                        // :3163
     float mean = sc.alpha_next * (xt * sc.one_minus_c / sc.alpha + sc.c * x0);  // :3164
     if (a.noise) mean += sc.noise_scale * a.noise[((long)tl * 3 + c) * per_tile + r];   // :3187-3188
@@ -318,6 +358,7 @@ int final_step(const FinalStepArgs& a, const TileBatch& tb, bool is_bf16, hipStr
   const long n = (long)tb.ntiles * tb.tile * tb.tile;
   const int grid = (int)((n + 255) / 256);
   if (a.C % (is_bf16 ? 8 : 4) != 0) SRGD_FAIL("final_step: C must be a multiple of the vector width");
+  if (((long)tb.tile * tb.tile) % 256 != 0) SRGD_FAIL("final_step: tile area must be a multiple of 256");
   if (is_bf16) hipLaunchKernelGGL((final_step_kernel<bf16>), dim3(grid), dim3(256), 0, st, a, tb);
   else hipLaunchKernelGGL((final_step_kernel<float>), dim3(grid), dim3(256), 0, st, a, tb);
   SRGD_HIP(hipGetLastError());
