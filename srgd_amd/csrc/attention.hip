@@ -359,6 +359,107 @@ __global__ __launch_bounds__(256) void full_attn_mfma_kernel(const T* __restrict
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 softmax attention for the production shape (N = 1024 positions, 4 heads x 32; reference Attention.forward
+// model.py:342-355 + Attend): K and V^T of one (sample, head) live in LDS (64 KB + 64.5 KB), every wave owns 32 queries.
+//   S^T = K . Q^T         v_mfma_f32_16x16x32_bf16, one instruction per 16 keys x 16 queries (K dim = dim_head = 32)
+//   online softmax        per query = per lane column: max over keys via two xor-shuffles, exp2 in fp32
+//   O^T += V^T . P^T      P^T goes from the accumulator registers of two S^T tiles straight into the B operand
+//                         (lane (query, g) holds keys {4g..4g+3} u {16+4g..16+4g+3} of the 32-key block); V^T is stored
+//                         in LDS with the keys of each block permuted the same way, so its A operand is one ds_read_b128.
+constexpr int FA_QB = 256;                 // queries per workgroup (8 waves x 32)
+constexpr int FA_NT = 512;
+__device__ __forceinline__ int fa_vpos(int key) {      // position of `key` inside V^T's permuted 32-key blocks
+  return (key & ~31) + (((key & 15) >> 2) << 3) + (((key >> 4) & 1) << 2) + (key & 3);
+}
+__global__ __launch_bounds__(FA_NT) void full_attn_bf16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int N,
+                                                               int heads, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char fa_smem[];
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int hid = heads * DH, C3 = 3 * hid;
+  const int vstride = N * 2 + 16;                       // bytes per V^T row (+16: ds_read_b128 of 16 rows conflict-free)
+  char* const Ks = fa_smem;                             // [N][32] bf16, 64-byte rows
+  char* const Vt = fa_smem + (size_t)N * 64;            // [32][N (permuted)] bf16
+  const bf16* base = qkv + (size_t)b * N * C3 + head * DH;
+  // ---- stage K (16-byte copies) and V^T (transposing 2-byte writes)
+  for (int c = tid; c < N * 4; c += FA_NT) {
+    const int key = c >> 2, ch = c & 3;
+    const bf16x8 kv = *reinterpret_cast<const bf16x8*>(base + (size_t)key * C3 + hid + ch * 8);
+    *reinterpret_cast<bf16x8*>(Ks + key * 64 + ch * 16) = kv;
+    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(base + (size_t)key * C3 + 2 * hid + ch * 8);
+    const int pos = fa_vpos(key);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16*>(Vt + (ch * 8 + j) * vstride + pos * 2) = vv[j];
+  }
+  // ---- this wave's queries: B operand of S^T, lane (query r16, channel chunk g)
+  const int q0 = blockIdx.x * FA_QB + wave * 32;
+  const bf16x8 qf0 = *reinterpret_cast<const bf16x8*>(base + (size_t)(q0 + r16) * C3 + g * 8);
+  const bf16x8 qf1 = *reinterpret_cast<const bf16x8*>(base + (size_t)(q0 + 16 + r16) * C3 + g * 8);
+  __syncthreads();
+
+  f32x4 o00 = 0, o01 = 0, o10 = 0, o11 = 0;             // [query block][channel block]
+  float m0 = -INFINITY, m1 = -INFINITY, l0 = 0.f, l1 = 0.f;
+  const char* kp = Ks + r16 * 64 + g * 16;
+  const char* vp = Vt + r16 * vstride + g * 16;
+  for (int kb = 0; kb < N; kb += 32) {
+    const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kp + kb * 64);
+    const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kp + (kb + 16) * 64);
+    const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(vp + kb * 2);
+    const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(vp + 16 * vstride + kb * 2);
+    const f32x4 z = 0;
+    f32x4 sa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf0, z, 0, 0, 0);
+    f32x4 sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf0, z, 0, 0, 0);
+    f32x4 sb0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf1, z, 0, 0, 0);
+    f32x4 sb1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf1, z, 0, 0, 0);
+#define SRGD_FA_SOFTMAX(S0, S1, M, L, OA, OB, PB)                                              \
+    {                                                                                          \
+      S0 *= scale_log2e;                                                                       \
+      S1 *= scale_log2e;                                                                       \
+      float bm = fmaxf(fmaxf(fmaxf(S0[0], S0[1]), fmaxf(S0[2], S0[3])),                        \
+                       fmaxf(fmaxf(S1[0], S1[1]), fmaxf(S1[2], S1[3])));                       \
+      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));                                                  \
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));                                                  \
+      const float mn = fmaxf(M, bm);                                                           \
+      const float corr = exp2f(M - mn);                                                        \
+      M = mn;                                                                                  \
+      float ps = 0.f;                                                                          \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                          \
+        const float e0 = exp2f(S0[j] - mn), e1 = exp2f(S1[j] - mn);                            \
+        ps += e0 + e1;                                                                         \
+        PB[j] = (bf16)e0;                                                                      \
+        PB[4 + j] = (bf16)e1;                                                                  \
+      }                                                                                        \
+      L = L * corr + ps;                                                                       \
+      OA *= corr;                                                                              \
+      OB *= corr;                                                                              \
+    }
+    bf16x8 pa, pb;
+    SRGD_FA_SOFTMAX(sa0, sa1, m0, l0, o00, o01, pa)
+    SRGD_FA_SOFTMAX(sb0, sb1, m1, l1, o10, o11, pb)
+#undef SRGD_FA_SOFTMAX
+    o00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pa, o00, 0, 0, 0);
+    o01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pa, o01, 0, 0, 0);
+    o10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pb, o10, 0, 0, 0);
+    o11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pb, o11, 0, 0, 0);
+  }
+  // each lane holds a partial denominator over its quarter of the keys
+  l0 += __shfl_xor(l0, 16, 64);
+  l0 += __shfl_xor(l0, 32, 64);
+  l1 += __shfl_xor(l1, 16, 64);
+  l1 += __shfl_xor(l1, 32, 64);
+  const float i0 = 1.0f / l0, i1 = 1.0f / l1;
+  // o[qb][cb][reg]: query q0 + qb*16 + r16, channel cb*16 + g*4 + reg  ->  8-byte stores
+  bf16* op0 = out + ((size_t)b * N + q0 + r16) * hid + head * DH + g * 4;
+  bf16* op1 = op0 + (size_t)16 * hid;
+  *reinterpret_cast<bf16x4*>(op0) = bf16x4{(bf16)(o00[0] * i0), (bf16)(o00[1] * i0), (bf16)(o00[2] * i0), (bf16)(o00[3] * i0)};
+  *reinterpret_cast<bf16x4*>(op0 + 16) = bf16x4{(bf16)(o01[0] * i0), (bf16)(o01[1] * i0), (bf16)(o01[2] * i0), (bf16)(o01[3] * i0)};
+  *reinterpret_cast<bf16x4*>(op1) = bf16x4{(bf16)(o10[0] * i1), (bf16)(o10[1] * i1), (bf16)(o10[2] * i1), (bf16)(o10[3] * i1)};
+  *reinterpret_cast<bf16x4*>(op1 + 16) = bf16x4{(bf16)(o11[0] * i1), (bf16)(o11[1] * i1), (bf16)(o11[2] * i1), (bf16)(o11[3] * i1)};
+}
+
 }  // namespace
 
 // positions per partial: long chunks amortise the 4.3 KB partial record; short ones keep small maps parallel
@@ -411,7 +512,20 @@ int linear_attention_combine(const float* pm, const float* pl, const float* pctx
 int full_attention(const void* qkv, void* out, int B, int N, int heads, int dh, bool is_bf16, hipStream_t st) {
   if (dh != DH) SRGD_FAIL("full_attention: dim_head must be 32");
   const float scale = 1.0f / sqrtf((float)dh);
-  if (N % 32 == 0) {                                       // MFMA kernel (every production shape: N = 1024)
+  if (is_bf16 && N % FA_QB == 0 && N <= 1024) {            // bf16 MFMA kernel, K / V^T resident in LDS (production: N = 1024)
+    const int lds = N * 64 + DH * (N * 2 + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+      SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_attn_bf16_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 64 + DH * (1024 * 2 + 16)));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(full_attn_bf16_kernel, dim3(N / FA_QB, heads, B), dim3(FA_NT), lds, st, (const bf16*)qkv, (bf16*)out, N,
+                       heads, scale * 1.4426950408889634f);
+    SRGD_HIP(hipGetLastError());
+    return 0;
+  }
+  if (N % 32 == 0) {                                       // fp32-MFMA kernel (fp32 mode and other N)
     dim3 g(cdiv(N, 128), heads, B);
     if (is_bf16)
       hipLaunchKernelGGL((full_attn_mfma_kernel<bf16>), g, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, N, heads, scale);
