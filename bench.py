@@ -7,10 +7,14 @@ One "step" = one HR tile = BASELINE.json config[1]: a 256x256 LR image -> x4 -> 
 class_cond_scale=1.0 -> 1,025 U-Net tile-forwards = 813.6 TFLOP), dim-128 U-Net, seeded synthetic
 weights with the reference state_dict schema (the published checkpoint is an LFS pointer), synthetic
 LR input already upsampled and resident in HBM when the clock starts.
+The K HR tiles of a rank advance in lock-step groups of ``--images`` (default 5): their 256x256 U-Net tiles share
+launches (125 / 80 tiles per launch), each image still sampled exactly as it would be alone.
 Ranks shard independent images (weak scaling, no data-path collective); weights are broadcast from
 rank 0 and the HR outputs gathered to rank 0 over RCCL inside the timed region.
+``--workload canvas --lr_size 2048`` is the secondary mode (BASELINE configs[3]): one 8192^2 image whose tiles are
+sharded over all ranks with a per-step tile all-gather (strong scaling).
 
-Prints ONE JSON line (rank 0).  `roofline` is the conv implicit-GEMM family (89% of the FLOPs):
+Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel, conv3x3_bf16_kernel (89% of the FLOPs):
 algorithmic FLOPs / HIP-event time on the launch stream, collected in an extra profiled pass right
 after the timed region; `cpu_baseline` is the CPU oracle (oracle/srgd_oracle.py, a port of the
 reference's PyTorch path) timed on this box's host cores on a bounded sample.
@@ -223,8 +227,9 @@ def main():
                                 "avg_launch_ms": conv_ms / max(n_launch, 1),
                                 "algorithmic_gflop_per_launch": fl / max(n_launch, 1) / 1e9,
                                 "family_time_share": conv_ms / sum(prof["ms"].values())}
-            all_conv_ms = prof["ms"]["conv_igemm"] + prof["ms"].get("conv3x3_bf16", 0.0)
-            line["conv_all_tflops"] = (prof["flops"]["conv_igemm"] + prof["flops"].get("conv3x3_bf16", 0.0)) / (all_conv_ms * 1e-3) / 1e12
+            conv_fams = ("conv_igemm", "conv3x3_bf16", "conv1x1_bf16")
+            all_conv_ms = sum(prof["ms"].get(k, 0.0) for k in conv_fams)
+            line["conv_all_tflops"] = sum(prof["flops"].get(k, 0.0) for k in conv_fams) / (all_conv_ms * 1e-3) / 1e12
             tot = sum(prof["ms"].values())
             line["kernel_time_share"] = {k: round(v / tot, 4) for k, v in prof["ms"].items() if v > 0}
             line["profiled_pass_ms"] = tot
