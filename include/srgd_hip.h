@@ -137,6 +137,17 @@ int srgd_sampler_q_start(srgd_engine* e, const float* cond01, const float* noise
 /* Crop, clamp to [-1,1], map to [0,1] (model.py:3403-3405).  out01: device fp32 [3,H,W]. */
 int srgd_sampler_end(srgd_engine* e, const float* img, float* out01, void* stream);
 
+/* ---- image front / back end (reference inference.py:66-73, :93) ------------------------------------------------
+ * Bicubic resize of an 8-bit RGB image, bit-exact with Pillow's Image.resize((out_w, out_h), BICUBIC) - what
+ * torchvision's T.Resize does for the PIL input of sr_target_image - followed by ToTensor:
+ * src_hwc: device uint8 [h][w][3]; dst01_chw: device fp32 [3][out_h][out_w] = resized / 255.
+ * Builds Pillow's fixed-point coefficient tables on the host; synchronises `stream` before returning. */
+int srgd_image_resize_bicubic_u8(const uint8_t* src_hwc, int h, int w, int out_h, int out_w, float* dst01_chw,
+                                 void* stream);
+/* ToPILImage of a float image: img01_chw device fp32 [3][h][w] in [0,1] -> dst_hwc device uint8 [h][w][3] =
+ * trunc(img * 255) (torchvision: pic.mul(255).byte()).  Asynchronous on `stream`. */
+int srgd_image_unit_to_u8(const float* img01_chw, int h, int w, uint8_t* dst_hwc, void* stream);
+
 /* Fills dst[n] with N(0,1) draws of the engine's counter-based generator (initial canvas noise
  * in throughput mode; the parity mode uploads torch's CPU stream instead). */
 int srgd_randn(srgd_engine* e, float* dst, size_t n, uint64_t seed, uint64_t stream_id, void* stream);

@@ -2,8 +2,9 @@
 skip-if-exists, per-image reseed) on top of the MI355X engine.
 
 Differences that are deliberate and documented: torchvision/logzero are not needed
-(PIL + numpy do the x4 bicubic resize and the uint8 conversions exactly as ``T.Resize`` on a PIL image,
-``ToTensor`` and ``ToPILImage`` do); ``--no_amp`` has a real meaning here (fp32 parity mode instead of
+(the x4 bicubic resize and the uint8 conversions run as integer kernels on the GPU, bit-identical to what
+``T.Resize`` on a PIL image, ``ToTensor`` and ``ToPILImage`` do; ``pil_to_unit_tensor`` / ``unit_tensor_to_pil`` are
+the host-side equivalents kept for tests); ``--no_amp`` has a real meaning here (fp32 parity mode instead of
 bf16); ``--device_noise`` switches from the reference-compatible host noise stream to on-device Philox.
 """
 from __future__ import annotations
@@ -72,13 +73,46 @@ def unit_tensor_to_pil(t: torch.Tensor) -> Image.Image:
     return Image.fromarray(arr, "RGB")
 
 
+def upsample_bicubic_on_device(image: Image.Image, scale: int, device) -> torch.Tensor:
+    """``T.Resize((h*scale, w*scale), BICUBIC)`` + ``ToTensor`` of the reference (inference.py:66-73) as integer HIP
+    kernels: the LR image goes to the GPU as uint8 HWC, the [1,3,H,W] condition comes out resident in HBM, bit-identical
+    to ``pil_to_unit_tensor(image.resize(..., Image.BICUBIC))``."""
+    import ctypes as C
+
+    from . import _lib
+    arr = np.asarray(image.convert("RGB"), dtype=np.uint8)
+    h, w, _ = arr.shape
+    src = torch.from_numpy(arr.copy()).to(device)
+    dst = torch.empty(1, 3, h * scale, w * scale, device=device, dtype=torch.float32)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().srgd_image_resize_bicubic_u8(C.c_void_p(src.data_ptr()), h, w, h * scale, w * scale,
+                                                          C.c_void_p(dst.data_ptr()),
+                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "srgd_image_resize_bicubic_u8")
+    return dst
+
+
+def unit_tensor_to_pil_on_device(t: torch.Tensor) -> Image.Image:
+    """``ToPILImage`` (mul(255).byte(), inference.py:93) on the GPU: only the uint8 HWC image crosses PCIe (1/4 of the bytes)."""
+    import ctypes as C
+
+    from . import _lib
+    t = t.contiguous()
+    _, h, w = t.shape
+    out = torch.empty(h, w, 3, device=t.device, dtype=torch.uint8)
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.lib().srgd_image_unit_to_u8(C.c_void_p(t.data_ptr()), h, w, C.c_void_p(out.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "srgd_image_unit_to_u8")
+    return Image.fromarray(out.cpu().numpy(), "RGB")
+
+
 def sr_target_image(image, sr_model, scale=4, batch_size=8, test_label=2, cond_scale=1.0, guidance_start_steps=0,
                     class_cond_scale=1.0, class_guidance_start_steps=0, generation_start_steps=0,
                     num_sample_steps=250, enable_amp=False, interpolation="bicubic", seed=71):
     width, height = image.size
     # the reference maps 'lanczos' to bicubic too (inference.py:66-69)
-    resized = image.resize((width * scale, height * scale), Image.BICUBIC)
-    condition_x = pil_to_unit_tensor(resized).unsqueeze(0).to(sr_model.device)
+    condition_x = upsample_bicubic_on_device(image, scale, sr_model.device)
     label = torch.LongTensor([test_label]).to(sr_model.device) if test_label is not None else None
     seed_everything(seed)
     sr_model.device_noise_seed = seed
@@ -89,7 +123,7 @@ def sr_target_image(image, sr_model, scale=4, batch_size=8, test_label=2, cond_s
                                        class_guidance_start_steps=class_guidance_start_steps,
                                        generation_start_steps=generation_start_steps,
                                        num_sample_steps=num_sample_steps, amp=enable_amp)
-    sr_img = unit_tensor_to_pil(output[0])
+    sr_img = unit_tensor_to_pil_on_device(output[0])
     assert sr_img.size == (width * 4, height * 4)
     return sr_img
 

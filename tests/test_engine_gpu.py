@@ -293,3 +293,32 @@ def test_streaming_pointwise_path_equals_generic_path_bitwise():
         unet.precision = "fp32"
     assert torch.isfinite(outs["1"]).all()
     assert torch.equal(outs["1"], outs["0"])
+
+
+@pytest.mark.parametrize("size", [(64, 64), (37, 53), (5, 7), (256, 256), (1, 9)], ids=lambda s: "%dx%d" % s)
+def test_device_bicubic_x4_is_bit_exact_with_pillow(size):
+    # integer path: the GPU result must equal Pillow's (= T.Resize on a PIL image + ToTensor) bit for bit, and the
+    # CPU restatement in oracle/pil_resample.py as well
+    from PIL import Image
+    from oracle.pil_resample import resize_bicubic_u8, to_unit_chw
+    from srgd_amd.inference import pil_to_unit_tensor, upsample_bicubic_on_device
+    h, w = size
+    rng = np.random.default_rng(h * 1000 + w)
+    arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    img = Image.fromarray(arr, "RGB")
+    got = upsample_bicubic_on_device(img, 4, torch.device("cuda")).cpu()
+    want = pil_to_unit_tensor(img.resize((w * 4, h * 4), Image.BICUBIC)).unsqueeze(0)
+    assert got.shape == want.shape
+    assert torch.equal(got, want)
+    assert np.array_equal(got[0].numpy(), to_unit_chw(resize_bicubic_u8(arr, 4 * h, 4 * w)))
+
+
+def test_device_unit_to_u8_matches_topilimage():
+    from oracle.pil_resample import to_u8_hwc
+    from srgd_amd.inference import unit_tensor_to_pil, unit_tensor_to_pil_on_device
+    g = torch.Generator().manual_seed(4)
+    t = torch.rand(3, 123, 77, generator=g)
+    t[0, 0, :4] = torch.tensor([0.0, 1.0, 254.999 / 255, 0.5])
+    got = np.asarray(unit_tensor_to_pil_on_device(t.cuda()))
+    assert np.array_equal(got, np.asarray(unit_tensor_to_pil(t)))
+    assert np.array_equal(got, to_u8_hwc(t.numpy()))

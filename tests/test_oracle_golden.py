@@ -114,3 +114,25 @@ def test_noise_stream_is_batch_size_independent():
     torch.manual_seed(5)
     b = torch.cat([torch.randn(3, 3, 256, 256), torch.randn(5, 3, 256, 256)])
     assert torch.equal(a, b)
+
+
+def test_pil_bicubic_restatement_is_bit_exact():
+    # oracle/pil_resample.py restates Pillow's Resample.c (un-vendored dependency of the reference's T.Resize on a PIL
+    # image); pinned here against Pillow itself on ragged, tiny, constant and x4 production-like inputs.
+    import numpy as np
+    from PIL import Image
+    from oracle.pil_resample import resize_bicubic_u8, to_u8_hwc, to_unit_chw
+    rng = np.random.default_rng(0)
+    for (h, w, sh, sw) in [(64, 64, 4, 4), (37, 53, 4, 4), (5, 7, 4, 4), (1, 9, 4, 4), (33, 20, 3, 3), (40, 40, 1, 1),
+                           (17, 31, 2, 5), (96, 128, 4, 4)]:
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = np.asarray(Image.fromarray(a, "RGB").resize((w * sw, h * sh), Image.BICUBIC))
+        assert np.array_equal(resize_bicubic_u8(a, h * sh, w * sw), want), (h, w)
+    flat = np.full((9, 9, 3), 255, np.uint8)
+    assert np.array_equal(resize_bicubic_u8(flat, 36, 36), np.asarray(Image.fromarray(flat, "RGB").resize((36, 36), Image.BICUBIC)))
+    # ToTensor / ToPILImage conversions (torch semantics: /255 in fp32, mul(255).byte() truncation)
+    import torch
+    u = rng.integers(0, 256, (6, 5, 3), dtype=np.uint8)
+    assert np.array_equal(to_unit_chw(u), torch.from_numpy(u).permute(2, 0, 1).float().div(255).numpy())
+    f = torch.rand(3, 6, 5)
+    assert np.array_equal(to_u8_hwc(f.numpy()), f.mul(255).byte().permute(1, 2, 0).numpy())
