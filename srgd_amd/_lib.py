@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsrgd_hip.so")
+LIB_PATH = os.environ.get("SRGD_HIP_LIB") or os.path.join(_HERE, "libsrgd_hip.so")   # override: A/B builds only
 
 MAX_STAGES = 8
 PRECISION_FP32 = 0

@@ -136,23 +136,22 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // GNIN: GroupNorm-apply + SiLU of the PRODUCER fused into this conv's staging (reference Block.forward
   // model.py:250-259 between two convs): once a wave's own DMA pieces of a chunk have landed it rewrites them in
   // place, y = silu(a*x + b); out-of-image halo chunks stay zero (the conv pads the activated tensor).
-  auto transform_piece = [&](int cc, int j, int a_pix, int a_sub) {
+  auto transform_half = [&](int cc, int j, int hf, int a_pix, int a_sub) {
     if (a_pix < 0) return;
     char* q = sA0 + (cc & 1) * A_BYTES + (wave + 8 * j) * 1024 + lane * 16;
     // the chunk's 32 scales | 32 shifts ride in the otherwise all-zero DMA piece 22 of the same A buffer
     const float* sC = reinterpret_cast<const float*>(sA0 + (cc & 1) * A_BYTES + 22 * 1024) + a_sub * 8;
-    // two 8-byte halves: keeps the live temporaries small (the kernel sits at the 128-VGPR cap of 2 workgroups/CU)
+    // 8-byte halves: small live temporaries (the kernel sits at the 128-VGPR cap of 2 workgroups/CU) and a unit of
+    // VALU work (8 transcendentals per lane) short enough to hide under one tap's MFMAs of the other waves
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(q + hf * 8);
+    const f32x4 ca = *reinterpret_cast<const f32x4*>(sC + hf * 4);
+    const f32x4 cb = *reinterpret_cast<const f32x4*>(sC + 32 + hf * 4);
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      bf16x4 v = *reinterpret_cast<const bf16x4*>(q + hf * 8);
-      const f32x4 ca = *reinterpret_cast<const f32x4*>(sC + hf * 4);
-      const f32x4 cb = *reinterpret_cast<const f32x4*>(sC + 32 + hf * 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (bf16)silu<false>(ca[e] * (float)v[e] + cb[e]);
-      *reinterpret_cast<bf16x4*>(q + hf * 8) = v;
-    }
+    for (int e = 0; e < 4; ++e) v[e] = (bf16)silu<false>(ca[e] * (float)v[e] + cb[e]);
+    *reinterpret_cast<bf16x4*>(q + hf * 8) = v;
   };
-#define transform_a_piece(CCV, J) transform_piece(CCV, J, (J) == 0 ? a_pix0 : ((J) == 1 ? a_pix1 : a_pix2), (J) == 0 ? a_sub0 : ((J) == 1 ? a_sub1 : a_sub2))
+#define transform_a_half(CCV, J, HF) transform_half(CCV, J, HF, (J) == 0 ? a_pix0 : ((J) == 1 ? a_pix1 : a_pix2), (J) == 0 ? a_sub0 : ((J) == 1 ? a_sub1 : a_sub2))
+#define transform_a_piece(CCV, J) do { transform_a_half(CCV, J, 0); transform_a_half(CCV, J, 1); } while (0)
 
   auto issue_a = [&](int cc, int j, int a_pix, int a_sub) {
     const int c = cc * KC;
@@ -253,10 +252,13 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int s = cc * 9 + tap;
-      if (tap < 3) issue_a_piece(cc + 1, tap);
+      // GNIN issues piece 2 first: piece 22 (wave 6) carries the GroupNorm coefficients of the chunk, which every wave
+      // needs before it can rewrite its own pieces
+      if (tap < 3) issue_a_piece(cc + 1, GNIN ? (tap == 0 ? 2 : tap - 1) : tap);
       issue_b(s + 2);                            // always < S here (cc < CC-1)
-      // the wait at the end of tap 3 retired this wave's three A pieces of chunk cc+1 (they are older than B[s+1])
-      if (GNIN && tap >= 4 && tap < 7) transform_a_piece(cc + 1, tap - 4);
+      // a wave rewrites only the pieces it DMA'd itself: piece issued at tap t has landed after the wait of tap t+1;
+      // six half-piece transforms spread over taps 2..7 (j = 2, 2, 0, 0, 1, 1)
+      if (GNIN && tap >= 2 && tap < 8) transform_a_half(cc + 1, (tap - 2) < 2 ? 2 : ((tap - 2) < 4 ? 0 : 1), (tap - 2) & 1);
       compute(cc, tap, s);
       if (tap < 3) WAIT_VM(2); else WAIT_VM(1);
       BARRIER();
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   }
 #undef issue_a_piece
 #undef transform_a_piece
+#undef transform_a_half
 
   // ------------------------------- epilogue -------------------------------------------
   // The accumulator layout (lane = output channel, register = pixel) would store 2 bytes per lane; instead the

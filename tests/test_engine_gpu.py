@@ -322,3 +322,30 @@ def test_device_unit_to_u8_matches_topilimage():
     got = np.asarray(unit_tensor_to_pil_on_device(t.cuda()))
     assert np.array_equal(got, np.asarray(unit_tensor_to_pil(t)))
     assert np.array_equal(got, to_u8_hwc(t.numpy()))
+
+
+def test_groupnorm_fused_into_conv_staging_matches_separate_pass():
+    # SRGD_GN_FUSION=1: GroupNorm1-apply + SiLU runs inside conv2's LDS staging (conv3x3_bf16 GNIN variant) instead of
+    # the separate gn_apply pass.  Same formula on the same bf16 inputs, rounded to bf16 at the same point.
+    import os
+    case = next(c for c in C.UNET_CASES if c["dim"] == 128)
+    sampler = build_sampler(128, weight_seed=case["weight_seed"])
+    unet = sampler.model
+    x, cnd, ls = C.unet_inputs(case)
+    label, c = C.unet_mode_args(case["modes"][0], case, cnd)
+    outs = {}
+    unet.precision = "bf16"
+    try:
+        for mode in ("1", "0"):
+            os.environ["SRGD_GN_FUSION"] = mode
+            unet._invalidate_engines()
+            outs[mode] = unet(x.cuda(), ls.cuda(), None if label is None else label.cuda(),
+                              None if c is None else c.cuda()).cpu()
+    finally:
+        os.environ.pop("SRGD_GN_FUSION", None)
+        unet._invalidate_engines()
+        unet.precision = "fp32"
+    assert torch.isfinite(outs["1"]).all()
+    d = (outs["1"] - outs["0"]).abs().max().item()
+    _report(test="gn_fusion_vs_separate", max_abs=d, ref_max=outs["0"].abs().max().item())
+    assert d <= 2e-2 * max(1.0, outs["0"].abs().max().item()), d
