@@ -137,6 +137,34 @@ int srgd_sampler_q_start(srgd_engine* e, const float* cond01, const float* noise
 /* Crop, clamp to [-1,1], map to [0,1] (model.py:3403-3405).  out01: device fp32 [3,H,W]. */
 int srgd_sampler_end(srgd_engine* e, const float* img, float* out01, void* stream);
 
+/* ---- EDM (Karras) sampler over the same U-Net: ConditionalElucidatedDiffusionSR.tiled_sample (model.py:2309-2475) ----
+ * Per step i the host supplies fp32 scalars computed with the reference's own ops (schedule and preconditioning of the
+ * un-vendored base class denoising_diffusion_pytorch.ElucidatedDiffusion, restated in srgd_amd/model.py). */
+typedef struct srgd_edm_scalars {
+  float s_noise, hat_coef;                      /* img_hat = img + hat_coef * (s_noise * z)        (model.py:2386-2389) */
+  float sigma_hat, sigma_next;                  /* sigma_next == 0 on the last step: no Heun correction */
+  float dt, half_dt;                            /* sigma_next - sigma_hat and half of it            (model.py:2407,:2414) */
+  float c_in_hat, c_skip_hat, c_out_hat;        /* preconditioning at sigma_hat                     (model.py:2140-2149) */
+  float c_in_next, c_skip_next, c_out_next;     /* ... at sigma_next */
+  float ring_sigma;                             /* sigmas[i]: odd-step ring = ring_sigma * z'       (model.py:2448-2452) */
+  float clamp;                                  /* != 0: clamp the denoised prediction to [-1, 1]   (model.py:2180) */
+  float pad0, pad1;
+} srgd_edm_scalars;
+
+/* As srgd_sampler_begin; c_noise_host: [2*n_steps] = c_noise(sigma_hat_i), c_noise(sigma_next_i) - the "time" input of
+ * the two network evaluations of step i (the second is unused on the last step). */
+int srgd_edm_begin(srgd_engine* e, const srgd_sampler_geometry* g, const float* cond01, float* cond_canvas,
+                   const int32_t* tiles_even_host, const int32_t* tiles_odd_host, int n_steps,
+                   const srgd_edm_scalars* scalars_host, const float* c_noise_host, int class_id, void* stream);
+
+/* One EDM step over every tile of grid (step % 2): Euler evaluation at sigma_hat, Heun correction at sigma_next, scatter,
+ * odd-step ring re-noise.  img / x_start (nullable) as in srgd_sampler_step; work: device fp32 scratch of two canvases
+ * [2][n_images,3,Hp,Wp]; noise_canvas: the step's z [3,Hp,Wp] (device) or NULL = drawn on the device (Philox, `seed`);
+ * ring_noise_canvas: z' of an odd step or NULL.  passes / guidance_* as in srgd_sampler_step.  Finish with srgd_sampler_end. */
+int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start, float* work,
+                  const float* noise_canvas, const float* ring_noise_canvas, int passes, int guidance_kind,
+                  float guidance_scale, int sub_batch, uint64_t seed, void* stream);
+
 /* ---- image front / back end (reference inference.py:66-73, :93) ------------------------------------------------
  * Bicubic resize of an 8-bit RGB image, bit-exact with Pillow's Image.resize((out_w, out_h), BICUBIC) - what
  * torchvision's T.Resize does for the PIL input of sr_target_image - followed by ToTensor:

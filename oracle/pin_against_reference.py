@@ -132,6 +132,32 @@ def main():
         print("[sampler] dim=128, 256x256 canvas, 4 steps, CFG off")
         got, want = run_sampler(128, 256, 256, 4, 4)
         ok &= report("final image", got, want, 1e-4)
+    # ---- EDM wrapper (model.py:2059-2475); its un-vendored base class is restated in refshim (same formulas as the oracle)
+    def run_edm(dim, h, w, steps, bs, ccs=1.0, cs=1.0, label=0, **extra):
+        sampler, _ = refshim.build_reference_sampler(rm, rc, dim=dim, num_sample_steps=steps, model="conditional_elucidated")
+        schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+        sd = synth_state_dict(schema, seed=0)
+        sampler.load_state_dict(sd, strict=True)
+        usd = {k[len("net."):]: v for k, v in sd.items()}
+        g = torch.Generator().manual_seed(1234)
+        cond = torch.rand(1, 3, h, w, generator=g)
+        lab = torch.tensor([label]) if label is not None else None
+        torch.manual_seed(71)
+        with torch.inference_mode():
+            want = sampler.tiled_sample(batch_size=bs, condition_x=cond.clone(), class_label=lab, cond_scale=cs,
+                                        class_cond_scale=ccs, num_sample_steps=steps, **extra)
+        torch.manual_seed(71)
+        with torch.inference_mode():
+            got = O.edm_tiled_sample(usd, O.UnetCfg(dim=dim), O.EdmCfg(), cond.clone(), lab, batch_size=bs,
+                                     num_sample_steps=steps, cond_scale=cs, class_cond_scale=ccs, **extra)
+        return got, want
+
+    print("[edm] dim=16: 256x256 6 steps; class CFG 2.0; 300x500 (768^2 canvas); LR CFG 1.5 from a noised start; zero_init, no clamp")
+    for kw in (dict(h=256, w=256, steps=6, bs=4), dict(h=256, w=256, steps=6, bs=4, ccs=2.0),
+               dict(h=300, w=500, steps=4, bs=4), dict(h=256, w=256, steps=8, bs=4, cs=1.5, generation_start_steps=2),
+               dict(h=300, w=300, steps=3, bs=8, zero_init=True, clamp=False)):
+        got, want = run_edm(16, **kw)
+        ok &= report("edm final image " + str({k: v for k, v in kw.items() if k not in ("h", "w", "bs")}), got, want, 1e-4)
     print("PINNED" if ok else "MISMATCH")
     return 0 if ok else 1
 

@@ -36,8 +36,38 @@ class GaussianDiffusion(nn.Module):
         super().__init__()
 
 class ElucidatedDiffusion(nn.Module):
-    def __init__(self, *args, **kwargs):
+    """Published algorithm of denoising-diffusion-pytorch==1.8.15 elucidated_diffusion.ElucidatedDiffusion, reduced to
+    what the reference's ConditionalElucidatedDiffusionSR.tiled_sample calls (model.py:2132-2194, :2309-2475):
+    the Karras preconditioning coefficients and the rho-schedule."""
+    def __init__(self, net, *, image_size, channels=3, num_sample_steps=32, sigma_min=0.002, sigma_max=80,
+                 sigma_data=0.5, rho=7, P_mean=-1.2, P_std=1.2, S_churn=80, S_tmin=0.05, S_tmax=50, S_noise=1.003):
         super().__init__()
+        self.net = net
+        self.channels, self.image_size = channels, image_size
+        self.sigma_min, self.sigma_max, self.sigma_data, self.rho = sigma_min, sigma_max, sigma_data, rho
+        self.P_mean, self.P_std, self.num_sample_steps = P_mean, P_std, num_sample_steps
+        self.S_churn, self.S_tmin, self.S_tmax, self.S_noise = S_churn, S_tmin, S_tmax, S_noise
+    @property
+    def device(self):
+        return next(self.net.parameters()).device
+    def c_skip(self, sigma):
+        return (self.sigma_data ** 2) / (sigma ** 2 + self.sigma_data ** 2)
+    def c_out(self, sigma):
+        return sigma * self.sigma_data * (self.sigma_data ** 2 + sigma ** 2) ** -0.5
+    def c_in(self, sigma):
+        return 1 * (sigma ** 2 + self.sigma_data ** 2) ** -0.5
+    def c_noise(self, sigma):
+        import torch
+        return torch.log(sigma.clamp(min=1e-20)) * 0.25
+    def sample_schedule(self, num_sample_steps=None):
+        import torch
+        import torch.nn.functional as F
+        num_sample_steps = self.num_sample_steps if num_sample_steps is None else num_sample_steps
+        N = num_sample_steps
+        inv_rho = 1 / self.rho
+        steps = torch.arange(num_sample_steps, device=self.device, dtype=torch.float32)
+        sigmas = (self.sigma_max ** inv_rho + steps / (N - 1) * (self.sigma_min ** inv_rho - self.sigma_max ** inv_rho)) ** self.rho
+        return F.pad(sigmas, (0, 1), value=0.)
 '''
 
 _DDP_ATTEND = '''
@@ -110,13 +140,16 @@ class _Logger:
         pass
 
 
-def build_reference_sampler(ref_model, ref_config, *, dim=None, dim_mults=None, num_sample_steps=50,
+def build_reference_sampler(ref_model, ref_config, *, dim=None, dim_mults=None, num_sample_steps=50, model=None,
                             yaml_path=os.path.join(REFERENCE_DIR, "conf",
                                                    "conditional_continuous_linear_df8kost_dim128.yaml")):
-    """get_model(conf) exactly as inference.py:147-156 does, optionally with a smaller width."""
+    """get_model(conf) exactly as inference.py:147-156 does, optionally with a smaller width; ``model`` overrides
+    conf.model (e.g. 'conditional_elucidated' for the EDM wrapper, model.py:3593-3614)."""
     conf = ref_config.load_config(yaml_path)
     conf.num_sample_steps = num_sample_steps
     conf.ckpt_path = ""
+    if model is not None:
+        conf.model = model
     if dim is not None:
         conf.unet_dim = dim
     if dim_mults is not None:

@@ -387,3 +387,118 @@ def tiled_sample(sd, cfg: UnetCfg, condition_x: Tensor, class_label: Optional[Te
             trace.setdefault("x_start", []).append(x_start.clone())
     out = img[:, :, top:bottom, left:right].clamp(-1.0, 1.0)             # :3403-3404
     return (out + 1) * 0.5                                               # :3405
+
+
+# --------------------------------------------------------------------------------------
+# EDM (Karras et al.) sampler over the same U-Net: ConditionalElucidatedDiffusionSR.tiled_sample
+# (model.py:2309-2475, preconditioned_network_forward :2132-2183, get_noised_images :2185-2194).
+# The schedule and the preconditioning coefficients live in the un-vendored base class
+# ``denoising_diffusion_pytorch.ElucidatedDiffusion`` (pinned 1.8.15); they are RESTATED here from the
+# published algorithm (parity unpinned at that boundary, like Attend) - anchored on the call sites above:
+#   c_in = (sigma^2 + sigma_data^2)^-1/2, c_skip = sigma_data^2 / (sigma^2 + sigma_data^2),
+#   c_out = sigma * sigma_data * (sigma^2 + sigma_data^2)^-1/2, c_noise = log(clamp(sigma, 1e-20)) / 4,
+#   sigmas_i = (sigma_max^(1/rho) + i/(N-1) * (sigma_min^(1/rho) - sigma_max^(1/rho)))^rho, then a trailing 0.
+# --------------------------------------------------------------------------------------
+@dataclass
+class EdmCfg:
+    sigma_min: float = 0.002
+    sigma_max: float = 80.0
+    sigma_data: float = 0.5
+    rho: float = 7.0
+    S_churn: float = 80.0
+    S_tmin: float = 0.05
+    S_tmax: float = 50.0
+    S_noise: float = 1.003
+
+
+def edm_sigmas(e: EdmCfg, n: int) -> Tensor:
+    inv_rho = 1 / e.rho
+    steps = torch.arange(n, dtype=torch.float32)
+    sig = (e.sigma_max ** inv_rho + steps / (n - 1) * (e.sigma_min ** inv_rho - e.sigma_max ** inv_rho)) ** e.rho
+    return F.pad(sig, (0, 1), value=0.0)
+
+
+def edm_gammas(e: EdmCfg, sigmas: Tensor, n: int) -> Tensor:            # model.py:2333-2337
+    return torch.where((sigmas >= e.S_tmin) & (sigmas <= e.S_tmax), min(e.S_churn / n, math.sqrt(2) - 1), 0.0)
+
+
+def edm_precond_coeffs(e: EdmCfg, sigma: Tensor) -> Dict[str, Tensor]:
+    sd2 = e.sigma_data ** 2
+    return {"c_in": 1 * (sigma ** 2 + sd2) ** -0.5, "c_skip": sd2 / (sigma ** 2 + sd2),
+            "c_out": sigma * e.sigma_data * (sd2 + sigma ** 2) ** -0.5,
+            "c_noise": torch.log(sigma.clamp(min=1e-20)) * 0.25}
+
+
+def edm_denoise(sd, cfg: UnetCfg, e: EdmCfg, x: Tensor, sigma: float, cond: Tensor, class_label: Optional[Tensor],
+                cond_scale: float, class_cond_scale: float, clamp: bool) -> Tensor:
+    """preconditioned_network_forward, model.py:2132-2183."""
+    s = torch.full((x.shape[0],), sigma)
+    c = edm_precond_coeffs(e, s)
+    pad = lambda v: v.reshape(-1, 1, 1, 1)
+    if cond_scale != 1.0 and class_cond_scale != 1.0:
+        raise NotImplementedError("Currently, you cannot specify both cond_scale and class_cond_scale at the same time.")
+    xin = pad(c["c_in"]) * x
+    out = pad(c["c_skip"]) * x + pad(c["c_out"]) * unet_forward(sd, cfg, xin, c["c_noise"], class_label, cond)
+    if cond_scale != 1.0:
+        null = pad(c["c_skip"]) * x + pad(c["c_out"]) * unet_forward(sd, cfg, xin, c["c_noise"], class_label, None)
+        out = null + (out - null) * cond_scale
+    if class_cond_scale != 1.0:
+        null = pad(c["c_skip"]) * x + pad(c["c_out"]) * unet_forward(sd, cfg, xin, c["c_noise"], None, cond)
+        out = null + (out - null) * class_cond_scale
+    return out.clamp(-1.0, 1.0) if clamp else out
+
+
+def edm_tiled_sample(sd, cfg: UnetCfg, e: EdmCfg, condition_x: Tensor, class_label: Optional[Tensor] = None, *,
+                     batch_size: int = 4, num_sample_steps: int = 32, cond_scale: float = 1.0,
+                     guidance_start_steps: int = 0, class_cond_scale: float = 1.0, class_guidance_start_steps: int = 0,
+                     generation_start_steps: int = 0, clamp: bool = True, zero_init: bool = False, tile: int = 256,
+                     noise: Optional["NoiseSource"] = None) -> Tensor:
+    """model.py:2309-2475.  condition_x [1,3,H,W] in [0,1] -> [1,3,H,W] in [0,1]."""
+    noise = noise or NoiseSource()
+    n = num_sample_steps
+    cond = condition_x * 2 - 1
+    _, _, h, w = cond.shape
+    (left, top, right, bottom), pad = canvas_box_and_pad(h, w)
+    cond = F.pad(cond, pad, mode="reflect")
+    shape = cond.shape
+    sigmas = edm_sigmas(e, n)
+    gammas = edm_gammas(e, sigmas, n)
+    if generation_start_steps > 0:                                       # get_noised_images(cond, step) :2185-2194
+        img = cond + sigmas[generation_start_steps] * noise.randn(shape)
+    elif zero_init:
+        img = torch.zeros(shape)
+    else:
+        img = sigmas[0] * noise.randn(shape)
+    hp, wp = shape[-2:]
+    grids = sampling_grids(hp, wp, tile, tile)
+    (il, it, ir, ib), ipad = grid_bbox(grids[1], hp, wp)
+    cond = F.pad(cond[:, :, it:ib, il:ir], ipad, mode="constant", value=0.0)
+    for i in range(n):
+        if i < generation_start_steps:
+            continue
+        cs = cond_scale if i >= guidance_start_steps else 1.0
+        ccs = class_cond_scale if i >= class_guidance_start_steps else 1.0
+        sigma, sigma_next, gamma = sigmas[i].item(), sigmas[i + 1].item(), gammas[i].item()
+        eps = e.S_noise * noise.randn(shape)                             # :2386
+        sigma_hat = sigma + gamma * sigma
+        img_hat = img + math.sqrt(sigma_hat ** 2 - sigma ** 2) * eps     # :2389
+        boxes = grids[i % 2]
+        for j in range(0, len(boxes), batch_size):
+            chunk = boxes[j:j + batch_size]
+            xb = torch.cat([img_hat[:, :, a:b, c:d] for (a, b, c, d) in chunk], dim=0)
+            cb = torch.cat([cond[:, :, a:b, c:d] for (a, b, c, d) in chunk], dim=0)
+            out = edm_denoise(sd, cfg, e, xb, sigma_hat, cb, class_label, cs, ccs, clamp)
+            d = (xb - out) / sigma_hat                                   # :2406
+            nxt = xb + (sigma_next - sigma_hat) * d                      # :2407
+            if sigma_next != 0:                                          # :2409-2414 Heun correction
+                out2 = edm_denoise(sd, cfg, e, nxt, sigma_next, cb, class_label, cs, ccs, clamp)
+                d2 = (nxt - out2) / sigma_next
+                nxt = xb + 0.5 * (sigma_next - sigma_hat) * (d + d2)
+            for k, (a, b, c, d_) in enumerate(chunk):
+                img[:, :, a:b, c:d_] = nxt[k]
+        if i % 2 == 1:                                                   # :2448-2452
+            inner = img[:, :, it:ib, il:ir].clone()
+            img = torch.zeros(shape) + sigmas[i] * noise.randn(shape)    # get_noised_images(0, i)
+            img[:, :, it:ib, il:ir] = inner
+    out = img[:, :, top:bottom, left:right].clamp(-1.0, 1.0)
+    return (out + 1) * 0.5

@@ -30,6 +30,12 @@ class StepScalars(C.Structure):
                 ("reserved", C.c_float)]
 
 
+class EdmScalars(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("s_noise", "hat_coef", "sigma_hat", "sigma_next", "dt", "half_dt", "c_in_hat",
+                                         "c_skip_hat", "c_out_hat", "c_in_next", "c_skip_next", "c_out_next", "ring_sigma",
+                                         "clamp", "pad0", "pad1")]
+
+
 class SamplerGeometry(C.Structure):
     _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("Hp", C.c_int32), ("Wp", C.c_int32),
                 ("left", C.c_int32), ("top", C.c_int32),
@@ -60,6 +66,11 @@ PROTOTYPES = {
                                           C.c_void_p]),
     "srgd_sampler_exchange_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_void_p]),
+    "srgd_edm_begin": (C.c_int, [C.c_void_p, C.POINTER(SamplerGeometry), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int32), C.c_int, C.POINTER(EdmScalars), C.POINTER(C.c_float), C.c_int,
+                                 C.c_void_p]),
+    "srgd_edm_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_void_p]),
     "srgd_sampler_q_start": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_uint64,
                                        C.c_void_p]),
     "srgd_sampler_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

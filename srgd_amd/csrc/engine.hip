@@ -226,6 +226,7 @@ struct srgd_engine {
   int n_steps = 0, run_class = -1;
   bool run_active = false;
   float* rng_tiles = nullptr; size_t rng_tiles_cap = 0;
+  EdmScalars* d_edm = nullptr; int edm_cap = 0; bool run_is_edm = false;
   float* rng_canvas = nullptr; size_t rng_canvas_cap = 0;
 
   // device-side step counter + per-run hipGraph cache: a DDPM step is one graph per (grid parity, guidance mode);
@@ -464,7 +465,8 @@ struct Ctx {
   const int* rows;           // conditioning row of each entry
   const float* table;        // conditioning table in use
   hipStream_t st;
-  const int* step_ptr = nullptr;   // sampler: device step counter (row += *step_ptr * 2)
+  const int* step_ptr = nullptr;   // sampler: device step counter (row += *step_ptr * step_mul)
+  int step_mul = 2;                // conditioning rows per step: 2 (DDPM: label / no label), 4 (EDM: x {sigma_hat, sigma_next})
 };
 
 // gn_in: the input is a raw conv output whose GroupNorm+SiLU (coefA/coefB) the fast 3x3 kernel applies while
@@ -516,7 +518,7 @@ int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_
   GnFinalizeArgs f;
   f.partial = e->gn_partial; f.nslots = e->stats_slots; f.B = x.nb; f.C = C; f.groups = e->cfg.groups; f.hw = hw;
   f.gamma = gamma; f.beta = beta;
-  f.ss_table = ss_offset >= 0 ? x.table : nullptr; f.ss_rows = x.rows; f.step_ptr = x.step_ptr; f.step_mul = 2;
+  f.ss_table = ss_offset >= 0 ? x.table : nullptr; f.ss_rows = x.rows; f.step_ptr = x.step_ptr; f.step_mul = x.step_mul;
   f.ss_stride = e->ss_stride; f.ss_offset = ss_offset < 0 ? 0 : ss_offset; f.eps = 1e-5f;
   f.coefA = e->coefA; f.coefB = e->coefB;
   SRGD_TRY(gn_finalize(f, x.st));
@@ -769,7 +771,8 @@ int srgd_destroy(srgd_engine* e) {
   for (void* p : e->weight_allocs) hipFree(p);
   e->pool.release_all();
   for (void* p : {(void*)e->gn_partial, (void*)e->coefA, (void*)e->la_ws, (void*)e->d_rows,
-                  (void*)e->d_tiles_even, (void*)e->d_tiles_odd, (void*)e->d_sc, (void*)e->rng_tiles, (void*)e->rng_canvas})
+                  (void*)e->d_tiles_even, (void*)e->d_tiles_odd, (void*)e->d_sc, (void*)e->d_edm, (void*)e->rng_tiles,
+                  (void*)e->rng_canvas})
     if (p) hipFree(p);
   for (CondTable* ct : {&e->ct_sampler, &e->ct_api})
     for (float* q : {ct->table, ct->ls, ct->feat, ct->h1, ct->t1, ct->trows, ct->c1, ct->c2})
@@ -896,11 +899,13 @@ int srgd_unet_forward(srgd_engine* e, const float* xin, const float* cond, const
   return 0;
 }
 
-int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const float* cond01, float* cond_canvas,
-                       const int32_t* tiles_even_host, const int32_t* tiles_odd_host, int n_steps,
-                       const srgd_step_scalars* scalars_host, const float* log_snr_host, int class_id, void* stream) {
+// shared by the DDPM and the EDM sampler: geometry checks, tile lists, condition canvas, conditioning table for the
+// n_times "time" inputs of the run (rows 2i: with the class embedding, 2i+1: without)
+static int sampler_begin_common(srgd_engine* e, const srgd_sampler_geometry* g, const float* cond01, float* cond_canvas,
+                                const int32_t* tiles_even_host, const int32_t* tiles_odd_host, int n_steps,
+                                const float* times_host, int n_times, int class_id, hipStream_t st) {
   if (!e || !e->finalized) SRGD_FAIL("srgd_sampler_begin: engine has no weights");
-  if (!g || !cond01 || !cond_canvas || !tiles_even_host || !tiles_odd_host || !scalars_host || !log_snr_host)
+  if (!g || !cond01 || !cond_canvas || !tiles_even_host || !tiles_odd_host || !times_host)
     SRGD_FAIL("srgd_sampler_begin: null argument");
   if (class_id >= 0 && e->cfg.num_classes <= 0) SRGD_FAIL("class label given but the U-Net has no class embedding");
   if (g->tile <= 0 || g->n_even <= 0 || g->n_odd <= 0 || n_steps <= 0 || g->n_images < 1)
@@ -909,7 +914,6 @@ int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const flo
   const int pl = g->left, pr = g->Wp - g->left - g->W, pt = g->top, pb = g->Hp - g->top - g->H;
   if (pl >= g->W || pr >= g->W || pt >= g->H || pb >= g->H)
     SRGD_FAIL("Padding size should be less than the corresponding input dimension (reflect pad)");
-  hipStream_t st = (hipStream_t)stream;
   SRGD_HIP(hipSetDevice(e->cfg.device));
   drop_step_graphs(e);                       // graphs bake in canvas / table / tile-list pointers of one run
   e->geo = *g;
@@ -932,21 +936,137 @@ int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const flo
   SRGD_TRY(ensure(&e->d_tiles_odd, &e->tiles_cap_odd, tl_odd.size()));
   SRGD_HIP(hipMemcpyAsync(e->d_tiles_even, tl_even.data(), tl_even.size() * 4, hipMemcpyHostToDevice, st));
   SRGD_HIP(hipMemcpyAsync(e->d_tiles_odd, tl_odd.data(), tl_odd.size() * 4, hipMemcpyHostToDevice, st));
-  if (e->sc_cap < n_steps) {
-    if (e->d_sc) hipFree(e->d_sc);
-    e->d_sc = nullptr;
-    SRGD_HIP(hipMalloc((void**)&e->d_sc, (size_t)n_steps * sizeof(StepScalars)));
-    e->sc_cap = n_steps;
-  }
-  static_assert(sizeof(StepScalars) == sizeof(srgd_step_scalars), "step scalar layout");
-  SRGD_HIP(hipMemcpyAsync(e->d_sc, scalars_host, (size_t)n_steps * sizeof(StepScalars), hipMemcpyHostToDevice, st));
   { Prof p(e, KC_CANVAS, st);
     SRGD_TRY(canvas_prepare_cond(cond01, 3 * g->n_images, g->H, g->W, g->left, g->top, g->Hp, g->Wp, g->inner_l, g->inner_t, g->inner_r,
                                  g->inner_b, cond_canvas, st)); }
-  SRGD_TRY(compute_conditioning(e, e->ct_sampler, log_snr_host, n_steps, class_id, st));
-  // the host arrays may be reused by the caller right after this call returns
+  SRGD_TRY(compute_conditioning(e, e->ct_sampler, times_host, n_times, class_id, st));
+  // the host arrays (ours and the caller's) may be reused right after this returns
   SRGD_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int srgd_sampler_begin(srgd_engine* e, const srgd_sampler_geometry* g, const float* cond01, float* cond_canvas,
+                       const int32_t* tiles_even_host, const int32_t* tiles_odd_host, int n_steps,
+                       const srgd_step_scalars* scalars_host, const float* log_snr_host, int class_id, void* stream) {
+  if (!scalars_host) SRGD_FAIL("srgd_sampler_begin: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (e && n_steps > 0) {
+    SRGD_HIP(hipSetDevice(e->cfg.device));
+    if (e->sc_cap < n_steps) {
+      if (e->d_sc) hipFree(e->d_sc);
+      e->d_sc = nullptr;
+      SRGD_HIP(hipMalloc((void**)&e->d_sc, (size_t)n_steps * sizeof(StepScalars)));
+      e->sc_cap = n_steps;
+    }
+    static_assert(sizeof(StepScalars) == sizeof(srgd_step_scalars), "step scalar layout");
+    SRGD_HIP(hipMemcpyAsync(e->d_sc, scalars_host, (size_t)n_steps * sizeof(StepScalars), hipMemcpyHostToDevice, st));
+  }
+  SRGD_TRY(sampler_begin_common(e, g, cond01, cond_canvas, tiles_even_host, tiles_odd_host, n_steps, log_snr_host, n_steps,
+                                class_id, st));
   e->run_active = true;
+  e->run_is_edm = false;
+  return 0;
+}
+
+int srgd_edm_begin(srgd_engine* e, const srgd_sampler_geometry* g, const float* cond01, float* cond_canvas,
+                   const int32_t* tiles_even_host, const int32_t* tiles_odd_host, int n_steps,
+                   const srgd_edm_scalars* scalars_host, const float* c_noise_host, int class_id, void* stream) {
+  if (!scalars_host) SRGD_FAIL("srgd_edm_begin: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (e && n_steps > 0) {
+    SRGD_HIP(hipSetDevice(e->cfg.device));
+    if (e->edm_cap < n_steps) {
+      if (e->d_edm) hipFree(e->d_edm);
+      e->d_edm = nullptr;
+      SRGD_HIP(hipMalloc((void**)&e->d_edm, (size_t)n_steps * sizeof(EdmScalars)));
+      e->edm_cap = n_steps;
+    }
+    static_assert(sizeof(EdmScalars) == sizeof(srgd_edm_scalars), "EDM scalar layout");
+    SRGD_HIP(hipMemcpyAsync(e->d_edm, scalars_host, (size_t)n_steps * sizeof(EdmScalars), hipMemcpyHostToDevice, st));
+  }
+  // two network evaluations per step: rows 4i..4i+1 for c_noise(sigma_hat_i), 4i+2..4i+3 for c_noise(sigma_next_i)
+  SRGD_TRY(sampler_begin_common(e, g, cond01, cond_canvas, tiles_even_host, tiles_odd_host, n_steps, c_noise_host,
+                                2 * n_steps, class_id, st));
+  e->run_active = true;
+  e->run_is_edm = true;
+  return 0;
+}
+
+// One EDM step (model.py:2377-2455) over every tile of grid (step % 2): Euler evaluation at sigma_hat, Heun correction at
+// sigma_next (skipped on the last step), odd-step ring re-noise.  Launched eagerly (no graph capture yet).
+int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start, float* work,
+                  const float* noise_canvas, const float* ring_noise_canvas, int passes, int guidance_kind,
+                  float guidance_scale, int sub_batch, uint64_t seed, void* stream) {
+  if (!e || !e->run_active || !e->run_is_edm) SRGD_FAIL("srgd_edm_step: call srgd_edm_begin first");
+  if (step < 0 || step >= e->n_steps) SRGD_FAIL("srgd_edm_step: step out of range");
+  if (!img || !cond_canvas || !work) SRGD_FAIL("srgd_edm_step: null argument");
+  if (passes != 1 && passes != 2) SRGD_FAIL("srgd_edm_step: passes must be 1 or 2");
+  if (passes == 2 && guidance_kind != 1 && guidance_kind != 2) SRGD_FAIL("srgd_edm_step: guidance_kind must be 1 or 2");
+  if (sub_batch < 1) SRGD_FAIL("srgd_edm_step: sub_batch must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  SRGD_HIP(hipSetDevice(e->cfg.device));
+  const srgd_sampler_geometry& g = e->geo;
+  const int parity = step & 1;
+  const int n_local = parity ? g.n_odd : g.n_even;
+  const int n = n_local * g.n_images;
+  const bool last = step == e->n_steps - 1;
+  const int* tiles = parity ? e->d_tiles_odd : e->d_tiles_even;
+  sub_batch = std::min(sub_batch, n);
+  const size_t canvas1 = (size_t)3 * g.Hp * g.Wp, canvas_elems = canvas1 * g.n_images;
+  SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
+  if (!noise_canvas) SRGD_TRY(ensure(&e->rng_tiles, &e->rng_tiles_cap, canvas1));
+  if (!ring_noise_canvas && parity == 1) SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, canvas1));
+  if (!e->d_step) SRGD_HIP(hipMalloc((void**)&e->d_step, sizeof(int)));
+  hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, e->d_step, step);
+  const float* z = noise_canvas;
+  if (!z) {
+    Prof p(e, KC_CANVAS, st);
+    SRGD_TRY(philox_normal(e->rng_tiles, canvas1, seed, 2ull << 32, e->d_step, st));
+    z = e->rng_tiles;
+  }
+  const int row_label = e->run_class >= 0 ? 0 : 1, row_null = 1;
+  const int mask = (passes == 2 && guidance_kind == 2) ? 0x1 : 0x3;
+  for (int first = 0; first < n; first += sub_batch) {
+    const int nt = std::min(sub_batch, n - first);
+    const int nb = nt * passes;
+    TileBatch tb{tiles, first, nt, g.Hp, g.Wp, g.tile, n_local};
+    for (int ep = 0; ep < (last ? 1 : 2); ++ep) {
+      void* x0 = e->pool.get((size_t)nb * g.tile * g.tile * e->dim * e->es);
+      if (!x0) return -1;
+      {
+        Prof p(e, KC_INIT, st);
+        void* padded = e->pool.get((size_t)nb * (g.tile + 6) * (g.tile + 8) * 8 * e->es);
+        if (!padded) return -1;
+        SRGD_TRY(init_gather_from_canvas_edm(ep == 0 ? img : work, ep == 0 ? z : nullptr, cond_canvas, tb, passes, mask,
+                                             e->d_edm, e->d_step, ep, padded, e->bf16, st));
+        SRGD_TRY(run_init7(e, padded, nb, g.tile, g.tile, x0, st));
+        e->pool.put(padded);
+      }
+      // conditioning row = base + 4 * step, base = 2 * (evaluation: 0 at sigma_hat, 1 at sigma_next) + (0 label / 1 none)
+      hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, e->d_rows, nb, nt, 2 * ep + row_label,
+                         2 * ep + ((passes == 2 && guidance_kind == 1) ? row_null : row_label));
+      Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st, e->d_step, 4};
+      void* act = nullptr;
+      SRGD_TRY(unet_body(x, x0, &act));
+      FinalStepArgs fa;
+      fa.act = act; fa.C = e->dim; fa.passes = passes; fa.guidance = guidance_scale;
+      fa.w = e->final_w; fa.bias = e->final_b; fa.img = img; fa.x_start = x_start; fa.noise = z;
+      fa.sc = nullptr; fa.step_ptr = e->d_step;
+      { Prof p(e, KC_FINAL, st); SRGD_TRY(final_step_edm(fa, e->d_edm, work, canvas_elems, ep, tb, e->bf16, st)); }
+      e->pool.put(act);
+      e->pool.put(x0);
+    }
+  }
+  if (parity == 1) {
+    Prof p(e, KC_CANVAS, st);
+    const float* nc = ring_noise_canvas;
+    if (!nc) {
+      SRGD_TRY(philox_normal(e->rng_canvas, canvas1, seed, (1ull << 32) | 0x80000000ull, e->d_step, st));
+      nc = e->rng_canvas;
+    }
+    SRGD_TRY(canvas_ring_renoise(img, 3 * g.n_images, nc, g.Hp, g.Wp, g.inner_l, g.inner_t, g.inner_r, g.inner_b,
+                                 &e->d_edm[0].ring_sigma, (int)(sizeof(EdmScalars) / sizeof(float)), e->d_step, st));
+  }
   return 0;
 }
 
@@ -1006,7 +1126,8 @@ static int sampler_step_launch(srgd_engine* e, bool last, int parity, int tile_f
       SRGD_TRY(philox_normal(e->rng_canvas, (size_t)3 * g.Hp * g.Wp, seed, (1ull << 32) | 0x80000000ull, e->d_step, st));
       nc = e->rng_canvas;
     }
-    SRGD_TRY(canvas_ring_renoise(img, 3 * g.n_images, nc, g.Hp, g.Wp, g.inner_l, g.inner_t, g.inner_r, g.inner_b, e->d_sc, e->d_step, st));
+    SRGD_TRY(canvas_ring_renoise(img, 3 * g.n_images, nc, g.Hp, g.Wp, g.inner_l, g.inner_t, g.inner_r, g.inner_b,
+                                 &e->d_sc[0].sigma_next, (int)(sizeof(StepScalars) / sizeof(float)), e->d_step, st));
   }
   return 0;
 }
@@ -1030,7 +1151,7 @@ int srgd_sampler_step_tiles(srgd_engine* e, int step, int tile_first, int tile_c
                             const float* cond_canvas, float* x_start, const float* noise_tiles,
                             const float* noise_canvas, int passes, int guidance_kind, float guidance_scale,
                             int sub_batch, uint64_t seed, void* stream) {
-  if (!e || !e->run_active) SRGD_FAIL("srgd_sampler_step: call srgd_sampler_begin first");
+  if (!e || !e->run_active || e->run_is_edm) SRGD_FAIL("srgd_sampler_step: call srgd_sampler_begin first");
   if (step < 0 || step >= e->n_steps) SRGD_FAIL("srgd_sampler_step: step out of range");
   if (passes != 1 && passes != 2) SRGD_FAIL("srgd_sampler_step: passes must be 1 or 2");
   if (passes == 2 && guidance_kind != 1 && guidance_kind != 2) SRGD_FAIL("srgd_sampler_step: guidance_kind must be 1 or 2");

@@ -121,6 +121,16 @@ struct StepScalars {       // fp32 values computed by the host exactly as the re
   float sigma_next;        // for the ring re-noise (q_sample(0, t'))
   float pad;
 };
+struct EdmScalars {        // == srgd_edm_scalars (include/srgd_hip.h); fp32 values computed by the host as the reference does
+  float s_noise, hat_coef;           // img_hat = img + hat_coef * (s_noise * z)            (model.py:2386-2389)
+  float sigma_hat, sigma_next;       // sigma_next == 0 on the last step (no Heun correction)
+  float dt, half_dt;                 // sigma_next - sigma_hat, half of it
+  float c_in_hat, c_skip_hat, c_out_hat;
+  float c_in_next, c_skip_next, c_out_next;
+  float ring_sigma;                  // sigmas[i]: odd-step ring = ring_sigma * z'            (model.py:2448-2452)
+  float clamp;                       // != 0: clamp the denoised prediction to [-1, 1]
+  float pad0, pad1;
+};
 struct TileBatch {
   const int* tile_yx;      // device [n_images * n_local][3] = (y, x, image) of each tile, image-major
   int first;               // first tile of this sub-batch in tile_yx
@@ -135,6 +145,12 @@ struct TileBatch {
 // stride is 8 elements (conv_igemm with ps0 = 8).  The 8th pixel and channels 6,7 carry zero weights.
 int init_gather_from_canvas(const float* img, const float* cond, const TileBatch& tb, int passes, int use_cond_mask,
                             void* padded, bool is_bf16, hipStream_t st);
+// EDM variant (model.py:2140-2146): the gathered input is c_in * x with, for edm_pass 0, x = img + hat_coef*(s_noise*z)
+// (z: one noise canvas [3][Hp][Wp] shared by all images) and c_in = c_in_hat; for edm_pass 1, x = img (the Euler
+// result canvas) and c_in = c_in_next.  Scalars are read on the device: sc[*step_ptr].
+int init_gather_from_canvas_edm(const float* img, const float* z, const float* cond, const TileBatch& tb, int passes,
+                                int use_cond_mask, const EdmScalars* sc, const int* step_ptr, int edm_pass, void* padded,
+                                bool is_bf16, hipStream_t st);
 int init_gather_from_nchw(const float* x, const float* cond, int B, int H, int W, void* padded, bool is_bf16,
                           hipStream_t st);
 // 1x1 output conv (model.py:675) -> eps; NCHW fp32 out (U-Net-only entry point)
@@ -155,6 +171,12 @@ struct FinalStepArgs {
   const int* step_ptr;     // optional device step counter indexing sc
 };
 int final_step(const FinalStepArgs& a, const TileBatch& tb, bool is_bf16, hipStream_t st);
+// EDM: 1x1 output conv + guidance combine + Karras preconditioning + Euler step (edm_pass 0) or Heun correction
+// (edm_pass 1), model.py:2403-2425.  `a.img` is the image canvas, `a.noise` the z canvas [3][Hp][Wp] (indexed by
+// position, not by tile), `work` = two canvases [2][n_images*3*Hp*Wp]: the Euler result and the slope d.
+// On the last step (sigma_next == 0) pass 0 writes the canvas directly.  a.sc / a.x_start as in final_step.
+int final_step_edm(const FinalStepArgs& a, const EdmScalars* sc, float* work, size_t canvas_elems, int edm_pass,
+                   const TileBatch& tb, bool is_bf16, hipStream_t st);
 
 // canvas kernels (model.py:3296-3303, :3337-3342, :3392-3396, :3403-3405)
 // `planes` = 3 * n_images; the noise canvas [3][Hp][Wp] is shared by every image (index taken modulo 3*Hp*Wp)
@@ -162,8 +184,9 @@ int canvas_prepare_cond(const float* cond01 /*[planes][H][W]*/, int planes, int 
                         int Wp, int il, int it, int ir, int ib, float* cond_canvas, hipStream_t st);
 int canvas_q_start(const float* cond01, int planes, int H, int W, int pad_l, int pad_t, int Hp, int Wp,
                    const float* noise, float alpha, float sigma, float* img, hipStream_t st);
+// sigma = sigma_base[*step_ptr * sigma_stride] (a float field of the per-step scalar records of either sampler)
 int canvas_ring_renoise(float* img, int planes, const float* noise /*[3][Hp][Wp]*/, int Hp, int Wp, int il, int it,
-                        int ir, int ib, const StepScalars* sc, const int* step_ptr, hipStream_t st);
+                        int ir, int ib, const float* sigma_base, int sigma_stride, const int* step_ptr, hipStream_t st);
 int canvas_finish(const float* img, int planes, int Hp, int Wp, int left, int top, int H, int W, float* out01,
                   hipStream_t st);
 // copies the tiles [tb.first, tb.first+tb.ntiles) between a canvas and a packed [ntiles][3][tile][tile] buffer

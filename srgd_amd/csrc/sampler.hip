@@ -19,6 +19,11 @@ struct InitSrc {
   int H, W;                // tile / image size
   int row_stride;          // canvas width or W
   long plane_stride;       // canvas plane or H*W
+  // EDM (canvas mode only): x = (x + hat_coef * (s_noise * z)) * c_in, scalars read on the device
+  const EdmScalars* edm;   // null: plain gather
+  const int* step_ptr;
+  const float* z;          // noise canvas [3][Hp][Wp] (edm_pass 0) or null
+  int edm_pass;
 };
 
 // Gather for the MFMA route of the 7x7 input conv (see kernels.hpp): one thread per padded position.
@@ -34,12 +39,13 @@ __global__ __launch_bounds__(256) void init_gather_kernel(InitSrc s, int entries
     const int y = py - 3, x = px - 3;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (y >= 0 && y < s.H && x >= 0 && x < s.W) {
-      long origin;
+      long origin, zorigin = 0;
       bool use_cond = s.cond != nullptr;
       if (s.canvas) {
         const int pass = entry / s.ntiles, tt = entry - pass * s.ntiles;
         const int* tyx = s.tile_yx + 3 * (s.first + tt);
-        origin = (long)tyx[2] * 3 * s.plane_stride + (long)tyx[0] * s.row_stride + tyx[1];
+        zorigin = (long)tyx[0] * s.row_stride + tyx[1];
+        origin = (long)tyx[2] * 3 * s.plane_stride + zorigin;
         use_cond = use_cond && ((s.use_cond_mask >> pass) & 1);
       } else {
         origin = (long)entry * 3 * s.plane_stride;
@@ -49,6 +55,16 @@ __global__ __launch_bounds__(256) void init_gather_kernel(InitSrc s, int entries
       for (int c = 0; c < 3; ++c) {
         v[c] = s.x[o + c * s.plane_stride];
         if (use_cond) v[3 + c] = s.cond[o + c * s.plane_stride];
+      }
+      if (s.edm) {
+        const EdmScalars sc = s.edm[s.step_ptr ? *s.step_ptr : 0];
+        const long oz = zorigin + (long)y * s.row_stride + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float xv = v[c];
+          if (s.edm_pass == 0) xv = xv + sc.hat_coef * (sc.s_noise * s.z[oz + c * s.plane_stride]);
+          v[c] = (s.edm_pass == 0 ? sc.c_in_hat : sc.c_in_next) * xv;
+        }
       }
     }
     T* dst = padded + i * 8;
@@ -174,6 +190,72 @@ __global__ __launch_bounds__(256) void final_step_kernel(FinalStepArgs a, TileBa
   }
 }
 
+// EDM epilogue (model.py:2140-2183 preconditioning + guidance, :2403-2425 Euler / Heun): same two phases as final_step_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void final_step_edm_kernel(FinalStepArgs a, const EdmScalars* __restrict__ scp,
+                                                             float* __restrict__ work, size_t canvas_elems, int edm_pass,
+                                                             TileBatch tb) {
+  __shared__ float eps[3][256];
+  const int tile = tb.tile;
+  const long per_tile = (long)tile * tile;
+  const long p0 = (long)blockIdx.x * 256;
+  const int lane16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const T* act = reinterpret_cast<const T*>(a.act);
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int q = i * 16 + grp;
+    float e[3];
+    out_conv3_coop<T>(act + (p0 + q) * a.C, a.C, a.w, a.bias, lane16, e);
+    if (a.passes == 2) {
+      float n[3];
+      out_conv3_coop<T>(act + (p0 + q + per_tile * tb.ntiles) * a.C, a.C, a.w, a.bias, lane16, n);
+      // guidance on the preconditioned outputs (model.py:2162, :2176) == guidance on the raw outputs: the
+      // preconditioning is the same affine map for both
+#pragma unroll
+      for (int c = 0; c < 3; ++c) e[c] = n[c] + (e[c] - n[c]) * a.guidance;
+    }
+    if (lane16 < 3) eps[lane16][q] = lane16 == 0 ? e[0] : (lane16 == 1 ? e[1] : e[2]);
+  }
+  __syncthreads();
+  const long p = p0 + threadIdx.x;
+  const int t = (int)(p / per_tile);
+  const int r = (int)(p - t * per_tile);
+  const int y = r / tile, x = r - y * tile;
+  const EdmScalars sc = scp[a.step_ptr ? *a.step_ptr : 0];
+  const int* tyx = tb.tile_yx + 3 * (tb.first + t);
+  const long plane = (long)tb.Hp * tb.Wp;
+  const long oz = (long)(tyx[0] + y) * tb.Wp + tyx[1] + x;
+  const long o = (long)tyx[2] * 3 * plane + oz;
+  float* nxt_c = work;
+  float* d_c = work + canvas_elems;
+  const bool last = sc.sigma_next == 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float xh = a.img[c * plane + o] + sc.hat_coef * (sc.s_noise * a.noise[c * plane + oz]);     // :2389
+    const float net = eps[c][threadIdx.x];
+    if (edm_pass == 0) {
+      float den = sc.c_skip_hat * xh + sc.c_out_hat * net;                     // :2149
+      if (sc.clamp != 0.0f) den = fminf(fmaxf(den, -1.0f), 1.0f);              // :2180-2181
+      const float d = (xh - den) / sc.sigma_hat;                               // :2406
+      const float nx = xh + sc.dt * d;                                         // :2407
+      if (last) {
+        a.img[c * plane + o] = nx;
+        if (a.x_start) a.x_start[c * plane + o] = d;                           // :2423-2424
+      } else {
+        nxt_c[c * plane + o] = nx;
+        d_c[c * plane + o] = d;
+      }
+    } else {
+      const float nx = nxt_c[c * plane + o], d = d_c[c * plane + o];
+      float den = sc.c_skip_next * nx + sc.c_out_next * net;
+      if (sc.clamp != 0.0f) den = fminf(fmaxf(den, -1.0f), 1.0f);
+      const float d2 = (nx - den) / sc.sigma_next;                             // :2413
+      a.img[c * plane + o] = xh + sc.half_dt * (d + d2);                       // :2414
+      if (a.x_start) a.x_start[c * plane + o] = d2;                            // :2421-2422
+    }
+  }
+}
+
 // ------------------------------------------------------------------ canvas kernels
 __global__ void canvas_prepare_cond_kernel(const float* __restrict__ c01, int planes, int H, int W, int pad_l, int pad_t,
                                            int Hp, int Wp, int il, int it, int ir, int ib,
@@ -219,8 +301,9 @@ __global__ void canvas_q_start_kernel(const float* __restrict__ c01, int planes,
 
 __global__ void canvas_ring_renoise_kernel(float* __restrict__ img, int planes, const float* __restrict__ noise, int Hp,
                                            int Wp, int il, int it, int ir, int ib,
-                                           const StepScalars* __restrict__ sc, const int* __restrict__ step_ptr) {
-  const float sigma = sc[step_ptr ? *step_ptr : 0].sigma_next;
+                                           const float* __restrict__ sigma_base, int sigma_stride,
+                                           const int* __restrict__ step_ptr) {
+  const float sigma = sigma_base[(long)(step_ptr ? *step_ptr : 0) * sigma_stride];
   const long n = (long)planes * Hp * Wp;
   const long nmod = 3L * Hp * Wp;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -315,10 +398,18 @@ int grid_for(long n) { return (int)std::min<long>((n + 255) / 256, 256L * 16); }
 
 int init_gather_from_canvas(const float* img, const float* cond, const TileBatch& tb, int passes, int use_cond_mask,
                             void* padded, bool is_bf16, hipStream_t st) {
+  return init_gather_from_canvas_edm(img, nullptr, cond, tb, passes, use_cond_mask, nullptr, nullptr, 0, padded, is_bf16, st);
+}
+
+int init_gather_from_canvas_edm(const float* img, const float* z, const float* cond, const TileBatch& tb, int passes,
+                                int use_cond_mask, const EdmScalars* sc, const int* step_ptr, int edm_pass, void* padded,
+                                bool is_bf16, hipStream_t st) {
+  if (sc && edm_pass == 0 && !z) SRGD_FAIL("init_gather: EDM pass 0 needs the noise canvas");
   InitSrc s;
   s.x = img; s.cond = cond; s.canvas = 1; s.tile_yx = tb.tile_yx; s.first = tb.first; s.ntiles = tb.ntiles;
   s.use_cond_mask = use_cond_mask; s.H = tb.tile; s.W = tb.tile; s.row_stride = tb.Wp;
   s.plane_stride = (long)tb.Hp * tb.Wp;
+  s.edm = sc; s.step_ptr = step_ptr; s.z = z; s.edm_pass = edm_pass;
   const int entries = passes * tb.ntiles;
   const int grid = grid_for((long)entries * (s.H + 6) * (s.W + 8));
   if (is_bf16) hipLaunchKernelGGL((init_gather_kernel<bf16>), dim3(grid), dim3(256), 0, st, s, entries, (bf16*)padded);
@@ -332,6 +423,7 @@ int init_gather_from_nchw(const float* x, const float* cond, int B, int H, int W
   InitSrc s;
   s.x = x; s.cond = cond; s.canvas = 0; s.tile_yx = nullptr; s.first = 0; s.ntiles = B; s.use_cond_mask = 1;
   s.H = H; s.W = W; s.row_stride = W; s.plane_stride = (long)H * W;
+  s.edm = nullptr; s.step_ptr = nullptr; s.z = nullptr; s.edm_pass = 0;
   const int grid = grid_for((long)B * (H + 6) * (W + 8));
   if (is_bf16) hipLaunchKernelGGL((init_gather_kernel<bf16>), dim3(grid), dim3(256), 0, st, s, B, (bf16*)padded);
   else hipLaunchKernelGGL((init_gather_kernel<float>), dim3(grid), dim3(256), 0, st, s, B, (float*)padded);
@@ -365,6 +457,19 @@ int final_step(const FinalStepArgs& a, const TileBatch& tb, bool is_bf16, hipStr
   return 0;
 }
 
+int final_step_edm(const FinalStepArgs& a, const EdmScalars* sc, float* work, size_t canvas_elems, int edm_pass,
+                   const TileBatch& tb, bool is_bf16, hipStream_t st) {
+  const long n = (long)tb.ntiles * tb.tile * tb.tile;
+  const int grid = (int)((n + 255) / 256);
+  if (a.C % (is_bf16 ? 8 : 4) != 0) SRGD_FAIL("final_step_edm: C must be a multiple of the vector width");
+  if (((long)tb.tile * tb.tile) % 256 != 0) SRGD_FAIL("final_step_edm: tile area must be a multiple of 256");
+  if (!sc || !work || !a.noise) SRGD_FAIL("final_step_edm: null argument");
+  if (is_bf16) hipLaunchKernelGGL((final_step_edm_kernel<bf16>), dim3(grid), dim3(256), 0, st, a, sc, work, canvas_elems, edm_pass, tb);
+  else hipLaunchKernelGGL((final_step_edm_kernel<float>), dim3(grid), dim3(256), 0, st, a, sc, work, canvas_elems, edm_pass, tb);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
 int canvas_prepare_cond(const float* cond01, int planes, int H, int W, int pad_l, int pad_t, int Hp, int Wp, int il,
                         int it, int ir, int ib, float* cond_canvas, hipStream_t st) {
   hipLaunchKernelGGL(canvas_prepare_cond_kernel, dim3(grid_for((long)planes * Hp * Wp)), dim3(256), 0, st, cond01, planes,
@@ -382,9 +487,9 @@ int canvas_q_start(const float* cond01, int planes, int H, int W, int pad_l, int
 }
 
 int canvas_ring_renoise(float* img, int planes, const float* noise, int Hp, int Wp, int il, int it, int ir, int ib,
-                        const StepScalars* sc, const int* step_ptr, hipStream_t st) {
+                        const float* sigma_base, int sigma_stride, const int* step_ptr, hipStream_t st) {
   hipLaunchKernelGGL(canvas_ring_renoise_kernel, dim3(grid_for((long)planes * Hp * Wp)), dim3(256), 0, st, img, planes,
-                     noise, Hp, Wp, il, it, ir, ib, sc, step_ptr);
+                     noise, Hp, Wp, il, it, ir, ib, sigma_base, sigma_stride, step_ptr);
   SRGD_HIP(hipGetLastError());
   return 0;
 }

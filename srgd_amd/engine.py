@@ -152,6 +152,30 @@ class HipEngine:
                                                       _dev_ptr(canvas), _dev_ptr(tiles), int(bool(to_canvas)),
                                                       _stream_ptr(self.device)), "srgd_sampler_exchange_tiles")
 
+    def edm_begin(self, geo: SamplerGeometry, cond01: torch.Tensor, cond_canvas: torch.Tensor,
+                  tiles_even: Sequence[Tuple[int, int]], tiles_odd: Sequence[Tuple[int, int]], scalars, c_noise: Sequence[float],
+                  class_id: int) -> None:
+        from ._lib import EdmScalars
+        n = len(scalars)
+        assert len(c_noise) == 2 * n
+        te = (C.c_int32 * (2 * len(tiles_even)))(*[v for yx in tiles_even for v in yx])
+        to = (C.c_int32 * (2 * len(tiles_odd)))(*[v for yx in tiles_odd for v in yx])
+        sc = (EdmScalars * n)(*scalars)
+        cn = (C.c_float * (2 * n))(*[float(v) for v in c_noise])
+        with torch.cuda.device(self.device):
+            check(self._L.srgd_edm_begin(self._h, C.byref(geo), _dev_ptr(cond01), _dev_ptr(cond_canvas), te, to, n, sc, cn,
+                                         int(class_id), _stream_ptr(self.device)), "srgd_edm_begin")
+
+    def edm_step(self, step: int, img: torch.Tensor, cond_canvas: torch.Tensor, x_start: Optional[torch.Tensor],
+                 work: torch.Tensor, noise_canvas: Optional[torch.Tensor], ring_noise_canvas: Optional[torch.Tensor],
+                 passes: int, guidance_kind: int, guidance_scale: float, sub_batch: int, seed: int = 0) -> None:
+        assert work.is_contiguous() and work.dtype == torch.float32 and work.numel() >= 2 * img.numel()
+        with torch.cuda.device(self.device):
+            check(self._L.srgd_edm_step(self._h, step, _dev_ptr(img), _dev_ptr(cond_canvas), _dev_ptr(x_start), _dev_ptr(work),
+                                        _dev_ptr(noise_canvas), _dev_ptr(ring_noise_canvas), passes, guidance_kind,
+                                        float(guidance_scale), int(sub_batch), int(seed) & (2 ** 64 - 1),
+                                        _stream_ptr(self.device)), "srgd_edm_step")
+
     def sampler_q_start(self, cond01: torch.Tensor, noise_canvas: Optional[torch.Tensor], alpha: float, sigma: float,
                         img: torch.Tensor, seed: int = 0) -> None:
         with torch.cuda.device(self.device):

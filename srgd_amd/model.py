@@ -26,7 +26,7 @@ from ._lib import SamplerGeometry, StepScalars
 from .engine import HipEngine
 
 __all__ = ["get_coord_and_pad", "get_coords", "get_area", "beta_linear_log_snr", "ConditionalSRUnet",
-           "ConditionalContinuousTimeGaussianDiffusionSR", "ModelEma", "get_model"]
+           "ConditionalContinuousTimeGaussianDiffusionSR", "ConditionalElucidatedDiffusionSR", "ModelEma", "get_model"]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -443,6 +443,181 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------
+# EDM (Karras et al.) sampler over the same U-Net (reference model.py:2059-2475)
+# ---------------------------------------------------------------------------------------------
+def _tiling(h: int, w: int, tile_size: int, tile_stride: int):
+    """Canvas + both tile grids of one image (reference model.py:2321-2323, :2360-2371 / :3301-3342)."""
+    (left, top, right, bottom), pad = get_coord_and_pad(h, w)
+    hp, wp = h + pad[2] + pad[3], w + pad[0] + pad[1]
+    if max(pad[0], pad[1]) >= w or max(pad[2], pad[3]) >= h:
+        raise RuntimeError("Padding size should be less than the corresponding input dimension "
+                           f"(reflect pad {pad} of a {h}x{w} image)")
+    coords0 = get_coords(hp, wp, tile_size, tile_size, diff=0)
+    if hp <= tile_size and wp <= tile_size:
+        coords1 = get_coords(hp, wp, tile_size, tile_stride, diff=0)
+    else:
+        coords1 = get_coords(hp - tile_size, wp - tile_size, tile_size, tile_stride, diff=tile_size // 2)
+    inner, _ = get_area(coords1, hp, wp)
+    return (left, top, right, bottom), (hp, wp), coords0, coords1, inner
+
+
+class ConditionalElucidatedDiffusionSR(nn.Module):
+    """``ConditionalElucidatedDiffusionSR`` of the reference (model.py:2059-2128 ctor, :2309-2475 ``tiled_sample``): Heun
+    2nd-order EDM sampling, two U-Net evaluations per step, same tiling as the DDPM wrapper.
+
+    The base class ``denoising_diffusion_pytorch.ElucidatedDiffusion`` (un-vendored, pinned 1.8.15) contributes the
+    rho-schedule and the preconditioning coefficients; they are restated here from the published algorithm
+    (``sample_schedule`` / ``c_in`` / ``c_skip`` / ``c_out`` / ``c_noise``) with torch fp32 ops, and handed to the engine as
+    per-step scalars.  Inference only; ``sample`` / ``sample_using_dpmpp`` / training are not built."""
+
+    def __init__(self, net, *, image_size, channels=3, num_sample_steps=32, sigma_min=0.002, sigma_max=80, sigma_data=0.5,
+                 rho=7, P_mean=-1.2, P_std=1.2, S_churn=80, S_tmin=0.05, S_tmax=50, S_noise=1.003, cond_drop_prob=0.0,
+                 class_cond_drop_prob=0.0, use_dpmpp_solver=False, loss_type="l2"):
+        super().__init__()
+        assert net.random_or_learned_sinusoidal_cond
+        self.self_condition = net.self_condition
+        self.net = net
+        self.channels, self.image_size = channels, image_size
+        self.sigma_min, self.sigma_max, self.sigma_data, self.rho = sigma_min, sigma_max, sigma_data, rho
+        self.P_mean, self.P_std, self.num_sample_steps = P_mean, P_std, num_sample_steps
+        self.S_churn, self.S_tmin, self.S_tmax, self.S_noise = S_churn, S_tmin, S_tmax, S_noise
+        self.cond_drop_prob, self.class_cond_drop_prob = cond_drop_prob, class_cond_drop_prob
+        self.use_dpmpp_solver, self.loss_type = use_dpmpp_solver, loss_type
+        # engine knobs (not part of the reference surface)
+        self.noise_source = "host"
+        self.device_noise_seed = 0
+        self.max_tiles_per_launch = None
+
+    def set_seed(self, seed):
+        torch.cuda.manual_seed(seed)
+        self.device_noise_seed = int(seed)
+
+    @property
+    def device(self):
+        return next(self.net.parameters()).device
+
+    # ---- the base class's published formulas (fp32 torch ops, as the reference evaluates them) ----
+    def c_skip(self, sigma):
+        return (self.sigma_data ** 2) / (sigma ** 2 + self.sigma_data ** 2)
+
+    def c_out(self, sigma):
+        return sigma * self.sigma_data * (self.sigma_data ** 2 + sigma ** 2) ** -0.5
+
+    def c_in(self, sigma):
+        return 1 * (sigma ** 2 + self.sigma_data ** 2) ** -0.5
+
+    def c_noise(self, sigma):
+        return torch.log(sigma.clamp(min=1e-20)) * 0.25
+
+    def sample_schedule(self, num_sample_steps=None):
+        n = self.num_sample_steps if num_sample_steps is None else num_sample_steps
+        inv_rho = 1 / self.rho
+        steps = torch.arange(n, dtype=torch.float32)
+        sigmas = (self.sigma_max ** inv_rho + steps / (n - 1) * (self.sigma_min ** inv_rho - self.sigma_max ** inv_rho)) ** self.rho
+        return torch.nn.functional.pad(sigmas, (0, 1), value=0.0)
+
+    def _step_tables(self, n: int, clamp: bool):
+        from ._lib import EdmScalars
+        sigmas = self.sample_schedule(n)
+        gammas = torch.where((sigmas >= self.S_tmin) & (sigmas <= self.S_tmax),
+                             min(self.S_churn / n, math.sqrt(2) - 1), 0.0)                      # model.py:2333-2337
+        scalars, c_noise = [], []
+        for i in range(n):
+            sigma, sigma_next, gamma = sigmas[i].item(), sigmas[i + 1].item(), gammas[i].item()
+            sigma_hat = sigma + gamma * sigma                                                    # :2388
+            sh, sn = torch.full((1,), sigma_hat), torch.full((1,), sigma_next)                   # :2137 fp32 tensors
+            scalars.append(EdmScalars(
+                s_noise=self.S_noise, hat_coef=math.sqrt(sigma_hat ** 2 - sigma ** 2), sigma_hat=sigma_hat,
+                sigma_next=sigma_next, dt=sigma_next - sigma_hat, half_dt=0.5 * (sigma_next - sigma_hat),
+                c_in_hat=float(self.c_in(sh)), c_skip_hat=float(self.c_skip(sh)), c_out_hat=float(self.c_out(sh)),
+                c_in_next=float(self.c_in(sn)), c_skip_next=float(self.c_skip(sn)), c_out_next=float(self.c_out(sn)),
+                ring_sigma=float(sigmas[i]), clamp=1.0 if clamp else 0.0, pad0=0.0, pad1=0.0))
+            c_noise += [float(self.c_noise(sh)), float(self.c_noise(sn))]
+        return sigmas, scalars, c_noise
+
+    @torch.inference_mode()
+    def tiled_sample(self, batch_size=4, tile_size=256, tile_stride=256, condition_x=None, class_label=None,
+                     cond_scale=1.0, guidance_start_steps=0, class_cond_scale=1.0, class_guidance_start_steps=0,
+                     generation_start_steps=0, num_sample_steps=None, clamp=True, zero_init=False, with_images=False,
+                     with_x0_images=False, start_white_noise=True, amp=False):
+        """Reference model.py:2309-2475 (``start_white_noise`` is accepted and unused there too)."""
+        n = self.num_sample_steps if num_sample_steps is None else num_sample_steps
+        if cond_scale != 1.0 and class_cond_scale != 1.0:
+            raise NotImplementedError("Currently, you cannot specify both cond_scale and class_cond_scale at the same time.")
+        if tile_size != 256 or tile_stride != 256:
+            raise NotImplementedError("tile_size/tile_stride other than 256 are unusable in the reference too "
+                                      "(get_coord_and_pad is called without them, model.py:2321)")
+        dev = self.device
+        if dev.type != "cuda":
+            raise _lib.SrgdHipError("tiled_sample runs on MI355X only (no CPU fallback)")
+        batch, c, h, w = condition_x.shape
+        if batch != 1 or c != 3:
+            raise ValueError("condition_x must be [1,3,H,W] (the reference's tile gather assumes batch 1)")
+        eng = self.net.engine("bf16" if amp else "fp32")
+        class_id = -1 if class_label is None else int(class_label.reshape(-1)[0])
+        (left, top, right, bottom), (hp, wp), coords0, coords1, (sl, st_, sr, sb) = _tiling(h, w, tile_size, tile_stride)
+        geo = SamplerGeometry(H=h, W=w, Hp=hp, Wp=wp, left=left, top=top, inner_l=sl, inner_t=st_, inner_r=sr,
+                              inner_b=sb, tile=tile_size, n_even=len(coords0), n_odd=len(coords1), n_images=1)
+        sigmas, scalars, c_noise = self._step_tables(n, clamp)
+        cond01 = condition_x.to(dev, torch.float32).contiguous()
+        cond_canvas = torch.empty(1, 3, hp, wp, device=dev, dtype=torch.float32)
+        eng.edm_begin(geo, cond01, cond_canvas, [(a, c_) for (a, _, c_, _) in coords0],
+                      [(a, c_) for (a, _, c_, _) in coords1], scalars, c_noise, class_id)
+        host_noise = self.noise_source == "host"
+        seed = self.device_noise_seed
+
+        def canvas_noise(stream_id):
+            if host_noise:
+                return torch.randn(1, 3, hp, wp).to(dev, non_blocking=True)
+            return eng.randn_(torch.empty(1, 3, hp, wp, device=dev), seed, stream_id)
+
+        if generation_start_steps > 0:                                  # get_noised_images(condition, step) :2340, :2185
+            img = torch.empty(1, 3, hp, wp, device=dev)
+            eng.sampler_q_start(cond01, canvas_noise(1), 1.0, float(sigmas[generation_start_steps]), img, seed)
+        elif zero_init:
+            img = torch.zeros(1, 3, hp, wp, device=dev)
+        else:
+            img = canvas_noise(1) * float(sigmas[0])                    # :2346 (a tensor * tensor product upstream)
+        x_start = img.clone() if with_x0_images else None
+        image_list = [img[:, :, top:bottom, left:right].clone().cpu()] if with_images else None
+        x0_image_list = [img[:, :, top:bottom, left:right].clone().cpu()] if with_x0_images else None
+        work = torch.empty(2, 3, hp, wp, device=dev, dtype=torch.float32)
+        sub_batch = self.max_tiles_per_launch or batch_size
+        for i in range(n):
+            if i < generation_start_steps:
+                continue
+            cur_cond_scale = 1.0 if i < guidance_start_steps else cond_scale
+            cur_class_scale = 1.0 if i < class_guidance_start_steps else class_cond_scale
+            if cur_cond_scale != 1.0:
+                passes, kind, scale = 2, 2, cur_cond_scale
+            elif cur_class_scale != 1.0:
+                passes, kind, scale = 2, 1, cur_class_scale
+            else:
+                passes, kind, scale = 1, 0, 1.0
+            z = canvas_noise(None) if host_noise else None              # eps of the step (:2386), before the ring draw
+            ring = canvas_noise(None) if (host_noise and i % 2 == 1) else None
+            eng.edm_step(i, img, cond_canvas, x_start, work, z, ring, passes, kind, scale, sub_batch, seed=seed)
+            if with_images:
+                image_list.append(img.clone().cpu())
+            if with_x0_images:
+                x0_image_list.append(x_start.clone().cpu())
+        out = torch.empty(1, 3, h, w, device=dev, dtype=torch.float32)
+        eng.sampler_end(img, out)
+        if with_images:
+            return (out, image_list, x0_image_list) if with_x0_images else (out, image_list)
+        return out
+
+    def sample(self, *args, **kwargs):
+        raise NotImplementedError("un-tiled EDM sampling (model.py:2196) is not on the shipped inference path; use tiled_sample")
+
+    def sample_using_dpmpp(self, *args, **kwargs):
+        raise NotImplementedError("the DPM++ solver variant (model.py:2478) is not built")
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("training is not part of the inference-only release this engine mirrors")
+
+
+# ---------------------------------------------------------------------------------------------
 # factory (reference model.py:3500-3666)
 # ---------------------------------------------------------------------------------------------
 class ModelEma(nn.Module):
@@ -467,10 +642,11 @@ def _parse_bool_list(text: str) -> Tuple[bool, ...]:
 def get_model(conf, logger):
     dim_mults = tuple(int(t) for t in conf.ddpm_unet_dim_mults.split(","))
     full_attn = _parse_bool_list(conf.full_attn)
-    if conf.model != "conditional_continuous":
+    if conf.model not in ("conditional_continuous", "conditional_elucidated"):
         raise NotImplementedError(
-            f"model={conf.model!r}: this engine accelerates the shipped 'conditional_continuous' path only "
-            "(SURVEY.md section 8; the other wrappers have no released config or weights)")
+            f"model={conf.model!r}: this engine covers the shipped 'conditional_continuous' path and the "
+            "'conditional_elucidated' (EDM) sampler over the same U-Net (SURVEY.md section 8; the other wrappers have "
+            "no released config or weights)")
     unet = ConditionalSRUnet(dim=conf.unet_dim, dim_mults=dim_mults, full_attn=full_attn,
                              learned_variance=conf.learned_variance,
                              learned_sinusoidal_cond=conf.learned_sinusoidal_cond,
@@ -479,6 +655,21 @@ def get_model(conf, logger):
     logger.info(f"ConditionalSRUnet: channels=6 dim={conf.unet_dim} dim_mults={conf.ddpm_unet_dim_mults} "
                 f"num_classes={conf.num_classes}")
     assert conf.learned_sinusoidal_cond
+    if conf.model == "conditional_elucidated":                          # reference model.py:3593-3614
+        model = ConditionalElucidatedDiffusionSR(
+            net=unet, image_size=conf.image_size, num_sample_steps=conf.num_sample_steps, sigma_min=conf.sigma_min,
+            sigma_max=conf.sigma_max, sigma_data=conf.sigma_data, rho=conf.rho, P_mean=conf.P_mean, P_std=conf.P_std,
+            S_churn=conf.S_churn, S_tmin=conf.S_tmin, S_tmax=conf.S_tmax, S_noise=conf.S_noise,
+            cond_drop_prob=conf.cond_drop_prob, class_cond_drop_prob=conf.class_cond_drop_prob,
+            use_dpmpp_solver=conf.use_dpmpp_solver, loss_type=conf.loss_type)
+        logger.info(f"ConditionalElucidatedDiffusionSR: image_size={conf.image_size} num_sample_steps={conf.num_sample_steps}")
+        ema_model = ModelEma(model, decay=conf.ema_decay)
+        if conf.ckpt_path:
+            ckpt = torch.load(conf.ckpt_path, map_location="cpu", weights_only=True)
+            check = ema_model.module.load_state_dict(ckpt["ema_model"], strict=conf.load_strict)
+            logger.info(f"load ema_model weight from : {conf.ckpt_path}")
+            logger.info(f"check: {check}")
+        return ema_model
     conf.use_dpmpp_solver = False
     model = ConditionalContinuousTimeGaussianDiffusionSR(
         unet, image_size=conf.image_size, noise_schedule=conf.noise_schedule,

@@ -39,6 +39,27 @@ SAMPLER_CASES = [
 ]
 
 
+# EDM sampler (ConditionalElucidatedDiffusionSR.tiled_sample, model.py:2309-2475) over the same U-Net; fixture files
+# sample_edm_<name>.npz hold the reference's outputs (its un-vendored base class restated in oracle/refshim.py)
+EDM_CASES = [
+    dict(name="dim16_256", dim=16, h=256, w=256, steps=6, batch_size=4, label=0, cond_scale=1.0, class_cond_scale=1.0,
+         weight_seed=0, cond="rand", cond_seed=1234, seed=71),
+    dict(name="dim16_256_cfg2", dim=16, h=256, w=256, steps=6, batch_size=4, label=0, cond_scale=1.0, class_cond_scale=2.0,
+         weight_seed=0, cond="rand", cond_seed=1234, seed=71),
+    dict(name="dim16_300x500", dim=16, h=300, w=500, steps=4, batch_size=4, label=2, cond_scale=1.0, class_cond_scale=1.0,
+         weight_seed=0, cond="rand", cond_seed=1235, seed=71),
+    dict(name="dim16_256_genstart_lrcfg", dim=16, h=256, w=256, steps=8, batch_size=4, label=1, cond_scale=1.5,
+         class_cond_scale=1.0, weight_seed=0, cond="rand", cond_seed=1236, seed=71, generation_start_steps=2),
+    dict(name="dim16_300x300_zeroinit_noclamp", dim=16, h=300, w=300, steps=3, batch_size=8, label=0, cond_scale=1.0,
+         class_cond_scale=1.0, weight_seed=0, cond="rand", cond_seed=1237, seed=71, zero_init=True, clamp=False),
+]
+
+
+def edm_extra_kwargs(case):
+    keys = ("generation_start_steps", "class_guidance_start_steps", "guidance_start_steps", "zero_init", "clamp")
+    return {k: case[k] for k in keys if k in case}
+
+
 def unet_inputs(case):
     g = torch.Generator().manual_seed(case["input_seed"])
     b, hw = case["batch"], case["hw"]

@@ -136,3 +136,28 @@ def test_pil_bicubic_restatement_is_bit_exact():
     assert np.array_equal(to_unit_chw(u), torch.from_numpy(u).permute(2, 0, 1).float().div(255).numpy())
     f = torch.rand(3, 6, 5)
     assert np.array_equal(to_u8_hwc(f.numpy()), f.mul(255).byte().permute(1, 2, 0).numpy())
+
+
+def _edm_state_dict(dim, seed):
+    """The EDM wrapper names its U-Net ``net`` (model.py:2099): same tensors, prefix ``net.`` instead of ``model.``."""
+    schema = {"net." + k[len("model."):]: v for k, v in _schema(dim).items()}
+    return synth_state_dict(schema, seed=seed)
+
+
+@pytest.mark.parametrize("case", C.EDM_CASES, ids=lambda c: c["name"])
+def test_edm_tiled_sample_matches_reference(case):
+    z = np.load(os.path.join(G, f"sample_edm_{case['name']}.npz"))
+    sd = _edm_state_dict(case["dim"], case["weight_seed"])
+    assert abs(sum(v.double().abs().sum().item() for v in sd.values()) - float(z["w_sum"])) < 1e-6
+    usd = {k[len("net."):]: v for k, v in sd.items()}
+    cond = C.sampler_condition(case)
+    assert abs(cond.double().sum().item() - float(z["cond_sum"])) < 1e-6
+    label = torch.tensor([case["label"]]) if case["label"] is not None else None
+    torch.manual_seed(case["seed"])
+    with torch.inference_mode():
+        got = O.edm_tiled_sample(usd, O.UnetCfg(dim=case["dim"]), O.EdmCfg(), cond, label, batch_size=case["batch_size"],
+                                 num_sample_steps=case["steps"], cond_scale=case["cond_scale"],
+                                 class_cond_scale=case["class_cond_scale"], **C.edm_extra_kwargs(case))
+    want = z["image"]
+    assert got.shape == want.shape
+    assert np.abs(got.numpy() - want).max() <= 1e-4
