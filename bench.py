@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 TFLOP_PER_HR_TILE = 813.6          # BASELINE.md section 3 (1,025 tile-forwards x 793.8 GFLOP)
 TILE_FORWARDS_PER_HR_TILE = 1025
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16_w8": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
 
 
 def parse():
@@ -49,7 +49,11 @@ def parse():
                     help="tiles: BASELINE configs[1] units, images sharded over ranks (weak scaling, the headline); "
                          "canvas: ONE --lr_size^2 image per step whose tiles are sharded over all ranks with a per-step "
                          "tile all-gather (configs[3] with --lr_size 2048; strong scaling, secondary)")
-    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp32", "bf16_w8"], default="bf16",
+                    help="bf16_w8: bf16 kernels with fp8-e4m3-rounded conv weights (BASELINE configs[4] numerics)")
+    ap.add_argument("--class_cond_scale", type=float, default=1.0,
+                    help="!= 1: class guidance, two U-Net passes per step batched into one launch (configs[4] uses 2.0 "
+                         "with --ddpm_steps 100); the headline metric is quoted at 1.0")
     ap.add_argument("--ddpm_steps", type=int, default=50)
     ap.add_argument("--lr_size", type=int, default=256)
     ap.add_argument("--sub_batch", type=int, default=0, help="tiles per U-Net launch (0: all tiles of a lock-step group)")
@@ -121,7 +125,8 @@ def main():
     from srgd_amd.synth import synthetic_lr_condition
     sampler, sd = build_sampler(args.dim, device, world, rank)
     sampler.noise_source = "device"
-    amp = args.precision == "bf16"
+    amp = args.precision != "fp32"
+    sampler.amp_precision = args.precision if amp else None
     label = torch.tensor([0], device=device)
     total = args.warmup + args.steps
     # inputs resident in HBM before the clock starts (already x4-upsampled condition images)
@@ -144,7 +149,8 @@ def main():
             sampler.device_noise_seed = 71
             res.append(sampler.tiled_sample(batch_size=args.sub_batch or min(125, n_even * (b - a)),
                                             condition_x=torch.cat(conds[a:b], 0), class_label=label,
-                                            class_cond_scale=1.0, num_sample_steps=args.ddpm_steps, amp=amp))
+                                            class_cond_scale=args.class_cond_scale, num_sample_steps=args.ddpm_steps,
+                                            amp=amp))
         return res
 
     run(0, args.warmup)
@@ -193,8 +199,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (seeded LR images, seeded weights with the reference state_dict schema)",
-            "config": {"workload": f"BASELINE configs[1]: one {args.lr_size}x{args.lr_size} LR tile x4 SR per step, "
-                                   f"{args.ddpm_steps} DDPM steps, class_cond_scale=1.0, dim-{args.dim} U-Net, "
+            "config": {"workload": f"{'BASELINE configs[1]' if (args.ddpm_steps == 50 and args.class_cond_scale == 1.0 and args.lr_size == 256 and args.precision == 'bf16') else 'BASELINE configs[4] (fp8-rounded weights on bf16 kernels)' if args.precision == 'bf16_w8' else 'variant'}: one {args.lr_size}x{args.lr_size} LR tile x4 SR per step, "
+                                   f"{args.ddpm_steps} DDPM steps, class_cond_scale={args.class_cond_scale}, dim-{args.dim} U-Net, "
                                    f"{args.precision}, device Philox noise; {min(args.images, args.steps)} steps "
                                    f"(HR tiles) advance in lock-step so their U-Net tiles share launches",
                        "images_in_lockstep": min(args.images, args.steps),
@@ -203,7 +209,15 @@ def main():
                        "parallelism": f"image-sharded x{world}"},
             "tflops_effective": value * TFLOP_PER_HR_TILE,
         }
-        if not args.no_profile and args.lr_size == 256 and args.ddpm_steps == 50 and args.dim == 128:
+        headline = args.lr_size == 256 and args.ddpm_steps == 50 and args.dim == 128 and args.class_cond_scale == 1.0
+        if not headline:
+            passes = 1 if args.class_cond_scale == 1.0 else 2
+            line["metric"] = (f"HR tiles/sec ({args.lr_size}->{4 * args.lr_size} x4, {args.ddpm_steps} steps, "
+                              f"CFG={args.class_cond_scale})")
+            line["config"]["tile_forwards_per_step"] = None
+            line["config"]["unet_passes_per_ddpm_step"] = passes
+            line.pop("tflops_effective", None)
+        if not args.no_profile and headline:
             eng = sampler.model.engine(args.precision)
             eng.profile_begin()
             run(args.warmup, args.warmup + min(args.images, args.steps))

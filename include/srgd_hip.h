@@ -26,6 +26,11 @@ typedef struct srgd_engine srgd_engine;
 #define SRGD_MAX_STAGES 8
 #define SRGD_PRECISION_FP32 0 /* fp32 activations, exact-fp32 MFMA: parity mode (<=1e-3 vs reference) */
 #define SRGD_PRECISION_BF16 1 /* bf16 activations/weights, fp32 accumulate: throughput mode */
+#define SRGD_PRECISION_BF16_W8 2 /* BF16 mode with every convolution weight (3x3, 1x1, attention to_qkv / to_out, resamplers,
+                                  * input / output conv) rounded through fp8 e4m3 with one scale per output channel
+                                  * (max|w| -> 448) when the weights are packed: the NUMERICS of fp8 weights (BASELINE
+                                  * configs[4]'s parity-vs-bf16 check) on the bf16 MFMA kernels; the MX-fp8 MFMA compute
+                                  * path is not built */
 
 /* Constructor arguments of ConditionalSRUnet (model.py:537-556) as get_model passes them
  * (model.py:3504-3514).  Unsupported combinations are rejected by srgd_create. */
@@ -164,6 +169,10 @@ int srgd_edm_begin(srgd_engine* e, const srgd_sampler_geometry* g, const float* 
 int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start, float* work,
                   const float* noise_canvas, const float* ring_noise_canvas, int passes, int guidance_kind,
                   float guidance_scale, int sub_batch, uint64_t seed, void* stream);
+
+/* Host helper (no GPU): out[i] = e4m3(in[i] / scale) * scale, round-to-nearest-even, saturating at +-448 (the OCP
+ * "fn" variant torch.float8_e4m3fn implements) - the weight rounding of SRGD_PRECISION_BF16_W8, exposed for tests. */
+int srgd_quantize_e4m3(const float* in, float* out, size_t n, float scale);
 
 /* ---- image front / back end (reference inference.py:66-73, :93) ------------------------------------------------
  * Bicubic resize of an 8-bit RGB image, bit-exact with Pillow's Image.resize((out_w, out_h), BICUBIC) - what

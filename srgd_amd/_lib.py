@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("SRGD_HIP_LIB") or os.path.join(_HERE, "libsrgd_hip.so
 MAX_STAGES = 8
 PRECISION_FP32 = 0
 PRECISION_BF16 = 1
+PRECISION_BF16_W8 = 2    # bf16 kernels, conv weights rounded through fp8 e4m3 (per-output-channel scale)
 
 
 class UnetConfig(C.Structure):
@@ -74,6 +75,7 @@ PROTOTYPES = {
     "srgd_sampler_q_start": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_uint64,
                                        C.c_void_p]),
     "srgd_sampler_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srgd_quantize_e4m3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float]),
     "srgd_image_resize_bicubic_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "srgd_image_unit_to_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "srgd_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_void_p]),

@@ -18,6 +18,23 @@ static thread_local std::string g_err;
 void set_error(const std::string& m) { g_err = m; }
 const char* last_error() { return g_err.c_str(); }
 
+// float -> OCP fp8 e4m3 "fn" (4 exponent bits, bias 7, 3 mantissa bits, max 448, no infinity) -> float,
+// round-to-nearest-even, saturating.  Subnormals of the format (multiples of 2^-9) are kept.
+float round_through_e4m3(float x) {
+  if (std::isnan(x)) return x;
+  const float ax = std::fabs(x);
+  if (ax >= 464.0f) return std::copysign(448.0f, x);        // halfway between 448 and the (absent) next value 480
+  if (ax < 0x1p-10f) return std::copysign(0.0f, x);          // below half of the smallest subnormal 2^-9
+  int ex;
+  (void)std::frexp(ax, &ex);                                 // ax = m * 2^ex, m in [0.5, 1)
+  int e = ex - 1;                                            // exponent of the leading bit
+  if (e < -6) e = -6;                                        // subnormal range shares the quantum of 2^-6
+  const float quantum = std::ldexp(1.0f, e - 3);             // 3 mantissa bits
+  float q = std::nearbyint(ax / quantum) * quantum;          // default rounding mode: nearest even
+  if (q > 448.0f) q = 448.0f;
+  return std::copysign(q, x);
+}
+
 unsigned short f32_to_bf16_host(float f) {
   uint32_t u;
   std::memcpy(&u, &f, 4);
@@ -209,6 +226,7 @@ struct srgd_engine {
   // conv3x3_bf16 can apply the producer's GroupNorm+SiLU while staging its input (GNIN).  Measured on MI355X it
   // LOSES: the 16 transcendentals per 16-byte chunk sit on the barrier-paced critical path of an MFMA-bound kernel
   // (+0.137 s of conv vs -0.055 s of gn_apply per HR tile), so it is off; kept for a staggered-schedule retry.
+  bool w8 = false;            // SRGD_PRECISION_BF16_W8: conv weights rounded through fp8 e4m3 (per-output-channel scale)
   bool no_gn_fusion = true;
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
 
@@ -328,7 +346,8 @@ int build_topology(srgd_engine* e) {
   if (c.sinus_dim < 2 || c.sinus_dim % 2) SRGD_FAIL("learned_sinusoidal_dim must be even");
   if (c.dim % 16 != 0) SRGD_FAIL("unet_dim must be a multiple of 16");
   if (c.groups < 1 || c.dim % c.groups != 0) SRGD_FAIL("unet_dim must be divisible by resnet_block_groups");
-  e->bf16 = c.precision == SRGD_PRECISION_BF16;
+  e->bf16 = c.precision == SRGD_PRECISION_BF16 || c.precision == SRGD_PRECISION_BF16_W8;
+  e->w8 = c.precision == SRGD_PRECISION_BF16_W8;
   e->es = e->bf16 ? 2 : 4;
   e->dim = c.dim; e->time_dim = 4 * c.dim; e->hid = c.heads * c.dim_head; e->n_stages = c.n_stages;
   e->dims.push_back(c.dim);
@@ -821,6 +840,21 @@ int srgd_finalize_weights(srgd_engine* e) {
     if (!t.loaded) missing += (missing.empty() ? "" : ", ") + t.name;
   if (!missing.empty()) SRGD_FAIL("Missing key(s) in state_dict: " + missing);
   SRGD_HIP(hipSetDevice(e->cfg.device));
+  if (e->w8) {
+    // every convolution weight [O, I, kh, kw] (RMSNorm gains are [1, C, 1, 1] and stay), one scale per output channel
+    for (auto& t : e->wt) {
+      if (t.shape.size() != 4 || t.shape[0] <= 1) continue;
+      const size_t per = t.numel() / (size_t)t.shape[0];
+      for (int64_t o = 0; o < t.shape[0]; ++o) {
+        float* w = t.data.data() + (size_t)o * per;
+        float amax = 0.f;
+        for (size_t i = 0; i < per; ++i) amax = std::max(amax, std::fabs(w[i]));
+        if (amax == 0.f) continue;
+        const float scale = amax / 448.0f;
+        for (size_t i = 0; i < per; ++i) w[i] = round_through_e4m3(w[i] / scale) * scale;
+      }
+    }
+  }
   // 7x7 input conv: OIHW [dim,6,7,7] -> 7 taps (dy) x 64 virtual channels (dx*8 + ci), see kernels.hpp
   {
     const std::vector<float>& s = e->wt[e->init_wi].data;
@@ -1286,6 +1320,13 @@ int srgd_profile_end(srgd_engine* e, double* ms, int64_t* launches, double* flop
     e->ev_free.push_back(r.a); e->ev_free.push_back(r.b);
   }
   e->prof.clear();
+  return 0;
+}
+
+int srgd_quantize_e4m3(const float* in, float* out, size_t n, float scale) {
+  if (!in || !out) SRGD_FAIL("srgd_quantize_e4m3: null argument");
+  if (!(scale > 0.f)) SRGD_FAIL("srgd_quantize_e4m3: scale must be positive");
+  for (size_t i = 0; i < n; ++i) out[i] = round_through_e4m3(in[i] / scale) * scale;
   return 0;
 }
 

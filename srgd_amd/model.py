@@ -314,6 +314,7 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
         self.noise_source = "host"     # "host": torch CPU generator in the reference's draw order; "device": Philox
         self.device_noise_seed = 0
         self.max_tiles_per_launch = None   # None: use the caller's batch_size as the reference does
+        self.amp_precision = None          # engine mode behind amp=True: None = "bf16"; "bf16_w8" = fp8-e4m3 conv weights
         # set by srgd_amd.parallel.shard_canvas: a torch.distributed group whose ranks share ONE canvas - each rank
         # runs a contiguous slice of every step's tiles and the updated tiles are all-gathered
         self.canvas_group = None
@@ -353,7 +354,7 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
             raise ValueError("condition_x must be [B,3,H,W] (B=1 in the reference, whose tile gather assumes batch 1)")
         f = self.model.downsample_factor
         assert tile_size % f == 0, f"your input dimensions need to be divisible by {f}, given the unet"
-        eng = self.model.engine("bf16" if amp else "fp32")
+        eng = self.model.engine((self.amp_precision or "bf16") if amp else "fp32")
         class_id = -1 if class_label is None else int(class_label.reshape(-1)[0])
 
         (left, top, right, bottom), pad = get_coord_and_pad(h, w)
@@ -487,6 +488,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         self.noise_source = "host"
         self.device_noise_seed = 0
         self.max_tiles_per_launch = None
+        self.amp_precision = None
 
     def set_seed(self, seed):
         torch.cuda.manual_seed(seed)
@@ -553,7 +555,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         batch, c, h, w = condition_x.shape
         if batch != 1 or c != 3:
             raise ValueError("condition_x must be [1,3,H,W] (the reference's tile gather assumes batch 1)")
-        eng = self.net.engine("bf16" if amp else "fp32")
+        eng = self.net.engine((self.amp_precision or "bf16") if amp else "fp32")
         class_id = -1 if class_label is None else int(class_label.reshape(-1)[0])
         (left, top, right, bottom), (hp, wp), coords0, coords1, (sl, st_, sr, sb) = _tiling(h, w, tile_size, tile_stride)
         geo = SamplerGeometry(H=h, W=w, Hp=hp, Wp=wp, left=left, top=top, inner_l=sl, inner_t=st_, inner_r=sr,

@@ -39,6 +39,14 @@ SAMPLER_CASES = [
 ]
 
 
+# BASELINE configs[4] at config-1 geometry: 100 DDPM steps, class_cond_scale = 2.0 (two passes), dim-128 U-Net, one 256^2
+# tile.  200 CPU U-Net forwards: generated once by make_golden.py --config5-only; used by the GPU tests only (fp32 parity
+# gate + bf16 and fp8-weight reports), the CPU suite skips it for time.
+LONG_CASES = [
+    dict(name="dim128_config5_256", dim=128, h=256, w=256, steps=100, batch_size=8, label=0, cond_scale=1.0,
+         class_cond_scale=2.0, weight_seed=0, cond="lr_bicubic", cond_seed=1234, seed=71),
+]
+
 # EDM sampler (ConditionalElucidatedDiffusionSR.tiled_sample, model.py:2309-2475) over the same U-Net; fixture files
 # sample_edm_<name>.npz hold the reference's outputs (its un-vendored base class restated in oracle/refshim.py)
 EDM_CASES = [

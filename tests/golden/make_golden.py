@@ -130,8 +130,33 @@ def make_edm():
         print("edm", case["name"], "done", tuple(img.shape), float(img.mean()))
 
 
+def make_long():
+    ref = refshim.load_reference()
+    assert ref is not None, "reference not present"
+    rm, rc = ref
+    torch.set_num_threads(8)
+    for case in C.LONG_CASES:
+        sampler, _ = refshim.build_reference_sampler(rm, rc, dim=case["dim"], num_sample_steps=case["steps"])
+        schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+        sd = synth_state_dict(schema, seed=case["weight_seed"])
+        sampler.load_state_dict(sd, strict=True)
+        cond = C.sampler_condition(case)
+        label = torch.tensor([case["label"]])
+        torch.manual_seed(case["seed"])
+        with torch.inference_mode():
+            img = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond.clone(), class_label=label,
+                                       cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
+                                       num_sample_steps=case["steps"])
+        np.savez_compressed(os.path.join(HERE, f"sample_{case['name']}.npz"), image=img.numpy(),
+                            cond_sum=np.float64(cond.double().sum().item()),
+                            w_sum=np.float64(sum(v.double().abs().sum().item() for v in sd.values())))
+        print("long", case["name"], "done", tuple(img.shape), float(img.mean()))
+
+
 if __name__ == "__main__":
-    if "--edm-only" in sys.argv:
+    if "--config5-only" in sys.argv:
+        make_long()
+    elif "--edm-only" in sys.argv:
         make_edm()
     else:
         main()

@@ -411,3 +411,37 @@ def test_edm_bf16_and_device_noise_modes_run():
         assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
     finally:
         sampler.noise_source = "host"
+
+
+def test_config5_cfg2_100_steps_fp32_parity_and_bf16_fp8_weight_reports():
+    # BASELINE configs[4] at one-tile geometry: 100 DDPM steps, class_cond_scale 2.0 (both passes in one launch),
+    # dim-128 U-Net.  fp32 engine gated at the north-star bar against the reference's own output; bf16 and the
+    # fp8-e4m3-weight mode (bf16 kernels, weights rounded through e4m3 per output channel) are reported against it
+    # and against each other ("parity-vs-bf16 check").
+    case = C.LONG_CASES[0]
+    z = np.load(os.path.join(G, f"sample_{case['name']}.npz"))
+    want = torch.from_numpy(z["image"])
+    sampler = build_sampler(case["dim"], weight_seed=case["weight_seed"])
+    cond = C.sampler_condition(case).cuda()
+    assert abs(cond.double().sum().item() - float(z["cond_sum"])) < 1e-6
+    label = torch.tensor([case["label"]]).cuda()
+    outs = {}
+    try:
+        for mode, amp, prec in (("fp32", False, None), ("bf16", True, None), ("bf16_w8", True, "bf16_w8")):
+            sampler.amp_precision = prec
+            torch.manual_seed(case["seed"])
+            outs[mode] = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label,
+                                              class_cond_scale=case["class_cond_scale"], num_sample_steps=case["steps"],
+                                              amp=amp).cpu()
+    finally:
+        sampler.amp_precision = None
+    psnr = lambda a, b: float(10 * np.log10(1.0 / max(float(((a - b) ** 2).mean()), 1e-20)))
+    err32 = (outs["fp32"] - want).abs().max().item()
+    _report(test="config5_256", fp32_max_abs=err32, bf16_psnr_vs_ref=psnr(outs["bf16"], want),
+            w8_psnr_vs_ref=psnr(outs["bf16_w8"], want), w8_psnr_vs_bf16=psnr(outs["bf16_w8"], outs["bf16"]),
+            w8_max_abs_vs_bf16=(outs["bf16_w8"] - outs["bf16"]).abs().max().item())
+    assert err32 <= 1e-3, err32
+    for k in ("bf16", "bf16_w8"):
+        assert torch.isfinite(outs[k]).all() and outs[k].min() >= 0 and outs[k].max() <= 1
+    assert not torch.equal(outs["bf16"], outs["bf16_w8"])
+    assert psnr(outs["bf16_w8"], outs["bf16"]) > 15.0

@@ -154,3 +154,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_e4m3_weight_rounding_matches_torch_float8():
+    # the fp8-weight mode (SRGD_PRECISION_BF16_W8) rounds weights on the host; the rounding must be OCP e4m3 "fn"
+    # round-to-nearest-even exactly as torch.float8_e4m3fn does it (saturating at 448 instead of NaN beyond)
+    import ctypes as C
+    from srgd_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(50000, generator=g) * s for s in (1e-3, 0.1, 1.0, 30.0, 300.0)] +
+                  [torch.tensor([0.0, -0.0, 448.0, 449.0, 463.9, 464.0, 500.0, -1000.0, 2.0 ** -9, 2.0 ** -10,
+                                 1.5 * 2.0 ** -10, 0.99 * 2.0 ** -10, 0.0175, 0.017578125])]).contiguous()
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().srgd_quantize_e4m3(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), x.numel(), 1.0), "quantize")
+    assert torch.equal(out, x.clamp(-448, 448).to(torch.float8_e4m3fn).float())
+    # per-channel scale: result is scale * e4m3(x / scale)
+    _lib.check(_lib.lib().srgd_quantize_e4m3(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), x.numel(), 0.37), "quantize")
+    assert torch.equal(out, (x / 0.37).clamp(-448, 448).to(torch.float8_e4m3fn).float() * 0.37)
