@@ -364,6 +364,9 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
         *reinterpret_cast<bf16x4*>(sT + swz(pr1, c >> 3) + (c & 7) * 2) = w1;
       }
     }
+    // the next tile's DMA (issued at the top of this iteration) has had the whole tile's compute to land; the stores
+    // below are NOT waited for here - they drain during the next iteration and retire at its vmcnt(0)
+    LA_WAIT_VM0();
     LA_SYNC();
     // y = staged RMSNorm(o) * g2 + x, whole 256-byte rows, 16 B per lane
 #pragma unroll
@@ -379,8 +382,7 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
         *reinterpret_cast<bf16x8*>(p.y + ((size_t)b * p.N + px0 + row) * 128 + c16 * 8) = yv;
       }
     }
-    LA_WAIT_VM0();
-    LA_SYNC();
+    LA_SYNC();                                             // every wave has read the x / output tiles from LDS
   }
 }
 
