@@ -247,7 +247,7 @@ def main():
             tot = sum(prof["ms"].values())
             line["kernel_time_share"] = {k: round(v / tot, 4) for k, v in prof["ms"].items() if v > 0}
             line["profiled_pass_ms"] = tot
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported once, at N = 1 (the other ranks would idle behind it)
             line["cpu_baseline"] = cpu_baseline(sd, args.dim, args.cpu_tile_forwards)
         print(json.dumps(line), flush=True)
     if dist:
