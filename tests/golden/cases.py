@@ -39,6 +39,32 @@ SAMPLER_CASES = [
 ]
 
 
+# G3: outputs of the reference's own sub-modules (dim 16 U-Net, seeded weights) on seeded inputs - pins each oracle
+# building block separately (tests/golden/modules_dim16.npz).  name -> (module path inside the U-Net, input shape)
+MODULE_DIM = 16
+MODULE_CASES = {
+    "resnet_same": ("downs.0.0", (2, 16, 32, 32)),          # ResnetBlock without res_conv
+    "resnet_concat": ("ups.0.0", (2, 128 + 64, 16, 16)),     # ResnetBlock with res_conv (skip concat widths)
+    "linear_attention": ("downs.0.2", (2, 16, 32, 32)),
+    "full_attention": ("downs.3.2", (2, 64, 16, 16)),
+    "mid_attention": ("mid_attn", (1, 128, 8, 8)),
+    "downsample": ("downs.0.3", (2, 16, 32, 32)),
+    "last_down_conv3x3": ("downs.3.3", (1, 64, 16, 16)),
+    "pixel_shuffle_up": ("ups.0.3", (2, 128, 8, 8)),
+    "rms_norm": ("downs.0.2.norm", (2, 16, 8, 8)),
+}
+
+
+def module_input(name):
+    g = torch.Generator().manual_seed(4000 + sorted(MODULE_CASES).index(name))
+    return torch.randn(*MODULE_CASES[name][1], generator=g)
+
+
+def module_time_embedding():
+    g = torch.Generator().manual_seed(3999)
+    return torch.randn(2, MODULE_DIM * 4, generator=g)
+
+
 # BASELINE configs[4] at config-1 geometry: 100 DDPM steps, class_cond_scale = 2.0 (two passes), dim-128 U-Net, one 256^2
 # tile.  200 CPU U-Net forwards: generated once by make_golden.py --config5-only; used by the GPU tests only (fp32 parity
 # gate + bf16 and fp8-weight reports), the CPU suite skips it for time.

@@ -130,6 +130,31 @@ def make_edm():
         print("edm", case["name"], "done", tuple(img.shape), float(img.mean()))
 
 
+def make_modules():
+    """G3: per-module outputs of the reference U-Net's own sub-modules."""
+    ref = refshim.load_reference()
+    assert ref is not None, "reference not present"
+    rm, rc = ref
+    torch.set_num_threads(8)
+    sampler, _ = refshim.build_reference_sampler(rm, rc, dim=C.MODULE_DIM)
+    schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+    sampler.load_state_dict(synth_state_dict(schema, seed=0), strict=True)
+    unet = sampler.model
+    out = {}
+    t = C.module_time_embedding()
+    with torch.inference_mode():
+        for name, (path, _) in C.MODULE_CASES.items():
+            mod = unet.get_submodule(path)
+            x = C.module_input(name)
+            y = mod(x, t[:x.shape[0]]) if name.startswith("resnet") else mod(x)
+            out[name] = y.numpy()
+        ls = torch.tensor([-3.0, 2.5])
+        out["time_mlp"] = unet.time_mlp(ls).numpy()
+        out["class_mlp"] = unet.class_mlp(torch.tensor([1])).numpy()
+    np.savez_compressed(os.path.join(HERE, f"modules_dim{C.MODULE_DIM}.npz"), **out)
+    print("modules done", {k: v.shape for k, v in out.items()})
+
+
 def make_long():
     ref = refshim.load_reference()
     assert ref is not None, "reference not present"
@@ -154,10 +179,13 @@ def make_long():
 
 
 if __name__ == "__main__":
-    if "--config5-only" in sys.argv:
+    if "--modules-only" in sys.argv:
+        make_modules()
+    elif "--config5-only" in sys.argv:
         make_long()
     elif "--edm-only" in sys.argv:
         make_edm()
     else:
         main()
         make_edm()
+        make_modules()

@@ -402,3 +402,62 @@ def test_conv1x1_production_shape_agrees_with_generic():
     fast, _ = run_conv(x0, x1, w, b, impl=3, **kw)
     generic, _ = run_conv(x0, x1, w, b, impl=1, **kw)
     assert (fast - generic).abs().max() <= tol(True, generic, k=2.0)
+
+
+# ------------------------------------------------------------------ kernels vs the reference's own sub-modules (G3 fixtures)
+def test_kernel_chains_match_reference_submodules_fp32():
+    # tests/golden/modules_dim16.npz holds outputs of the REFERENCE nn.Modules (dim-16 U-Net, seeded weights); here the HIP
+    # kernels, driven one by one through the kernel-level C ABI in fp32 mode, must reproduce them.
+    import json
+    import os
+    from srgd_amd.synth import synth_state_dict
+    from tests.golden import cases as GC
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(gdir, f"modules_dim{GC.MODULE_DIM}.npz"))
+    with open(os.path.join(gdir, f"schema_dim{GC.MODULE_DIM}.json")) as f:
+        schema = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = O.strip_model_prefix(synth_state_dict(schema, seed=0))
+    lib = L().lib()
+
+    def check(name, got, k=1.0):
+        want = torch.from_numpy(z[name])
+        assert got.shape == want.shape, name
+        assert (got - want).abs().max() <= tol(False, want, k=k), (name, float((got - want).abs().max()))
+
+    def rmsnorm(x, gain, residual=None):
+        d = to_dev_nhwc(x, False)
+        out = torch.empty_like(d)
+        dres = None if residual is None else to_dev_nhwc(residual, False)
+        dg = gain.reshape(-1).float().contiguous().to(DEV)
+        B, Cc, H, W = x.shape
+        L().check(lib.srgd_k_rmsnorm(ptr(d), ptr(out), ptr(dres), ptr(dg), B * H * W, Cc, 0, stream()), "rmsnorm")
+        return from_dev_nhwc(out)
+
+    def attention(x, p, full):
+        B, Cc, H, W = x.shape
+        xn = rmsnorm(x, sd[p + ".norm.g"])
+        qkv, _ = run_conv(xn, None, sd[p + ".to_qkv.weight"], None, ks=1, stride=1, pad=0, kind=0, bf16=False)
+        d = to_dev_nhwc(qkv, False)
+        out = torch.empty(B, H, W, 128, device=DEV, dtype=torch.float32)
+        fn = lib.srgd_k_full_attention if full else lib.srgd_k_linear_attention
+        L().check(fn(ptr(d), ptr(out), B, H * W, 4, 0, stream()), "attention core")
+        core = from_dev_nhwc(out)
+        if full:
+            y, _ = run_conv(core, None, sd[p + ".to_out.weight"], sd[p + ".to_out.bias"], ks=1, stride=1, pad=0, kind=0, bf16=False)
+            return y
+        y, _ = run_conv(core, None, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"], ks=1, stride=1, pad=0, kind=0, bf16=False)
+        return rmsnorm(y, sd[p + ".to_out.1.g"])
+
+    check("rms_norm", rmsnorm(GC.module_input("rms_norm"), sd["downs.0.2.norm.g"]))
+    got, _ = run_conv(GC.module_input("downsample"), None, sd["downs.0.3.1.weight"], sd["downs.0.3.1.bias"], ks=2, stride=2,
+                      pad=0, kind=1, bf16=False)
+    check("downsample", got)
+    got, _ = run_conv(GC.module_input("pixel_shuffle_up"), None, sd["ups.0.3.net.0.weight"], sd["ups.0.3.net.0.bias"], ks=1,
+                      stride=1, pad=0, kind=2, bf16=False)
+    check("pixel_shuffle_up", got)
+    got, _ = run_conv(GC.module_input("last_down_conv3x3"), None, sd["downs.3.3.weight"], sd["downs.3.3.bias"], ks=3, stride=1,
+                      pad=1, kind=0, bf16=False)
+    check("last_down_conv3x3", got)
+    check("linear_attention", attention(GC.module_input("linear_attention"), "downs.0.2", False), k=2.0)
+    check("full_attention", attention(GC.module_input("full_attention"), "downs.3.2", True), k=2.0)
+    check("mid_attention", attention(GC.module_input("mid_attention"), "mid_attn", True), k=2.0)

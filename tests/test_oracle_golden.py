@@ -161,3 +161,32 @@ def test_edm_tiled_sample_matches_reference(case):
     want = z["image"]
     assert got.shape == want.shape
     assert np.abs(got.numpy() - want).max() <= 1e-4
+
+
+def test_oracle_building_blocks_match_the_reference_submodules():
+    # G3: each oracle function against the output of the reference's own nn.Module (dim-16 U-Net, seeded weights)
+    z = np.load(os.path.join(G, f"modules_dim{C.MODULE_DIM}.npz"))
+    sd = O.strip_model_prefix(synth_state_dict(_schema(C.MODULE_DIM), seed=0))
+    t = C.module_time_embedding()
+    heads, dh, groups = 4, 32, 8
+
+    def check(name, got, tol=2e-5):
+        want = torch.from_numpy(z[name])
+        assert got.shape == want.shape, name
+        assert (got - want).abs().max().item() <= tol * max(1.0, want.abs().max().item()), name
+
+    with torch.inference_mode():
+        x = C.module_input("resnet_same")
+        check("resnet_same", O.resnet_block(sd, "downs.0.0", x, t, groups))
+        x = C.module_input("resnet_concat")
+        check("resnet_concat", O.resnet_block(sd, "ups.0.0", x, t, groups))
+        check("linear_attention", O.linear_attention(sd, "downs.0.2", C.module_input("linear_attention"), heads, dh))
+        check("full_attention", O.full_attention(sd, "downs.3.2", C.module_input("full_attention"), heads, dh))
+        check("mid_attention", O.full_attention(sd, "mid_attn", C.module_input("mid_attention"), heads, dh))
+        check("downsample", O.space_to_depth_conv(sd, "downs.0.3", C.module_input("downsample")))
+        x = C.module_input("last_down_conv3x3")
+        check("last_down_conv3x3", torch.nn.functional.conv2d(x, sd["downs.3.3.weight"], sd["downs.3.3.bias"], padding=1))
+        check("pixel_shuffle_up", O.pixel_shuffle_up(sd, "ups.0.3", C.module_input("pixel_shuffle_up")))
+        check("rms_norm", O.rms_norm(C.module_input("rms_norm"), sd["downs.0.2.norm.g"]))
+        check("time_mlp", O.time_embedding(sd, torch.tensor([-3.0, 2.5])))
+        check("class_mlp", O.class_embedding(sd, torch.tensor([1])))
