@@ -114,12 +114,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # SRGD_DIST_BACKEND=gloo is a test hook: several ranks may then share one GPU (tests/test_bench_multirank_gpu.py runs the
+    # N > 1 code path on a 1-GPU box that way); the driver's runs use nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("SRGD_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from srgd_amd.synth import synthetic_lr_condition

@@ -24,6 +24,8 @@ def broadcast_state_dict(schema: Mapping[str, Sequence[int]], state_dict: Option
     travel as ONE flat buffer (550 MB fp32 for the dim-128 model): a single broadcast instead of 280."""
     keys = list(schema.keys())
     sizes = [int(torch.Size(schema[k]).numel()) for k in keys]
+    if dist.get_backend() != "nccl":
+        device = torch.device("cpu")                 # gloo (CPU tests, shared-GPU test hook): stage through host memory
     flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
     if dist.get_rank() == src:
         assert state_dict is not None
@@ -40,13 +42,15 @@ def broadcast_state_dict(schema: Mapping[str, Sequence[int]], state_dict: Option
 def gather_outputs(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
     """Gather equally-shaped per-rank output stacks to ``dst`` (returns the list there, None elsewhere)."""
     world = dist.get_world_size()
+    if dist.get_backend() != "nccl" and local.is_cuda:
+        local = local.cpu()
     bucket = [torch.empty_like(local) for _ in range(world)] if dist.get_rank() == dst else None
     dist.gather(local, bucket, dst=dst)
     return bucket
 
 
 def max_over_ranks(seconds: float, device: torch.device) -> float:
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
