@@ -445,3 +445,24 @@ def test_config5_cfg2_100_steps_fp32_parity_and_bf16_fp8_weight_reports():
         assert torch.isfinite(outs[k]).all() and outs[k].min() >= 0 and outs[k].max() <= 1
     assert not torch.equal(outs["bf16"], outs["bf16_w8"])
     assert psnr(outs["bf16_w8"], outs["bf16"]) > 15.0
+
+
+def test_headline_config_bf16_vs_fp32_engine_full_size():
+    # BASELINE configs[1] in full (256^2 LR -> 1024^2, canvas 1280^2, 25/16 tiles, 50 steps, dim 128): the reference takes
+    # ~1 h on CPU for this, so the fp32 engine - gated against the reference on every small fixture - stands in for it and the
+    # bf16 throughput mode is reported against it on the identical host noise stream.
+    sampler = build_sampler(128)
+    cond = C.synthetic_lr_condition(0, 256, 256).cuda()
+    label = torch.tensor([0]).cuda()
+    outs = {}
+    for amp in (False, True):
+        torch.manual_seed(71)
+        outs[amp] = sampler.tiled_sample(batch_size=25, condition_x=cond, class_label=label, num_sample_steps=50, amp=amp).cpu()
+    assert outs[False].shape == (1, 3, 1024, 1024)
+    err = (outs[True] - outs[False]).abs()
+    mse = float((err ** 2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    _report(test="config2_full_bf16_vs_fp32_engine", max_abs=float(err.max()), mean_abs=float(err.mean()), psnr_db=psnr)
+    for o in outs.values():
+        assert torch.isfinite(o).all() and o.min() >= 0 and o.max() <= 1
+    assert psnr > 30.0, psnr
