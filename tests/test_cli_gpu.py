@@ -1,0 +1,59 @@
+"""The reference's command line end to end on the GPU (inference.py:21-168 semantics): YAML config + .pth checkpoint
+(`ema_model` state_dict, weights_only load, strict) + a directory of PNGs -> `*_out.png`, skip-if-exists, unreadable files
+reported and skipped, and pixel-exact agreement with the CPU oracle pipeline (Pillow bicubic -> oracle tiled_sample ->
+ToPILImage) up to the fp32 tolerance."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import pil_resample as PR
+from oracle import srgd_oracle as O
+from srgd_amd.synth import synth_state_dict
+from tests.test_engine_gpu import _schema
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_inference_cli_writes_out_pngs_and_matches_the_oracle_pipeline(tmp_path):
+    dim, steps, seed, label = 16, 4, 71, 1
+    conf_src = open(os.path.join(ROOT, "conf", "conditional_continuous_linear_df8kost_dim128.yaml")).read()
+    assert "unet_dim: 128" in conf_src
+    conf = tmp_path / "dim16.yaml"
+    conf.write_text(conf_src.replace("unet_dim: 128", f"unet_dim: {dim}"))
+    sd = synth_state_dict(_schema(dim), seed=3)
+    ckpt = tmp_path / "ckpt.pth"
+    torch.save({"ema_model": sd, "epoch": 300}, ckpt)
+    indir, outdir = tmp_path / "in", tmp_path / "out"
+    indir.mkdir()
+    rng = np.random.default_rng(5)
+    lr = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    Image.fromarray(lr, "RGB").save(indir / "a.png")
+    (indir / "broken.png").write_bytes(b"not a png")
+    cmd = [sys.executable, os.path.join(ROOT, "inference.py"), "-c", str(conf), "-m", str(ckpt), "--input_dir", str(indir),
+           "--output_dir", str(outdir), "--num_sample_steps", str(steps), "--test_label", str(label), "--no_amp",
+           "--seed", str(seed), "--batch_size", "3"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Invalid image or unable to open image" in r.stdout
+    out_png = outdir / "a_out.png"
+    assert out_png.exists() and not (outdir / "broken_out.png").exists()
+    got = np.asarray(Image.open(out_png).convert("RGB"))
+    assert got.shape == (160, 224, 3)
+    # the same pipeline on the CPU: Pillow bicubic x4 (restated) -> /255 -> oracle tiled_sample (same torch seed) -> *255 trunc
+    cond = torch.from_numpy(PR.to_unit_chw(PR.resize_bicubic_u8(lr, 160, 224)))[None]
+    torch.manual_seed(seed)
+    with torch.inference_mode():
+        ref = O.tiled_sample(O.strip_model_prefix(sd), O.UnetCfg(dim=dim), cond, torch.tensor([label]), batch_size=3,
+                             num_sample_steps=steps)
+    want = PR.to_u8_hwc(ref[0].numpy())
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())    # truncation may flip at x.9999
+    # second run: everything already there -> "skip"
+    r2 = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and "skip" in r2.stdout
