@@ -514,11 +514,10 @@ int full_attention(const void* qkv, void* out, int B, int N, int heads, int dh, 
   const float scale = 1.0f / sqrtf((float)dh);
   if (is_bf16 && N % FA_QB == 0 && N <= 1024) {            // bf16 MFMA kernel, K / V^T resident in LDS (production: N = 1024)
     const int lds = N * 64 + DH * (N * 2 + 16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    if (first_use_on_device(attr_set)) {
       SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_attn_bf16_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 64 + DH * (1024 * 2 + 16)));
-      attr_set = true;
     }
     hipLaunchKernelGGL(full_attn_bf16_kernel, dim3(N / FA_QB, heads, B), dim3(FA_NT), lds, st, (const bf16*)qkv, (bf16*)out, N,
                        heads, scale * 1.4426950408889634f);

@@ -93,4 +93,14 @@ enum KClass {
   KC_COUNT
 };
 
+// One-time per-device setup guard (kernel attributes such as the dynamic-LDS limit are per device): returns true the first
+// time it is called for `flags` on the current HIP device.  Engines are one-per-device and single-threaded per device.
+inline bool first_use_on_device(bool (&flags)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;      // unknown device: redo the setup
+  if (flags[dev]) return false;
+  flags[dev] = true;
+  return true;
+}
+
 }  // namespace srgd

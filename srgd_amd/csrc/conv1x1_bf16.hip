@@ -288,14 +288,13 @@ int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st) {
   const long m_tiles = (long)a.B * a.Hout * a.Wout / BM1;
   const long grid = m_tiles * (a.Cout / BN1);
   if (grid <= 0 || grid > 0x7fffffffL) SRGD_FAIL("conv1x1_bf16: bad grid");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (first_use_on_device(attr_set)) {
 #define SRGD_SET1(E_)                                                                                   \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bf16_kernel<E_>),                 \
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));
     SRGD_SET1(EPI_PLAIN) SRGD_SET1(EPI_RESIDUAL) SRGD_SET1(EPI_GNTAIL) SRGD_SET1(EPI_PS_SILU)
 #undef SRGD_SET1
-    attr_set = true;
   }
 #define SRGD_GO1(E_) hipLaunchKernelGGL((conv1x1_bf16_kernel<E_>), dim3((unsigned)grid), dim3(NT1), LDS1_BYTES, st, p)
   if (a.mode == CONV_PIXEL_SHUFFLE_SILU) SRGD_GO1(EPI_PS_SILU);

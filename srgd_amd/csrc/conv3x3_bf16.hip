@@ -455,15 +455,14 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   p.gn_in_a = gn_in_a;
   p.gn_in_b_off = gnin ? (int)((const char*)gn_in_b - (const char*)gn_in_a) : 0;
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (first_use_on_device(attr_set)) {
 #define SRGD_SET(S_, G_, M_)                                                                              \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_, M_>),           \
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     SRGD_SET(true, false, false) SRGD_SET(false, false, false) SRGD_SET(true, true, false) SRGD_SET(false, true, false)
     SRGD_SET(true, false, true) SRGD_SET(false, false, true) SRGD_SET(true, true, true) SRGD_SET(false, true, true)
 #undef SRGD_SET
-    attr_set = true;
   }
   const bool stats = a.gn_partial != nullptr;
 #define SRGD_GO(S_, G_, M_) hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_, M_>), dim3(grid), dim3(NT3), LDS_BYTES, st, p)

@@ -302,11 +302,10 @@ int launch(const ConvArgs& a, hipStream_t st) {
   if (sizeof(T) == 2) lds = std::max(lds, (size_t)BM * (BN * 2 + 16));     // bf16 epilogue staging tile
   const int M = a.B * a.Hout * a.Wout;
   const int grid = cdiv(M, BM) * (a.CoutPad / BN);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (first_use_on_device(attr_set)) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BKC, PRECISE>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_igemm_kernel<T, BKC, PRECISE>), dim3(grid), dim3(NT), lds, st, a);
   SRGD_HIP(hipGetLastError());

@@ -431,13 +431,12 @@ int linattn_fused(const void* x, void* y, int B, int N, const void* wkv_img, con
   float* pl = pm + bh * nch * 32;
   float* pctx = pl + bh * nch * 32;
   float* ctxn = pctx + bh * nch * 1024;
-  static bool attr = false;
+  static bool attr[64] = {};
   const int lds1 = 65536 + 2 * TILE_BYTES + 2 * TM * 4;
   const int lds2 = 3 * TILE_BYTES + 2 * TM * 4 + 4 * TM * 4;
-  if (!attr) {
+  if (first_use_on_device(attr)) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-    attr = true;
   }
   hipLaunchKernelGGL(la1_kernel, dim3(nstrips, B), dim3(NTH), lds1, st, (const bf16*)x, N, (const bf16*)wkv_img, strip, pm,
                      pl, pctx);
