@@ -553,16 +553,17 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         if dev.type != "cuda":
             raise _lib.SrgdHipError("tiled_sample runs on MI355X only (no CPU fallback)")
         batch, c, h, w = condition_x.shape
-        if batch != 1 or c != 3:
-            raise ValueError("condition_x must be [1,3,H,W] (the reference's tile gather assumes batch 1)")
+        if batch < 1 or c != 3:
+            raise ValueError("condition_x must be [B,3,H,W] (B=1 in the reference; B>1 = same-sized images in lock-step, "
+                             "each sampled as it would be alone with the same seed)")
         eng = self.net.engine((self.amp_precision or "bf16") if amp else "fp32")
         class_id = -1 if class_label is None else int(class_label.reshape(-1)[0])
         (left, top, right, bottom), (hp, wp), coords0, coords1, (sl, st_, sr, sb) = _tiling(h, w, tile_size, tile_stride)
         geo = SamplerGeometry(H=h, W=w, Hp=hp, Wp=wp, left=left, top=top, inner_l=sl, inner_t=st_, inner_r=sr,
-                              inner_b=sb, tile=tile_size, n_even=len(coords0), n_odd=len(coords1), n_images=1)
+                              inner_b=sb, tile=tile_size, n_even=len(coords0), n_odd=len(coords1), n_images=batch)
         sigmas, scalars, c_noise = self._step_tables(n, clamp)
         cond01 = condition_x.to(dev, torch.float32).contiguous()
-        cond_canvas = torch.empty(1, 3, hp, wp, device=dev, dtype=torch.float32)
+        cond_canvas = torch.empty(batch, 3, hp, wp, device=dev, dtype=torch.float32)
         eng.edm_begin(geo, cond01, cond_canvas, [(a, c_) for (a, _, c_, _) in coords0],
                       [(a, c_) for (a, _, c_, _) in coords1], scalars, c_noise, class_id)
         host_noise = self.noise_source == "host"
@@ -574,16 +575,16 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
             return eng.randn_(torch.empty(1, 3, hp, wp, device=dev), seed, stream_id)
 
         if generation_start_steps > 0:                                  # get_noised_images(condition, step) :2340, :2185
-            img = torch.empty(1, 3, hp, wp, device=dev)
+            img = torch.empty(batch, 3, hp, wp, device=dev)
             eng.sampler_q_start(cond01, canvas_noise(1), 1.0, float(sigmas[generation_start_steps]), img, seed)
         elif zero_init:
-            img = torch.zeros(1, 3, hp, wp, device=dev)
+            img = torch.zeros(batch, 3, hp, wp, device=dev)
         else:
-            img = canvas_noise(1) * float(sigmas[0])                    # :2346 (a tensor * tensor product upstream)
+            img = (canvas_noise(1) * float(sigmas[0])).repeat(batch, 1, 1, 1)   # :2346 (a tensor * tensor product upstream)
         x_start = img.clone() if with_x0_images else None
         image_list = [img[:, :, top:bottom, left:right].clone().cpu()] if with_images else None
         x0_image_list = [img[:, :, top:bottom, left:right].clone().cpu()] if with_x0_images else None
-        work = torch.empty(2, 3, hp, wp, device=dev, dtype=torch.float32)
+        work = torch.empty(2, batch, 3, hp, wp, device=dev, dtype=torch.float32)
         sub_batch = self.max_tiles_per_launch or batch_size
         for i in range(n):
             if i < generation_start_steps:
@@ -603,7 +604,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
                 image_list.append(img.clone().cpu())
             if with_x0_images:
                 x0_image_list.append(x_start.clone().cpu())
-        out = torch.empty(1, 3, h, w, device=dev, dtype=torch.float32)
+        out = torch.empty(batch, 3, h, w, device=dev, dtype=torch.float32)
         eng.sampler_end(img, out)
         if with_images:
             return (out, image_list, x0_image_list) if with_x0_images else (out, image_list)

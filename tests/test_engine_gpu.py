@@ -466,3 +466,21 @@ def test_headline_config_bf16_vs_fp32_engine_full_size():
     for o in outs.values():
         assert torch.isfinite(o).all() and o.min() >= 0 and o.max() <= 1
     assert psnr > 30.0, psnr
+
+
+def test_edm_lockstep_images_equal_their_solo_runs():
+    sampler = build_edm_sampler(16)
+    conds = torch.cat([C.synthetic_lr_condition(s, 96, 96) for s in (0, 1)]).cuda()       # 2 x (384^2 -> canvas 768^2)
+    label = torch.tensor([1]).cuda()
+    solo = []
+    for i in range(2):
+        torch.manual_seed(9)
+        solo.append(sampler.tiled_sample(batch_size=9, condition_x=conds[i:i + 1], class_label=label, num_sample_steps=4,
+                                         class_cond_scale=1.3, amp=False).cpu())
+    for bs in (18, 5):
+        torch.manual_seed(9)
+        both = sampler.tiled_sample(batch_size=bs, condition_x=conds, class_label=label, num_sample_steps=4,
+                                    class_cond_scale=1.3, amp=False).cpu()
+        assert both.shape == (2, 3, 384, 384)
+        for i in range(2):
+            assert torch.equal(both[i:i + 1], solo[i]), (bs, i)
