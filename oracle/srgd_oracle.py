@@ -502,3 +502,29 @@ def edm_tiled_sample(sd, cfg: UnetCfg, e: EdmCfg, condition_x: Tensor, class_lab
             img[:, :, it:ib, il:ir] = inner
     out = img[:, :, top:bottom, left:right].clamp(-1.0, 1.0)
     return (out + 1) * 0.5
+
+
+# --------------------------------------------------------------------------------------
+# un-tiled sampling: ConditionalContinuousTimeGaussianDiffusionSR.sample / p_sample_loop (model.py:3191-3247, :3417-3432)
+# --------------------------------------------------------------------------------------
+def sample(sd, cfg: UnetCfg, condition_x: Tensor, class_label: Optional[Tensor] = None, *, num_sample_steps: int = 50,
+           cond_scale: float = 1.0, guidance_start_steps: int = 0, class_cond_scale: float = 1.0,
+           class_guidance_start_steps: int = 0, generation_start_steps: int = 0,
+           noise: Optional["NoiseSource"] = None) -> Tensor:
+    """condition_x: [B,3,S,S] in [0,1] (S = image_size); every image of the batch has its own noise (one randn over the
+    whole batch tensor per draw).  Returns [B,3,S,S] in [0,1]."""
+    noise = noise or NoiseSource()
+    cond = condition_x * 2 - 1                                           # :3424
+    if generation_start_steps > 0:                                       # :3198-3201 q_sample(condition, t_start)
+        ls0 = log_snr_linear(1.0 - torch.tensor(generation_start_steps / num_sample_steps))
+        img = cond * ls0.sigmoid().sqrt() + noise.randn(cond.shape) * (-ls0).sigmoid().sqrt()
+    else:
+        img = noise.randn(cond.shape)                                    # :3203
+    steps = torch.linspace(1.0, 0.0, num_sample_steps + 1)
+    for i in range(num_sample_steps):
+        if i < generation_start_steps:
+            continue
+        cs = cond_scale if i >= guidance_start_steps else 1.0
+        ccs = class_cond_scale if i >= class_guidance_start_steps else 1.0
+        img, _ = predict_and_step(sd, cfg, img, steps[i], steps[i + 1], cond, class_label, cs, ccs, noise)
+    return (img.clamp(-1.0, 1.0) + 1) * 0.5                              # :3239-3240

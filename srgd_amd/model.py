@@ -435,9 +435,79 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
             return (out, image_list, x0_image_list) if with_x0_images else (out, image_list)
         return out
 
-    def sample(self, *args, **kwargs):
-        raise NotImplementedError("un-tiled p_sample_loop (model.py:3417) is not on the shipped inference path; "
-                                  "use tiled_sample")
+    @torch.inference_mode()
+    def sample(self, batch_size=16, condition_x=None, class_label=None, cond_scale=1.0, guidance_start_steps=0,
+               class_cond_scale=1.0, class_guidance_start_steps=0, generation_start_steps=0, num_sample_steps=None,
+               with_images=False, with_x0_images=False, x0=None, amp=False):
+        """Un-tiled sampling of a batch of ``image_size`` x ``image_size`` images (reference model.py:3417-3432,
+        p_sample_loop :3191-3247): every image has its own noise (one ``randn`` over ``[B,3,S,S]`` per draw, host mode).
+
+        Runs on the tiled machinery: the batch is laid out as one canvas of B stacked tiles (``[3, B*S, S]``, no padding, no
+        ring re-noise), so one U-Net launch covers the whole batch.  Needs ``image_size == 256`` (the tile edge of the kernels;
+        the shipped config).  ``amp`` selects the bf16 mode as in ``tiled_sample``."""
+        num_sample_steps = self.num_sample_steps if num_sample_steps is None else num_sample_steps
+        if cond_scale != 1.0 and class_cond_scale != 1.0:
+            raise NotImplementedError("Currently, you cannot specify both cond_scale and class_cond_scale at the same time.")
+        s_ = self.image_size
+        if s_ != 256:
+            raise NotImplementedError(f"sample(): image_size={s_}; this engine's un-tiled path needs image_size == 256")
+        dev = self.device
+        if dev.type != "cuda":
+            raise _lib.SrgdHipError("sample runs on MI355X only (no CPU fallback)")
+        b = int(batch_size)
+        if tuple(condition_x.shape) != (b, self.channels, s_, s_):
+            raise ValueError(f"condition_x must be [{b},{self.channels},{s_},{s_}] (model.py:3426 pairs it with the noise batch)")
+        eng = self.model.engine((self.amp_precision or "bf16") if amp else "fp32")
+        class_id = -1 if class_label is None else int(class_label.reshape(-1)[0])
+        to_canvas = lambda t: t.permute(1, 0, 2, 3).reshape(1, 3, b * s_, s_).contiguous()       # [B,3,S,S] -> [1,3,B*S,S]
+        from_canvas = lambda t: t.reshape(3, b, s_, s_).permute(1, 0, 2, 3).contiguous()
+        tiles = [(i * s_, 0) for i in range(b)]
+        geo = SamplerGeometry(H=b * s_, W=s_, Hp=b * s_, Wp=s_, left=0, top=0, inner_l=0, inner_t=0, inner_r=s_, inner_b=b * s_,
+                              tile=s_, n_even=b, n_odd=b, n_images=1)
+        scalars, log_snrs = _schedule(num_sample_steps)
+        cond01 = to_canvas(condition_x.to(dev, torch.float32))
+        cond_canvas = torch.empty(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
+        eng.sampler_begin(geo, cond01, cond_canvas, tiles, tiles, scalars, log_snrs, class_id)
+        host_noise = self.noise_source == "host"
+        seed = self.device_noise_seed
+        if generation_start_steps > 0:                                   # q_sample(condition, t_start) :3198-3201
+            ls0 = beta_linear_log_snr(1.0 - torch.tensor(generation_start_steps / num_sample_steps))
+            img = torch.empty(1, 3, b * s_, s_, device=dev)
+            nz = to_canvas(torch.randn(b, 3, s_, s_).to(dev)) if host_noise else None
+            eng.sampler_q_start(cond01, nz, float(ls0.sigmoid().sqrt()), float((-ls0).sigmoid().sqrt()), img, seed)
+        elif host_noise:
+            img = to_canvas(torch.randn(b, 3, s_, s_).to(dev))           # :3203
+        else:
+            img = eng.randn_(torch.empty(1, 3, b * s_, s_, device=dev), seed, 0)
+        x_start = img.clone() if with_x0_images else None
+        image_list = [from_canvas(img).cpu()] if with_images else None
+        x0_image_list = [from_canvas(img).cpu()] if with_x0_images else None
+        for i in range(num_sample_steps):
+            if i < generation_start_steps:
+                continue
+            cur_cond_scale = 1.0 if i < guidance_start_steps else cond_scale
+            cur_class_scale = 1.0 if i < class_guidance_start_steps else class_cond_scale
+            if cur_cond_scale != 1.0:
+                passes, kind, scale = 2, 2, cur_cond_scale
+            elif cur_class_scale != 1.0:
+                passes, kind, scale = 2, 1, cur_class_scale
+            else:
+                passes, kind, scale = 1, 0, 1.0
+            last = i == num_sample_steps - 1
+            noise_tiles = torch.randn(b, 3, s_, s_).to(dev, non_blocking=True) if (host_noise and not last) else None
+            # no ring re-noise in the un-tiled loop: run the step over all tiles with do_ring = False
+            eng.sampler_step_tiles(i, 0, b, False, img, cond_canvas, x_start, noise_tiles, None, passes, kind, scale,
+                                   self.max_tiles_per_launch or b, seed=seed)
+            if with_images:
+                image_list.append(from_canvas(img).cpu())
+            if with_x0_images:
+                x0_image_list.append(from_canvas(x_start).cpu())
+        out = torch.empty(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
+        eng.sampler_end(img, out)
+        out = from_canvas(out)
+        if with_images:
+            return (out, image_list, x0_image_list) if with_x0_images else (out, image_list)
+        return out
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError("training (p_losses) is not part of the inference-only release this engine mirrors")

@@ -73,6 +73,25 @@ LONG_CASES = [
          class_cond_scale=2.0, weight_seed=0, cond="lr_bicubic", cond_seed=1234, seed=71),
 ]
 
+# un-tiled sample() (model.py:3417-3432): a batch of independent image_size^2 images, per-image noise
+SAMPLE_CASES = [
+    dict(name="dim16_b3_cfg", dim=16, batch=3, steps=6, label=2, cond_scale=1.0, class_cond_scale=1.5, weight_seed=0,
+         cond_seed=1240, seed=71, class_guidance_start_steps=2),
+    dict(name="dim16_b2_genstart", dim=16, batch=2, steps=6, label=0, cond_scale=1.0, class_cond_scale=1.0, weight_seed=0,
+         cond_seed=1241, seed=71, generation_start_steps=2),
+]
+
+
+def sample_condition(case):
+    g = torch.Generator().manual_seed(case["cond_seed"])
+    return torch.rand(case["batch"], 3, 256, 256, generator=g)
+
+
+def sample_extra_kwargs(case):
+    keys = ("generation_start_steps", "class_guidance_start_steps", "guidance_start_steps")
+    return {k: case[k] for k in keys if k in case}
+
+
 # EDM sampler (ConditionalElucidatedDiffusionSR.tiled_sample, model.py:2309-2475) over the same U-Net; fixture files
 # sample_edm_<name>.npz hold the reference's outputs (its un-vendored base class restated in oracle/refshim.py)
 EDM_CASES = [

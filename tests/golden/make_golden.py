@@ -155,6 +155,29 @@ def make_modules():
     print("modules done", {k: v.shape for k, v in out.items()})
 
 
+def make_sample():
+    """un-tiled sample() fixtures."""
+    ref = refshim.load_reference()
+    assert ref is not None, "reference not present"
+    rm, rc = ref
+    torch.set_num_threads(8)
+    for case in C.SAMPLE_CASES:
+        sampler, _ = refshim.build_reference_sampler(rm, rc, dim=case["dim"], num_sample_steps=case["steps"])
+        schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+        sd = synth_state_dict(schema, seed=case["weight_seed"])
+        sampler.load_state_dict(sd, strict=True)
+        cond = C.sample_condition(case)
+        label = torch.tensor([case["label"]])
+        torch.manual_seed(case["seed"])
+        with torch.inference_mode():
+            img = sampler.sample(batch_size=case["batch"], condition_x=cond.clone(), class_label=label,
+                                 cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
+                                 num_sample_steps=case["steps"], **C.sample_extra_kwargs(case))
+        np.savez_compressed(os.path.join(HERE, f"sample_untiled_{case['name']}.npz"), image=img.numpy(),
+                            cond_sum=np.float64(cond.double().sum().item()))
+        print("sample", case["name"], "done", tuple(img.shape), float(img.mean()))
+
+
 def make_long():
     ref = refshim.load_reference()
     assert ref is not None, "reference not present"
@@ -179,7 +202,9 @@ def make_long():
 
 
 if __name__ == "__main__":
-    if "--modules-only" in sys.argv:
+    if "--sample-only" in sys.argv:
+        make_sample()
+    elif "--modules-only" in sys.argv:
         make_modules()
     elif "--config5-only" in sys.argv:
         make_long()
@@ -189,3 +214,4 @@ if __name__ == "__main__":
         main()
         make_edm()
         make_modules()
+        make_sample()

@@ -484,3 +484,22 @@ def test_edm_lockstep_images_equal_their_solo_runs():
         assert both.shape == (2, 3, 384, 384)
         for i in range(2):
             assert torch.equal(both[i:i + 1], solo[i]), (bs, i)
+
+
+@pytest.mark.parametrize("case", C.SAMPLE_CASES, ids=lambda c: c["name"])
+def test_untiled_sample_fp32_matches_reference(case):
+    # sample() / p_sample_loop (model.py:3191-3247, :3417-3432): a batch of independent 256^2 images, per-image noise
+    z = np.load(os.path.join(G, f"sample_untiled_{case['name']}.npz"))
+    sampler = build_sampler(case["dim"], steps=case["steps"], weight_seed=case["weight_seed"])
+    cond = C.sample_condition(case).cuda()
+    torch.manual_seed(case["seed"])
+    got = sampler.sample(batch_size=case["batch"], condition_x=cond, class_label=torch.tensor([case["label"]]).cuda(),
+                         cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
+                         num_sample_steps=case["steps"], **C.sample_extra_kwargs(case)).cpu()
+    want = torch.from_numpy(z["image"])
+    err = (got - want).abs().max().item()
+    _report(test="untiled_sample", case=case["name"], precision="fp32", max_abs=err)
+    assert got.shape == want.shape
+    assert err <= 1e-3 and err <= 2e-4, err
+    with pytest.raises(ValueError):
+        sampler.sample(batch_size=case["batch"] + 1, condition_x=cond, num_sample_steps=2)

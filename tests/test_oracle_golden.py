@@ -190,3 +190,18 @@ def test_oracle_building_blocks_match_the_reference_submodules():
         check("rms_norm", O.rms_norm(C.module_input("rms_norm"), sd["downs.0.2.norm.g"]))
         check("time_mlp", O.time_embedding(sd, torch.tensor([-3.0, 2.5])))
         check("class_mlp", O.class_embedding(sd, torch.tensor([1])))
+
+
+@pytest.mark.parametrize("case", C.SAMPLE_CASES, ids=lambda c: c["name"])
+def test_untiled_sample_matches_reference(case):
+    z = np.load(os.path.join(G, f"sample_untiled_{case['name']}.npz"))
+    sd = synth_state_dict(_schema(case["dim"]), seed=case["weight_seed"])
+    cond = C.sample_condition(case)
+    assert abs(cond.double().sum().item() - float(z["cond_sum"])) < 1e-6
+    torch.manual_seed(case["seed"])
+    with torch.inference_mode():
+        got = O.sample(O.strip_model_prefix(sd), O.UnetCfg(dim=case["dim"]), cond, torch.tensor([case["label"]]),
+                       num_sample_steps=case["steps"], cond_scale=case["cond_scale"],
+                       class_cond_scale=case["class_cond_scale"], **C.sample_extra_kwargs(case))
+    assert got.shape == z["image"].shape
+    assert np.abs(got.numpy() - z["image"]).max() <= 1e-4
