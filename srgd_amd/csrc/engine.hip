@@ -257,6 +257,7 @@ struct srgd_engine {
   struct StepGraph {
     int parity, passes, kind, sub_batch; float scale; const void *img, *cond, *xs; uint64_t seed; bool last;
     int tile_first, tile_count; bool ring;
+    int mode; const void* work;      // 0: DDPM step, 1: EDM step (work = its scratch canvases)
     int seen; hipGraphExec_t exec; hipGraph_t graph;
   };
   std::vector<StepGraph> graphs;
@@ -758,6 +759,44 @@ int compute_conditioning(srgd_engine* e, CondTable& ct, const float* ls_host, in
 
 static void drop_step_graphs(srgd_engine* e);
 
+// Graph cache shared by the DDPM and the EDM step: the first occurrence of a key runs eagerly (it warms the activation pool and
+// every lazily-set kernel attribute), the second is captured on a private stream (the caller's may be the legacy default
+// stream, which cannot capture; nothing executes during capture), later ones replay on the caller's stream.
+extern "C++" {
+template <typename Launch>
+static int run_step_through_graph(srgd_engine* e, const srgd_engine::StepGraph& key, hipStream_t st, Launch&& launch) {
+  srgd_engine::StepGraph* sg = nullptr;
+  for (auto& c : e->graphs)
+    if (c.mode == key.mode && c.parity == key.parity && c.passes == key.passes && c.kind == key.kind &&
+        c.sub_batch == key.sub_batch && c.scale == key.scale && c.img == key.img && c.cond == key.cond && c.xs == key.xs &&
+        c.seed == key.seed && c.last == key.last && c.tile_first == key.tile_first && c.tile_count == key.tile_count &&
+        c.ring == key.ring && c.work == key.work)
+      sg = &c;
+  if (!sg) {
+    e->graphs.push_back(key);
+    return launch(st);
+  }
+  if (!sg->exec) {
+    if (!e->cap_stream) SRGD_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    SRGD_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+    e->pool.no_alloc = true;
+    const int rc = launch(e->cap_stream);
+    e->pool.no_alloc = false;
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(e->cap_stream, &graph);
+    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess || !graph) SRGD_FAIL(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ie != hipSuccess) { (void)hipGraphDestroy(graph); SRGD_FAIL(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+    sg->graph = graph;
+    sg->exec = exec;
+  }
+  SRGD_HIP(hipGraphLaunch(sg->exec, st));
+  return 0;
+}
+}  // extern "C++"
+
 // ======================================================================= C ABI
 extern "C" {
 
@@ -1026,32 +1065,15 @@ int srgd_edm_begin(srgd_engine* e, const srgd_sampler_geometry* g, const float* 
   return 0;
 }
 
-// One EDM step (model.py:2377-2455) over every tile of grid (step % 2): Euler evaluation at sigma_hat, Heun correction at
-// sigma_next (skipped on the last step), odd-step ring re-noise.  Launched eagerly (no graph capture yet).
-int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start, float* work,
-                  const float* noise_canvas, const float* ring_noise_canvas, int passes, int guidance_kind,
-                  float guidance_scale, int sub_batch, uint64_t seed, void* stream) {
-  if (!e || !e->run_active || !e->run_is_edm) SRGD_FAIL("srgd_edm_step: call srgd_edm_begin first");
-  if (step < 0 || step >= e->n_steps) SRGD_FAIL("srgd_edm_step: step out of range");
-  if (!img || !cond_canvas || !work) SRGD_FAIL("srgd_edm_step: null argument");
-  if (passes != 1 && passes != 2) SRGD_FAIL("srgd_edm_step: passes must be 1 or 2");
-  if (passes == 2 && guidance_kind != 1 && guidance_kind != 2) SRGD_FAIL("srgd_edm_step: guidance_kind must be 1 or 2");
-  if (sub_batch < 1) SRGD_FAIL("srgd_edm_step: sub_batch must be >= 1");
-  hipStream_t st = (hipStream_t)stream;
-  SRGD_HIP(hipSetDevice(e->cfg.device));
+// all launches of one EDM step (model.py:2377-2455); step-dependent values come through e->d_step
+static int edm_step_launch(srgd_engine* e, bool last, int parity, float* img, const float* cond_canvas, float* x_start,
+                           float* work, const float* noise_canvas, const float* ring_noise_canvas, int passes,
+                           int guidance_kind, float guidance_scale, int sub_batch, uint64_t seed, hipStream_t st) {
   const srgd_sampler_geometry& g = e->geo;
-  const int parity = step & 1;
   const int n_local = parity ? g.n_odd : g.n_even;
   const int n = n_local * g.n_images;
-  const bool last = step == e->n_steps - 1;
   const int* tiles = parity ? e->d_tiles_odd : e->d_tiles_even;
-  sub_batch = std::min(sub_batch, n);
   const size_t canvas1 = (size_t)3 * g.Hp * g.Wp, canvas_elems = canvas1 * g.n_images;
-  SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
-  if (!noise_canvas) SRGD_TRY(ensure(&e->rng_tiles, &e->rng_tiles_cap, canvas1));
-  if (!ring_noise_canvas && parity == 1) SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, canvas1));
-  if (!e->d_step) SRGD_HIP(hipMalloc((void**)&e->d_step, sizeof(int)));
-  hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, e->d_step, step);
   const float* z = noise_canvas;
   if (!z) {
     Prof p(e, KC_CANVAS, st);
@@ -1102,6 +1124,43 @@ int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas
                                  &e->d_edm[0].ring_sigma, (int)(sizeof(EdmScalars) / sizeof(float)), e->d_step, st));
   }
   return 0;
+}
+
+// One EDM step over every tile of grid (step % 2): Euler evaluation at sigma_hat, Heun correction at sigma_next (skipped on the
+// last step), odd-step ring re-noise.  In device-noise mode the step is captured and replayed like the DDPM step.
+int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start, float* work,
+                  const float* noise_canvas, const float* ring_noise_canvas, int passes, int guidance_kind,
+                  float guidance_scale, int sub_batch, uint64_t seed, void* stream) {
+  if (!e || !e->run_active || !e->run_is_edm) SRGD_FAIL("srgd_edm_step: call srgd_edm_begin first");
+  if (step < 0 || step >= e->n_steps) SRGD_FAIL("srgd_edm_step: step out of range");
+  if (!img || !cond_canvas || !work) SRGD_FAIL("srgd_edm_step: null argument");
+  if (passes != 1 && passes != 2) SRGD_FAIL("srgd_edm_step: passes must be 1 or 2");
+  if (passes == 2 && guidance_kind != 1 && guidance_kind != 2) SRGD_FAIL("srgd_edm_step: guidance_kind must be 1 or 2");
+  if (sub_batch < 1) SRGD_FAIL("srgd_edm_step: sub_batch must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  SRGD_HIP(hipSetDevice(e->cfg.device));
+  const srgd_sampler_geometry& g = e->geo;
+  const int parity = step & 1;
+  const int n = (parity ? g.n_odd : g.n_even) * g.n_images;
+  const bool last = step == e->n_steps - 1;
+  sub_batch = std::min(sub_batch, n);
+  const size_t canvas1 = (size_t)3 * g.Hp * g.Wp;
+  // every allocation happens here, before any capture
+  SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
+  if (!noise_canvas) SRGD_TRY(ensure(&e->rng_tiles, &e->rng_tiles_cap, canvas1));
+  if (!ring_noise_canvas && parity == 1) SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, canvas1));
+  if (!e->d_step) SRGD_HIP(hipMalloc((void**)&e->d_step, sizeof(int)));
+  hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, e->d_step, step);
+  const bool graphable = e->use_graphs && !e->prof_on && !noise_canvas && !ring_noise_canvas;
+  if (!graphable)
+    return edm_step_launch(e, last, parity, img, cond_canvas, x_start, work, noise_canvas, ring_noise_canvas, passes,
+                           guidance_kind, guidance_scale, sub_batch, seed, st);
+  const srgd_engine::StepGraph key{parity, passes, guidance_kind, sub_batch, guidance_scale, img, cond_canvas, x_start, seed, last,
+                                   0, n, true, 1, work, 1, nullptr, nullptr};
+  return run_step_through_graph(e, key, st, [&](hipStream_t s2) {
+    return edm_step_launch(e, last, parity, img, cond_canvas, x_start, work, nullptr, nullptr, passes, guidance_kind,
+                           guidance_scale, sub_batch, seed, s2);
+  });
 }
 
 // all launches of one DDPM step; step-dependent values come through e->d_step (set by the caller on the stream)
@@ -1212,39 +1271,12 @@ int srgd_sampler_step_tiles(srgd_engine* e, int step, int tile_first, int tile_c
   if (!graphable)
     return sampler_step_launch(e, last, parity, tile_first, tile_count, ring, img, cond_canvas, x_start, noise_tiles,
                                noise_canvas, passes, guidance_kind, guidance_scale, sub_batch, seed, st);
-  srgd_engine::StepGraph* sg = nullptr;
-  for (auto& c : e->graphs)
-    if (c.parity == parity && c.passes == passes && c.kind == guidance_kind && c.sub_batch == sub_batch &&
-        c.scale == guidance_scale && c.img == img && c.cond == cond_canvas && c.xs == x_start && c.seed == seed &&
-        c.last == last && c.tile_first == tile_first && c.tile_count == tile_count && c.ring == ring)
-      sg = &c;
-  if (!sg) {   // first time: run eagerly (warms the activation pool and every lazily-set kernel attribute)
-    e->graphs.push_back({parity, passes, guidance_kind, sub_batch, guidance_scale, img, cond_canvas, x_start, seed, last,
-                         tile_first, tile_count, ring, 1, nullptr, nullptr});
-    return sampler_step_launch(e, last, parity, tile_first, tile_count, ring, img, cond_canvas, x_start, nullptr, nullptr,
-                               passes, guidance_kind, guidance_scale, sub_batch, seed, st);
-  }
-  if (!sg->exec) {   // second time: capture the identical launch sequence
-    // capture on a private stream (the caller's may be the legacy default stream, which cannot capture); nothing
-    // executes during capture, the graph is then launched on the caller's stream
-    if (!e->cap_stream) SRGD_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
-    SRGD_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
-    e->pool.no_alloc = true;
-    const int rc = sampler_step_launch(e, last, parity, tile_first, tile_count, ring, img, cond_canvas, x_start, nullptr,
-                                       nullptr, passes, guidance_kind, guidance_scale, sub_batch, seed, e->cap_stream);
-    e->pool.no_alloc = false;
-    hipGraph_t graph = nullptr;
-    const hipError_t ce = hipStreamEndCapture(e->cap_stream, &graph);
-    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (ce != hipSuccess || !graph) SRGD_FAIL(std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-    hipGraphExec_t exec = nullptr;
-    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (ie != hipSuccess) { (void)hipGraphDestroy(graph); SRGD_FAIL(std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
-    sg->graph = graph;
-    sg->exec = exec;
-  }
-  SRGD_HIP(hipGraphLaunch(sg->exec, st));
-  return 0;
+  const srgd_engine::StepGraph key{parity, passes, guidance_kind, sub_batch, guidance_scale, img, cond_canvas, x_start, seed, last,
+                                   tile_first, tile_count, ring, 0, nullptr, 1, nullptr, nullptr};
+  return run_step_through_graph(e, key, st, [&](hipStream_t s2) {
+    return sampler_step_launch(e, last, parity, tile_first, tile_count, ring, img, cond_canvas, x_start, nullptr, nullptr, passes,
+                               guidance_kind, guidance_scale, sub_batch, seed, s2);
+  });
 }
 
 int srgd_sampler_exchange_tiles(srgd_engine* e, int parity, int tile_first, int tile_count, float* canvas, float* tiles,

@@ -503,3 +503,25 @@ def test_untiled_sample_fp32_matches_reference(case):
     assert err <= 1e-3 and err <= 2e-4, err
     with pytest.raises(ValueError):
         sampler.sample(batch_size=case["batch"] + 1, condition_x=cond, num_sample_steps=2)
+
+
+def test_edm_hipgraph_replay_is_bitwise_identical_to_eager_launches():
+    import os
+    sampler = build_edm_sampler(16)
+    cond = C.synthetic_lr_condition(3, 96, 96).cuda()            # 384x384 -> canvas 768^2 (9 / 4 tiles)
+    label = torch.tensor([2]).cuda()
+    outs = {}
+    try:
+        sampler.noise_source = "device"
+        sampler.device_noise_seed = 5
+        for mode in ("1", "0"):
+            os.environ["SRGD_GRAPHS"] = mode
+            sampler.net._invalidate_engines()
+            outs[mode] = sampler.tiled_sample(batch_size=9, condition_x=cond, class_label=label, num_sample_steps=9,
+                                              class_cond_scale=1.5, class_guidance_start_steps=3, amp=True).cpu()
+    finally:
+        os.environ.pop("SRGD_GRAPHS", None)
+        sampler.net._invalidate_engines()
+        sampler.noise_source = "host"
+    assert torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["1"], outs["0"])
