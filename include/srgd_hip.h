@@ -20,6 +20,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef struct srgd_engine srgd_engine;
 
@@ -199,6 +203,9 @@ int srgd_profile_num_families(void);
 const char* srgd_profile_family_name(int i);
 int64_t srgd_device_bytes_in_use(const srgd_engine* e);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* Convolution as implicit GEMM on MFMA.  replaces: nn.Conv2d call sites of the U-Net - Block.proj
  * (model.py:246), res_conv (:271), to_qkv/to_out (:300,:303,:341,:342), Downsample (:106-110, kind 1:
@@ -66,6 +70,9 @@ int srgd_k_linattn_block_fused(const void* x, void* y, int B, int N, int C, cons
                                const float* norm_g_host, const float* to_out_w_host, const float* to_out_b_host,
                                const float* out_g_host, void* stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

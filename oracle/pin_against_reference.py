@@ -128,13 +128,17 @@ def main():
     print("[sampler] dim=16, 300x300 -> 768x768 canvas, 3 steps, start_white_noise=False")
     got, want = run_sampler(16, 300, 300, 3, 8, start_white_noise=False)
     ok &= report("final image", got, want, 1e-4)
+    print("[sampler] dim=16, 300x300 -> 768x768 canvas, 5 steps, cond_scale=1.5 from step 2 (LR-condition guidance)")
+    got, want = run_sampler(16, 300, 300, 5, 4, cs=1.5, label=1, guidance_start_steps=2)
+    ok &= report("final image", got, want, 1e-4)
     if not args.quick:
         print("[sampler] dim=128, 256x256 canvas, 4 steps, CFG off")
         got, want = run_sampler(128, 256, 256, 4, 4)
         ok &= report("final image", got, want, 1e-4)
     # ---- EDM wrapper (model.py:2059-2475); its un-vendored base class is restated in refshim (same formulas as the oracle)
-    def run_edm(dim, h, w, steps, bs, ccs=1.0, cs=1.0, label=0, **extra):
-        sampler, _ = refshim.build_reference_sampler(rm, rc, dim=dim, num_sample_steps=steps, model="conditional_elucidated")
+    def run_edm(dim, h, w, steps, bs, ccs=1.0, cs=1.0, label=0, ctor_steps=None, **extra):
+        ctor_steps = ctor_steps or steps
+        sampler, _ = refshim.build_reference_sampler(rm, rc, dim=dim, num_sample_steps=ctor_steps, model="conditional_elucidated")
         schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
         sd = synth_state_dict(schema, seed=0)
         sampler.load_state_dict(sd, strict=True)
@@ -148,14 +152,15 @@ def main():
                                         class_cond_scale=ccs, num_sample_steps=steps, **extra)
         torch.manual_seed(71)
         with torch.inference_mode():
-            got = O.edm_tiled_sample(usd, O.UnetCfg(dim=dim), O.EdmCfg(), cond.clone(), lab, batch_size=bs,
+            got = O.edm_tiled_sample(usd, O.UnetCfg(dim=dim), O.EdmCfg(num_sample_steps=ctor_steps), cond.clone(), lab, batch_size=bs,
                                      num_sample_steps=steps, cond_scale=cs, class_cond_scale=ccs, **extra)
         return got, want
 
     print("[edm] dim=16: 256x256 6 steps; class CFG 2.0; 300x500 (768^2 canvas); LR CFG 1.5 from a noised start; zero_init, no clamp")
     for kw in (dict(h=256, w=256, steps=6, bs=4), dict(h=256, w=256, steps=6, bs=4, ccs=2.0),
                dict(h=300, w=500, steps=4, bs=4), dict(h=256, w=256, steps=8, bs=4, cs=1.5, generation_start_steps=2),
-               dict(h=300, w=300, steps=3, bs=8, zero_init=True, clamp=False)):
+               dict(h=300, w=300, steps=3, bs=8, zero_init=True, clamp=False),
+               dict(h=300, w=300, steps=5, bs=4, ctor_steps=8, generation_start_steps=1)):   # per-call steps != ctor steps
         got, want = run_edm(16, **kw)
         ok &= report("edm final image " + str({k: v for k, v in kw.items() if k not in ("h", "w", "bs")}), got, want, 1e-4)
     print("PINNED" if ok else "MISMATCH")

@@ -409,6 +409,7 @@ class EdmCfg:
     S_tmin: float = 0.05
     S_tmax: float = 50.0
     S_noise: float = 1.003
+    num_sample_steps: int = 32      # the CONSTRUCTOR's step count: get_noised_images (model.py:2186-2189) falls back to it
 
 
 def edm_sigmas(e: EdmCfg, n: int) -> Tensor:
@@ -463,8 +464,10 @@ def edm_tiled_sample(sd, cfg: UnetCfg, e: EdmCfg, condition_x: Tensor, class_lab
     shape = cond.shape
     sigmas = edm_sigmas(e, n)
     gammas = edm_gammas(e, sigmas, n)
+    # get_noised_images is called WITHOUT num_sample_steps (:2342, :2457): its sigmas are the constructor's schedule
+    noised_sigmas = edm_sigmas(e, e.num_sample_steps)
     if generation_start_steps > 0:                                       # get_noised_images(cond, step) :2185-2194
-        img = cond + sigmas[generation_start_steps] * noise.randn(shape)
+        img = cond + noised_sigmas[generation_start_steps] * noise.randn(shape)
     elif zero_init:
         img = torch.zeros(shape)
     else:
@@ -498,7 +501,7 @@ def edm_tiled_sample(sd, cfg: UnetCfg, e: EdmCfg, condition_x: Tensor, class_lab
                 img[:, :, a:b, c:d_] = nxt[k]
         if i % 2 == 1:                                                   # :2448-2452
             inner = img[:, :, it:ib, il:ir].clone()
-            img = torch.zeros(shape) + sigmas[i] * noise.randn(shape)    # get_noised_images(0, i)
+            img = torch.zeros(shape) + noised_sigmas[i] * noise.randn(shape)    # get_noised_images(0, i)
             img[:, :, it:ib, il:ir] = inner
     out = img[:, :, top:bottom, left:right].clamp(-1.0, 1.0)
     return (out + 1) * 0.5

@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libsrgd_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 SOURCES = ["conv_igemm.hip", "conv3x3_bf16.hip", "conv1x1_bf16.hip", "norm_act.hip", "attention.hip", "linattn_fused.hip", "cond.hip", "sampler.hip", "imageio.hip", "engine.hip", "kernel_api.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value",
-         "-fno-gpu-rdc", "-DNDEBUG"]
+         "-fno-gpu-rdc", "-DNDEBUG", "-fvisibility=hidden"]
 
 
 def _hipcc() -> str:

@@ -58,9 +58,14 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
   const int xcd = blockIdx.x & 7, xloc = blockIdx.x >> 3;
   const int bid = xcd * xq + (xcd < xr ? xcd : xr) + xloc;
   const int mt = bid / n_tiles, nt = bid - mt * n_tiles;
-  const int m0 = mt * BM, n0 = nt * BN;
+  const int n0 = nt * BN;
   const int HWo = p.Hout * p.Wout;
-  const int M = p.B * HWo;
+  // M tiles never straddle samples (the GroupNorm partials are per sample): sample tb owns ceil(HWo / BM) tiles and the
+  // rows past its last pixel are masked.  For HWo % BM == 0 (every production shape) this is the plain M = B*HWo tiling.
+  const int tps = (HWo + BM - 1) / BM;
+  const int tb = mt / tps, tslot = mt - tb * tps;
+  const int r0 = tslot * BM;                       // first pixel of the tile inside its sample
+  const int m0 = tb * HWo + r0;                    // ... and in the flattened [B*HWo] order
   const int Cin = p.C0 + p.C1;
   const int CC = Cin / BKC;
   const int steps = p.KH * p.KW * CC;
@@ -76,10 +81,8 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
     const int cid = tid + NT * I;                                           \
     arow_##I = cid / CPR;                                                   \
     aq_##I = cid - arow_##I * CPR;                                          \
-    const int m = m0 + arow_##I;                                            \
-    mval_##I = m < M;                                                       \
-    const int mm = mval_##I ? m : 0;                                        \
-    const int b = mm / HWo, rem = mm - b * HWo;                             \
+    mval_##I = r0 + arow_##I < HWo;                                         \
+    const int b = tb, rem = mval_##I ? r0 + arow_##I : 0;                   \
     const int oy = rem / p.Wout, ox = rem - oy * p.Wout;                    \
     iy0_##I = oy * p.stride - p.pad;                                        \
     ix0_##I = ox * p.stride - p.pad;                                        \
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
         for (int reg = 0; reg < 16; ++reg) {
           const int row = wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
           float v = accv[reg] + bias;
-          if (m0 + row < M && cval) {
+          if (r0 + row < HWo && cval) {
             s1[ni] += v;
             s2[ni] += v * v;
           }
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
       const int q = tid + NT * i;                          // 16-byte chunk: tile row q/16, columns (q%16)*8..+7
       const int row = q >> 4, c16 = q & 15;
       const int m = m0 + row, col = n0 + c16 * 8;
-      if (m < M && col < p.Cout) {
+      if (r0 + row < HWo && col < p.Cout) {
         bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + row * EROW + c16 * 16);
         if (p.mode == CONV_PIXEL_SHUFFLE_SILU) {
           const int ij = col / CoutPS, pc = col - ij * CoutPS;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
           const int row = wm * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
           const int m = m0 + row;
           float v = accv[reg] + bias;
-          if (m < M && cval) {
+          if (r0 + row < HWo && cval) {
             s1[ni] += v;
             s2[ni] += v * v;
             if (p.mode == CONV_PIXEL_SHUFFLE_SILU) {
@@ -283,10 +286,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
           a1 += cs[cl * 2 + 0] + cs[(BN + cl) * 2 + 0];
           a2 += cs[cl * 2 + 1] + cs[(BN + cl) * 2 + 1];
         }
-        const int b = m0 / HWo;
-        const int slot = (m0 - b * HWo) / BM;
-        const int nslots = HWo / BM;
-        float* dst = p.gn_partial + ((size_t)(b * p.groups + g) * nslots + slot) * 2;
+        float* dst = p.gn_partial + ((size_t)(tb * p.groups + g) * tps + tslot) * 2;
         dst[0] = a1;
         dst[1] = a2;
       }
@@ -300,8 +300,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
   constexpr int STRIDE = ROWB + 16;
   size_t lds = (size_t)4 * BM * STRIDE;
   if (sizeof(T) == 2) lds = std::max(lds, (size_t)BM * (BN * 2 + 16));     // bf16 epilogue staging tile
-  const int M = a.B * a.Hout * a.Wout;
-  const int grid = cdiv(M, BM) * (a.CoutPad / BN);
+  const int grid = a.B * cdiv(a.Hout * a.Wout, BM) * (a.CoutPad / BN);
   static bool attr_set[64] = {};
   if (first_use_on_device(attr_set)) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BKC, PRECISE>),
@@ -332,7 +331,6 @@ int conv_igemm(const ConvArgs& a, bool is_bf16, hipStream_t st) {
   if (a.CoutPad % BN != 0 || a.CoutPad < a.Cout) SRGD_FAIL("conv_igemm: CoutPad must be a multiple of 128 and >= Cout");
   if (a.C1 > 0 && a.in1 == nullptr) SRGD_FAIL("conv_igemm: second source missing");
   if (a.gn_partial) {
-    if ((a.Hout * a.Wout) % BM != 0) SRGD_FAIL("conv_igemm: GroupNorm statistics need Hout*Wout % 128 == 0");
     if (a.Cout % a.groups != 0 || (a.Cout / a.groups) > BN || BN % (a.Cout / a.groups) != 0)
       SRGD_FAIL("conv_igemm: unsupported channels-per-group for fused GroupNorm statistics");
   }

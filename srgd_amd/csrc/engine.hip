@@ -174,6 +174,11 @@ struct Pool {
     for (auto& b : bufs)
       if (b.p == p) { b.busy = false; return; }
   }
+  // Buffers are only ever held within one C-ABI call; an entry point that failed half-way (SRGD_TRY returns) leaves some
+  // marked busy, so every entry point starts from a clean slate instead of leaking them forever.
+  void reset_busy() {
+    for (auto& b : bufs) b.busy = false;
+  }
   void release_all() {
     for (auto& b : bufs) hipFree(b.p);
     bufs.clear();
@@ -277,6 +282,8 @@ struct srgd_engine {
     return (int)wt.size() - 1;
   }
 };
+
+static void drop_step_graphs(srgd_engine* e);
 
 namespace {
 
@@ -469,8 +476,12 @@ int pack_attn(srgd_engine* e, AttnW& a) {
   return 0;
 }
 
-template <typename T> int ensure(T** p, size_t* cap, size_t need_elems) {
+// Grow-only scratch.  Captured step graphs bake device pointers in: whenever a buffer actually moves, every cached graph
+// is dropped (it would otherwise replay onto freed memory, e.g. passes 1 -> 2 -> 1 with device noise, or a larger
+// srgd_unet_forward between two steps of a run).
+template <typename T> int ensure(srgd_engine* e, T** p, size_t* cap, size_t need_elems) {
   if (*cap >= need_elems) return 0;
+  drop_step_graphs(e);
   if (*p) hipFree(*p);
   *p = nullptr;
   SRGD_HIP(hipMalloc((void**)p, need_elems * sizeof(T)));
@@ -527,7 +538,7 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
     return conv3x3_bf16(a, c.w3, gn_in ? e->coefA : nullptr, gn_in ? e->coefB : nullptr, x.st);
   }
   if (gn_in) SRGD_FAIL("internal: fused input GroupNorm requested on the generic conv path");
-  if (stats) e->stats_slots = (a.Hout * a.Wout) / conv_tile_m();
+  if (stats) e->stats_slots = cdiv(a.Hout * a.Wout, conv_tile_m());
   return conv_igemm(a, e->bf16, x.st);
 }
 
@@ -618,19 +629,23 @@ int attn_block(Ctx& x, const AttnW& a, const void* in, void** out) {
 
 int ensure_scratch(srgd_engine* e, int nb, int H, int W) {
   const int hw = H * W;
-  SRGD_TRY(ensure(&e->gn_partial, &e->gn_partial_cap, (size_t)nb * e->cfg.groups * (hw / conv_tile_m()) * 2));
   const int cmax = *std::max_element(e->dims.begin(), e->dims.end());
+  // GroupNorm partial slots per (sample, group): generic kernel one per 128-pixel tile, conv3x3_bf16 one per 256-pixel patch
+  // (x the 128-channel tiles a group spans)
+  const size_t slots = std::max((size_t)cdiv(hw, conv_tile_m()), (size_t)cdiv(hw, 256) * std::max(1, cmax / e->cfg.groups / 128));
+  SRGD_TRY(ensure(e, &e->gn_partial, &e->gn_partial_cap, (size_t)nb * e->cfg.groups * slots * 2));
   size_t need = (size_t)nb * cmax;
   if (e->coef_cap < need) {
+    drop_step_graphs(e);
     if (e->coefA) hipFree(e->coefA);
     e->coefA = e->coefB = nullptr;
     SRGD_HIP(hipMalloc((void**)&e->coefA, 2 * need * 4));     // one allocation: [scale | shift] (conv3x3 GNIN reads both)
     e->coefB = e->coefA + need;
     e->coef_cap = need;
   }
-  SRGD_TRY(ensure(&e->la_ws, &e->la_ws_cap,
+  SRGD_TRY(ensure(e, &e->la_ws, &e->la_ws_cap,
                   std::max(linear_attention_workspace(nb, hw, e->cfg.heads, e->cfg.dim_head), linattn_fused_workspace(nb, hw)) / 4));
-  SRGD_TRY(ensure(&e->d_rows, &e->rows_cap, (size_t)nb));
+  SRGD_TRY(ensure(e, &e->d_rows, &e->rows_cap, (size_t)nb));
   return 0;
 }
 
@@ -654,8 +669,6 @@ int unet_body(Ctx& x, void* x0, void** out) {
   const int n = e->n_stages;
   const int f = 1 << (n - 1);
   if (x.H % f || x.W % f) SRGD_FAIL("your input dimensions need to be divisible by " + std::to_string(f) + ", given the unet");
-  if (((x.H / f) * (x.W / f)) % conv_tile_m() != 0)
-    SRGD_FAIL("this build needs (H/" + std::to_string(f) + ")*(W/" + std::to_string(f) + ") to be a multiple of 128 (e.g. 128x128, 256x256 tiles)");
   std::vector<void*> skips;
   void* cur = x0;
   const int H0 = x.H, W0 = x.W;
@@ -756,8 +769,6 @@ int compute_conditioning(srgd_engine* e, CondTable& ct, const float* ls_host, in
 }
 
 }  // namespace
-
-static void drop_step_graphs(srgd_engine* e);
 
 // Graph cache shared by the DDPM and the EDM step: the first occurrence of a key runs eagerly (it warms the activation pool and
 // every lazily-set kernel attribute), the second is captured on a private stream (the caller's may be the legacy default
@@ -950,6 +961,7 @@ int srgd_unet_forward(srgd_engine* e, const float* xin, const float* cond, const
   if (class_id >= 0 && e->cfg.num_classes <= 0) SRGD_FAIL("class label given but the U-Net has no class embedding");
   hipStream_t st = (hipStream_t)stream;
   SRGD_HIP(hipSetDevice(e->cfg.device));
+  e->pool.reset_busy();
   SRGD_TRY(ensure_scratch(e, B, H, W));
   SRGD_TRY(compute_conditioning(e, e->ct_api, log_snr_host, B, class_id, st));
   hipLaunchKernelGGL(rows_api_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, e->d_rows, B, class_id >= 0 ? 0 : 1);
@@ -1005,8 +1017,8 @@ static int sampler_begin_common(srgd_engine* e, const srgd_sampler_geometry* g, 
   for (size_t t = 0; t < tl_odd.size(); t += 3)
     if (tl_odd[t] < 0 || tl_odd[t + 1] < 0 || tl_odd[t] + g->tile > g->Hp || tl_odd[t + 1] + g->tile > g->Wp)
       SRGD_FAIL("srgd_sampler_begin: odd-grid tile outside the canvas");
-  SRGD_TRY(ensure(&e->d_tiles_even, &e->tiles_cap_even, tl_even.size()));
-  SRGD_TRY(ensure(&e->d_tiles_odd, &e->tiles_cap_odd, tl_odd.size()));
+  SRGD_TRY(ensure(e, &e->d_tiles_even, &e->tiles_cap_even, tl_even.size()));
+  SRGD_TRY(ensure(e, &e->d_tiles_odd, &e->tiles_cap_odd, tl_odd.size()));
   SRGD_HIP(hipMemcpyAsync(e->d_tiles_even, tl_even.data(), tl_even.size() * 4, hipMemcpyHostToDevice, st));
   SRGD_HIP(hipMemcpyAsync(e->d_tiles_odd, tl_odd.data(), tl_odd.size() * 4, hipMemcpyHostToDevice, st));
   { Prof p(e, KC_CANVAS, st);
@@ -1145,10 +1157,11 @@ int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas
   const bool last = step == e->n_steps - 1;
   sub_batch = std::min(sub_batch, n);
   const size_t canvas1 = (size_t)3 * g.Hp * g.Wp;
+  e->pool.reset_busy();
   // every allocation happens here, before any capture
   SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
-  if (!noise_canvas) SRGD_TRY(ensure(&e->rng_tiles, &e->rng_tiles_cap, canvas1));
-  if (!ring_noise_canvas && parity == 1) SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, canvas1));
+  if (!noise_canvas) SRGD_TRY(ensure(e, &e->rng_tiles, &e->rng_tiles_cap, canvas1));
+  if (!ring_noise_canvas && parity == 1) SRGD_TRY(ensure(e, &e->rng_canvas, &e->rng_canvas_cap, canvas1));
   if (!e->d_step) SRGD_HIP(hipMalloc((void**)&e->d_step, sizeof(int)));
   hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, e->d_step, step);
   const bool graphable = e->use_graphs && !e->prof_on && !noise_canvas && !ring_noise_canvas;
@@ -1260,10 +1273,11 @@ int srgd_sampler_step_tiles(srgd_engine* e, int step, int tile_first, int tile_c
   if (tile_first < 0 || tile_count < 0 || tile_first + tile_count > n) SRGD_FAIL("srgd_sampler_step_tiles: tile range outside the grid");
   const bool ring = do_ring != 0;
   sub_batch = std::max(1, std::min(sub_batch, std::max(tile_count, 1)));
+  e->pool.reset_busy();
   // every allocation happens here, before any capture
   SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
-  if (!noise_tiles) SRGD_TRY(ensure(&e->rng_tiles, &e->rng_tiles_cap, (size_t)n_local * 3 * g.tile * g.tile));
-  if (!noise_canvas && ring) SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, (size_t)3 * g.Hp * g.Wp));
+  if (!noise_tiles) SRGD_TRY(ensure(e, &e->rng_tiles, &e->rng_tiles_cap, (size_t)n_local * 3 * g.tile * g.tile));
+  if (!noise_canvas && ring) SRGD_TRY(ensure(e, &e->rng_canvas, &e->rng_canvas_cap, (size_t)3 * g.Hp * g.Wp));
   if (!e->d_step) SRGD_HIP(hipMalloc((void**)&e->d_step, sizeof(int)));
   hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, e->d_step, step);
 
@@ -1304,7 +1318,7 @@ int srgd_sampler_q_start(srgd_engine* e, const float* cond01, const float* noise
   const float* nz = noise_canvas;
   if (!nz) {
     const size_t cn = (size_t)3 * g.Hp * g.Wp;
-    SRGD_TRY(ensure(&e->rng_canvas, &e->rng_canvas_cap, cn));
+    SRGD_TRY(ensure(e, &e->rng_canvas, &e->rng_canvas_cap, cn));
     SRGD_TRY(philox_normal(e->rng_canvas, cn, seed, 0, nullptr, st));
     nz = e->rng_canvas;
   }

@@ -4,8 +4,10 @@ skip-if-exists, per-image reseed) on top of the MI355X engine.
 Differences that are deliberate and documented: torchvision/logzero are not needed
 (the x4 bicubic resize and the uint8 conversions run as integer kernels on the GPU, bit-identical to what
 ``T.Resize`` on a PIL image, ``ToTensor`` and ``ToPILImage`` do; ``pil_to_unit_tensor`` / ``unit_tensor_to_pil`` are
-the host-side equivalents kept for tests); ``--no_amp`` has a real meaning here (fp32 parity mode instead of
-bf16); ``--device_noise`` switches from the reference-compatible host noise stream to on-device Philox.
+the host-side equivalents kept for tests); ``--no_amp`` is accepted and, as upstream (whose sampler ignores ``amp`` and
+always computes fp32), changes nothing: the default run reproduces the reference's fp32 numerics.
+Engine-only switches: ``--precision {fp32,bf16,bf16_w8}`` opts into a throughput mode, ``--device_noise`` switches from
+the reference-compatible host noise stream to on-device Philox.
 """
 from __future__ import annotations
 
@@ -46,7 +48,10 @@ def parse_args(argv=None):
     p.add_argument("--no_dpmpp_solver", dest="use_dpmpp_solver", action="store_false")
     p.add_argument("--seed", type=int, default=71)
     p.add_argument("--backend", type=str, default="ddp")
-    # engine-only switch (absent upstream)
+    # engine-only switches (absent upstream)
+    p.add_argument("--precision", choices=["fp32", "bf16", "bf16_w8"], default="fp32",
+                   help="fp32 (default): the reference's numerics (<= 1e-3 of its CPU path); bf16 / bf16_w8: "
+                        "throughput modes of the MI355X engine (explicit opt-in)")
     p.add_argument("--device_noise", action="store_true",
                    help="draw DDPM noise on the GPU (Philox) instead of replaying torch's CPU stream")
     return p.parse_args(argv)
@@ -92,8 +97,8 @@ def upsample_bicubic_on_device(image: Image.Image, scale: int, device) -> torch.
     return dst
 
 
-def unit_tensor_to_pil_on_device(t: torch.Tensor) -> Image.Image:
-    """``ToPILImage`` (mul(255).byte(), inference.py:93) on the GPU: only the uint8 HWC image crosses PCIe (1/4 of the bytes)."""
+def unit_tensor_to_u8_on_device(t: torch.Tensor) -> torch.Tensor:
+    """``mul(255).byte()`` of ``ToPILImage`` (inference.py:93) as a HIP kernel: [3,H,W] fp32 in [0,1] -> [H,W,3] uint8, on the GPU."""
     import ctypes as C
 
     from . import _lib
@@ -104,7 +109,12 @@ def unit_tensor_to_pil_on_device(t: torch.Tensor) -> Image.Image:
         _lib.check(_lib.lib().srgd_image_unit_to_u8(C.c_void_p(t.data_ptr()), h, w, C.c_void_p(out.data_ptr()),
                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                    "srgd_image_unit_to_u8")
-    return Image.fromarray(out.cpu().numpy(), "RGB")
+    return out
+
+
+def unit_tensor_to_pil_on_device(t: torch.Tensor) -> Image.Image:
+    """``ToPILImage`` on the GPU: only the uint8 HWC image crosses PCIe (1/4 of the bytes)."""
+    return Image.fromarray(unit_tensor_to_u8_on_device(t).cpu().numpy(), "RGB")
 
 
 def sr_target_image(image, sr_model, scale=4, batch_size=8, test_label=2, cond_scale=1.0, guidance_start_steps=0,
@@ -170,6 +180,8 @@ def main(argv=None):
         raise SystemExit("srgd_amd needs an MI355X: no GPU visible and there is no CPU fallback")
     sr_model = ema_model.module.eval().to(torch.device("cuda"))
     sr_model.noise_source = "device" if args.device_noise else "host"
+    sr_model.precision = args.precision
+    print(f"engine precision: {args.precision} (noise: {sr_model.noise_source})")
     print(args)
     batch_sr_target_images(args.input_dir, args.output_dir, sr_model, scale=4, batch_size=args.batch_size,
                            test_label=args.test_label, cond_scale=args.cond_scale,

@@ -158,6 +158,19 @@ class _ShuffleUp(_Params):                              # PixelShuffleUpsample: 
         self.net = nn.Sequential(conv, nn.SiLU(), nn.PixelShuffle(2))
 
 
+def _single_class_id(class_label) -> int:
+    """The samplers condition every tile on ONE class (the reference passes a ``[1]`` label that broadcasts over the
+    tile batch, model.py:694).  A ``[B]`` label with differing entries (legal for the reference's un-tiled ``sample``)
+    is refused rather than silently collapsed to its first element."""
+    if class_label is None:
+        return -1
+    flat = class_label.reshape(-1)
+    if flat.numel() > 1 and not bool((flat == flat[0]).all()):
+        raise NotImplementedError("per-image class labels: this engine conditions one run on one class "
+                                  "(pass a [1] label, or equal labels)")
+    return int(flat[0])
+
+
 def _as_tuple(v, n):
     return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
 
@@ -314,7 +327,10 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
         self.noise_source = "host"     # "host": torch CPU generator in the reference's draw order; "device": Philox
         self.device_noise_seed = 0
         self.max_tiles_per_launch = None   # None: use the caller's batch_size as the reference does
-        self.amp_precision = None          # engine mode behind amp=True: None = "bf16"; "bf16_w8" = fp8-e4m3 conv weights
+        # engine precision: "fp32" (default: the reference's numerics - upstream ignores ``amp`` and always computes fp32,
+        # SURVEY App. E), "bf16" (throughput mode), "bf16_w8" (bf16 kernels, fp8-e4m3-rounded conv weights),
+        # "fp8" (MX-fp8 3x3 convolutions, BASELINE configs[4]).  tiled_sample(precision=...) overrides it per call.
+        self.precision = "fp32"
         # set by srgd_amd.parallel.shard_canvas: a torch.distributed group whose ranks share ONE canvas - each rank
         # runs a contiguous slice of every step's tiles and the updated tiles are all-gathered
         self.canvas_group = None
@@ -331,11 +347,12 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
     def tiled_sample(self, batch_size=4, tile_size=256, tile_stride=256, condition_x=None, class_label=None,
                      cond_scale=1.0, guidance_start_steps=0, class_cond_scale=1.0, class_guidance_start_steps=0,
                      generation_start_steps=0, num_sample_steps=None, with_images=False, with_x0_images=False,
-                     start_white_noise=True, amp=False):
+                     start_white_noise=True, amp=False, precision=None):
         """Tiled CFG-DDPM sampling (reference model.py:3288-3413).
 
-        ``amp`` is accepted and ignored by the reference; here it selects the engine's bf16 mode
-        (False: exact-fp32 parity mode).  ``condition_x`` is ``[1,3,H,W]`` as in the reference, or
+        ``amp`` is accepted and ignored exactly as in the reference (which always computes fp32); the engine
+        precision is ``precision`` (engine-only keyword) or, if None, ``self.precision`` - "fp32" by default, i.e.
+        the reference's numerics.  ``condition_x`` is ``[1,3,H,W]`` as in the reference, or
         ``[B,3,H,W]``: B same-sized images sampled in lock-step, each exactly as the reference would
         sample it on its own after ``seed_everything(seed)`` (inference.py:73) - i.e. all B see the
         same noise stream - with every U-Net launch spanning tiles of all images (fills the GPU
@@ -354,8 +371,8 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
             raise ValueError("condition_x must be [B,3,H,W] (B=1 in the reference, whose tile gather assumes batch 1)")
         f = self.model.downsample_factor
         assert tile_size % f == 0, f"your input dimensions need to be divisible by {f}, given the unet"
-        eng = self.model.engine((self.amp_precision or "bf16") if amp else "fp32")
-        class_id = -1 if class_label is None else int(class_label.reshape(-1)[0])
+        eng = self.model.engine(precision or self.precision)
+        class_id = _single_class_id(class_label)
 
         (left, top, right, bottom), pad = get_coord_and_pad(h, w)
         hp, wp = h + pad[2] + pad[3], w + pad[0] + pad[1]
@@ -438,13 +455,13 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
     @torch.inference_mode()
     def sample(self, batch_size=16, condition_x=None, class_label=None, cond_scale=1.0, guidance_start_steps=0,
                class_cond_scale=1.0, class_guidance_start_steps=0, generation_start_steps=0, num_sample_steps=None,
-               with_images=False, with_x0_images=False, x0=None, amp=False):
+               with_images=False, with_x0_images=False, x0=None, amp=False, precision=None):
         """Un-tiled sampling of a batch of ``image_size`` x ``image_size`` images (reference model.py:3417-3432,
         p_sample_loop :3191-3247): every image has its own noise (one ``randn`` over ``[B,3,S,S]`` per draw, host mode).
 
         Runs on the tiled machinery: the batch is laid out as one canvas of B stacked tiles (``[3, B*S, S]``, no padding, no
         ring re-noise), so one U-Net launch covers the whole batch.  Needs ``image_size == 256`` (the tile edge of the kernels;
-        the shipped config).  ``amp`` selects the bf16 mode as in ``tiled_sample``."""
+        the shipped config).  ``amp`` / ``precision`` as in ``tiled_sample``."""
         num_sample_steps = self.num_sample_steps if num_sample_steps is None else num_sample_steps
         if cond_scale != 1.0 and class_cond_scale != 1.0:
             raise NotImplementedError("Currently, you cannot specify both cond_scale and class_cond_scale at the same time.")
@@ -457,8 +474,8 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
         b = int(batch_size)
         if tuple(condition_x.shape) != (b, self.channels, s_, s_):
             raise ValueError(f"condition_x must be [{b},{self.channels},{s_},{s_}] (model.py:3426 pairs it with the noise batch)")
-        eng = self.model.engine((self.amp_precision or "bf16") if amp else "fp32")
-        class_id = -1 if class_label is None else int(class_label.reshape(-1)[0])
+        eng = self.model.engine(precision or self.precision)
+        class_id = _single_class_id(class_label)
         to_canvas = lambda t: t.permute(1, 0, 2, 3).reshape(1, 3, b * s_, s_).contiguous()       # [B,3,S,S] -> [1,3,B*S,S]
         from_canvas = lambda t: t.reshape(3, b, s_, s_).permute(1, 0, 2, 3).contiguous()
         tiles = [(i * s_, 0) for i in range(b)]
@@ -558,7 +575,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         self.noise_source = "host"
         self.device_noise_seed = 0
         self.max_tiles_per_launch = None
-        self.amp_precision = None
+        self.precision = "fp32"            # as in the DDPM wrapper
 
     def set_seed(self, seed):
         torch.cuda.manual_seed(seed)
@@ -591,6 +608,9 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
     def _step_tables(self, n: int, clamp: bool):
         from ._lib import EdmScalars
         sigmas = self.sample_schedule(n)
+        # get_noised_images (model.py:2186-2189) is called without num_sample_steps at :2342 and :2457, so the
+        # generation-start sigma and the odd-step ring sigmas come from the CONSTRUCTOR's schedule, not the per-call one
+        noised_sigmas = self.sample_schedule(self.num_sample_steps)
         gammas = torch.where((sigmas >= self.S_tmin) & (sigmas <= self.S_tmax),
                              min(self.S_churn / n, math.sqrt(2) - 1), 0.0)                      # model.py:2333-2337
         scalars, c_noise = [], []
@@ -603,16 +623,19 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
                 sigma_next=sigma_next, dt=sigma_next - sigma_hat, half_dt=0.5 * (sigma_next - sigma_hat),
                 c_in_hat=float(self.c_in(sh)), c_skip_hat=float(self.c_skip(sh)), c_out_hat=float(self.c_out(sh)),
                 c_in_next=float(self.c_in(sn)), c_skip_next=float(self.c_skip(sn)), c_out_next=float(self.c_out(sn)),
-                ring_sigma=float(sigmas[i]), clamp=1.0 if clamp else 0.0, pad0=0.0, pad1=0.0))
+                # read on odd steps only; upstream indexes its constructor-length schedule there (IndexError beyond it)
+                ring_sigma=float(noised_sigmas[i]) if (i % 2 == 1 or i < len(noised_sigmas)) else 0.0,
+                clamp=1.0 if clamp else 0.0, pad0=0.0, pad1=0.0))
             c_noise += [float(self.c_noise(sh)), float(self.c_noise(sn))]
-        return sigmas, scalars, c_noise
+        return sigmas, noised_sigmas, scalars, c_noise
 
     @torch.inference_mode()
     def tiled_sample(self, batch_size=4, tile_size=256, tile_stride=256, condition_x=None, class_label=None,
                      cond_scale=1.0, guidance_start_steps=0, class_cond_scale=1.0, class_guidance_start_steps=0,
                      generation_start_steps=0, num_sample_steps=None, clamp=True, zero_init=False, with_images=False,
-                     with_x0_images=False, start_white_noise=True, amp=False):
-        """Reference model.py:2309-2475 (``start_white_noise`` is accepted and unused there too)."""
+                     with_x0_images=False, start_white_noise=True, amp=False, precision=None):
+        """Reference model.py:2309-2475 (``start_white_noise`` and ``amp`` are accepted and unused there too; ``precision``
+        is the engine-only override of ``self.precision``)."""
         n = self.num_sample_steps if num_sample_steps is None else num_sample_steps
         if cond_scale != 1.0 and class_cond_scale != 1.0:
             raise NotImplementedError("Currently, you cannot specify both cond_scale and class_cond_scale at the same time.")
@@ -626,12 +649,12 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         if batch < 1 or c != 3:
             raise ValueError("condition_x must be [B,3,H,W] (B=1 in the reference; B>1 = same-sized images in lock-step, "
                              "each sampled as it would be alone with the same seed)")
-        eng = self.net.engine((self.amp_precision or "bf16") if amp else "fp32")
-        class_id = -1 if class_label is None else int(class_label.reshape(-1)[0])
+        eng = self.net.engine(precision or self.precision)
+        class_id = _single_class_id(class_label)
         (left, top, right, bottom), (hp, wp), coords0, coords1, (sl, st_, sr, sb) = _tiling(h, w, tile_size, tile_stride)
         geo = SamplerGeometry(H=h, W=w, Hp=hp, Wp=wp, left=left, top=top, inner_l=sl, inner_t=st_, inner_r=sr,
                               inner_b=sb, tile=tile_size, n_even=len(coords0), n_odd=len(coords1), n_images=batch)
-        sigmas, scalars, c_noise = self._step_tables(n, clamp)
+        sigmas, noised_sigmas, scalars, c_noise = self._step_tables(n, clamp)
         cond01 = condition_x.to(dev, torch.float32).contiguous()
         cond_canvas = torch.empty(batch, 3, hp, wp, device=dev, dtype=torch.float32)
         eng.edm_begin(geo, cond01, cond_canvas, [(a, c_) for (a, _, c_, _) in coords0],
@@ -646,7 +669,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
 
         if generation_start_steps > 0:                                  # get_noised_images(condition, step) :2340, :2185
             img = torch.empty(batch, 3, hp, wp, device=dev)
-            eng.sampler_q_start(cond01, canvas_noise(1), 1.0, float(sigmas[generation_start_steps]), img, seed)
+            eng.sampler_q_start(cond01, canvas_noise(1), 1.0, float(noised_sigmas[generation_start_steps]), img, seed)
         elif zero_init:
             img = torch.zeros(batch, 3, hp, wp, device=dev)
         else:

@@ -49,6 +49,17 @@ def gather_outputs(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Ten
     return bucket
 
 
+def gather_outputs_u8(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
+    """Gather the HR outputs the way they leave the pipeline (``ToPILImage``: uint8 HWC, inference.py:93): each rank converts
+    its ``[n,3,H,W]`` fp32 stack on the GPU and 3.1 MB per 1024^2 tile travel instead of 12.6 MB."""
+    if local.is_cuda:
+        from .inference import unit_tensor_to_u8_on_device
+        local = torch.stack([unit_tensor_to_u8_on_device(img) for img in local], 0)
+    else:                                            # CPU tests (gloo): same arithmetic, torch ops
+        local = local.mul(255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    return gather_outputs(local, dst=dst)
+
+
 def max_over_ranks(seconds: float, device: torch.device) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -29,3 +29,28 @@ def test_two_rank_bench_emits_one_valid_json_line():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["unit"] == "HR tiles/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"] + 1e-9
+
+
+def _run_bare(extra):
+    """`python bench.py --gpus 2 ...` with NO launcher: bench.py must start its two ranks itself."""
+    env = dict(os.environ, SRGD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--ddpm_steps", "4",
+           "--dim", "16", "--no_cpu_baseline", "--no_profile", *extra]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bare_gpus2_self_launches_two_ranks():
+    d = _run_bare(["--images", "2"])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "image-sharded x2"
+
+
+def test_bare_gpus2_canvas_workload_self_launches_two_ranks():
+    d = _run_bare(["--workload", "canvas", "--lr_size", "128"])        # 512^2 image, canvas 768^2, 9/4 tiles over 2 ranks
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "strong" and d["value"] > 0

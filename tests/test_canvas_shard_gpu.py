@@ -25,10 +25,23 @@ def _sample(sampler, case, noise, amp, **kw):
     sampler.device_noise_seed = 17
     torch.manual_seed(case["seed"])
     return sampler.tiled_sample(batch_size=4, condition_x=cond, class_label=label, num_sample_steps=case["steps"],
-                                class_cond_scale=1.4, amp=amp, **kw)
+                                class_cond_scale=1.4, precision="bf16" if amp else "fp32", **kw)
 
 
-def _worker(rank, world, port, out_dir):
+def _case(name):
+    return next(c for c in C.SAMPLER_CASES + C.WIDE_CASES if c["name"] == name)
+
+
+def _run_all(sampler, case):
+    out = {"host_fp32": _sample(sampler, case, "host", False).cpu(),
+           "device_bf16": _sample(sampler, case, "device", True).cpu()}
+    o, imgs, x0s = _sample(sampler, case, "host", False, with_images=True, with_x0_images=True)
+    out["x0_last"] = x0s[-1]
+    sampler.noise_source = "host"
+    return out
+
+
+def _worker(rank, world, port, out_dir, case_name):
     import datetime
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -36,31 +49,26 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from srgd_amd.parallel import shard_canvas
     from tests.test_engine_gpu import build_sampler
-    case = next(c for c in C.SAMPLER_CASES if c["name"] == "dim16_300x500")
+    case = _case(case_name)
     sampler = shard_canvas(build_sampler(case["dim"]))
-    out = {"host_fp32": _sample(sampler, case, "host", False).cpu(),
-           "device_bf16": _sample(sampler, case, "device", True).cpu()}
-    o, imgs, x0s = _sample(sampler, case, "host", False, with_images=True, with_x0_images=True)
-    out["x0_last"] = x0s[-1]
-    torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.save(_run_all(sampler, case), os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_sharing_a_canvas_equal_the_single_process_run(tmp_path):
+# dim 16 on a 768^2 canvas (9 / 4 tiles) and the dim-128 U-Net on BASELINE configs[1]'s 1280^2 canvas (25 / 16 tiles: slices of
+# 13 + 12 and 8 + 8 tiles, CFG pairs batched per launch)
+@pytest.mark.parametrize("case_name", ["dim16_300x500", "dim128_config2_1024_2steps"])
+def test_two_ranks_sharing_a_canvas_equal_the_single_process_run(tmp_path, case_name):
     from tests.test_engine_gpu import build_sampler
-    case = next(c for c in C.SAMPLER_CASES if c["name"] == "dim16_300x500")
+    case = _case(case_name)
     sampler = build_sampler(case["dim"])
     assert sampler.canvas_group is None
-    want = {"host_fp32": _sample(sampler, case, "host", False).cpu(),
-            "device_bf16": _sample(sampler, case, "device", True).cpu()}
-    o, imgs, x0s = _sample(sampler, case, "host", False, with_images=True, with_x0_images=True)
-    want["x0_last"] = x0s[-1]
-    sampler.noise_source = "host"
+    want = _run_all(sampler, case)
     # bounded wait: a rendezvous or collective that never completes must fail this test, not stall the suite
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), case_name)) for r in range(2)]
     for pr in procs:
         pr.start()
     for pr in procs:

@@ -36,11 +36,12 @@ def test_inference_cli_writes_out_pngs_and_matches_the_oracle_pipeline(tmp_path)
     Image.fromarray(lr, "RGB").save(indir / "a.png")
     (indir / "broken.png").write_bytes(b"not a png")
     cmd = [sys.executable, os.path.join(ROOT, "inference.py"), "-c", str(conf), "-m", str(ckpt), "--input_dir", str(indir),
-           "--output_dir", str(outdir), "--num_sample_steps", str(steps), "--test_label", str(label), "--no_amp",
+           "--output_dir", str(outdir), "--num_sample_steps", str(steps), "--test_label", str(label),
            "--seed", str(seed), "--batch_size", "3"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "Invalid image or unable to open image" in r.stdout
+    assert "engine precision: fp32" in r.stdout      # the DEFAULT run computes in the reference's precision (no --no_amp needed)
     out_png = outdir / "a_out.png"
     assert out_png.exists() and not (outdir / "broken_out.png").exists()
     got = np.asarray(Image.open(out_png).convert("RGB"))
@@ -57,3 +58,11 @@ def test_inference_cli_writes_out_pngs_and_matches_the_oracle_pipeline(tmp_path)
     # second run: everything already there -> "skip"
     r2 = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0 and "skip" in r2.stdout
+    # explicit opt-in to the throughput mode: same image within bf16's distance of the fp32 result
+    out_bf = tmp_path / "out_bf16"
+    cmd_bf = [c if c != str(outdir) else str(out_bf) for c in cmd] + ["--precision", "bf16", "--no_amp"]
+    r3 = subprocess.run(cmd_bf, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r3.returncode == 0 and "engine precision: bf16" in r3.stdout, r3.stderr[-2000:]
+    bf = np.asarray(Image.open(out_bf / "a_out.png").convert("RGB")).astype(np.float64)
+    mse = ((bf - got.astype(np.float64)) ** 2).mean() / 255.0 ** 2
+    assert 10 * np.log10(1.0 / max(mse, 1e-20)) > 40.0

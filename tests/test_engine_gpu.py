@@ -76,7 +76,8 @@ def test_unet_forward_matches_reference(case, precision):
             scale = max(1.0, want.abs().max().item())
             _report(test="unet_forward", case=case["name"], mode=mode, precision=precision, max_abs=err, ref_max=scale)
             assert torch.isfinite(got).all()
-            assert err <= (1e-4 if precision == "fp32" else 8e-2) * scale, (mode, err)
+            # bf16 measured on MI355X: 2.4e-2 (dim 16) / 1.3e-2 (dim 128) of the eps range; gate at ~1.7x that
+            assert err <= (1e-4 if precision == "fp32" else 4e-2) * scale, (mode, err)
     finally:
         unet.precision = "fp32"
 
@@ -93,7 +94,7 @@ def test_tiled_sample_fp32_matches_reference(case):
     sampler.noise_source = "host"
     got = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond.cuda(), class_label=label,
                                cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
-                               num_sample_steps=case["steps"], amp=False, **C.extra_kwargs(case))
+                               num_sample_steps=case["steps"], precision="fp32", **C.extra_kwargs(case))
     torch.cuda.synchronize()
     want = torch.from_numpy(z["image"])
     assert got.shape == want.shape and got.dtype == torch.float32
@@ -113,7 +114,7 @@ def test_tiled_sample_bf16_vs_reference_reported(case):
     torch.manual_seed(case["seed"])
     sampler.noise_source = "host"
     got = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond.cuda(), class_label=label,
-                               num_sample_steps=case["steps"], amp=True).cpu()
+                               num_sample_steps=case["steps"], precision="bf16").cpu()
     want = torch.from_numpy(z["image"])
     err = (got - want).abs()
     mse = float((err ** 2).mean())
@@ -121,7 +122,9 @@ def test_tiled_sample_bf16_vs_reference_reported(case):
     _report(test="tiled_sample", case=case["name"], precision="bf16", max_abs=float(err.max()),
             mean_abs=float(err.mean()), psnr_db=psnr)
     assert torch.isfinite(got).all() and got.min() >= 0 and got.max() <= 1
-    assert psnr > 20.0, psnr
+    # measured on MI355X: 54.3 dB (dim 16) / 55.9 dB (dim 128) against the REFERENCE's image; gate 3 dB below
+    assert psnr > 51.0, psnr
+    assert float(err.max()) < 0.1, float(err.max())      # measured 4.4e-2 ... 5.1e-2
 
 
 def test_result_is_independent_of_batch_size_and_bitwise_repeatable():
@@ -135,7 +138,7 @@ def test_result_is_independent_of_batch_size_and_bitwise_repeatable():
     for bs in (1, 4, 9, 4):
         torch.manual_seed(3)
         outs.append(sampler.tiled_sample(batch_size=bs, condition_x=cond, class_label=label,
-                                         num_sample_steps=3, amp=False).cpu())
+                                         num_sample_steps=3, precision="fp32").cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
 
 
@@ -151,7 +154,7 @@ def test_device_noise_mode_full_size_properties():
         for seed in (71, 71, 72):
             sampler.device_noise_seed = seed
             outs.append(sampler.tiled_sample(batch_size=25, condition_x=cond, class_label=label,
-                                             num_sample_steps=4, amp=True).cpu())
+                                             num_sample_steps=4, precision="bf16").cpu())
         assert outs[0].shape == (1, 3, 1024, 1024)
         assert torch.isfinite(outs[0]).all() and outs[0].min() >= 0 and outs[0].max() <= 1
         assert torch.equal(outs[0], outs[1])
@@ -215,7 +218,7 @@ def test_hipgraph_replay_is_bitwise_identical_to_eager_launches():
             os.environ["SRGD_GRAPHS"] = mode
             sampler.model._invalidate_engines()                   # the switch is read at engine creation
             outs[mode] = sampler.tiled_sample(batch_size=9, condition_x=cond, class_label=label, num_sample_steps=9,
-                                              class_cond_scale=1.5, class_guidance_start_steps=3, amp=True).cpu()
+                                              class_cond_scale=1.5, class_guidance_start_steps=3, precision="bf16").cpu()
     finally:
         os.environ.pop("SRGD_GRAPHS", None)
         sampler.model._invalidate_engines()
@@ -224,8 +227,8 @@ def test_hipgraph_replay_is_bitwise_identical_to_eager_launches():
     assert torch.equal(outs["1"], outs["0"])
 
 
-@pytest.mark.parametrize("noise,amp", [("host", False), ("device", True)])
-def test_lockstep_images_equal_their_solo_runs(noise, amp):
+@pytest.mark.parametrize("noise,prec", [("host", "fp32"), ("device", "bf16")])
+def test_lockstep_images_equal_their_solo_runs(noise, prec):
     # [B,3,H,W] condition: B same-sized images advance together, every U-Net launch spanning tiles of all of them.
     # Each must come out bit-identical to sampling it alone with the same seed (what the reference's per-image
     # seed_everything gives, inference.py:73), for a sub-batch that straddles image boundaries too.
@@ -239,11 +242,11 @@ def test_lockstep_images_equal_their_solo_runs(noise, amp):
         for i in range(3):
             torch.manual_seed(9)
             solo.append(sampler.tiled_sample(batch_size=9, condition_x=conds[i:i + 1], class_label=label,
-                                             num_sample_steps=5, class_cond_scale=1.3, amp=amp).cpu())
+                                             num_sample_steps=5, class_cond_scale=1.3, precision=prec).cpu())
         for bs in (27, 7):
             torch.manual_seed(9)
             both = sampler.tiled_sample(batch_size=bs, condition_x=conds, class_label=label, num_sample_steps=5,
-                                        class_cond_scale=1.3, amp=amp).cpu()
+                                        class_cond_scale=1.3, precision=prec).cpu()
             assert both.shape == (3, 3, 384, 384)
             for i in range(3):
                 assert torch.equal(both[i:i + 1], solo[i]), (bs, i)
@@ -260,8 +263,8 @@ def test_lockstep_full_size_batch_of_five():
     sampler.noise_source = "device"
     sampler.device_noise_seed = 71
     try:
-        five = sampler.tiled_sample(batch_size=125, condition_x=conds, class_label=label, num_sample_steps=3, amp=True).cpu()
-        solo = sampler.tiled_sample(batch_size=25, condition_x=conds[3:4], class_label=label, num_sample_steps=3, amp=True).cpu()
+        five = sampler.tiled_sample(batch_size=125, condition_x=conds, class_label=label, num_sample_steps=3, precision="bf16").cpu()
+        solo = sampler.tiled_sample(batch_size=25, condition_x=conds[3:4], class_label=label, num_sample_steps=3, precision="bf16").cpu()
     finally:
         sampler.noise_source = "host"
     assert torch.isfinite(five).all()
@@ -380,9 +383,15 @@ def test_edm_tiled_sample_fp32_matches_reference(case):
     cond = C.sampler_condition(case).cuda()
     label = torch.tensor([case["label"]]).cuda() if case["label"] is not None else None
     torch.manual_seed(case["seed"])
-    got = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label,
-                               cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
-                               num_sample_steps=case["steps"], amp=False, **C.edm_extra_kwargs(case)).cpu()
+    ctor_steps = sampler.num_sample_steps
+    try:
+        # the constructor's step count matters when it differs from the per-call one (noised start / ring sigmas)
+        sampler.num_sample_steps = case.get("ctor_steps", case["steps"])
+        got = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label,
+                                   cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
+                                   num_sample_steps=case["steps"], precision="fp32", **C.edm_extra_kwargs(case)).cpu()
+    finally:
+        sampler.num_sample_steps = ctor_steps
     want = torch.from_numpy(z["image"])
     err = (got - want).abs().max().item()
     _report(test="edm_tiled_sample", case=case["name"], precision="fp32", max_abs=err)
@@ -398,7 +407,7 @@ def test_edm_bf16_and_device_noise_modes_run():
     cond = C.sampler_condition(case).cuda()
     label = torch.tensor([case["label"]]).cuda()
     torch.manual_seed(case["seed"])
-    bf = sampler.tiled_sample(batch_size=4, condition_x=cond, class_label=label, num_sample_steps=case["steps"], amp=True).cpu()
+    bf = sampler.tiled_sample(batch_size=4, condition_x=cond, class_label=label, num_sample_steps=case["steps"], precision="bf16").cpu()
     mse = float(((bf - torch.from_numpy(z["image"])) ** 2).mean())
     _report(test="edm_tiled_sample", case=case["name"], precision="bf16", psnr_db=10 * np.log10(1.0 / max(mse, 1e-20)))
     assert torch.isfinite(bf).all() and bf.min() >= 0 and bf.max() <= 1
@@ -407,7 +416,7 @@ def test_edm_bf16_and_device_noise_modes_run():
         outs = []
         for seed in (3, 3, 4):
             sampler.device_noise_seed = seed
-            outs.append(sampler.tiled_sample(batch_size=4, condition_x=cond, class_label=label, num_sample_steps=4, amp=True).cpu())
+            outs.append(sampler.tiled_sample(batch_size=4, condition_x=cond, class_label=label, num_sample_steps=4, precision="bf16").cpu())
         assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
     finally:
         sampler.noise_source = "host"
@@ -426,15 +435,11 @@ def test_config5_cfg2_100_steps_fp32_parity_and_bf16_fp8_weight_reports():
     assert abs(cond.double().sum().item() - float(z["cond_sum"])) < 1e-6
     label = torch.tensor([case["label"]]).cuda()
     outs = {}
-    try:
-        for mode, amp, prec in (("fp32", False, None), ("bf16", True, None), ("bf16_w8", True, "bf16_w8")):
-            sampler.amp_precision = prec
-            torch.manual_seed(case["seed"])
-            outs[mode] = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label,
-                                              class_cond_scale=case["class_cond_scale"], num_sample_steps=case["steps"],
-                                              amp=amp).cpu()
-    finally:
-        sampler.amp_precision = None
+    for mode in ("fp32", "bf16", "bf16_w8"):
+        torch.manual_seed(case["seed"])
+        outs[mode] = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label,
+                                          class_cond_scale=case["class_cond_scale"], num_sample_steps=case["steps"],
+                                          precision=mode).cpu()
     psnr = lambda a, b: float(10 * np.log10(1.0 / max(float(((a - b) ** 2).mean()), 1e-20)))
     err32 = (outs["fp32"] - want).abs().max().item()
     _report(test="config5_256", fp32_max_abs=err32, bf16_psnr_vs_ref=psnr(outs["bf16"], want),
@@ -444,7 +449,8 @@ def test_config5_cfg2_100_steps_fp32_parity_and_bf16_fp8_weight_reports():
     for k in ("bf16", "bf16_w8"):
         assert torch.isfinite(outs[k]).all() and outs[k].min() >= 0 and outs[k].max() <= 1
     assert not torch.equal(outs["bf16"], outs["bf16_w8"])
-    assert psnr(outs["bf16_w8"], outs["bf16"]) > 15.0
+    assert psnr(outs["bf16"], want) > 54.0                # measured 57.9 dB vs the reference
+    assert psnr(outs["bf16_w8"], outs["bf16"]) > 32.0     # measured 35.2 dB (random-init weights, per-channel e4m3 scales)
 
 
 def test_headline_config_bf16_vs_fp32_engine_full_size():
@@ -455,9 +461,10 @@ def test_headline_config_bf16_vs_fp32_engine_full_size():
     cond = C.synthetic_lr_condition(0, 256, 256).cuda()
     label = torch.tensor([0]).cuda()
     outs = {}
-    for amp in (False, True):
+    for amp in (False, True):   # keys: False = fp32 engine, True = bf16 engine
         torch.manual_seed(71)
-        outs[amp] = sampler.tiled_sample(batch_size=25, condition_x=cond, class_label=label, num_sample_steps=50, amp=amp).cpu()
+        outs[amp] = sampler.tiled_sample(batch_size=25, condition_x=cond, class_label=label, num_sample_steps=50,
+                                         precision="bf16" if amp else "fp32").cpu()
     assert outs[False].shape == (1, 3, 1024, 1024)
     err = (outs[True] - outs[False]).abs()
     mse = float((err ** 2).mean())
@@ -465,7 +472,8 @@ def test_headline_config_bf16_vs_fp32_engine_full_size():
     _report(test="config2_full_bf16_vs_fp32_engine", max_abs=float(err.max()), mean_abs=float(err.mean()), psnr_db=psnr)
     for o in outs.values():
         assert torch.isfinite(o).all() and o.min() >= 0 and o.max() <= 1
-    assert psnr > 30.0, psnr
+    assert psnr > 55.0, psnr                              # measured 58.5 dB (max 2.4e-2) on MI355X
+    assert float(err.max()) < 5e-2
 
 
 def test_edm_lockstep_images_equal_their_solo_runs():
@@ -476,11 +484,11 @@ def test_edm_lockstep_images_equal_their_solo_runs():
     for i in range(2):
         torch.manual_seed(9)
         solo.append(sampler.tiled_sample(batch_size=9, condition_x=conds[i:i + 1], class_label=label, num_sample_steps=4,
-                                         class_cond_scale=1.3, amp=False).cpu())
+                                         class_cond_scale=1.3, precision="fp32").cpu())
     for bs in (18, 5):
         torch.manual_seed(9)
         both = sampler.tiled_sample(batch_size=bs, condition_x=conds, class_label=label, num_sample_steps=4,
-                                    class_cond_scale=1.3, amp=False).cpu()
+                                    class_cond_scale=1.3, precision="fp32").cpu()
         assert both.shape == (2, 3, 384, 384)
         for i in range(2):
             assert torch.equal(both[i:i + 1], solo[i]), (bs, i)
@@ -518,10 +526,158 @@ def test_edm_hipgraph_replay_is_bitwise_identical_to_eager_launches():
             os.environ["SRGD_GRAPHS"] = mode
             sampler.net._invalidate_engines()
             outs[mode] = sampler.tiled_sample(batch_size=9, condition_x=cond, class_label=label, num_sample_steps=9,
-                                              class_cond_scale=1.5, class_guidance_start_steps=3, amp=True).cpu()
+                                              class_cond_scale=1.5, class_guidance_start_steps=3, precision="bf16").cpu()
     finally:
         os.environ.pop("SRGD_GRAPHS", None)
         sampler.net._invalidate_engines()
         sampler.noise_source = "host"
     assert torch.isfinite(outs["1"]).all()
     assert torch.equal(outs["1"], outs["0"])
+
+
+def test_graph_cache_survives_scratch_growth_between_guidance_modes():
+    # with device noise, a passes=2 step grows the per-launch scratch (GroupNorm partials, coefficient rows, ...);
+    # graphs captured for passes=1 before that hold the OLD pointers.  Guidance toggled 1 -> 2 -> 1 inside one run (legal for
+    # a C-ABI caller) must still equal the all-eager run bit for bit.
+    import os
+    from srgd_amd.model import _schedule, get_coord_and_pad, get_coords, get_area
+    from srgd_amd._lib import SamplerGeometry
+    sampler = build_sampler(16)
+    dev = sampler.device
+    cond = C.synthetic_lr_condition(4, 96, 96).to(dev)             # 384^2 -> canvas 768^2 (9 / 4 tiles)
+    _, _, h, w = cond.shape
+    (left, top, right, bottom), pad = get_coord_and_pad(h, w)
+    hp, wp = h + pad[2] + pad[3], w + pad[0] + pad[1]
+    c0 = get_coords(hp, wp, 256, 256)
+    c1 = get_coords(hp - 256, wp - 256, 256, 256, diff=128)
+    (sl, st_, sr, sb), _ = get_area(c1, hp, wp)
+    geo = SamplerGeometry(H=h, W=w, Hp=hp, Wp=wp, left=left, top=top, inner_l=sl, inner_t=st_, inner_r=sr, inner_b=sb,
+                          tile=256, n_even=len(c0), n_odd=len(c1), n_images=1)
+    n = 14
+    scalars, log_snrs = _schedule(n)
+    passes_of = [1] * 5 + [2] * 4 + [1] * 5          # 1 (eager, captured, replayed) -> 2 (scratch grows) -> 1 (replay again)
+    outs = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["SRGD_GRAPHS"] = mode
+            sampler.model._invalidate_engines()
+            eng = sampler.model.engine("bf16")
+            cc = torch.empty(1, 3, hp, wp, device=dev)
+            eng.sampler_begin(geo, cond, cc, [(a, c_) for (a, _, c_, _) in c0], [(a, c_) for (a, _, c_, _) in c1], scalars,
+                              log_snrs, 1)
+            img = eng.randn_(torch.empty(1, 3, hp, wp, device=dev), 9, 0)
+            for i in range(n):
+                p = passes_of[i]
+                eng.sampler_step(i, img, cc, None, None, None, p, 1 if p == 2 else 0, 1.5 if p == 2 else 1.0, 9, seed=9)
+            out = torch.empty(1, 3, h, w, device=dev)
+            eng.sampler_end(img, out)
+            outs[mode] = out.cpu()
+    finally:
+        os.environ.pop("SRGD_GRAPHS", None)
+        sampler.model._invalidate_engines()
+    assert torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["1"], outs["0"])
+
+
+# ------------------------------------------------------------------ BASELINE configs[1] at its real geometry and width
+def test_config2_geometry_dim128_matches_reference_fp32_and_bf16():
+    # 256^2 LR -> 1024^2, canvas 1280^2, 25 (even) / 16 (odd) tiles, dim 128, batch_size 8 (ragged
+    # minibatches), 2 DDPM steps = 41 tile-forwards through the reference's minibatch loop, scatter and odd-step ring re-noise
+    # (model.py:3364-3396).  The fixture is the REFERENCE's output (uint16 steps of 1/65535: +-7.7e-6).
+    case = C.WIDE_CASES[0]
+    z = np.load(os.path.join(G, f"sample_{case['name']}.npz"))
+    want = torch.from_numpy(z["image_u16"].astype(np.float32) / 65535.0)
+    assert abs(want.double().sum().item() - float(z["checksum"])) < 3.2e6 * 7.7e-6     # the dequantised fixture is intact
+    sampler = build_sampler(case["dim"], weight_seed=case["weight_seed"])
+    cond = C.sampler_condition(case).cuda()
+    assert abs(cond.double().sum().item() - float(z["cond_sum"])) < 1e-6
+    label = torch.tensor([case["label"]]).cuda()
+    sampler.noise_source = "host"
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(case["seed"])
+        outs[prec] = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label,
+                                          num_sample_steps=case["steps"], precision=prec).cpu()
+    e32 = (outs["fp32"] - want).abs()
+    ebf = (outs["bf16"] - want).abs()
+    psnr = float(10 * np.log10(1.0 / max(float((ebf ** 2).mean()), 1e-20)))
+    _report(test="config2_geometry_2steps", case=case["name"], fp32_max_abs=float(e32.max()), bf16_max_abs=float(ebf.max()),
+            bf16_mean_abs=float(ebf.mean()), bf16_psnr_vs_reference=psnr)
+    assert outs["fp32"].shape == (1, 3, 1024, 1024)
+    assert float(e32.max()) <= 1e-3                        # north-star bar, against the reference itself
+    assert float(e32.max()) <= 3e-4                        # regression guard (fp32 residual is summation order only)
+    assert torch.isfinite(outs["bf16"]).all() and outs["bf16"].min() >= 0 and outs["bf16"].max() <= 1
+    assert psnr > 40.0, psnr                               # 2 steps from pure noise: large pixel range; tightened to measured - 3 dB below
+    # sub-batching is invisible: 25 tiles in one launch == the reference's minibatches of 8
+    torch.manual_seed(case["seed"])
+    again = sampler.tiled_sample(batch_size=25, condition_x=cond, class_label=label, num_sample_steps=case["steps"],
+                                 precision="fp32").cpu()
+    assert torch.equal(again, outs["fp32"])
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] geometry on one GPU (property test)
+def test_config4_geometry_8448_canvas_properties():
+    # 2048^2 LR -> 8192^2 HR: canvas 8448^2, 1089 (even) / 1024 (odd) tiles per step.  The reference needs ~15 h of CPU for
+    # one step here, so the properties the domain offers are checked instead: finite, in range, deterministic, and invariant to
+    # how the tile list is cut into launches (125 vs 64 tiles per launch, bit-identical) - plus the activation tensors of a
+    # 125-tile launch (4.2 GB at 256^2 x 128 ch bf16) exercise every >2^31-byte offset path of the kernels.
+    sampler = build_sampler(128)
+    lr = 2048
+    cond = C.synthetic_lr_condition(0, lr, lr).cuda()
+    assert cond.shape == (1, 3, 8192, 8192)
+    label = torch.tensor([0]).cuda()
+    sampler.noise_source = "device"
+    outs = []
+    try:
+        for sub in (125, 64, 125):
+            sampler.device_noise_seed = 71
+            outs.append(sampler.tiled_sample(batch_size=sub, condition_x=cond, class_label=label, num_sample_steps=3,
+                                             precision="bf16"))
+            torch.cuda.synchronize()
+    finally:
+        sampler.noise_source = "host"
+    a, b, c = outs
+    assert a.shape == (1, 3, 8192, 8192)
+    assert bool(torch.isfinite(a).all()) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    assert torch.equal(a, c), "same seed, same launch shape: must repeat bit for bit"
+    assert torch.equal(a, b), "tiles are independent within a step: 125 vs 64 tiles per launch must not change a bit"
+    assert float(a.std()) > 0.05                           # not a constant image
+    del outs, a, b, c
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("hw", [(64, 64), (192, 320), (8, 8)], ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_unet_forward_accepts_any_size_divisible_by_8(hw, precision):
+    # model.py:679 only asks for H, W divisible by the down-sampling factor (8); 64x64 is BASELINE configs[0]'s tile.
+    # Sizes whose pixel counts are not multiples of the GEMM tiles run with masked tail tiles.
+    dim = 16
+    sampler = build_sampler(dim)
+    unet = sampler.model
+    sd = O.strip_model_prefix(synth_state_dict(_schema(dim), seed=0))
+    g = torch.Generator().manual_seed(77)
+    h, w = hw
+    x = torch.randn(2, 3, h, w, generator=g)
+    cnd = torch.rand(2, 3, h, w, generator=g) * 2 - 1
+    ls = torch.tensor([-1.5, 3.0])
+    lab = torch.tensor([2])
+    with torch.inference_mode():
+        want = O.unet_forward(sd, O.UnetCfg(dim=dim), x, ls, lab, cnd)
+    unet.precision = precision
+    try:
+        got = unet(x.cuda(), ls.cuda(), lab.cuda(), cnd.cuda()).cpu()
+    finally:
+        unet.precision = "fp32"
+    err = (got - want).abs().max().item()
+    scale = max(1.0, want.abs().max().item())
+    _report(test="unet_forward_any_size", hw=list(hw), precision=precision, max_abs=err, ref_max=scale)
+    assert err <= (1e-4 if precision == "fp32" else 4e-2) * scale, err
+
+
+def test_mixed_class_labels_are_refused_not_collapsed():
+    sampler = build_sampler(16)
+    cond = torch.rand(2, 3, 256, 256).cuda()
+    with pytest.raises(NotImplementedError):
+        sampler.sample(batch_size=2, condition_x=cond, class_label=torch.tensor([0, 2]).cuda(), num_sample_steps=2)
+    out = sampler.sample(batch_size=2, condition_x=cond, class_label=torch.tensor([1, 1]).cuda(), num_sample_steps=2)
+    assert out.shape == (2, 3, 256, 256)

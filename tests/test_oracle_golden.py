@@ -155,7 +155,7 @@ def test_edm_tiled_sample_matches_reference(case):
     label = torch.tensor([case["label"]]) if case["label"] is not None else None
     torch.manual_seed(case["seed"])
     with torch.inference_mode():
-        got = O.edm_tiled_sample(usd, O.UnetCfg(dim=case["dim"]), O.EdmCfg(), cond, label, batch_size=case["batch_size"],
+        got = O.edm_tiled_sample(usd, O.UnetCfg(dim=case["dim"]), O.EdmCfg(num_sample_steps=case.get("ctor_steps", case["steps"])), cond, label, batch_size=case["batch_size"],
                                  num_sample_steps=case["steps"], cond_scale=case["cond_scale"],
                                  class_cond_scale=case["class_cond_scale"], **C.edm_extra_kwargs(case))
     want = z["image"]

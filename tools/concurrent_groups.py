@@ -19,7 +19,7 @@ def run_group(sampler, conds, stream, reps, out):
         for _ in range(reps):
             sampler.device_noise_seed = 71
             out.append(sampler.tiled_sample(batch_size=25 * conds.shape[0], condition_x=conds, class_label=torch.tensor([0], device="cuda"),
-                                            num_sample_steps=50, amp=True))
+                                            num_sample_steps=50, precision="bf16"))
         stream.synchronize()
 
 
