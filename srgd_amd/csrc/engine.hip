@@ -233,6 +233,7 @@ struct srgd_engine {
   // (+0.137 s of conv vs -0.055 s of gn_apply per HR tile), so it is off; kept for a staggered-schedule retry.
   bool w8 = false;            // SRGD_PRECISION_BF16_W8: conv weights rounded through fp8 e4m3 (per-output-channel scale)
   bool no_gn_fusion = true;
+  int gn_fusion_max_ntiles = 1 << 30;   // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile)
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
 
   Pool pool;
@@ -504,6 +505,7 @@ struct Ctx {
 // staging; *gn_in_done tells the caller whether that happened (otherwise it must run gn_apply first).
 bool conv_can_fuse_gn_in(srgd_engine* e, const ConvW& c, int nb, int H, int W) {
   if (!e->bf16 || !c.w3 || e->force_generic_conv || e->no_gn_fusion) return false;
+  if (c.Cout / 128 > e->gn_fusion_max_ntiles) return false;
   ConvArgs a{};
   a.C0 = c.Cin; a.C1 = 0; a.ps0 = c.Cin; a.B = nb; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W;
   a.KH = a.KW = c.KS; a.stride = c.stride; a.pad = c.pad; a.Cout = c.Cout; a.CoutPad = c.CoutPad; a.mode = c.mode;
@@ -824,6 +826,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   e->cfg = *cfg;
   SRGD_TRY(build_topology(e.get()));
   if (const char* v = getenv("SRGD_GN_FUSION")) e->no_gn_fusion = atoi(v) == 0;   // experiment switch (see no_gn_fusion)
+  if (const char* v = getenv("SRGD_GN_FUSION_NTILES")) e->gn_fusion_max_ntiles = atoi(v);
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
   *out = e.release();

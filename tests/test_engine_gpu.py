@@ -607,7 +607,7 @@ def test_config2_geometry_dim128_matches_reference_fp32_and_bf16():
     assert float(e32.max()) <= 1e-3                        # north-star bar, against the reference itself
     assert float(e32.max()) <= 3e-4                        # regression guard (fp32 residual is summation order only)
     assert torch.isfinite(outs["bf16"]).all() and outs["bf16"].min() >= 0 and outs["bf16"].max() <= 1
-    assert psnr > 40.0, psnr                               # 2 steps from pure noise: large pixel range; tightened to measured - 3 dB below
+    assert psnr > 40.5, psnr                               # measured 43.5 dB on MI355X (2 steps from pure noise: the image is still mostly noise, a clamp flip costs up to 0.67)
     # sub-batching is invisible: 25 tiles in one launch == the reference's minibatches of 8
     torch.manual_seed(case["seed"])
     again = sampler.tiled_sample(batch_size=25, condition_x=cond, class_label=label, num_sample_steps=case["steps"],
