@@ -137,7 +137,7 @@ int srgd_k_linattn_block_fused(const void* x, void* y, int B, int N, int C, cons
                                const float* norm_g_host, const float* to_out_w_host, const float* to_out_b_host,
                                const float* out_g_host, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (!linattn_fused_eligible(C, 4, 32, N, true)) SRGD_FAIL("linattn_block_fused: needs C = 128, N % 128 == 0");
+  if (!linattn_fused_eligible(C, 4, 32, N, true)) SRGD_FAIL("linattn_block_fused: needs C = 128, N % 64 == 0");
   std::vector<unsigned short> wkv, wq, wo;
   linattn_fused_pack(to_qkv_host, norm_g_host, to_out_w_host, C, wkv, wq, wo);
   std::vector<float> g2(C);

@@ -5,27 +5,31 @@
 // in two kernels that touch HBM three times per pixel (read x, read x, write y) instead of the ten tensor
 // passes of the unfused chain (q, k, v are never materialised):
 //
-//   la1_kernel  per 128-pixel tile: x -> LDS (LDS-DMA, swizzled), row norms, [k|v] = x . Wkv'^T on MFMA with the
-//               wave tiling chosen so that ONE wave owns the k-columns and the v-columns of one head for its
-//               rows; exp(k - m) and v then feed the context product  ctx[d][e] += sum_n p[n][d] v[n][e]  straight
+//   la1_kernel  per 64-pixel tile: x -> LDS (LDS-DMA ring, swizzled), row norms, [k|v] = x . Wkv'^T on MFMA with the
+//               wave tiling chosen so that ONE wave owns the k-columns and the v-columns of one head for the tile's
+//               rows (its slice of Wkv' stays in registers); exp(k - m) and v then feed the context product  ctx[d][e] += sum_n p[n][d] v[n][e]  straight
 //               from the accumulator registers (an accumulator tile is a valid MFMA operand for a product that sums
 //               over its row index) - no LDS round trip.  Online max/sum per column, one partial per wave.
 //   (la_combine_kernel from attention.hip merges the partials: fixed order, deterministic.)
-//   la2_kernel  per 128-pixel tile: q^T = Wq' . x^T (pixels on lanes, so the d-softmax is a per-lane register
+//   la2_kernel  per 64-pixel tile: q^T = Wq' . x^T (pixels on lanes, so the d-softmax is a per-lane register
 //               reduction), att^T = ctx^T . q' again from accumulator registers, att -> LDS, o^T = Wout . att^T
 //               + bias, RMSNorm over c (cross-wave sum of squares through LDS), * g2, + x (the x tile is still in
 //               LDS), staged and stored as whole 256-byte rows.  Wq', Wout and ctx live in registers for the
 //               lifetime of the (persistent) workgroup.
-// bf16-mode only, so exponentials use the hardware v_exp_f32 path (__expf).
-// The RMSNorm gains g1*sqrt(C) are folded into Wkv'/Wq' on the host; 1/||x|| is applied to the GEMM result.
+// Both kernels run 256-thread workgroups (one wave per head / channel block) with 48-68 KiB of LDS, so 2 workgroups share a
+// CU and their MFMA, exponential and store phases overlap; 1/||x|| is computed once (la1) and handed to la2 (4 B / pixel).
+// bf16-mode only, so exponentials are bare v_exp_f32 in the log2 domain (1/||x|| * log2(e) rides in the argument).
+// The RMSNorm gains g1*sqrt(C) are folded into Wkv'/Wq' on the host.
 #include "kernels.hpp"
 
 namespace srgd {
 namespace {
 
-constexpr int TM = 128;                 // pixels per tile
-constexpr int TILE_BYTES = TM * 256;    // [128 rows][128 bf16]
-constexpr int NTH = 512;
+constexpr int TM = 64;                  // pixels per tile
+constexpr int TILE_BYTES = TM * 256;    // [64 rows][128 bf16] = 16 KiB
+constexpr int NTH = 256;                // 4 waves: one per head (la1) / per 32-channel block (la2)
+constexpr int RING = 3;                 // x tiles in flight per workgroup (LDS-DMA ring)
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -35,7 +39,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voffset, 0, 0, 0);
 }
 
-#define LA_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define LA_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define LA_BARRIER()                     \
   do {                                   \
     __builtin_amdgcn_s_barrier();        \
@@ -47,21 +51,19 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
     LA_BARRIER();                                         \
   } while (0)
 
-// stage one 128-pixel x tile (rows px0..px0+127 of the image behind rsrc) into `buf`, XOR-swizzled
-__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* buf, int wave, int lane, int px0,
-                                           int npx) {
+// stage one 64-pixel x tile (rows px0..px0+63 of the image behind rsrc) into `buf`, XOR-swizzled: 4 LDS-DMA pieces per wave
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* buf, int wave, int lane, int px0) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int q = wave * 4 + j;
     const int g = q * 64 + lane;
     const int row = g >> 4, cs = g & 15;
     const int c = cs ^ (row & 15);
-    const int voff = (px0 + row < npx) ? ((px0 + row) * 128 + c * 8) * 2 : 0x7ffffff0;
-    dma16(rsrc, buf + q * 1024, voff);
+    dma16(rsrc, buf + q * 1024, ((px0 + row) * 128 + c * 8) * 2);
   }
 }
 
-// 1 / max(||x_row||, 1e-12) for the 128 rows of a staged tile (4 threads per row)
+// 1 / max(||x_row||, 1e-12) for the 64 rows of a staged tile (4 threads per row)
 __device__ __forceinline__ void row_rinv(const char* tile, float* rinv, int tid) {
   const int row = tid >> 2, part = tid & 3;
   float ss = 0.f;
@@ -76,6 +78,9 @@ __device__ __forceinline__ void row_rinv(const char* tile, float* rinv, int tid)
   if (part == 0) rinv[row] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
 }
 
+// raw v_exp_f32 (arguments here are <= 0 up to rounding: no denormal-range rescue needed)
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
   bf16x8 o;
 #pragma unroll
@@ -84,84 +89,91 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
 }
 
 // ------------------------------------------------------------------------------------------- phase 1
+// Workgroup = 4 waves = the 4 heads; each wave owns the k-columns and the v-columns of its head for all 64 rows of a tile.
+// Its slice of Wkv' (64 rows x 128) lives in registers as MFMA B fragments for the lifetime of the workgroup, so LDS holds
+// only the x ring (48 KiB) and several workgroups share a CU: while one is in its exponentials another runs its MFMAs
+// (the 8-wave version kept Wkv' in LDS, fitted once per CU and ran its phases in lock-step at 36 % of the HBM rate).
 __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x, int N, const bf16* __restrict__ wkv,
                                                       int strip, float* __restrict__ pm, float* __restrict__ pl,
-                                                      float* __restrict__ pctx) {
+                                                      float* __restrict__ pctx, float* __restrict__ rinv_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const sW = smem;                          // [256 rows][256 B] swizzled image of Wkv'
-  char* const sA = smem + 65536;                  // 2 x x tile
-  float* const sR = reinterpret_cast<float*>(smem + 65536 + 2 * TILE_BYTES);   // [2][128]
+  char* const sA = smem;                                                   // RING x tiles
+  float* const sR = reinterpret_cast<float*>(smem + RING * TILE_BYTES);    // [2][64]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
-  const int rh = wave >> 2, head = wave & 3;
   const int b = blockIdx.y, sidx = blockIdx.x, nstrips = gridDim.x;
   const int px_begin = sidx * strip;
-  const int T = (min(strip, N - px_begin) + TM - 1) / TM;
+  const int T = min(strip, N - px_begin) / TM;
 
   const __amdgpu_buffer_rsrc_t rsx =
       __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * N * 128), 0, N * 256, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wkv, 0, 65536, 0x00020000);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) dma16(rsw, sW + (wave * 8 + j) * 1024, (wave * 8 + j) * 1024 + lane * 16);
-  stage_tile(rsx, sA, wave, lane, px_begin, N);
-
-  float m = -INFINITY, l = 0.f;
-  f32x16 ctx = 0;
-  LA_WAIT_VM0();
-  LA_BARRIER();
-
-  for (int t = 0; t < T; ++t) {
-    const char* A = sA + (t & 1) * TILE_BYTES;
-    float* rinv = sR + (t & 1) * TM;
-    if (t + 1 < T) stage_tile(rsx, sA + ((t + 1) & 1) * TILE_BYTES, wave, lane, px_begin + (t + 1) * TM, N);
-    row_rinv(A, rinv, tid);
-    LA_SYNC();
-
-    // [k | v] of this wave's head for its 64 rows
-    f32x16 k0 = 0, k1 = 0, v0 = 0, v1 = 0;
-    const int ar0 = rh * 64 + r, ar1 = ar0 + 32;
+  // B fragments of the head's k rows and v rows of Wkv' (host image: [256 rows][128 c], 16-byte chunks XOR-swizzled by row & 15)
+  bf16x8 fk[8], fv[8];
+  {
     const int wk = head * 32 + r, wv = 128 + head * 32 + r;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int c = 2 * s + hh;
-      const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + swz(ar0, c));
-      const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + swz(ar1, c));
-      const bf16x8 fk = *reinterpret_cast<const bf16x8*>(sW + swz(wk, c));
-      const bf16x8 fv = *reinterpret_cast<const bf16x8*>(sW + swz(wv, c));
-      k0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fk, k0, 0, 0, 0);
-      k1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fk, k1, 0, 0, 0);
-      v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fv, v0, 0, 0, 0);
-      v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fv, v1, 0, 0, 0);
+      fk[s] = *reinterpret_cast<const bf16x8*>(wkv + wk * 128 + ((c ^ (wk & 15)) << 3));
+      fv[s] = *reinterpret_cast<const bf16x8*>(wkv + wv * 128 + ((c ^ (wv & 15)) << 3));
     }
-    // rows of the accumulator = pixels: apply 1/||x_n||; rows beyond the image contribute nothing
-    const int px_tile = px_begin + t * TM;
+  }
+  stage_tile(rsx, sA, head, lane, px_begin);
+  if (T > 1) stage_tile(rsx, sA + TILE_BYTES, head, lane, px_begin + TM);
+  float m = -INFINITY, l = 0.f;                     // running max (log2 domain) / sum of this lane's k column d = r
+  f32x16 ctx = 0;
+  // tile 0 has landed once at most the second tile's 4 pieces are outstanding (wherever the compiler put the fragment
+  // loads relative to the DMAs, "all but the 4 youngest" covers tile 0)
+  if (T > 1) LA_WAIT_VM(4); else LA_WAIT_VM(0);
+  LA_BARRIER();
+
+  for (int t = 0; t < T; ++t) {
+    const char* A = sA + (t % RING) * TILE_BYTES;
+    float* rinv = sR + (t & 1) * TM;
+    if (t + 2 < T) stage_tile(rsx, sA + ((t + 2) % RING) * TILE_BYTES, head, lane, px_begin + (t + 2) * TM);
+    row_rinv(A, rinv, tid);
+    LA_SYNC();
+    if (head == 0 && lane < 16)                     // la2 re-uses the row norms: 4 B per pixel instead of a second reduction
+      *reinterpret_cast<f32x4*>(rinv_out + (size_t)b * N + px_begin + t * TM + lane * 4) = *reinterpret_cast<const f32x4*>(rinv + lane * 4);
+
+    // [k | v] of this wave's head for the tile's 64 rows
+    f32x16 k0 = 0, k1 = 0, v0 = 0, v1 = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int c = 2 * s + hh;
+      const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + swz(r, c));
+      const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + swz(32 + r, c));
+      k0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fk[s], k0, 0, 0, 0);
+      k1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fk[s], k1, 0, 0, 0);
+      v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fv[s], v0, 0, 0, 0);
+      v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fv[s], v1, 0, 0, 0);
+    }
+    // rows of the accumulator = pixels: k -> k / ||x_n|| in the log2 domain (one multiply), v -> v / ||x_n||
     float bm = -INFINITY;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 ri0 = *reinterpret_cast<const f32x4*>(rinv + rh * 64 + 8 * g + 4 * hh);
-      const f32x4 ri1 = *reinterpret_cast<const f32x4*>(rinv + rh * 64 + 32 + 8 * g + 4 * hh);
+      const f32x4 ri0 = *reinterpret_cast<const f32x4*>(rinv + 8 * g + 4 * hh);
+      const f32x4 ri1 = *reinterpret_cast<const f32x4*>(rinv + 32 + 8 * g + 4 * hh);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int reg = 4 * g + i;
-        const bool ok0 = px_tile + rh * 64 + 8 * g + 4 * hh + i < N;
-        const bool ok1 = px_tile + rh * 64 + 32 + 8 * g + 4 * hh + i < N;
-        k0[reg] = ok0 ? k0[reg] * ri0[i] : -INFINITY;
-        k1[reg] = ok1 ? k1[reg] * ri1[i] : -INFINITY;
-        v0[reg] = ok0 ? v0[reg] * ri0[i] : 0.f;
-        v1[reg] = ok1 ? v1[reg] * ri1[i] : 0.f;
+        k0[reg] *= ri0[i] * LOG2E;
+        k1[reg] *= ri1[i] * LOG2E;
+        v0[reg] *= ri0[i];
+        v1[reg] *= ri1[i];
         bm = fmaxf(bm, fmaxf(k0[reg], k1[reg]));
       }
     }
     bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
     const float mn = fmaxf(m, bm);
-    const float f = __expf(m - mn);                 // first tile: exp(-inf) = 0
+    const float f = ex2(m - mn);                  // first tile: exp2(-inf) = 0
     m = mn;
     l *= f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      k0[i] = __expf(k0[i] - mn);
-      k1[i] = __expf(k1[i] - mn);
+      k0[i] = ex2(k0[i] - mn);
+      k1[i] = ex2(k1[i] - mn);
       l += k0[i] + k1[i];
     }
     if (!__all(f == 1.0f)) {
@@ -177,14 +189,14 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
       ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(k0, s), pack8(v0, s), ctx, 0, 0, 0);
       ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(k1, s), pack8(v1, s), ctx, 0, 0, 0);
     }
-    LA_WAIT_VM0();
+    // tile t+1 must have landed before the next iteration reads it; the DMA of tile t+2 (4 pieces) stays in flight
+    if (t + 2 < T) LA_WAIT_VM(4); else LA_WAIT_VM(0);
     LA_BARRIER();
   }
   l += __shfl_xor(l, 32, 64);
-  const int nch = nstrips * 2;
-  const size_t pidx = (size_t)(b * 4 + head) * nch + sidx * 2 + rh;
+  const size_t pidx = (size_t)(b * 4 + head) * nstrips + sidx;
   if (hh == 0) {
-    pm[pidx * 32 + r] = m;
+    pm[pidx * 32 + r] = m * LN2;                    // la_combine works in the natural-log domain
     pl[pidx * 32 + r] = l;
   }
 #pragma unroll
@@ -202,27 +214,35 @@ struct La2Args {
   const float* bout;     // [128]
   const float* g2;       // [128] = to_out.1.g * sqrt(C)
   const float* ctxn;     // [B*4][32 d][32 e] fp32: normalised context * dh^-0.5
+  const float* rinv;     // [B][N] 1/||x_n|| written by la1
   int tiles_per_wg;
 };
 
 __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const sA = smem;                                   // 2 x x tile
-  char* const sT = smem + 2 * TILE_BYTES;                  // att tile, later the staged output tile
-  float* const sR = reinterpret_cast<float*>(smem + 3 * TILE_BYTES);   // [2][128] 1/||x||
-  float* const sS = sR + 2 * TM;                           // [4][128] partial sum of squares of o
+  char* const sA = smem;                                   // RING x tiles
+  char* const sT = smem + RING * TILE_BYTES;               // att tile, later the staged output tile
+  float* const sS = reinterpret_cast<float*>(smem + (RING + 1) * TILE_BYTES);   // [4][64] partial sum of squares of o
+  float* const sRv = sS + 4 * TM;                          // [RING][4 waves][64] 1/||x_n|| of the staged tiles (one private copy per wave)
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hd = __builtin_amdgcn_readfirstlane(tid >> 6);  // head (GEMM-q) / output channel block (GEMM-out)
   const int r = lane & 31, hh = lane >> 5;
-  const int ph = wave >> 2, hd = wave & 3;                 // pixel half; head (GEMM-q) / channel block (GEMM-out)
   const int b = blockIdx.y;
   const int tile0 = blockIdx.x * p.tiles_per_wg;
-  const int ntiles = (p.N + TM - 1) / TM;
+  const int ntiles = p.N / TM;
   const int T = min(p.tiles_per_wg, ntiles - tile0);
+  if (T <= 0) return;
 
   const __amdgpu_buffer_rsrc_t rsx =
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)b * p.N * 128), 0, p.N * 256, 0x00020000);
-  if (T > 0) stage_tile(rsx, sA, wave, lane, tile0 * TM, p.N);
+  // la1 left 1/||x_n|| in the workspace: it rides along with the tile as a fifth LDS-DMA piece (256 B), so the loop has no
+  // VGPR-destination loads (hipcc would wait vmcnt(0) for those and drain the tile prefetch with them)
+  const __amdgpu_buffer_rsrc_t rsr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.rinv + (size_t)b * p.N), 0, p.N * 4, 0x00020000);
+  auto stage = [&](int slot, int px0) {
+    stage_tile(rsx, sA + slot * TILE_BYTES, hd, lane, px0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsr, (lds_ptr_t)(sRv + (slot * 4 + hd) * TM), 4, (px0 + lane) * 4, 0, 0, 0);
+  };
 
   // register-resident operands: rows (hd*32 + r) of Wq' and Wout as MFMA A fragments for the 8 k16 steps
   bf16x8 wq[8], wo[8];
@@ -248,46 +268,44 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
     bo[reg] = p.bout[c];
     g2v[reg] = p.g2[c];
   }
-  LA_WAIT_VM0();
+  stage(0, tile0 * TM);
+  if (T > 1) stage(1, (tile0 + 1) * TM);
+  if (T > 1) LA_WAIT_VM(5); else LA_WAIT_VM(0);            // tile 0 (and every operand load) landed; tile 1's 5 pieces may fly
   LA_BARRIER();
 
   for (int t = 0; t < T; ++t) {
-    const char* A = sA + (t & 1) * TILE_BYTES;
-    float* rinv = sR + (t & 1) * TM;
+    const char* A = sA + (t % RING) * TILE_BYTES;
     const int px0 = (tile0 + t) * TM;
-    if (t + 1 < T) stage_tile(rsx, sA + ((t + 1) & 1) * TILE_BYTES, wave, lane, px0 + TM, p.N);
-    row_rinv(A, rinv, tid);
-    LA_SYNC();
+    if (t + 2 < T) stage((t + 2) % RING, px0 + 2 * TM);
+    const float* rvt = sRv + ((t % RING) * 4 + hd) * TM;
+    const float ri0 = rvt[r] * LOG2E, ri1 = rvt[32 + r] * LOG2E;       // this lane's two pixel columns, log2 domain
 
-    // q^T (rows d of head hd, columns = this wave's 64 pixels)
+    // q^T (rows d of head hd, columns = the tile's 64 pixels)
     f32x16 q0 = 0, q1 = 0;
-    const int pr0 = ph * 64 + r, pr1 = pr0 + 32;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int c = 2 * s + hh;
-      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(A + swz(pr0, c));
-      const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(A + swz(pr1, c));
+      const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(A + swz(r, c));
+      const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(A + swz(32 + r, c));
       q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s], x0, q0, 0, 0, 0);
       q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s], x1, q1, 0, 0, 0);
     }
-    // softmax over d: registers (16) x lane halves (2) of one pixel column
+    // softmax over d: registers (16) x lane halves (2) of one pixel column; 1/||x|| rides in the exp2 argument
     {
-      const float ri0 = rinv[pr0], ri1 = rinv[pr1];
       float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        q0[i] *= ri0;
-        q1[i] *= ri1;
         m0 = fmaxf(m0, q0[i]);
         m1 = fmaxf(m1, q1[i]);
       }
       m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
       m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
+      const float c0 = -m0 * ri0, c1 = -m1 * ri1;          // ri > 0: the max commutes with the scaling
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        q0[i] = __expf(q0[i] - m0);
-        q1[i] = __expf(q1[i] - m1);
+        q0[i] = ex2(fmaf(q0[i], ri0, c0));
+        q1[i] = ex2(fmaf(q1[i], ri1, c1));
         s0 += q0[i];
         s1 += q1[i];
       }
@@ -317,18 +335,18 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
         w1[i] = (bf16)a1[4 * g + i];
       }
       const int k = hd * 32 + 8 * g + 4 * hh;              // first of the 4 channels
-      *reinterpret_cast<bf16x4*>(sT + swz(pr0, k >> 3) + (k & 7) * 2) = w0;
-      *reinterpret_cast<bf16x4*>(sT + swz(pr1, k >> 3) + (k & 7) * 2) = w1;
+      *reinterpret_cast<bf16x4*>(sT + swz(r, k >> 3) + (k & 7) * 2) = w0;
+      *reinterpret_cast<bf16x4*>(sT + swz(32 + r, k >> 3) + (k & 7) * 2) = w1;
     }
     LA_SYNC();
 
-    // o^T (rows c of block hd, columns = this wave's 64 pixels) = Wout . att^T + bias
+    // o^T (rows c of block hd, columns = the tile's 64 pixels) = Wout . att^T + bias
     f32x16 o0 = 0, o1 = 0;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int c = 2 * s + hh;
-      const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(sT + swz(pr0, c));
-      const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(sT + swz(pr1, c));
+      const bf16x8 t0 = *reinterpret_cast<const bf16x8*>(sT + swz(r, c));
+      const bf16x8 t1 = *reinterpret_cast<const bf16x8*>(sT + swz(32 + r, c));
       o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[s], t0, o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[s], t1, o1, 0, 0, 0);
     }
@@ -343,13 +361,13 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
     ss0 += __shfl_xor(ss0, 32, 64);
     ss1 += __shfl_xor(ss1, 32, 64);
     if (hh == 0) {
-      sS[hd * TM + pr0] = ss0;
-      sS[hd * TM + pr1] = ss1;
+      sS[hd * TM + r] = ss0;
+      sS[hd * TM + 32 + r] = ss1;
     }
     LA_SYNC();                                             // also: every wave is done reading the att tile
     {
-      const float n0 = sS[pr0] + sS[TM + pr0] + sS[2 * TM + pr0] + sS[3 * TM + pr0];
-      const float n1 = sS[pr1] + sS[TM + pr1] + sS[2 * TM + pr1] + sS[3 * TM + pr1];
+      const float n0 = sS[r] + sS[TM + r] + sS[2 * TM + r] + sS[3 * TM + r];
+      const float n1 = sS[32 + r] + sS[TM + 32 + r] + sS[2 * TM + 32 + r] + sS[3 * TM + 32 + r];
       const float r0 = 1.0f / fmaxf(sqrtf(n0), 1e-12f), r1 = 1.0f / fmaxf(sqrtf(n1), 1e-12f);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -360,28 +378,26 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
           w1[i] = (bf16)(o1[4 * g + i] * r1 * g2v[4 * g + i]);
         }
         const int c = hd * 32 + 8 * g + 4 * hh;
-        *reinterpret_cast<bf16x4*>(sT + swz(pr0, c >> 3) + (c & 7) * 2) = w0;
-        *reinterpret_cast<bf16x4*>(sT + swz(pr1, c >> 3) + (c & 7) * 2) = w1;
+        *reinterpret_cast<bf16x4*>(sT + swz(r, c >> 3) + (c & 7) * 2) = w0;
+        *reinterpret_cast<bf16x4*>(sT + swz(32 + r, c >> 3) + (c & 7) * 2) = w1;
       }
     }
-    // the next tile's DMA (issued at the top of this iteration) has had the whole tile's compute to land; the stores
-    // below are NOT waited for here - they drain during the next iteration and retire at its vmcnt(0)
-    LA_WAIT_VM0();
     LA_SYNC();
     // y = staged RMSNorm(o) * g2 + x, whole 256-byte rows, 16 B per lane
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = tid + NTH * i;
       const int row = q >> 4, c16 = q & 15;
-      if (px0 + row < p.N) {
-        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(sT + swz(row, c16));
-        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(A + swz(row, c16));
-        bf16x8 yv;
+      const bf16x8 ov = *reinterpret_cast<const bf16x8*>(sT + swz(row, c16));
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(A + swz(row, c16));
+      bf16x8 yv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) yv[e] = (bf16)((float)ov[e] + (float)xv[e]);
-        *reinterpret_cast<bf16x8*>(p.y + ((size_t)b * p.N + px0 + row) * 128 + c16 * 8) = yv;
-      }
+      for (int e = 0; e < 8; ++e) yv[e] = (bf16)((float)ov[e] + (float)xv[e]);
+      *reinterpret_cast<bf16x8*>(p.y + ((size_t)b * p.N + px0 + row) * 128 + c16 * 8) = yv;
     }
+    // Tile t+1 (issued one iteration ago) must have landed before the next iteration reads it; this iteration's DMA of
+    // tile t+2 (5 pieces) and its 4 stores (younger still) stay in flight.
+    if (t + 2 < T) LA_WAIT_VM(9); else LA_WAIT_VM(4);
     LA_SYNC();                                             // every wave has read the x / output tiles from LDS
   }
 }
@@ -392,11 +408,11 @@ bool linattn_fused_eligible(int C, int heads, int dh, int N, bool is_bf16) {
   return is_bf16 && C == 128 && heads == 4 && dh == 32 && N % TM == 0 && (size_t)N * 256 < (1ull << 31);
 }
 
-static int la1_strip(int N) { return N >= 65536 ? 2048 : (N >= 16384 ? 1024 : 512); }
+static int la1_strip(int N) { return N >= 65536 ? 2048 : (N >= 16384 ? 1024 : (N >= 2048 ? 512 : 256)); }
 
 size_t linattn_fused_workspace(int B, int N) {
-  const size_t nch = (size_t)cdiv(N, la1_strip(N)) * 2;
-  return ((size_t)B * 4 * nch * (64 + 1024) + (size_t)B * 4 * 1024) * sizeof(float);
+  const size_t nch = (size_t)cdiv(N, la1_strip(N));
+  return ((size_t)B * 4 * nch * (64 + 1024) + (size_t)B * 4 * 1024 + (size_t)B * N) * sizeof(float);
 }
 
 // host-side operand preparation
@@ -425,30 +441,32 @@ int linattn_fused(const void* x, void* y, int B, int N, const void* wkv_img, con
                   const float* bout, const float* g2_scaled, float* ws, hipStream_t st) {
   const int strip = la1_strip(N);
   const int nstrips = cdiv(N, strip);
-  const int nch = nstrips * 2;
+  const int nch = nstrips;
   const size_t bh = (size_t)B * 4;
   float* pm = ws;
   float* pl = pm + bh * nch * 32;
   float* pctx = pl + bh * nch * 32;
   float* ctxn = pctx + bh * nch * 1024;
+  float* rinv = ctxn + bh * 1024;
   static bool attr[64] = {};
-  const int lds1 = 65536 + 2 * TILE_BYTES + 2 * TM * 4;
-  const int lds2 = 3 * TILE_BYTES + 2 * TM * 4 + 4 * TM * 4;
+  const int lds1 = RING * TILE_BYTES + 2 * TM * 4;
+  const int lds2 = (RING + 1) * TILE_BYTES + 4 * TM * 4 + RING * 4 * TM * 4;
   if (first_use_on_device(attr)) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
   }
   hipLaunchKernelGGL(la1_kernel, dim3(nstrips, B), dim3(NTH), lds1, st, (const bf16*)x, N, (const bf16*)wkv_img, strip, pm,
-                     pl, pctx);
+                     pl, pctx, rinv);
   SRGD_HIP(hipGetLastError());
   SRGD_TRY(linear_attention_combine(pm, pl, pctx, (int)bh, nch, 1.0f / sqrtf(32.0f), ctxn, st));
   La2Args a;
   a.x = (const bf16*)x; a.y = (bf16*)y; a.N = N; a.wq = (const bf16*)wq; a.wout = (const bf16*)wout; a.bout = bout;
-  a.g2 = g2_scaled; a.ctxn = ctxn;
+  a.g2 = g2_scaled; a.ctxn = ctxn; a.rinv = rinv;
   const int ntiles = N / TM;
-  // persistent-ish: enough tiles per workgroup to amortise the register-resident operands, enough workgroups to fill 256 CUs
+  // persistent-ish: enough tiles per workgroup to amortise the register-resident operands (64 + 40 VGPRs of weights, context,
+  // bias and gain), enough workgroups to fill 256 CUs x 2-3 resident workgroups
   int tpw = 1;
-  while (tpw < 8 && (long)B * cdiv(ntiles, tpw * 2) >= 512) tpw *= 2;
+  while (tpw < 16 && (long)B * cdiv(ntiles, tpw * 2) >= 1024) tpw *= 2;
   a.tiles_per_wg = tpw;
   hipLaunchKernelGGL(la2_kernel, dim3(cdiv(ntiles, tpw), B), dim3(NTH), lds2, st, a);
   SRGD_HIP(hipGetLastError());
