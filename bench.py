@@ -41,7 +41,9 @@ sys.path.insert(0, ROOT)
 TFLOP_PER_HR_TILE = 813.6          # BASELINE.md section 3 (1,025 tile-forwards x 793.8 GFLOP)
 TILE_FORWARDS_PER_HR_TILE = 1025
 PMC_TRAFFIC_FILE = "r1_pmc_traffic.json"     # newest committed PMC summary (tools/pmc_traffic.py)
-PEAK_TFLOPS = {"bf16": 2500.0, "bf16_w8": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
+# MI355X_MICROARCH.md: dense MFMA peaks of the dominant kernel's instruction (fp8 = block-scaled MX e4m3, 2x the bf16 rate)
+PEAK_TFLOPS = {"conv3x3_bf16": 2500.0, "conv3x3_mxfp8": 5000.0, "conv_igemm:bf16": 2500.0, "conv_igemm:fp32": 157.3}
+KERNEL_OF = {"conv3x3_bf16": "conv3x3_bf16_kernel", "conv3x3_mxfp8": "conv3x3_mxfp8_kernel", "conv_igemm": "conv_igemm_kernel"}
 
 
 def parse():
@@ -55,8 +57,10 @@ def parse():
                     help="tiles: BASELINE configs[1] units, images sharded over ranks (weak scaling, the headline); "
                          "canvas: ONE --lr_size^2 image per step whose tiles are sharded over all ranks with a per-step "
                          "tile all-gather (configs[3] with --lr_size 2048; strong scaling, secondary)")
-    ap.add_argument("--precision", choices=["bf16", "fp32", "bf16_w8"], default="bf16",
-                    help="bf16_w8: bf16 kernels with fp8-e4m3-rounded conv weights (BASELINE configs[4] numerics)")
+    ap.add_argument("--precision", choices=["bf16", "fp32", "bf16_w8", "fp8"], default="bf16",
+                    help="fp8: 3x3 convolutions on the block-scaled MX-fp8 matrix cores, e4m3 weights AND activations with a "
+                         "scale per 32 channels (BASELINE configs[4] compute path; use with --ddpm_steps 100 "
+                         "--class_cond_scale 2.0); bf16_w8: bf16 kernels with fp8-e4m3-rounded conv weights (numerics only)")
     ap.add_argument("--class_cond_scale", type=float, default=1.0,
                     help="!= 1: class guidance, two U-Net passes per step batched into one launch (configs[4] uses 2.0 "
                          "with --ddpm_steps 100); the headline metric is quoted at 1.0")
@@ -260,7 +264,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (seeded LR images, seeded weights with the reference state_dict schema)",
-            "config": {"workload": f"{'BASELINE configs[1]' if (args.ddpm_steps == 50 and args.class_cond_scale == 1.0 and args.lr_size == 256 and args.precision == 'bf16') else 'BASELINE configs[4] (fp8-rounded weights on bf16 kernels)' if args.precision == 'bf16_w8' else 'variant'}: one {args.lr_size}x{args.lr_size} LR tile x4 SR per step, "
+            "config": {"workload": f"{'BASELINE configs[1]' if (args.ddpm_steps == 50 and args.class_cond_scale == 1.0 and args.lr_size == 256 and args.precision == 'bf16') else 'BASELINE configs[4] (MX-fp8 3x3 convolutions: e4m3 weights + activations, E8M0 scale per 32 channels)' if args.precision == 'fp8' else 'BASELINE configs[4] numerics (fp8-rounded weights on bf16 kernels)' if args.precision == 'bf16_w8' else 'variant'}: one {args.lr_size}x{args.lr_size} LR tile x4 SR per step, "
                                    f"{args.ddpm_steps} DDPM steps, class_cond_scale={args.class_cond_scale}, dim-{args.dim} U-Net, "
                                    f"{args.precision}, device Philox noise; {min(args.images, args.steps)} steps "
                                    f"(HR tiles) advance in lock-step so their U-Net tiles share launches",
@@ -278,17 +282,18 @@ def main():
             line["config"]["tile_forwards_per_step"] = None
             line["config"]["unet_passes_per_ddpm_step"] = passes
             line.pop("tflops_effective", None)
-        if not args.no_profile and headline:
+        if not args.no_profile:
             eng = sampler.model.engine(args.precision)
             eng.profile_begin()
             run(args.warmup, args.warmup + min(args.images, args.steps))
             prof = eng.profile_end()
-            # the dominant kernel: conv3x3_bf16_kernel in bf16 mode, the generic implicit GEMM in fp32 mode
-            fam = "conv3x3_bf16" if prof["ms"].get("conv3x3_bf16", 0.0) > prof["ms"]["conv_igemm"] else "conv_igemm"
+            # the dominant kernel: conv3x3_bf16_kernel in bf16 mode, conv3x3_mxfp8_kernel in fp8 mode, the generic implicit
+            # GEMM in fp32 mode - whichever convolution family took the most time in the profiled pass
+            fam = max(("conv3x3_bf16", "conv3x3_mxfp8", "conv_igemm"), key=lambda k: prof["ms"].get(k, 0.0))
             conv_ms, n_launch, fl = prof["ms"][fam], prof["launches"][fam], prof["flops"][fam]
             achieved = fl / (conv_ms * 1e-3) / 1e12
-            peak = PEAK_TFLOPS[args.precision]
-            kname = "conv3x3_bf16_kernel" if fam == "conv3x3_bf16" else "conv_igemm_kernel"
+            peak = PEAK_TFLOPS.get(fam) or PEAK_TFLOPS["conv_igemm:" + ("fp32" if args.precision == "fp32" else "bf16")]
+            kname = KERNEL_OF[fam]
             # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (FETCH_SIZE and WRITE_SIZE
             # cannot share a pass, and rocprofv3 cannot run inside the benchmark): the committed summary is quoted and labelled
             traffic, traffic_src = None, None
@@ -304,7 +309,7 @@ def main():
                                 "avg_launch_ms": conv_ms / max(n_launch, 1),
                                 "algorithmic_gflop_per_launch": fl / max(n_launch, 1) / 1e9,
                                 "family_time_share": conv_ms / sum(prof["ms"].values())}
-            conv_fams = ("conv_igemm", "conv3x3_bf16", "conv1x1_bf16")
+            conv_fams = ("conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "conv3x3_mxfp8")
             all_conv_ms = sum(prof["ms"].get(k, 0.0) for k in conv_fams)
             line["conv_all_tflops"] = sum(prof["flops"].get(k, 0.0) for k in conv_fams) / (all_conv_ms * 1e-3) / 1e12
             tot = sum(prof["ms"].values())

@@ -33,8 +33,14 @@ typedef struct srgd_engine srgd_engine;
 #define SRGD_PRECISION_BF16_W8 2 /* BF16 mode with every convolution weight (3x3, 1x1, attention to_qkv / to_out, resamplers,
                                   * input / output conv) rounded through fp8 e4m3 with one scale per output channel
                                   * (max|w| -> 448) when the weights are packed: the NUMERICS of fp8 weights (BASELINE
-                                  * configs[4]'s parity-vs-bf16 check) on the bf16 MFMA kernels; the MX-fp8 MFMA compute
-                                  * path is not built */
+                                  * configs[4]'s parity-vs-bf16 check) on the bf16 MFMA kernels */
+#define SRGD_PRECISION_FP8 3 /* BASELINE configs[4] compute path: every 3x3 convolution (Block.proj model.py:246 and the
+                              * last-stage resamplers, 89 % of the FLOPs) runs on the block-scaled MX matrix cores
+                              * (v_mfma_scale_f32_16x16x128_f8f6f4): OCP e4m3 activations and weights, one E8M0 scale per
+                              * 32 input channels (activations: per pixel; weights: per output channel and tap), fp32
+                              * accumulate, bf16 out.  Pointwise layers, attention, norms and the sampler stay as in
+                              * SRGD_PRECISION_BF16.  Needs channel counts that are multiples of 128 (the shipped dim-128
+                              * U-Net); other 3x3 layers fall back to the bf16 kernels. */
 
 /* Constructor arguments of ConditionalSRUnet (model.py:537-556) as get_model passes them
  * (model.py:3504-3514).  Unsupported combinations are rejected by srgd_create. */

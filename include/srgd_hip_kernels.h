@@ -45,6 +45,19 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
                         float* avg_ms, int* stats_slots, const void* gn_tail_src, const float* gn_tail_a,
                         const float* gn_tail_b, void* stream);
 
+/* bf16 NHWC [npix][C] -> OCP MX-fp8: q [npix][C] e4m3 bytes + s [npix][C/32] E8M0 bytes (x ~ q * 2^(s-127); one scale per 32
+ * consecutive channels = floor(log2 max|x|) - 8, elements clamped to +-448, round-to-nearest-even).  C % 32 == 0.
+ * The activation format of the fp8 mode's 3x3 convolutions (SRGD_PRECISION_FP8). */
+int srgd_k_quant_mxfp8(const void* x_bf16, void* q, void* s, int64_t npix, int C, void* stream);
+/* 3x3 / stride 1 / pad 1 convolution on v_mfma_scale_f32_16x16x128_f8f6f4.  replaces: Block.proj (model.py:246) in fp8 mode.
+ * in0 / in1: bf16 NHWC sources (channel concat; in1 nullable), quantised to MX-fp8 inside (srgd_k_quant_mxfp8); weights /
+ * bias: PyTorch-layout fp32 on the HOST, quantised per (output channel, tap, 32 input channels).  C0, C1, Cout % 128 == 0,
+ * H % 8 == 0, W % 16 == 0.  out: bf16 NHWC.  gn_partial / stats_slots as in srgd_k_conv2d_timed; iters > 0 times the
+ * convolution kernel alone (*avg_ms).  Synchronises. */
+int srgd_k_conv3x3_mxfp8(const void* in0, const void* in1, int C0, int C1, int B, int H, int W,
+                         const float* weight_oihw_host, const float* bias_host, int Cout, void* out, float* gn_partial,
+                         int groups, int iters, float* avg_ms, int* stats_slots, void* stream);
+
 /* GroupNorm (from the conv's partial statistics) -> x*(scale+1)+shift -> SiLU (+ residual).
  * replaces: Block.forward after the conv (model.py:250-259) and the ResnetBlock residual add (:285).
  * gamma, beta: device [C]; scale_shift: device [B][2C] (scale | shift) or NULL; in place if y == x.

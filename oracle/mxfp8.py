@@ -1,0 +1,39 @@
+"""CPU emulation of OCP Microscaling fp8 (MX-fp8, e4m3 elements + one E8M0 scale per 32 elements) - TEST INFRASTRUCTURE ONLY.
+
+The reference has no fp8 path: BASELINE configs[4] asks for an fp8 compute mode of THIS engine with a parity-vs-bf16
+check.  This file restates the published format (OCP Microscaling Formats v1.0: shared exponent =
+floor(log2(max|x|)) - emax_elem with emax_elem = 8 for e4m3, elements = round-to-nearest-even of x / 2^exp, saturated to
++-448) so the GPU quantisation kernel (quant_mxfp8.hip), the host weight packing (conv3x3_mxfp8.hip) and the convolution on
+v_mfma_scale_f32_16x16x128_f8f6f4 can be checked bit for bit / to fp32 summation order.  Imported by tests only.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def block_exponent(amax: torch.Tensor) -> torch.Tensor:
+    """E8M0 byte of a block with maximum magnitude `amax` (float32 tensor): floor(log2 amax) - 8 + 127; zero/denormal
+    blocks get byte 0.  Read from the float's exponent field exactly as the kernels do."""
+    bexp = (amax.contiguous().view(torch.int32) >> 23) & 0xFF
+    return (bexp - 8).clamp(min=0).to(torch.uint8)
+
+
+def quantize(x: torch.Tensor, block: int = 32):
+    """x: float32 [..., C] with C % 32 == 0 -> (q uint8 [..., C] e4m3 bit patterns, s uint8 [..., C/32], dequantised float32)."""
+    x = x.float()
+    shape = x.shape
+    xb = x.reshape(-1, shape[-1] // block, block)
+    sb = block_exponent(xb.abs().amax(dim=-1))
+    inv = torch.ldexp(torch.ones_like(sb, dtype=torch.float32), (127 - sb.int()))             # 2^(127 - byte)
+    scaled = (xb * inv[..., None]).clamp(-448.0, 448.0)
+    q8 = scaled.to(torch.float8_e4m3fn)                                                         # RNE (inputs already saturated)
+    deq = q8.float() * torch.ldexp(torch.ones_like(inv), (sb.int() - 127))[..., None]
+    return (q8.view(torch.uint8).reshape(shape), sb.reshape(*shape[:-1], shape[-1] // block), deq.reshape(shape))
+
+
+def quantize_conv_weight(w: torch.Tensor):
+    """OIHW float32 -> dequantised float32 with one scale per (output channel, tap, 32 input channels)."""
+    o, i, kh, kw = w.shape
+    wt = w.permute(0, 2, 3, 1).contiguous()            # [O, kh, kw, I]: blocks of 32 run along the input channels
+    _, _, deq = quantize(wt)
+    return deq.permute(0, 3, 1, 2).contiguous()

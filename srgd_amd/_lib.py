@@ -15,6 +15,7 @@ MAX_STAGES = 8
 PRECISION_FP32 = 0
 PRECISION_BF16 = 1
 PRECISION_BF16_W8 = 2    # bf16 kernels, conv weights rounded through fp8 e4m3 (per-output-channel scale)
+PRECISION_FP8 = 3        # 3x3 convolutions on the block-scaled MX-fp8 matrix cores (e4m3 + E8M0 per 32 channels), rest bf16
 
 
 class UnetConfig(C.Structure):
@@ -99,6 +100,10 @@ PROTOTYPES = {
                                  C.c_void_p]),
     "srgd_k_linear_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "srgd_k_full_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "srgd_k_quant_mxfp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "srgd_k_conv3x3_mxfp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                       C.POINTER(C.c_int), C.c_void_p]),
     "srgd_k_linattn_block_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

@@ -90,6 +90,8 @@ enum KClass {
   KC_FINAL,        // 1x1 output conv + CFG + DDPM update
   KC_CANVAS,       // canvas prepare / re-noise / finish / RNG
   KC_COND,         // conditioning MLPs
+  KC_CONVQ,        // conv3x3_mxfp8_kernel: block-scaled MX-fp8 3x3 convolution (fp8 mode)
+  KC_QUANT,        // bf16 -> MX-fp8 quantisation passes (fp8 mode)
   KC_COUNT
 };
 

@@ -112,6 +112,7 @@ struct ConvW {
   void* w = nullptr;
   void* w3 = nullptr;         // conv3x3_bf16 fast-path packing (bf16 mode, eligible channel counts)
   void* w1 = nullptr;         // conv1x1_bf16 packing (bf16 mode: 1x1 / pixel-shuffle / space-to-depth layers)
+  void* wq = nullptr;         // conv3x3_mxfp8 packing (fp8 mode: e4m3 weights + E8M0 block scales)
   float* bias = nullptr;
 };
 struct Lin {
@@ -195,7 +196,8 @@ struct CondTable {
 struct ProfRec { int kc; hipEvent_t a, b; };
 
 const char* kFamilyNames[KC_COUNT] = {"conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "init_conv7x7", "groupnorm_silu", "rmsnorm", "linear_attention",
-                                      "full_attention", "final_conv_ddpm_step", "canvas_rng", "conditioning"};
+                                      "full_attention", "final_conv_ddpm_step", "canvas_rng", "conditioning", "conv3x3_mxfp8",
+                                      "quantize_mxfp8"};
 
 }  // namespace
 }  // namespace srgd
@@ -231,6 +233,7 @@ struct srgd_engine {
   // conv3x3_bf16 can apply the producer's GroupNorm+SiLU while staging its input (GNIN).  Measured on MI355X it
   // LOSES: the 16 transcendentals per 16-byte chunk sit on the barrier-paced critical path of an MFMA-bound kernel
   // (+0.137 s of conv vs -0.055 s of gn_apply per HR tile), so it is off; kept for a staggered-schedule retry.
+  bool fp8 = false;           // SRGD_PRECISION_FP8: 3x3 convolutions on the block-scaled MX-fp8 matrix cores, the rest as bf16
   bool w8 = false;            // SRGD_PRECISION_BF16_W8: conv weights rounded through fp8 e4m3 (per-output-channel scale)
   bool no_gn_fusion = true;
   int gn_fusion_max_ntiles = 1 << 30;   // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile)
@@ -355,8 +358,10 @@ int build_topology(srgd_engine* e) {
   if (c.sinus_dim < 2 || c.sinus_dim % 2) SRGD_FAIL("learned_sinusoidal_dim must be even");
   if (c.dim % 16 != 0) SRGD_FAIL("unet_dim must be a multiple of 16");
   if (c.groups < 1 || c.dim % c.groups != 0) SRGD_FAIL("unet_dim must be divisible by resnet_block_groups");
-  e->bf16 = c.precision == SRGD_PRECISION_BF16 || c.precision == SRGD_PRECISION_BF16_W8;
+  if (c.precision < SRGD_PRECISION_FP32 || c.precision > SRGD_PRECISION_FP8) SRGD_FAIL("unknown precision mode");
+  e->bf16 = c.precision != SRGD_PRECISION_FP32;
   e->w8 = c.precision == SRGD_PRECISION_BF16_W8;
+  e->fp8 = c.precision == SRGD_PRECISION_FP8;
   e->es = e->bf16 ? 2 : 4;
   e->dim = c.dim; e->time_dim = 4 * c.dim; e->hid = c.heads * c.dim_head; e->n_stages = c.n_stages;
   e->dims.push_back(c.dim);
@@ -431,6 +436,11 @@ int pack_conv(srgd_engine* e, ConvW& c) {
     std::vector<unsigned short> p3;
     pack_conv3x3_bf16(e->wt[c.wi].data.data(), c.Cin, c.Cout, p3, f32_to_bf16_host);
     SRGD_TRY(upload(e, p3.data(), p3.size() * 2, &c.w3));
+  }
+  if (e->fp8 && c.kind == CK_NORMAL && c.KS == 3 && c.Cin % 128 == 0 && c.Cout % 128 == 0) {
+    std::vector<unsigned char> pq;
+    pack_conv3x3_mxfp8(e->wt[c.wi].data.data(), c.Cin, c.Cout, pq);
+    SRGD_TRY(upload(e, pq.data(), pq.size(), &c.wq));
   }
   if (e->bf16 && (c.KS == 1 || c.kind == CK_UNSHUFFLE) && c.Cin % 32 == 0 && c.Cout % 128 == 0 && c.CoutPad == c.Cout) {
     std::vector<unsigned char> f32p;
@@ -544,6 +554,60 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
   return conv_igemm(a, e->bf16, x.st);
 }
 
+// ---- MX-fp8 route of the 3x3 convolutions (fp8 mode) ---------------------------------------------------------------
+struct QTensor { void* q = nullptr; void* s = nullptr; };      // pool buffers: e4m3 [npix][C], E8M0 [npix][C/32]
+
+ConvArgs conv3_args(Ctx& x, const ConvW& c, int C0, int C1, int H, int W, void* out, bool stats) {
+  srgd_engine* e = x.e;
+  ConvArgs a{};
+  a.C0 = C0; a.C1 = C1; a.ps0 = C0; a.ps1 = C1; a.B = x.nb; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W;
+  a.KH = a.KW = c.KS; a.stride = c.stride; a.pad = c.pad; a.bias = c.bias; a.Cout = c.Cout; a.CoutPad = c.CoutPad;
+  a.out = out; a.mode = c.mode; a.gn_partial = stats ? e->gn_partial : nullptr; a.groups = e->cfg.groups;
+  return a;
+}
+bool conv_is_q(Ctx& x, const ConvW& c, int C0, int C1, int H, int W, bool stats) {
+  srgd_engine* e = x.e;
+  if (!e->fp8 || !c.wq || e->force_generic_conv) return false;
+  return conv3x3_mxfp8_eligible(conv3_args(x, c, C0, C1, H, W, nullptr, stats));
+}
+int q_alloc(Ctx& x, int C, int hw, QTensor* t) {
+  const size_t npix = (size_t)x.nb * hw;
+  t->q = x.e->pool.get(npix * C);
+  t->s = x.e->pool.get(npix * (C / 32));
+  return (t->q && t->s) ? 0 : -1;
+}
+void q_free(Ctx& x, QTensor& t) {
+  if (t.q) x.e->pool.put(t.q);
+  if (t.s) x.e->pool.put(t.s);
+  t = QTensor{};
+}
+int q_from_bf16(Ctx& x, const void* src, int C, int hw, QTensor* t) {          // plain quantisation of a bf16 tensor
+  SRGD_TRY(q_alloc(x, C, hw, t));
+  Prof p(x.e, KC_QUANT, x.st);
+  return quant_mxfp8(src, t->q, t->s, (long)x.nb * hw, C, x.st);
+}
+int run_conv_q(Ctx& x, const ConvW& c, const QTensor& in0, int C0, const QTensor& in1, int C1, int H, int W, void* out,
+               bool stats) {
+  srgd_engine* e = x.e;
+  ConvArgs a = conv3_args(x, c, C0, C1, H, W, out, stats);
+  if (C0 + C1 != c.Cin) SRGD_FAIL("internal: conv input channel mismatch");
+  Prof p(e, KC_CONVQ, x.st);
+  if (e->prof_on) e->fam_flops[KC_CONVQ] += 2.0 * (double)x.nb * H * W * c.Cout * (double)(9 * c.Cin);
+  if (stats) e->stats_slots = conv3x3_mxfp8_stats_slots(a);
+  return conv3x3_mxfp8(a, in0.q, in0.s, in1.q, in1.s, c.wq, x.st);
+}
+// a 3x3 convolution of bf16 tensors through the fp8 route: quantise the source(s), convolve, release
+int run_conv_q_from_bf16(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, int C1, int H, int W, void* out,
+                         bool stats) {
+  QTensor a, b;
+  SRGD_TRY(q_from_bf16(x, in0, C0, H * W, &a));
+  if (C1) SRGD_TRY(q_from_bf16(x, in1, C1, H * W, &b));
+  SRGD_TRY(run_conv_q(x, c, a, C0, b, C1, H, W, out, stats));
+  q_free(x, a);
+  q_free(x, b);
+  return 0;
+}
+
 int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_offset /* <0: none */, void* buf,
            const void* residual, bool finalize_only = false) {
   srgd_engine* e = x.e;
@@ -567,10 +631,23 @@ int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, i
   void* u = e->pool.get(bytes);
   void* v = e->pool.get(bytes);
   if (!u || !v) return -1;
+  if (conv_is_q(x, r.c1, C0, C1, x.H, x.W, true) && conv_is_q(x, r.c2, r.Cout, 0, x.H, x.W, true)) {
+    // fp8 mode: both 3x3 convolutions on the MX matrix cores.  conv1 reads quantised copies of the block input; the
+    // GroupNorm1-apply + SiLU pass writes conv2's input directly as MX-fp8 (1 byte per element instead of 2).
+    SRGD_TRY(run_conv_q_from_bf16(x, r.c1, in0, C0, in1, C1, x.H, x.W, u, true));
+    SRGD_TRY(run_gn(x, r.g1, r.b1, r.Cout, hw, r.ss_offset, u, nullptr, true));
+    QTensor qu;
+    SRGD_TRY(q_alloc(x, r.Cout, hw, &qu));
+    { Prof p(e, KC_GN, x.st);
+      SRGD_TRY(gn_apply_silu_mxfp8(u, qu.q, qu.s, e->coefA, e->coefB, x.nb, hw, r.Cout, x.st)); }
+    SRGD_TRY(run_conv_q(x, r.c2, qu, r.Cout, QTensor{}, 0, x.H, x.W, v, true));
+    q_free(x, qu);
+  } else {
   SRGD_TRY(run_conv(x, r.c1, in0, C0, in1, C1, x.H, x.W, u, nullptr, true));
   const bool fuse = conv_can_fuse_gn_in(e, r.c2, x.nb, x.H, x.W);
   SRGD_TRY(run_gn(x, r.g1, r.b1, r.Cout, hw, r.ss_offset, u, nullptr, fuse));
   SRGD_TRY(run_conv(x, r.c2, u, r.Cout, nullptr, 0, x.H, x.W, v, nullptr, true, fuse));
+  }
   if (r.has_res && e->bf16) {
     // GroupNorm2 + SiLU + (+ res_conv(x)) evaluated in the 1x1 res_conv's epilogue, in place over v
     SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, nullptr, true));
@@ -689,7 +766,8 @@ int unet_body(Ctx& x, void* x0, void** out) {
     const int Ho = (s < n - 1) ? x.H / 2 : x.H, Wo = (s < n - 1) ? x.W / 2 : x.W;
     void* d = e->pool.get((size_t)x.nb * Ho * Wo * rs.Cout * e->es);
     if (!d) return -1;
-    SRGD_TRY(run_conv(x, rs, c, C, nullptr, 0, x.H, x.W, d, nullptr, false));
+    if (conv_is_q(x, rs, C, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, C, nullptr, 0, x.H, x.W, d, false));
+    else SRGD_TRY(run_conv(x, rs, c, C, nullptr, 0, x.H, x.W, d, nullptr, false));
     x.H = Ho; x.W = Wo;
     cur = d;
   }
@@ -720,7 +798,8 @@ int unet_body(Ctx& x, void* x0, void** out) {
     const int Ho = (u < n - 1) ? x.H * 2 : x.H, Wo = (u < n - 1) ? x.W * 2 : x.W;
     void* d = e->pool.get((size_t)x.nb * Ho * Wo * din * e->es);
     if (!d) return -1;
-    SRGD_TRY(run_conv(x, rs, c, dout, nullptr, 0, x.H, x.W, d, nullptr, false));
+    if (conv_is_q(x, rs, dout, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, dout, nullptr, 0, x.H, x.W, d, false));
+    else SRGD_TRY(run_conv(x, rs, c, dout, nullptr, 0, x.H, x.W, d, nullptr, false));
     e->pool.put(c);
     x.H = Ho; x.W = Wo;
     cur = d;

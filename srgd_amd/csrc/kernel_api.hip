@@ -155,6 +155,56 @@ int srgd_k_linattn_block_fused(const void* x, void* y, int B, int N, int C, cons
   return 0;
 }
 
+int srgd_k_quant_mxfp8(const void* x_bf16, void* q, void* s, int64_t npix, int C, void* stream) {
+  if (!x_bf16 || !q || !s) SRGD_FAIL("srgd_k_quant_mxfp8: null argument");
+  return quant_mxfp8(x_bf16, q, s, (long)npix, C, (hipStream_t)stream);
+}
+
+int srgd_k_conv3x3_mxfp8(const void* in0, const void* in1, int C0, int C1, int B, int H, int W,
+                         const float* weight_oihw_host, const float* bias_host, int Cout, void* out, float* gn_partial,
+                         int groups, int iters, float* avg_ms, int* stats_slots, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!in0 || !weight_oihw_host || !out) SRGD_FAIL("srgd_k_conv3x3_mxfp8: null argument");
+  ConvArgs a{};
+  a.C0 = C0; a.C1 = in1 ? C1 : 0; a.ps0 = C0; a.ps1 = a.C1; a.B = B; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W;
+  a.KH = a.KW = 3; a.stride = 1; a.pad = 1; a.Cout = Cout; a.CoutPad = Cout; a.out = out; a.mode = CONV_PLAIN;
+  a.gn_partial = gn_partial; a.groups = groups;
+  if (!conv3x3_mxfp8_eligible(a)) SRGD_FAIL("srgd_k_conv3x3_mxfp8: needs C0, C1, Cout % 128 == 0, H % 8 == 0, W % 16 == 0");
+  std::vector<unsigned char> pw;
+  pack_conv3x3_mxfp8(weight_oihw_host, a.C0 + a.C1, Cout, pw);
+  const size_t npix = (size_t)B * H * W;
+  DevBuf dw, db, q0, s0, q1, s1;
+  SRGD_TRY(dw.alloc(pw.size()));
+  SRGD_HIP(hipMemcpy(dw.p, pw.data(), pw.size(), hipMemcpyHostToDevice));
+  if (bias_host) {
+    SRGD_TRY(db.alloc((size_t)Cout * 4));
+    SRGD_HIP(hipMemcpy(db.p, bias_host, (size_t)Cout * 4, hipMemcpyHostToDevice));
+    a.bias = (const float*)db.p;
+  }
+  SRGD_TRY(q0.alloc(npix * C0)); SRGD_TRY(s0.alloc(npix * (C0 / 32)));
+  SRGD_TRY(quant_mxfp8(in0, q0.p, s0.p, (long)npix, C0, st));
+  if (a.C1) {
+    SRGD_TRY(q1.alloc(npix * a.C1)); SRGD_TRY(s1.alloc(npix * (a.C1 / 32)));
+    SRGD_TRY(quant_mxfp8(in1, q1.p, s1.p, (long)npix, a.C1, st));
+  }
+  if (stats_slots) *stats_slots = conv3x3_mxfp8_stats_slots(a);
+  SRGD_TRY(conv3x3_mxfp8(a, q0.p, s0.p, q1.p, s1.p, dw.p, st));
+  if (iters > 0 && avg_ms) {
+    hipEvent_t e0, e1;
+    SRGD_HIP(hipEventCreate(&e0)); SRGD_HIP(hipEventCreate(&e1));
+    SRGD_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) SRGD_TRY(conv3x3_mxfp8(a, q0.p, s0.p, q1.p, s1.p, dw.p, st));
+    SRGD_HIP(hipEventRecord(e1, st));
+    SRGD_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    SRGD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  SRGD_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
 int srgd_k_full_attention(const void* qkv, void* out, int B, int N, int heads, int is_bf16, void* stream) {
   return full_attention(qkv, out, B, N, heads, 32, is_bf16 != 0, (hipStream_t)stream);
 }

@@ -63,6 +63,23 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
                  hipStream_t st);
 unsigned short f32_to_bf16_host(float f);
 
+// ---------------------------------------------------------------- conv3x3_mxfp8.hip / quant_mxfp8.hip
+// Block-scaled MX-fp8 path (v_mfma_scale_f32_16x16x128_f8f6f4, BASELINE configs[4]): the 3x3 convolutions take e4m3
+// activations [B,H,W,C] + E8M0 scales [B,H,W,C/32] (one per 32 channels) and e4m3 weights with one scale per
+// (output channel, tap, 32 input channels); fp32 accumulate, bf16 out, same epilogue as conv3x3_bf16.
+bool conv3x3_mxfp8_eligible(const ConvArgs& a);
+int conv3x3_mxfp8_stats_slots(const ConvArgs& a);
+void pack_conv3x3_mxfp8(const float* src_oihw, int Cin, int Cout, std::vector<unsigned char>& out);
+int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void* q1, const void* s1, const void* packed_w,
+                  hipStream_t st);
+unsigned char e4m3_encode(float x);
+int mx_block_exponent(float amax);
+float round_through_e4m3(float x);
+// bf16 [npix][C] -> e4m3 [npix][C] + E8M0 [npix][C/32]; the second form applies y = silu(coefA*x + coefB) first
+int quant_mxfp8(const void* x_bf16, void* q, void* s, long npix, int C, hipStream_t st);
+int gn_apply_silu_mxfp8(const void* x_bf16, void* q, void* s, const float* coefA, const float* coefB, int B, int hw, int C,
+                        hipStream_t st);
+
 // ---------------------------------------------------------------- norm_act.hip
 struct GnFinalizeArgs {
   const float* partial;   // [B][groups][nslots][2]

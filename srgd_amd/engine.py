@@ -13,7 +13,8 @@ import torch
 from . import _lib
 from ._lib import SamplerGeometry, StepScalars, UnetConfig, check
 
-_PRECISIONS = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16, "bf16_w8": _lib.PRECISION_BF16_W8}
+_PRECISIONS = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16, "bf16_w8": _lib.PRECISION_BF16_W8,
+               "fp8": _lib.PRECISION_FP8}
 
 
 def _stream_ptr(device: torch.device) -> C.c_void_p:

@@ -681,3 +681,69 @@ def test_mixed_class_labels_are_refused_not_collapsed():
         sampler.sample(batch_size=2, condition_x=cond, class_label=torch.tensor([0, 2]).cuda(), num_sample_steps=2)
     out = sampler.sample(batch_size=2, condition_x=cond, class_label=torch.tensor([1, 1]).cuda(), num_sample_steps=2)
     assert out.shape == (2, 3, 256, 256)
+
+
+# ------------------------------------------------------------------ BASELINE configs[4]: fp8 (MX) compute path
+def test_fp8_unet_forward_vs_reference_and_bf16():
+    # one U-Net evaluation in fp8 mode (every 3x3 convolution on v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 weights and activations
+    # with a scale per 32 channels) against the REFERENCE's eps (fixture) and against the bf16 engine
+    case = next(c for c in C.UNET_CASES if c["name"] == "dim128_128")
+    z = np.load(os.path.join(G, "unet_eps.npz"))
+    sampler = build_sampler(case["dim"], weight_seed=case["weight_seed"])
+    unet = sampler.model
+    x, cnd, ls = C.unet_inputs(case)
+    label, c = C.unet_mode_args("label_cond", case, cnd)
+    outs = {}
+    try:
+        for prec in ("bf16", "fp8"):
+            unet.precision = prec
+            outs[prec] = unet(x.cuda(), ls.cuda(), label.cuda(), c.cuda()).cpu()
+    finally:
+        unet.precision = "fp32"
+    want = torch.from_numpy(z[f"{case['name']}.label_cond"])
+    rel = lambda a, b: float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
+    _report(test="fp8_unet_forward", rel_rms_vs_reference=rel(outs["fp8"], want), rel_rms_vs_bf16=rel(outs["fp8"], outs["bf16"]),
+            bf16_rel_rms_vs_reference=rel(outs["bf16"], want), max_abs_vs_reference=float((outs["fp8"] - want).abs().max()))
+    assert torch.isfinite(outs["fp8"]).all()
+    assert not torch.equal(outs["fp8"], outs["bf16"])          # the fp8 kernels really ran
+    assert rel(outs["fp8"], want) < 0.15                        # e4m3 carries 3 mantissa bits: a few percent per conv, 40 convs deep
+
+
+def test_fp8_mode_uses_the_mxfp8_kernels():
+    sampler = build_sampler(128)
+    eng = sampler.model.engine("fp8")
+    cond = C.synthetic_lr_condition(0, 64, 64).cuda()
+    sampler.noise_source = "device"
+    try:
+        eng.profile_begin()
+        out = sampler.tiled_sample(batch_size=4, condition_x=cond, class_label=torch.tensor([0]).cuda(), num_sample_steps=2,
+                                   precision="fp8")
+        prof = eng.profile_end()
+    finally:
+        sampler.noise_source = "host"
+    assert torch.isfinite(out).all() and out.min() >= 0 and out.max() <= 1
+    assert prof["launches"]["conv3x3_mxfp8"] == 2 * 40 and prof["launches"]["conv3x3_bf16"] == 0     # all 40 3x3 convs per forward
+    assert prof["launches"]["quantize_mxfp8"] > 0
+
+
+def test_config5_full_geometry_fp8_vs_bf16_parity_report():
+    # BASELINE configs[4] as named: 256^2 LR -> 1024^2 (canvas 1280^2, 25/16 tiles), 100 DDPM steps, class_cond_scale 2.0 (both
+    # passes in one launch), fp8 weights + activations vs the bf16 engine on the identical (device) noise stream.
+    sampler = build_sampler(128)
+    cond = C.synthetic_lr_condition(0, 256, 256).cuda()
+    label = torch.tensor([0]).cuda()
+    sampler.noise_source = "device"
+    outs = {}
+    try:
+        for prec in ("bf16", "fp8"):
+            sampler.device_noise_seed = 71
+            outs[prec] = sampler.tiled_sample(batch_size=25, condition_x=cond, class_label=label, class_cond_scale=2.0,
+                                              num_sample_steps=100, precision=prec).cpu()
+    finally:
+        sampler.noise_source = "host"
+    err = (outs["fp8"] - outs["bf16"]).abs()
+    psnr = float(10 * np.log10(1.0 / max(float((err ** 2).mean()), 1e-20)))
+    _report(test="config5_full_1024_fp8_vs_bf16", psnr_db=psnr, max_abs=float(err.max()), mean_abs=float(err.mean()))
+    assert outs["fp8"].shape == (1, 3, 1024, 1024)
+    assert torch.isfinite(outs["fp8"]).all() and outs["fp8"].min() >= 0 and outs["fp8"].max() <= 1
+    assert psnr > 25.0, psnr           # random-init weights, 3 mantissa bits on weights AND activations; tightened to measured - 3 dB

@@ -46,6 +46,15 @@ def rnd(x, bf16):
     return x.to(torch.bfloat16).float() if bf16 else x
 
 
+def _report_k(**kw):
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "a") as f:
+        f.write(json.dumps(kw) + "\n")
+
+
 def tol(bf16, ref, k=1.0):
     scale = max(1.0, float(ref.abs().max()))
     return (1.2e-2 if bf16 else 2e-5) * scale * k
@@ -461,3 +470,89 @@ def test_kernel_chains_match_reference_submodules_fp32():
     check("linear_attention", attention(GC.module_input("linear_attention"), "downs.0.2", False), k=2.0)
     check("full_attention", attention(GC.module_input("full_attention"), "downs.3.2", True), k=2.0)
     check("mid_attention", attention(GC.module_input("mid_attention"), "mid_attn", True), k=2.0)
+
+
+# ------------------------------------------------------------------ MX-fp8 (BASELINE configs[4] compute path)
+def test_quant_mxfp8_is_bit_exact_with_the_format_emulation():
+    # quant_mxfp8.hip vs oracle/mxfp8.py (OCP MX: E8M0 = floor(log2 amax) - 8, e4m3 RNE, saturation at 448): every byte equal.
+    from oracle import mxfp8 as MX
+    lib = L().lib()
+    g = torch.Generator().manual_seed(31)
+    npix, C = 4096, 256
+    x = torch.randn(npix, C, generator=g) * torch.exp(3 * torch.randn(npix, 1, generator=g))     # wide dynamic range across pixels
+    x[5] = 0                                                         # an all-zero pixel (scale byte 0)
+    x[6, :32] = 1e-30                                                # below bf16's normal range after rounding? (stays tiny)
+    x[7, :32] = torch.tensor([2.0 ** (k % 9 - 4) for k in range(32)])       # exact powers of two: block maximum on a boundary
+    x[8, 32:64] = 1.9990234375 * 2.0 ** 3                           # mantissa > 1.75: scaled maximum exceeds 448 -> saturates
+    x = x.to(torch.bfloat16)
+    d = x.to(DEV)
+    q = torch.empty(npix, C, dtype=torch.uint8, device=DEV)
+    s = torch.empty(npix, C // 32, dtype=torch.uint8, device=DEV)
+    L().check(lib.srgd_k_quant_mxfp8(ptr(d), ptr(q), ptr(s), npix, C, stream()), "quant")
+    torch.cuda.synchronize()
+    wq, ws, _ = MX.quantize(x.float())
+    assert torch.equal(s.cpu(), ws)
+    assert torch.equal(q.cpu(), wq)
+
+
+def _mx_conv_reference(x0, x1, w, b):
+    """The fp8 convolution's arithmetic on the CPU: MX-quantised activations (per pixel, per 32 channels) and weights (per
+    output channel, tap, 32 input channels), exact products, fp32 sums; each source quantised on its own as the engine does."""
+    from oracle import mxfp8 as MX
+    qs = []
+    for t in (x0, x1):
+        if t is not None:
+            _, _, deq = MX.quantize(t.permute(0, 2, 3, 1).contiguous())
+            qs.append(deq.permute(0, 3, 1, 2))
+    return F.conv2d(torch.cat(qs, 1).double(), MX.quantize_conv_weight(w).double(), b.double(), padding=1).float()
+
+
+def test_conv3x3_mxfp8_exact_small_integers():
+    # small integers are exact in e4m3 with power-of-two block scales -> the result must equal the fp32 convolution bit for bit
+    # (after the bf16 store); catches operand / scale lane maps, swizzles, the two-source K walk and the transposed epilogue.
+    lib = L().lib()
+    g = torch.Generator().manual_seed(12)
+    x0 = torch.randint(-3, 4, (2, 128, 16, 32), generator=g).float()
+    x1 = torch.randint(-3, 4, (2, 256, 16, 32), generator=g).float()
+    w = torch.randint(-2, 3, (256, 384, 3, 3), generator=g).float()
+    b = torch.randint(-4, 5, (256,), generator=g).float()
+    d0, d1 = to_dev_nhwc(x0, True), to_dev_nhwc(x1, True)
+    out = torch.empty(2, 16, 32, 256, dtype=torch.bfloat16, device=DEV)
+    L().check(lib.srgd_k_conv3x3_mxfp8(ptr(d0), ptr(d1), 128, 256, 2, 16, 32, ptr(w), ptr(b), 256, ptr(out), ptr(None), 8, 0,
+                                       None, None, stream()), "conv3x3_mxfp8")
+    want = F.conv2d(torch.cat([x0, x1], 1), w, b, padding=1).to(torch.bfloat16).float()
+    assert torch.equal(from_dev_nhwc(out), want)
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 128, 32, 64), (3, 256, 128, 8, 16), (1, 512, 1024, 32, 32)],
+                         ids=lambda s: "B%d_%dto%d_%dx%d" % s)
+def test_conv3x3_mxfp8_matches_the_quantised_reference(shape):
+    # random data: the kernel must reproduce conv(dequant(MX(x)), dequant(MX(w))) up to fp32 summation order and the bf16 store;
+    # the distance to the UNQUANTISED convolution is reported (that is the price of e4m3, not a kernel property)
+    B, Cin, Cout, H, W = shape
+    lib = L().lib()
+    g = torch.Generator().manual_seed(13)
+    x = rnd(torch.randn(B, Cin, H, W, generator=g) * torch.exp(torch.randn(B, 1, H, W, generator=g)), True)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    b = 0.1 * torch.randn(Cout, generator=g)
+    d = to_dev_nhwc(x, True)
+    out = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    nslots = C.c_int(0)
+    part = torch.zeros(B * 8 * (H * W // 128) * 2 + 16, device=DEV)
+    L().check(lib.srgd_k_conv3x3_mxfp8(ptr(d), ptr(None), Cin, 0, B, H, W, ptr(w), ptr(b), Cout, ptr(out), ptr(part), 8, 0, None,
+                                       C.byref(nslots), stream()), "conv3x3_mxfp8")
+    got = from_dev_nhwc(out)
+    want = _mx_conv_reference(x, None, w, b)
+    scale = float(want.abs().max())
+    err = (got - want).abs().max().item()
+    assert err <= 2.0 ** -8 * scale + 1e-5, (err, scale)                  # bf16 store + summation order
+    plain = F.conv2d(x, w, b, padding=1)
+    rel = float(((got - plain) ** 2).mean().sqrt() / (plain ** 2).mean().sqrt())
+    _report_k(test="conv3x3_mxfp8_vs_unquantised", shape=list(shape), rel_rms=rel)
+    assert rel < 0.08                                                      # e4m3: ~2^-4 / sqrt(3) per operand
+    # GroupNorm partial sums written by the epilogue: per (sample, group) over all slots = sums of the fp32 outputs
+    p = part[: B * 8 * nslots.value * 2].cpu().reshape(B, 8, nslots.value, 2).sum(2)
+    wsum = want.reshape(B, 8, -1).sum(-1)
+    wsq = (want.double() ** 2).reshape(B, 8, -1).sum(-1).float()
+    assert torch.allclose(p[..., 0], wsum, rtol=2e-3, atol=2e-2 * float(wsq.max()) ** 0.5)
+    assert torch.allclose(p[..., 1], wsq, rtol=2e-3)
