@@ -52,7 +52,7 @@ int srgd_k_quant_mxfp8(const void* x_bf16, void* q, void* s, int64_t npix, int C
 /* 3x3 / stride 1 / pad 1 convolution on v_mfma_scale_f32_16x16x128_f8f6f4.  replaces: Block.proj (model.py:246) in fp8 mode.
  * in0 / in1: bf16 NHWC sources (channel concat; in1 nullable), quantised to MX-fp8 inside (srgd_k_quant_mxfp8); weights /
  * bias: PyTorch-layout fp32 on the HOST, quantised per (output channel, tap, 32 input channels).  C0, C1, Cout % 128 == 0,
- * H % 8 == 0, W % 16 == 0.  out: bf16 NHWC.  gn_partial / stats_slots as in srgd_k_conv2d_timed; iters > 0 times the
+ * H % 8 == 0, W % 32 == 0.  out: bf16 NHWC.  gn_partial / stats_slots as in srgd_k_conv2d_timed; iters > 0 times the
  * convolution kernel alone (*avg_ms).  Synchronises. */
 int srgd_k_conv3x3_mxfp8(const void* in0, const void* in1, int C0, int C1, int B, int H, int W,
                          const float* weight_oihw_host, const float* bias_host, int Cout, void* out, float* gn_partial,

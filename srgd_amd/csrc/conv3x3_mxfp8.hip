@@ -13,10 +13,13 @@
 //
 // Implicit GEMM like conv3x3_bf16.hip (halo patch staged once per channel chunk, all 9 taps read it at shifted addresses,
 // all staging by LDS-DMA, counted vmcnt + raw barriers), re-tiled for 128-channel (= one MFMA K) chunks:
-//   * workgroup = 256 threads = 4 waves (2 along M x 2 along N), output tile = 8 x 16 pixel patch (M = 128) x 128 channels,
-//     wave tile 64 x 64 = 4 x 4 MFMA blocks; <= 256 VGPRs, 76 KiB LDS -> two workgroups per CU
-//   * per chunk: the (8+2) x (16+2) halo patch x 128 B (23 KiB) + its scale bytes (4 B / pixel); per K-step (tap, chunk) one
-//     16 KiB weight tile + 512 B of weight scales, 3-deep ring; rows XOR-swizzled (chunk ^= row & 6): every ds_read_b128 of
+//   * workgroup = 256 threads = 4 waves (2 along M x 2 along N), output tile = 8 x 32 pixel patch (M = 256) x 128 channels,
+//     wave tile 128 x 64 = 8 x 4 MFMA blocks (128 accumulator registers); <= 256 VGPRs, 79 KiB LDS -> two workgroups per CU.
+//     (The first version used M = 128 tiles: at twice the bf16 MFMA rate every workgroup then re-streamed the weight tiles at
+//     ~68 GB/s per CU, the L2 -> LDS ceiling of this part, and the 128-channel layers ran at 1.2x the bf16 kernel instead of
+//     1.5x; M = 256 halves the weight bytes per FLOP.)
+//   * per chunk: the (8+2) x (32+2) halo patch x 128 B (42.5 KiB) + its scale bytes (4 B / pixel); per K-step (tap, chunk) one
+//     16 KiB weight tile + 512 B of weight scales, double-buffered; rows XOR-swizzled (chunk ^= row & 6): every ds_read_b128 of
 //     the operand pattern is conflict-free at every tap shift (exhaustive search over the lane groups of ds_read_b128)
 //   * epilogue as in the bf16 kernel: + bias, GroupNorm partial sums, LDS transpose, 16-byte stores.
 #include <cmath>
@@ -28,34 +31,36 @@
 namespace srgd {
 namespace {
 
-constexpr int QPH = 8, QPW = 16;                 // output patch
-constexpr int QHP = QPH + 2, QWP = QPW + 2;      // halo patch: 10 x 18 = 180 pixels
+constexpr int QPH = 8, QPW = 32;                 // output patch
+constexpr int QHP = QPH + 2, QWP = QPW + 2;      // halo patch: 10 x 34 = 340 pixels
 constexpr int QKC = 128;                         // channels per chunk = K of one MFMA
 constexpr int QBN = 128;
 constexpr int QNT = 256;
-constexpr int QA_BYTES = 24 * 1024;              // 24 wave-instructions x 1 KiB (180 px * 128 B = 23,040 used)
-constexpr int QAS_BYTES = 1024;                  // activation scales: 4 B per halo pixel (720 used)
+constexpr int QA_PIECES = 11;                    // 1 KiB LDS-DMA pieces per wave and chunk
+constexpr int QA_BYTES = 4 * QA_PIECES * 1024;   // 44 KiB (340 px * 128 B = 43,520 used)
+constexpr int QAS_BYTES = 2048;                  // activation scales: 4 B per halo pixel (1,360 used), 2 dword pieces per wave
 constexpr int QB_TILE = QBN * QKC;               // 16 KiB of e4m3 weights per K-step
-constexpr int QB_BYTES = QB_TILE + 1024;         // + [128 n][4 g] scale bytes (512) + 512 zero pad: one 17 KiB DMA unit
-constexpr int QRING = 3;
-constexpr int QLDS = QA_BYTES + QAS_BYTES + QRING * QB_BYTES;   // 77,824 B: two workgroups per CU
+constexpr int QB_BYTES = QB_TILE + 512;          // + [128 n][4 g] scale bytes: one 16.5 KiB unit per (tap, chunk, n-tile)
+constexpr int QRING = 2;
+constexpr int QLDS = QA_BYTES + QAS_BYTES + QRING * QB_BYTES;   // 80,896 B: two workgroups per CU (<= 81,920)
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)lds_wave_base, 16, voffset, 0, 0, 0);
+// voffset: per-lane byte offset (VGPR); soffset: wave-uniform byte offset (SGPR) - keeping the uniform part out of the VGPRs
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset, int soffset = 0) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
-__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)lds_wave_base, 4, voffset, 0, 0, 0);
+__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset, int soffset = 0) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)lds_wave_base, 4, voffset, soffset, 0, 0);
 }
 
 struct ConvQArgs {
   const unsigned char* q0; const unsigned char* s0; int C0;     // MX-fp8 source 0: [B,H,W,C0] e4m3, [B,H,W,C0/32] E8M0
   const unsigned char* q1; const unsigned char* s1; int C1;     // optional source 1 (channel concat)
   int B, H, W;
-  const unsigned char* w;     // packed [tap][cc][ntile][17 KiB]
+  const unsigned char* w;     // packed [tap][cc][ntile][16.5 KiB]
   const float* bias;
   int Cout;
   bf16* out;
@@ -100,30 +105,16 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   const int CC0 = p.C0 / QKC, CC = (p.C0 + p.C1) / QKC;
   const int S = CC * 9;
 
-  // ---- A staging: 24 pieces of 1 KiB per chunk, wave w issues pieces w, w+4, ..., w+20; 16-byte chunk index in the LDS image
+  // ---- A staging: 44 pieces of 1 KiB per chunk, wave w issues pieces w, w+4, ..., w+40; 16-byte chunk index in the LDS image
   // = piece*64 + lane -> pixel P = idx >> 3, stored position idx & 7 holds logical chunk (idx & 7) ^ (P & 6).
-  // Per-lane (pixel offset or -1, logical chunk) of the six pieces as NAMED scalars (indexed arrays would go to scratch).
-#define SRGD_QA_DECL(J)                                                       \
-  int a_pix##J, a_sub##J;                                                     \
-  {                                                                           \
-    const int idx = (wave + 4 * J) * 64 + lane;                               \
-    const int P = idx >> 3;                                                   \
-    const int py = P / QWP, px = P - py * QWP;                                \
-    const int y = y0 + py - 1, x = x0 + px - 1;                               \
-    const bool ok = P < QHP * QWP && y >= 0 && y < p.H && x >= 0 && x < p.W;  \
-    a_pix##J = ok ? y * p.W + x : -1;                                         \
-    a_sub##J = (idx & 7) ^ (P & 6);                                           \
-  }
-  SRGD_QA_DECL(0) SRGD_QA_DECL(1) SRGD_QA_DECL(2) SRGD_QA_DECL(3) SRGD_QA_DECL(4) SRGD_QA_DECL(5)
-#undef SRGD_QA_DECL
-  int as_pix;                                     // scale piece: wave w stages the scale dwords of halo pixels 64w .. 64w+63
-  {
-    const int P = wave * 64 + lane;
+  // Per-lane state: global pixel offset of the first piece (or -1) is recomputed per piece from (py, px): cheap integer
+  // arithmetic once per chunk, nothing kept in registers across the K loop except the tile origin.
+  auto halo_pix = [&](int P) {                    // pixel offset y*W + x of halo position P, -1 outside the image / patch
     const int py = P / QWP, px = P - py * QWP;
     const int y = y0 + py - 1, x = x0 + px - 1;
     const bool ok = P < QHP * QWP && y >= 0 && y < p.H && x >= 0 && x < p.W;
-    as_pix = ok ? y * p.W + x : -1;
-  }
+    return ok ? y * p.W + x : -1;
+  };
   const size_t npix = (size_t)p.H * p.W;
   const __amdgpu_buffer_rsrc_t rq0 =
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.q0 + (size_t)b * npix * p.C0), 0, (int)(npix * p.C0), 0x00020000);
@@ -137,96 +128,139 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.w + (size_t)nt * QB_BYTES), 0, (int)((size_t)(9 * CC - 1) * w_step_stride + QB_BYTES), 0x00020000);
 
-  auto issue_a_piece = [&](int cc, int j, int a_pix, int a_sub) {
+  auto issue_a = [&](int cc) {                    // 11 + 2 DMA instructions per wave
     const bool first = cc < CC0;
     const int Cs = first ? p.C0 : p.C1;
-    const int coff = (first ? cc : cc - CC0) * QKC;
-    const int voff = a_pix >= 0 ? a_pix * Cs + coff + a_sub * 16 : 0x7ffffff0;
-    char* dst = sA + (wave + 4 * j) * 1024;
-    if (first) dma16(rq0, dst, voff); else dma16(rq1, dst, voff);
+    const int ccl = first ? cc : cc - CC0;
+    int opq_a = 0;
+    asm volatile("" : "+v"(opq_a));               // per-chunk recomputation of the 13 staging offsets (they are invariant
+                                                  // across chunks, and hoisted out of the K loop they cost 26 long-lived VGPRs)
+#pragma unroll
+    for (int j = 0; j < QA_PIECES; ++j) {
+      const int idx = (wave + 4 * j) * 64 + lane + opq_a;
+      const int P = idx >> 3;
+      const int pix = halo_pix(P);
+      const int sub = (idx & 7) ^ (P & 6);
+      const int voff = pix >= 0 ? pix * Cs + ccl * QKC + sub * 16 : 0x7ffffff0;
+      char* dst = sA + (wave + 4 * j) * 1024;
+      if (first) dma16(rq0, dst, voff); else dma16(rq1, dst, voff);
+    }
+    const int Cs32 = Cs / 32;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {                 // scale dwords of halo pixels (wave + 4k)*64 .. +63
+      const int pix = halo_pix((wave + 4 * k) * 64 + lane + opq_a);
+      const int voff = pix >= 0 ? pix * Cs32 + ccl * 4 : 0x7ffffff0;
+      if (first) dma4(rs0, sAs + (wave + 4 * k) * 256, voff); else dma4(rs1, sAs + (wave + 4 * k) * 256, voff);
+    }
   };
-  auto issue_a = [&](int cc) {                    // 7 DMA instructions per wave
-    issue_a_piece(cc, 0, a_pix0, a_sub0); issue_a_piece(cc, 1, a_pix1, a_sub1); issue_a_piece(cc, 2, a_pix2, a_sub2);
-    issue_a_piece(cc, 3, a_pix3, a_sub3); issue_a_piece(cc, 4, a_pix4, a_sub4); issue_a_piece(cc, 5, a_pix5, a_sub5);
-    const bool first = cc < CC0;
-    const int Cs32 = (first ? p.C0 : p.C1) / 32;
-    const int voff = as_pix >= 0 ? as_pix * Cs32 + (first ? cc : cc - CC0) * 4 : 0x7ffffff0;
-    if (first) dma4(rs0, sAs + wave * 256, voff); else dma4(rs1, sAs + wave * 256, voff);
-  };
-  auto issue_b = [&](int s) {                     // K-step s = cc*9 + tap -> weight unit (tap, cc); 5 DMA instructions per wave
+  auto issue_b = [&](int s, int slot) {           // K-step s = cc*9 + tap -> weight unit (tap, cc) into ring slot `slot`
     const int cc = s / 9, tap = s - cc * 9;
     const int base = (int)((size_t)(tap * CC + cc) * w_step_stride);
-    char* dst = sB0 + (s % QRING) * QB_BYTES;     // (a clamped re-fetch of the last unit lands in the last unit's own slot)
+    char* dst = sB0 + slot * QB_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma16(rsw, dst + (wave + 4 * j) * 1024, base + (wave + 4 * j) * 1024 + lane * 16);
-    dma4(rsw, dst + QB_TILE + wave * 256, base + QB_TILE + wave * 256 + lane * 4);
+    for (int j = 0; j < 4; ++j) dma16(rsw, dst + (wave + 4 * j) * 1024, lane * 16, base + (wave + 4 * j) * 1024);
+    // the 512 scale bytes: waves 0 and 1 would do; waves 2 and 3 repeat their transfers (same bytes to the same place) so
+    // that every wave issues the same five instructions and the tap loop stays branch-free
+    dma4(rsw, dst + QB_TILE + (wave & 1) * 256, lane * 4, base + QB_TILE + (wave & 1) * 256);
   };
 
-  f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c10 = 0, c11 = 0, c12 = 0, c13 = 0,
-        c20 = 0, c21 = 0, c22 = 0, c23 = 0, c30 = 0, c31 = 0, c32 = 0, c33 = 0;
+  // accumulators: [8 pixel blocks (patch row 4 wm + (i >> 1), x half i & 1)][4 channel blocks of 16]
+  f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c10 = 0, c11 = 0, c12 = 0, c13 = 0, c20 = 0, c21 = 0, c22 = 0, c23 = 0,
+        c30 = 0, c31 = 0, c32 = 0, c33 = 0, c40 = 0, c41 = 0, c42 = 0, c43 = 0, c50 = 0, c51 = 0, c52 = 0, c53 = 0,
+        c60 = 0, c61 = 0, c62 = 0, c63 = 0, c70 = 0, c71 = 0, c72 = 0, c73 = 0;
 
   // operand addresses: row P (pixel of the halo patch / weight row n), logical chunks g and 4+g, swizzle chunk ^= row & 6
-  auto row_lo = [&](int row) { return row * 128 + ((g ^ (row & 6)) << 4); };        // the hi chunk is this ^ 64
-  int opq = 0;                                    // opaque zero: keeps the per-tap addresses out of long-lived registers
+  auto row_lo = [&](int row, int gg) { return row * 128 + ((gg ^ (row & 6)) << 4); };        // the hi chunk is this ^ 64
+  // Per-tap opaque copies of the lane coordinates: every operand address of a tap is derived from them, so hipcc cannot
+  // precompute (row + tap offset) terms for all nine taps outside the K loop (that cost ~12 long-lived VGPRs and, at the
+  // 256-register cap of two workgroups per CU, spills whose scratch reloads wait behind the in-flight weight DMA).
+  int r16t = r16, gt = g;
+  // One K-step: the 4 weight fragments (64 output channels of this wave) stay in registers, the 8 pixel fragments stream
+  // through one at a time - 24 ds_read_b128 per 32 MFMAs, and 128 + 32 + 8 operand/accumulator registers instead of
+  // 128 + 64 + 8 (which spilled into the loop).
   auto compute = [&](int tap, int s) {
     const char* Bt = sB0 + (s % QRING) * QB_BYTES;
     const int dy = tap / 3, dx = tap - dy * 3;
-    v8i a0, a1, a2, a3;
-    int sa0, sa1, sa2, sa3;
-#define SRGD_QLOAD_A(I)                                                              \
+    v8i b0, b1, b2, b3;
+    int sb0, sb1, sb2, sb3;
+#define SRGD_QLOAD_B(J)                                                              \
     {                                                                                \
-      const int P = (4 * wm + I + dy) * QWP + r16 + dx + opq;                        \
-      const int o = row_lo(P);                                                       \
+      const int n = wn * 64 + J * 16 + r16t;                                         \
+      const int o = row_lo(n, gt);                                                   \
+      const v4i lo = *reinterpret_cast<const v4i*>(Bt + o);                          \
+      const v4i hi = *reinterpret_cast<const v4i*>(Bt + (o ^ 64));                   \
+      b##J = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};            \
+      sb##J = *reinterpret_cast<const unsigned char*>(Bt + QB_TILE + n * 4 + gt);    \
+    }
+    SRGD_QLOAD_B(0) SRGD_QLOAD_B(1) SRGD_QLOAD_B(2) SRGD_QLOAD_B(3)
+#undef SRGD_QLOAD_B
+#define SRGD_QLOAD_A(I)                                                              \
+    v8i a##I; int sa##I;                                                             \
+    {                                                                                \
+      const int P = (4 * wm + (I >> 1) + dy) * QWP + (I & 1) * 16 + r16t + dx;       \
+      const int o = row_lo(P, gt);                                                   \
       const v4i lo = *reinterpret_cast<const v4i*>(sA + o);                          \
       const v4i hi = *reinterpret_cast<const v4i*>(sA + (o ^ 64));                   \
       a##I = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};            \
-      sa##I = *reinterpret_cast<const unsigned char*>(sAs + P * 4 + g);              \
+      sa##I = *reinterpret_cast<const unsigned char*>(sAs + P * 4 + gt);             \
     }
-    SRGD_QLOAD_A(0) SRGD_QLOAD_A(1) SRGD_QLOAD_A(2) SRGD_QLOAD_A(3)
+#define SRGD_QMM(C_, A_, SA_, B_, SB_) C_ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A_, B_, C_, 0, 0, 0, SA_, 0, SB_)
+#define SRGD_QROW(I)                                                                 \
+    SRGD_QMM(c##I##0, a##I, sa##I, b0, sb0); SRGD_QMM(c##I##1, a##I, sa##I, b1, sb1);  \
+    SRGD_QMM(c##I##2, a##I, sa##I, b2, sb2); SRGD_QMM(c##I##3, a##I, sa##I, b3, sb3);
+    // software pipeline over the pixel fragments, fenced for the scheduler (left alone it hoists all eight fragment loads to
+    // the top of the step and spills ~130 registers into the loop): the loads of fragment i+1 are issued ahead of the 4 MFMAs
+    // (128 cycles of matrix pipe) of fragment i; two fragments live at a time
+    SRGD_QLOAD_A(0)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QLOAD_A(1) SRGD_QROW(0)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QLOAD_A(2) SRGD_QROW(1)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QLOAD_A(3) SRGD_QROW(2)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QLOAD_A(4) SRGD_QROW(3)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QLOAD_A(5) SRGD_QROW(4)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QLOAD_A(6) SRGD_QROW(5)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QLOAD_A(7) SRGD_QROW(6)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QROW(7)
+#undef SRGD_QROW
+#undef SRGD_QMM
 #undef SRGD_QLOAD_A
-#define SRGD_QCOL(J, C0_, C1_, C2_, C3_)                                             \
-    {                                                                                \
-      const int n = wn * 64 + J * 16 + r16;                                          \
-      const int o = row_lo(n);                                                       \
-      const v4i lo = *reinterpret_cast<const v4i*>(Bt + o);                          \
-      const v4i hi = *reinterpret_cast<const v4i*>(Bt + (o ^ 64));                   \
-      const v8i bf = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};    \
-      const int sb = *reinterpret_cast<const unsigned char*>(Bt + QB_TILE + n * 4 + g); \
-      C0_ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a0, bf, C0_, 0, 0, 0, sa0, 0, sb); \
-      C1_ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a1, bf, C1_, 0, 0, 0, sa1, 0, sb); \
-      C2_ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a2, bf, C2_, 0, 0, 0, sa2, 0, sb); \
-      C3_ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a3, bf, C3_, 0, 0, 0, sa3, 0, sb); \
-    }
-    SRGD_QCOL(0, c00, c10, c20, c30) SRGD_QCOL(1, c01, c11, c21, c31) SRGD_QCOL(2, c02, c12, c22, c32) SRGD_QCOL(3, c03, c13, c23, c33)
-#undef SRGD_QCOL
     // Pin the accumulators here: hipcc otherwise SINKS the (register-only) MFMA chains of all nine taps below the chunk's last
     // barrier and carries every tap's operand fragments there through scratch (617 spilled VGPRs); s_setprio brackets
     // (cdna_hip_programming.md T5) did not hold them.  Empty asm, no instruction emitted.
     asm volatile("" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
     asm volatile("" : "+v"(c20), "+v"(c21), "+v"(c22), "+v"(c23), "+v"(c30), "+v"(c31), "+v"(c32), "+v"(c33));
+    asm volatile("" : "+v"(c40), "+v"(c41), "+v"(c42), "+v"(c43), "+v"(c50), "+v"(c51), "+v"(c52), "+v"(c53));
+    asm volatile("" : "+v"(c60), "+v"(c61), "+v"(c62), "+v"(c63), "+v"(c70), "+v"(c71), "+v"(c72), "+v"(c73));
   };
 
-  // ---- prologue: A(0), B[0], B[1]
+  // ---- prologue: A(0), B[0]
   issue_a(0);
-  issue_b(0);
-  issue_b(1);                                    // S >= 9 always
-  QWAIT_VM(5);                                   // everything but B[1]
+  issue_b(0, 0);
+  QWAIT_VM(0);
   QBARRIER();
 
-  // ---- main loop.  Per K-step: issue B[s+2]; compute(s); wait for B[s+1]; barrier.  Every step issues exactly one weight
-  // unit (the last two steps re-fetch the final unit into a ring slot nobody reads any more) so that the unrolled tap loop is
-  // branch-free: with data-dependent branches around the DMAs hipcc tail-merges the MFMA blocks of different taps and
-  // passes their operands through scratch.  The halo patch is single-buffered (two of them would not leave room for two
-  // workgroups per CU): at a chunk boundary the next patch is fetched after the barrier that retires the last tap's reads,
-  // and the co-resident workgroup keeps the matrix pipe busy meanwhile.
+  // ---- main loop.  Per K-step: issue B[s+1] into the other ring slot; compute(s) (32 MFMAs per wave, ~2,000 cycles with the
+  // SIMD's second wave: plenty for a 16.5 KiB L2 hit to land); wait for it; barrier.  Every step issues one weight unit (the
+  // last step re-fetches the final one into the slot nobody reads any more) so that the unrolled tap loop is branch-free:
+  // with data-dependent branches around the DMAs hipcc tail-merges the MFMA blocks of different taps.  The halo patch is
+  // single-buffered (two would not leave room for two workgroups per CU): at a chunk boundary the next patch is fetched after
+  // the barrier that retires the last tap's reads, and the co-resident workgroup keeps the matrix pipe busy meanwhile.
   for (int cc = 0; cc < CC; ++cc) {
-    asm volatile("" : "+v"(opq));
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int s = cc * 9 + tap;
-      issue_b(min(s + 2, S - 1));
+      r16t = r16; gt = g;
+      asm volatile("" : "+v"(r16t), "+v"(gt));     // fresh per tap: the tap's ~36 operand addresses are recomputed from these
+      issue_b(min(s + 1, S - 1), (s + 1) % QRING);   // (the last step re-fetches its own unit into the idle slot)
       compute(tap, s);
-      QWAIT_VM(5);                                 // everything but the unit issued in this step
+      QWAIT_VM(0);
       QBARRIER();
     }
     if (cc + 1 < CC) {
@@ -235,12 +269,13 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
       QBARRIER();
     }
   }
-  QWAIT_VM(0);                                     // the dummy re-fetches must not land in the epilogue's staging area
+  QWAIT_VM(0);                                     // (nothing is in flight here; kept next to the epilogue's reuse of the ring)
 
   // ------------------------------- epilogue -------------------------------------------
-  // tile transposed through LDS ([128 pixels][128 ch] bf16, rows padded to 272 B), stored as whole 256-byte channel rows
+  // tile transposed through LDS ([256 pixels][128 ch] bf16, rows padded to 272 B), stored as whole 256-byte channel rows
   constexpr int EROW = QBN * 2 + 16;
   float s1[4], s2[4];                                     // (the loop's last barrier retired every operand read)
+#define SRGD_QACC(MI, NI) (NI == 0 ? c##MI##0 : NI == 1 ? c##MI##1 : NI == 2 ? c##MI##2 : c##MI##3)
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     s1[ni] = 0.f;
@@ -248,13 +283,11 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     const int cl = wn * 64 + ni * 16 + r16;               // column inside the tile
     const float bias = p.bias ? p.bias[nt * QBN + cl] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const f32x4 av = mi == 0 ? (ni == 0 ? c00 : ni == 1 ? c01 : ni == 2 ? c02 : c03)
-                     : mi == 1 ? (ni == 0 ? c10 : ni == 1 ? c11 : ni == 2 ? c12 : c13)
-                     : mi == 2 ? (ni == 0 ? c20 : ni == 1 ? c21 : ni == 2 ? c22 : c23)
-                               : (ni == 0 ? c30 : ni == 1 ? c31 : ni == 2 ? c32 : c33);
-      // D map: column = lane & 15, row = (lane >> 4) * 4 + reg -> pixel (patch row 4 wm + mi, x = 4 g + reg)
-      char* trow = smem + ((4 * wm + mi) * QPW + g * 4) * EROW + cl * 2;
+    for (int mi = 0; mi < 8; ++mi) {
+      const f32x4 av = mi == 0 ? SRGD_QACC(0, ni) : mi == 1 ? SRGD_QACC(1, ni) : mi == 2 ? SRGD_QACC(2, ni) : mi == 3 ? SRGD_QACC(3, ni)
+                     : mi == 4 ? SRGD_QACC(4, ni) : mi == 5 ? SRGD_QACC(5, ni) : mi == 6 ? SRGD_QACC(6, ni) : SRGD_QACC(7, ni);
+      // D map: column = lane & 15, row = (lane >> 4) * 4 + reg -> pixel (patch row 4 wm + (mi >> 1), x = 16 (mi & 1) + 4 g + reg)
+      char* trow = smem + ((4 * wm + (mi >> 1)) * QPW + (mi & 1) * 16 + g * 4) * EROW + cl * 2;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const float v = av[reg] + bias;
@@ -266,6 +299,7 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
       }
     }
   }
+#undef SRGD_QACC
   __syncthreads();
   {
     bf16* obase = p.out + ((size_t)(b * p.H + y0) * p.W + x0) * p.Cout + nt * QBN;
@@ -366,7 +400,7 @@ int conv3x3_mxfp8_stats_slots(const ConvArgs& a) {
   return (a.Hin / QPH) * (a.Win / QPW) * (cpg >= QBN ? cpg / QBN : 1);
 }
 
-// OIHW fp32 -> [tap][cc][ntile][17 KiB]: 128 rows x 128 B of e4m3 (swizzled LDS image) + [128][4] E8M0 bytes + zero pad.
+// OIHW fp32 -> [tap][cc][ntile][16.5 KiB]: 128 rows x 128 B of e4m3 (swizzled LDS image) + [128][4] E8M0 bytes.
 // One scale per (output channel, tap, 32 input channels): w = q * 2^(byte - 127).
 void pack_conv3x3_mxfp8(const float* src_oihw, int Cin, int Cout, std::vector<unsigned char>& out) {
   const int CC = Cin / QKC, NTL = Cout / QBN;

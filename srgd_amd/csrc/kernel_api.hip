@@ -169,7 +169,7 @@ int srgd_k_conv3x3_mxfp8(const void* in0, const void* in1, int C0, int C1, int B
   a.C0 = C0; a.C1 = in1 ? C1 : 0; a.ps0 = C0; a.ps1 = a.C1; a.B = B; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W;
   a.KH = a.KW = 3; a.stride = 1; a.pad = 1; a.Cout = Cout; a.CoutPad = Cout; a.out = out; a.mode = CONV_PLAIN;
   a.gn_partial = gn_partial; a.groups = groups;
-  if (!conv3x3_mxfp8_eligible(a)) SRGD_FAIL("srgd_k_conv3x3_mxfp8: needs C0, C1, Cout % 128 == 0, H % 8 == 0, W % 16 == 0");
+  if (!conv3x3_mxfp8_eligible(a)) SRGD_FAIL("srgd_k_conv3x3_mxfp8: needs C0, C1, Cout % 128 == 0, H % 8 == 0, W % 32 == 0");
   std::vector<unsigned char> pw;
   pack_conv3x3_mxfp8(weight_oihw_host, a.C0 + a.C1, Cout, pw);
   const size_t npix = (size_t)B * H * W;

@@ -524,7 +524,7 @@ def test_conv3x3_mxfp8_exact_small_integers():
     assert torch.equal(from_dev_nhwc(out), want)
 
 
-@pytest.mark.parametrize("shape", [(1, 128, 128, 32, 64), (3, 256, 128, 8, 16), (1, 512, 1024, 32, 32)],
+@pytest.mark.parametrize("shape", [(1, 128, 128, 32, 64), (3, 256, 128, 8, 32), (1, 512, 1024, 32, 32)],
                          ids=lambda s: "B%d_%dto%d_%dx%d" % s)
 def test_conv3x3_mxfp8_matches_the_quantised_reference(shape):
     # random data: the kernel must reproduce conv(dequant(MX(x)), dequant(MX(w))) up to fp32 summation order and the bf16 store;
