@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 TFLOP_PER_HR_TILE = 813.6          # BASELINE.md section 3 (1,025 tile-forwards x 793.8 GFLOP)
 TILE_FORWARDS_PER_HR_TILE = 1025
-PMC_TRAFFIC_FILE = "r1_pmc_traffic.json"     # newest committed PMC summary (tools/pmc_traffic.py)
+PMC_TRAFFIC_FILE = "r2_pmc_traffic.json"     # newest committed PMC summary (tools/pmc_traffic.py)
 # MI355X_MICROARCH.md: dense MFMA peaks of the dominant kernel's instruction (fp8 = block-scaled MX e4m3, 2x the bf16 rate)
 PEAK_TFLOPS = {"conv3x3_bf16": 2500.0, "conv3x3_mxfp8": 5000.0, "conv_igemm:bf16": 2500.0, "conv_igemm:fp32": 157.3}
 KERNEL_OF = {"conv3x3_bf16": "conv3x3_bf16_kernel", "conv3x3_mxfp8": "conv3x3_mxfp8_kernel", "conv_igemm": "conv_igemm_kernel"}
@@ -298,7 +298,7 @@ def main():
             # cannot share a pass, and rocprofv3 cannot run inside the benchmark): the committed summary is quoted and labelled
             traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
-            if os.path.exists(pmc) and args.precision == "bf16":
+            if os.path.exists(pmc) and args.precision in ("bf16", "fp8"):
                 t = json.load(open(pmc)).get(kname)
                 if t:   # gfx950: FETCH_SIZE counts half of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> x2
                     traffic = (2.0 * t["FETCH_SIZE"]["avg_kb"] + t["WRITE_SIZE"]["avg_kb"]) * 1024.0

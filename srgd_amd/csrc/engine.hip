@@ -147,6 +147,10 @@ struct StageW {
 struct Pool {
   struct Buf { void* p; size_t cap; bool busy; };
   std::vector<Buf> bufs;
+  // fp8 mode: MX-fp8 twin (e4m3 bytes, E8M0 scales; both pool buffers) of a bf16 activation buffer, made the first time a
+  // 3x3 convolution consumes the tensor and reused by later consumers (block inputs feed a second conv as skip connections);
+  // released together with the bf16 buffer
+  std::map<const void*, std::pair<void*, void*>> twins;
   int64_t total = 0;
   bool no_alloc = false;
   void* get(size_t bytes) {
@@ -172,6 +176,13 @@ struct Pool {
     return p;
   }
   void put(void* p) {
+    auto t = twins.find(p);
+    if (t != twins.end()) {
+      const std::pair<void*, void*> qs = t->second;
+      twins.erase(t);
+      put(qs.first);
+      put(qs.second);
+    }
     for (auto& b : bufs)
       if (b.p == p) { b.busy = false; return; }
   }
@@ -179,10 +190,12 @@ struct Pool {
   // marked busy, so every entry point starts from a clean slate instead of leaking them forever.
   void reset_busy() {
     for (auto& b : bufs) b.busy = false;
+    twins.clear();
   }
   void release_all() {
     for (auto& b : bufs) hipFree(b.p);
     bufs.clear();
+    twins.clear();
     total = 0;
   }
 };
@@ -581,8 +594,16 @@ void q_free(Ctx& x, QTensor& t) {
   if (t.s) x.e->pool.put(t.s);
   t = QTensor{};
 }
-int q_from_bf16(Ctx& x, const void* src, int C, int hw, QTensor* t) {          // plain quantisation of a bf16 tensor
+// the MX-fp8 twin of a bf16 pool tensor: quantised on first use, found again afterwards, freed with the tensor (Pool::put)
+int q_twin(Ctx& x, const void* src, int C, int hw, QTensor* t) {
+  Pool& pool = x.e->pool;
+  auto it = pool.twins.find(src);
+  if (it != pool.twins.end()) {
+    t->q = it->second.first; t->s = it->second.second;
+    return 0;
+  }
   SRGD_TRY(q_alloc(x, C, hw, t));
+  pool.twins[src] = {t->q, t->s};
   Prof p(x.e, KC_QUANT, x.st);
   return quant_mxfp8(src, t->q, t->s, (long)x.nb * hw, C, x.st);
 }
@@ -596,16 +617,13 @@ int run_conv_q(Ctx& x, const ConvW& c, const QTensor& in0, int C0, const QTensor
   if (stats) e->stats_slots = conv3x3_mxfp8_stats_slots(a);
   return conv3x3_mxfp8(a, in0.q, in0.s, in1.q, in1.s, c.wq, x.st);
 }
-// a 3x3 convolution of bf16 tensors through the fp8 route: quantise the source(s), convolve, release
+// a 3x3 convolution of bf16 pool tensors through the fp8 route, on their MX-fp8 twins
 int run_conv_q_from_bf16(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, int C1, int H, int W, void* out,
                          bool stats) {
   QTensor a, b;
-  SRGD_TRY(q_from_bf16(x, in0, C0, H * W, &a));
-  if (C1) SRGD_TRY(q_from_bf16(x, in1, C1, H * W, &b));
-  SRGD_TRY(run_conv_q(x, c, a, C0, b, C1, H, W, out, stats));
-  q_free(x, a);
-  q_free(x, b);
-  return 0;
+  SRGD_TRY(q_twin(x, in0, C0, H * W, &a));
+  if (C1) SRGD_TRY(q_twin(x, in1, C1, H * W, &b));
+  return run_conv_q(x, c, a, C0, b, C1, H, W, out, stats);
 }
 
 int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_offset /* <0: none */, void* buf,
