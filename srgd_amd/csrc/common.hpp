@@ -64,6 +64,42 @@ template <bool PRECISE> __device__ __forceinline__ float silu(float x) {
   return x * __frcp_rn(1.0f + __expf(-x));
 }
 
+// OCP MX-fp8 quantisation of 8 consecutive channels held by this lane; lanes (lane & ~3) .. (lane | 3) hold one 32-channel
+// block and must all be active.  Returns the 8 e4m3 bytes; *scale_byte = E8M0 shared exponent of the block
+// (floor(log2 max|y|) - 8 + 127).  Same arithmetic in every kernel that writes MX-fp8 (quant_mxfp8.hip and the fused
+// epilogues), so a fused twin equals the separate quantisation pass bit for bit.
+__device__ __forceinline__ uint2 mx_quant8(const float (&y)[8], int* scale_byte) {
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(y[j]));
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  // floor(log2 amax) = biased exponent - 127 for a normal float; zero / denormal blocks get the smallest scale
+  const int bexp = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  const int sb = max(bexp - 8, 0);
+  const float inv = __uint_as_float((unsigned)(254 - sb) << 23);      // 2^(127 - sb)
+  float t[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = fminf(fmaxf(y[j] * inv, -448.f), 448.f);
+  unsigned w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], w1, true);
+  *scale_byte = sb;
+  return make_uint2(w0, w1);
+}
+// the MX-fp8 twin of a bf16x8 chunk that is being stored: element offset `elem` (a multiple of 8) of a [.., C] tensor
+__device__ __forceinline__ void mx_store_twin(const bf16x8& v, unsigned char* q, unsigned char* s, size_t elem, int lane_in_quad) {
+  float y[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) y[j] = (float)v[j];
+  int sb;
+  const uint2 w = mx_quant8(y, &sb);
+  *reinterpret_cast<uint2*>(q + elem) = w;
+  if (lane_in_quad == 0) s[elem >> 5] = (unsigned char)sb;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -52,6 +52,7 @@ struct Conv1Args {
   bf16* out;
   const bf16* aux;        // EPI_RESIDUAL: tensor added to the output; EPI_GNTAIL: tensor the GroupNorm tail is applied to
   const float* gn_a; const float* gn_b;   // EPI_GNTAIL: [B][Cout] scale / shift
+  unsigned char* oq; unsigned char* os;   // optional MX-fp8 twin of the output (ConvArgs::out_q / out_s)
 };
 
 __device__ __forceinline__ int row_swz1(int row) { return (row >> 1) & 3; }
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
       const size_t o = ((size_t)(b * 2 * p.Hout + 2 * oy + (ps_ij >> 1)) * (2 * p.Wout) + 2 * ox + (ps_ij & 1)) * CoutPS +
                        ps_c0 + c16 * 8;
       *reinterpret_cast<bf16x8*>(p.out + o) = v;
+      if (p.oq) mx_store_twin(v, p.oq, p.os, o, tid & 3);
     } else {
       const size_t o = obase + (size_t)pix * p.Cout + c16 * 8;
       if (EPI == EPI_RESIDUAL) {
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
         }
       }
       *reinterpret_cast<bf16x8*>(p.out + o) = v;
+      if (p.oq) mx_store_twin(v, p.oq, p.os, o, tid & 3);
     }
   }
 }
@@ -285,6 +288,8 @@ int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st) {
   p.w = (const bf16*)packed_w; p.bias = a.bias; p.Cout = a.Cout; p.out = (bf16*)a.out;
   p.aux = a.gn_res_src ? (const bf16*)a.gn_res_src : (const bf16*)a.residual;
   p.gn_a = a.gn_res_a; p.gn_b = a.gn_res_b;
+  p.oq = (unsigned char*)a.out_q; p.os = (unsigned char*)a.out_s;
+  if ((p.oq != nullptr) != (p.os != nullptr)) SRGD_FAIL("conv1x1_bf16: MX-fp8 twin needs both the element and the scale buffer");
   const long m_tiles = (long)a.B * a.Hout * a.Wout / BM1;
   const long grid = m_tiles * (a.Cout / BN1);
   if (grid <= 0 || grid > 0x7fffffffL) SRGD_FAIL("conv1x1_bf16: bad grid");

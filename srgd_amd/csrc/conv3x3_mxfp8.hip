@@ -18,6 +18,8 @@
 //     (The first version used M = 128 tiles: at twice the bf16 MFMA rate every workgroup then re-streamed the weight tiles at
 //     ~68 GB/s per CU, the L2 -> LDS ceiling of this part, and the 128-channel layers ran at 1.2x the bf16 kernel instead of
 //     1.5x; M = 256 halves the weight bytes per FLOP.)
+//   * operand addresses: halo pixel P = 136 wm + Pc + r16 with Pc a compile-time constant per (tap, fragment); 136 = 17 * 8,
+//     so the swizzle term (P & 6) needs only (Pc & 7) and the lane, and Pc * 128 rides in the ds_read offset field
 //   * per chunk: the (8+2) x (32+2) halo patch x 128 B (42.5 KiB) + its scale bytes (4 B / pixel); per K-step (tap, chunk) one
 //     16 KiB weight tile + 512 B of weight scales, double-buffered; rows XOR-swizzled (chunk ^= row & 6): every ds_read_b128 of
 //     the operand pattern is conflict-free at every tap shift (exhaustive search over the lane groups of ds_read_b128)
@@ -65,6 +67,7 @@ struct ConvQArgs {
   int Cout;
   bf16* out;
   float* gn_partial; int groups;
+  unsigned char* oq; unsigned char* os;   // optional MX-fp8 twin of the output (ConvArgs::out_q / out_s)
 };
 
 #define QWAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
@@ -169,40 +172,49 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
         c30 = 0, c31 = 0, c32 = 0, c33 = 0, c40 = 0, c41 = 0, c42 = 0, c43 = 0, c50 = 0, c51 = 0, c52 = 0, c53 = 0,
         c60 = 0, c61 = 0, c62 = 0, c63 = 0, c70 = 0, c71 = 0, c72 = 0, c73 = 0;
 
-  // operand addresses: row P (pixel of the halo patch / weight row n), logical chunks g and 4+g, swizzle chunk ^= row & 6
-  auto row_lo = [&](int row, int gg) { return row * 128 + ((gg ^ (row & 6)) << 4); };        // the hi chunk is this ^ 64
-  // Per-tap opaque copies of the lane coordinates: every operand address of a tap is derived from them, so hipcc cannot
-  // precompute (row + tap offset) terms for all nine taps outside the K loop (that cost ~12 long-lived VGPRs and, at the
-  // 256-register cap of two workgroups per CU, spills whose scratch reloads wait behind the in-flight weight DMA).
-  int r16t = r16, gt = g;
+  // ---- operand addresses.  Row P of the halo patch / weight row n, logical chunks g and 4+g, swizzle chunk ^= row & 6.
+  // A: P = 136 wm + Pc + r16 with Pc = (patch row + dy) * 34 + 16 (x half) + dx a compile-time constant per (tap, fragment).
+  // 136 = 17 * 8, so (P & 6) depends only on (Pc & 7) and the lane: eight per-lane bases (one per value of Pc & 7) are
+  // computed once, and every fragment read is base[Pc & 7] + an immediate - no address arithmetic inside the K loop
+  // (the first version recomputed ~100 VALU instructions per tap next to 32 MFMAs).
+  const int lanepix = 4 * wm * QWP + r16;
+  const int apix = lanepix * 128;                                   // byte offset of the lane's pixel row (before Pc)
+  const int r7 = r16 & 7;
+  const int asb = lanepix * 4 + g;                                  // scale byte of (pixel, channel block g)
+  // B: n = 64 wn + 16 J + r16 -> n & 6 = r16 & 6
+  const int bb = (wn * 64 + r16) * 128 + ((g ^ (r16 & 6)) << 4);
+  const int bsb = QB_TILE + (wn * 64 + r16) * 4 + g;
+
   // One K-step: the 4 weight fragments (64 output channels of this wave) stay in registers, the 8 pixel fragments stream
-  // through one at a time - 24 ds_read_b128 per 32 MFMAs, and 128 + 32 + 8 operand/accumulator registers instead of
-  // 128 + 64 + 8 (which spilled into the loop).
+  // through one at a time - 24 ds_read_b128 per 32 MFMAs, and 128 + 32 + 16 operand/accumulator registers.
   auto compute = [&](int tap, int s) {
     const char* Bt = sB0 + (s % QRING) * QB_BYTES;
     const int dy = tap / 3, dx = tap - dy * 3;
+    // The swizzle term of a fragment, ((Pc & 7) + r7) & 6) ^ g, costs 3 VALU instructions from the opaque copy of r7
+    // (refreshed per tap) + 1 for the second chunk at (address ^ 64): 32 per tap.  Kept as 16 per-lane bases instead it
+    // would need no arithmetic at all, but those registers do not exist next to 128 accumulators (26 spills, measured).
+    int r7t = r7;
+    asm volatile("" : "+v"(r7t));
     v8i b0, b1, b2, b3;
     int sb0, sb1, sb2, sb3;
 #define SRGD_QLOAD_B(J)                                                              \
     {                                                                                \
-      const int n = wn * 64 + J * 16 + r16t;                                         \
-      const int o = row_lo(n, gt);                                                   \
-      const v4i lo = *reinterpret_cast<const v4i*>(Bt + o);                          \
-      const v4i hi = *reinterpret_cast<const v4i*>(Bt + (o ^ 64));                   \
+      const v4i lo = *reinterpret_cast<const v4i*>(Bt + bb + J * 2048);              \
+      const v4i hi = *reinterpret_cast<const v4i*>(Bt + (bb ^ 64) + J * 2048);       \
       b##J = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};            \
-      sb##J = *reinterpret_cast<const unsigned char*>(Bt + QB_TILE + n * 4 + gt);    \
+      sb##J = *reinterpret_cast<const unsigned char*>(Bt + bsb + J * 64);            \
     }
     SRGD_QLOAD_B(0) SRGD_QLOAD_B(1) SRGD_QLOAD_B(2) SRGD_QLOAD_B(3)
 #undef SRGD_QLOAD_B
 #define SRGD_QLOAD_A(I)                                                              \
     v8i a##I; int sa##I;                                                             \
     {                                                                                \
-      const int P = (4 * wm + (I >> 1) + dy) * QWP + (I & 1) * 16 + r16t + dx;       \
-      const int o = row_lo(P, gt);                                                   \
-      const v4i lo = *reinterpret_cast<const v4i*>(sA + o);                          \
-      const v4i hi = *reinterpret_cast<const v4i*>(sA + (o ^ 64));                   \
+      const int Pc = ((I >> 1) + dy) * QWP + (I & 1) * 16 + dx;                      \
+      const int o = apix + ((g ^ (((Pc & 7) + r7t) & 6)) << 4);                      \
+      const v4i lo = *reinterpret_cast<const v4i*>(sA + o + Pc * 128);               \
+      const v4i hi = *reinterpret_cast<const v4i*>(sA + (o ^ 64) + Pc * 128);        \
       a##I = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};            \
-      sa##I = *reinterpret_cast<const unsigned char*>(sAs + P * 4 + gt);             \
+      sa##I = *reinterpret_cast<const unsigned char*>(sAs + asb + Pc * 4);           \
     }
 #define SRGD_QMM(C_, A_, SA_, B_, SB_) C_ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A_, B_, C_, 0, 0, 0, SA_, 0, SB_)
 #define SRGD_QROW(I)                                                                 \
@@ -256,8 +268,6 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int s = cc * 9 + tap;
-      r16t = r16; gt = g;
-      asm volatile("" : "+v"(r16t), "+v"(gt));     // fresh per tap: the tap's ~36 operand addresses are recomputed from these
       issue_b(min(s + 1, S - 1), (s + 1) % QRING);   // (the last step re-fetches its own unit into the idle slot)
       compute(tap, s);
       QWAIT_VM(0);
@@ -309,7 +319,9 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
       const int pix = q >> 4, c16 = q & 15;
       const int py = pix / QPW, px = pix - py * QPW;
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + pix * EROW + c16 * 16);
-      *reinterpret_cast<bf16x8*>(obase + ((size_t)py * p.W + px) * p.Cout + c16 * 8) = v;
+      const size_t oo = ((size_t)py * p.W + px) * p.Cout + c16 * 8;
+      *reinterpret_cast<bf16x8*>(obase + oo) = v;
+      if (p.oq) mx_store_twin(v, p.oq, p.os, (size_t)(obase - p.out) + oo, tid & 3);
     }
   }
   if (STATS) {
@@ -441,6 +453,7 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   p.q1 = a.C1 ? (const unsigned char*)q1 : nullptr; p.s1 = a.C1 ? (const unsigned char*)s1 : nullptr; p.C1 = a.C1;
   p.B = a.B; p.H = a.Hin; p.W = a.Win; p.w = (const unsigned char*)packed_w; p.bias = a.bias; p.Cout = a.Cout;
   p.out = (bf16*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
+  p.oq = (unsigned char*)a.out_q; p.os = (unsigned char*)a.out_s;
   const int grid = a.B * (a.Hin / QPH) * (a.Win / QPW) * (a.Cout / QBN);
   static bool attr_set[64] = {};
   if (first_use_on_device(attr_set)) {

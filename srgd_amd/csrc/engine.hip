@@ -251,6 +251,7 @@ struct srgd_engine {
   bool no_gn_fusion = true;
   int gn_fusion_max_ntiles = 1 << 30;   // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile)
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
+  bool no_twin_fusion = false;   // SRGD_Q_FUSED=0: fp8 mode quantises every conv input in a separate pass (A/B + bit-equality test)
 
   Pool pool;
   float* gn_partial = nullptr; size_t gn_partial_cap = 0;
@@ -536,8 +537,21 @@ bool conv_can_fuse_gn_in(srgd_engine* e, const ConvW& c, int nb, int H, int W) {
   return conv3x3_bf16_eligible(a);
 }
 
+struct QTensor { void* q = nullptr; void* s = nullptr; };      // pool buffers: e4m3 [npix][C], E8M0 [npix][C/32]
+
+// fp8 mode: the producer of a tensor that a 3x3 convolution will read writes its MX-fp8 twin in the same epilogue (1 extra
+// byte per element) instead of a separate quantisation pass (2 B read + 1 B written); the twin is registered with the pool
+// under the bf16 buffer's address and found by q_twin().  A producer without the fused epilogue simply registers nothing.
+bool twin_wanted(const srgd_engine* e, bool want, int C) { return e->fp8 && want && !e->no_twin_fusion && C % 128 == 0; }
+int twin_alloc(srgd_engine* e, size_t npix, int C, QTensor* t) {
+  t->q = e->pool.get(npix * C);
+  t->s = e->pool.get(npix * (C / 32));
+  return (t->q && t->s) ? 0 : -1;
+}
+void twin_register(srgd_engine* e, const void* bf16_buf, const QTensor& t) { e->pool.twins[bf16_buf] = {t.q, t.s}; }
+
 int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, int C1, int Hin, int Win, void* out,
-             const void* residual, bool stats, bool gn_in = false, const void* gn_res_src = nullptr) {
+             const void* residual, bool stats, bool gn_in = false, const void* gn_res_src = nullptr, bool want_twin = false) {
   srgd_engine* e = x.e;
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.ps0 = C0; a.ps1 = C1;
@@ -557,7 +571,18 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
   Prof p(e, fam, x.st);
   if (e->prof_on)
     e->fam_flops[fam] += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
-  if (fast1) return conv1x1_bf16(a, c.w1, x.st);
+  if (fast1) {
+    const bool ps = c.mode == CONV_PIXEL_SHUFFLE_SILU;
+    const int Cq = ps ? c.Cout / 4 : c.Cout;
+    QTensor tw;
+    if (twin_wanted(e, want_twin, Cq)) {
+      SRGD_TRY(twin_alloc(e, (size_t)x.nb * a.Hout * a.Wout * (ps ? 4 : 1), Cq, &tw));
+      a.out_q = tw.q; a.out_s = tw.s;
+    }
+    SRGD_TRY(conv1x1_bf16(a, c.w1, x.st));
+    if (tw.q) twin_register(e, out, tw);
+    return 0;
+  }
   if (fast) {
     if (stats) e->stats_slots = conv3x3_bf16_stats_slots(a);
     return conv3x3_bf16(a, c.w3, gn_in ? e->coefA : nullptr, gn_in ? e->coefB : nullptr, x.st);
@@ -568,7 +593,6 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
 }
 
 // ---- MX-fp8 route of the 3x3 convolutions (fp8 mode) ---------------------------------------------------------------
-struct QTensor { void* q = nullptr; void* s = nullptr; };      // pool buffers: e4m3 [npix][C], E8M0 [npix][C/32]
 
 ConvArgs conv3_args(Ctx& x, const ConvW& c, int C0, int C1, int H, int W, void* out, bool stats) {
   srgd_engine* e = x.e;
@@ -608,26 +632,33 @@ int q_twin(Ctx& x, const void* src, int C, int hw, QTensor* t) {
   return quant_mxfp8(src, t->q, t->s, (long)x.nb * hw, C, x.st);
 }
 int run_conv_q(Ctx& x, const ConvW& c, const QTensor& in0, int C0, const QTensor& in1, int C1, int H, int W, void* out,
-               bool stats) {
+               bool stats, bool want_twin = false) {
   srgd_engine* e = x.e;
   ConvArgs a = conv3_args(x, c, C0, C1, H, W, out, stats);
   if (C0 + C1 != c.Cin) SRGD_FAIL("internal: conv input channel mismatch");
+  QTensor tw;
+  if (twin_wanted(e, want_twin, c.Cout)) {
+    SRGD_TRY(twin_alloc(e, (size_t)x.nb * H * W, c.Cout, &tw));
+    a.out_q = tw.q; a.out_s = tw.s;
+  }
   Prof p(e, KC_CONVQ, x.st);
   if (e->prof_on) e->fam_flops[KC_CONVQ] += 2.0 * (double)x.nb * H * W * c.Cout * (double)(9 * c.Cin);
   if (stats) e->stats_slots = conv3x3_mxfp8_stats_slots(a);
-  return conv3x3_mxfp8(a, in0.q, in0.s, in1.q, in1.s, c.wq, x.st);
+  SRGD_TRY(conv3x3_mxfp8(a, in0.q, in0.s, in1.q, in1.s, c.wq, x.st));
+  if (tw.q) twin_register(e, out, tw);
+  return 0;
 }
 // a 3x3 convolution of bf16 pool tensors through the fp8 route, on their MX-fp8 twins
 int run_conv_q_from_bf16(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, int C1, int H, int W, void* out,
-                         bool stats) {
+                         bool stats, bool want_twin = false) {
   QTensor a, b;
   SRGD_TRY(q_twin(x, in0, C0, H * W, &a));
   if (C1) SRGD_TRY(q_twin(x, in1, C1, H * W, &b));
-  return run_conv_q(x, c, a, C0, b, C1, H, W, out, stats);
+  return run_conv_q(x, c, a, C0, b, C1, H, W, out, stats, want_twin);
 }
 
 int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_offset /* <0: none */, void* buf,
-           const void* residual, bool finalize_only = false) {
+           const void* residual, bool finalize_only = false, bool want_twin = false) {
   srgd_engine* e = x.e;
   Prof p(e, KC_GN, x.st);
   GnFinalizeArgs f;
@@ -638,11 +669,15 @@ int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_
   f.coefA = e->coefA; f.coefB = e->coefB;
   SRGD_TRY(gn_finalize(f, x.st));
   if (finalize_only) return 0;                     // the consumer conv applies y = silu(A x + B) while staging
-  return gn_apply_silu(buf, buf, residual, e->coefA, e->coefB, x.nb, hw, C, e->bf16, x.st);
+  QTensor tw;
+  if (twin_wanted(e, want_twin, C)) SRGD_TRY(twin_alloc(e, (size_t)x.nb * hw, C, &tw));
+  SRGD_TRY(gn_apply_silu(buf, buf, residual, e->coefA, e->coefB, x.nb, hw, C, e->bf16, x.st, tw.q, tw.s));
+  if (tw.q) twin_register(e, buf, tw);
+  return 0;
 }
 
 // ResnetBlock (model.py:261-285); returns a pool buffer [nb,H,W,Cout]
-int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, int C1, void** out) {
+int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, int C1, void** out, bool want_twin = false) {
   srgd_engine* e = x.e;
   const int hw = x.H * x.W;
   const size_t bytes = (size_t)x.nb * hw * r.Cout * e->es;
@@ -669,13 +704,13 @@ int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, i
   if (r.has_res && e->bf16) {
     // GroupNorm2 + SiLU + (+ res_conv(x)) evaluated in the 1x1 res_conv's epilogue, in place over v
     SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, nullptr, true));
-    SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, v, nullptr, false, false, v));
+    SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, v, nullptr, false, false, v, want_twin));
   } else if (r.has_res) {
     SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, u, nullptr, false));   // u is free again: reuse it
     SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, u));
   } else {
     if (in1) SRGD_FAIL("internal: identity residual with two sources");
-    SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, in0));
+    SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, in0, false, want_twin));
   }
   e->pool.put(u);
   *out = v;
@@ -683,7 +718,7 @@ int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, i
 }
 
 // x + attn(x)  (model.py:703,:709,:718); returns a pool buffer [nb,H,W,C]
-int attn_block(Ctx& x, const AttnW& a, const void* in, void** out) {
+int attn_block(Ctx& x, const AttnW& a, const void* in, void** out, bool want_twin = false) {
   srgd_engine* e = x.e;
   const int hw = x.H * x.W;
   const long npix = (long)x.nb * hw;
@@ -692,7 +727,10 @@ int attn_block(Ctx& x, const AttnW& a, const void* in, void** out) {
     void* y = e->pool.get((size_t)npix * a.C * e->es);
     if (!y) return -1;
     if (linattn_fused_workspace(x.nb, hw) / sizeof(float) > e->la_ws_cap) SRGD_FAIL("internal: fused attention workspace too small");
-    SRGD_TRY(linattn_fused(in, y, x.nb, hw, a.f_wkv, a.f_wq, a.f_wout, a.out.bias, a.f_g2, e->la_ws, x.st));
+    QTensor tw;
+    if (twin_wanted(e, want_twin, a.C)) SRGD_TRY(twin_alloc(e, (size_t)npix, a.C, &tw));
+    SRGD_TRY(linattn_fused(in, y, x.nb, hw, a.f_wkv, a.f_wq, a.f_wout, a.out.bias, a.f_g2, e->la_ws, x.st, tw.q, tw.s));
+    if (tw.q) twin_register(e, y, tw);
     *out = y;
     return 0;
   }
@@ -713,7 +751,7 @@ int attn_block(Ctx& x, const AttnW& a, const void* in, void** out) {
   }
   e->pool.put(qkv);
   if (a.full) {
-    SRGD_TRY(run_conv(x, a.out, att, e->hid, nullptr, 0, x.H, x.W, nrm, in, false));        // + bias + residual x
+    SRGD_TRY(run_conv(x, a.out, att, e->hid, nullptr, 0, x.H, x.W, nrm, in, false, false, nullptr, want_twin));   // + bias + residual x
   } else {
     SRGD_TRY(run_conv(x, a.out, att, e->hid, nullptr, 0, x.H, x.W, nrm, nullptr, false));
     Prof p(e, KC_RMS, x.st);
@@ -755,8 +793,16 @@ int run_init7(srgd_engine* e, const void* padded, int entries, int H, int W, voi
   a.w = e->init7_w; a.bias = e->init_b; a.Cout = e->dim; a.CoutPad = e->init7_coutpad;
   a.out = out; a.residual = nullptr; a.mode = CONV_PLAIN; a.gn_partial = nullptr; a.groups = e->cfg.groups;
   a.gn_res_src = nullptr; a.gn_res_a = a.gn_res_b = nullptr;
-  if (e->bf16 && e->init7_w1 && !e->no_conv1x1 && !e->force_generic_conv && conv1x1_bf16_eligible(a))
-    return conv1x1_bf16(a, e->init7_w1, st);
+  if (e->bf16 && e->init7_w1 && !e->no_conv1x1 && !e->force_generic_conv && conv1x1_bf16_eligible(a)) {
+    QTensor tw;                                    // fp8 mode: x0 feeds the first and the last ResnetBlock's 3x3 convolutions
+    if (twin_wanted(e, true, e->dim)) {
+      SRGD_TRY(twin_alloc(e, (size_t)entries * H * W, e->dim, &tw));
+      a.out_q = tw.q; a.out_s = tw.s;
+    }
+    SRGD_TRY(conv1x1_bf16(a, e->init7_w1, st));
+    if (tw.q) twin_register(e, out, tw);
+    return 0;
+  }
   return conv_igemm(a, e->bf16, st);
 }
 
@@ -773,19 +819,21 @@ int unet_body(Ctx& x, void* x0, void** out) {
     const StageW& sw = e->downs[s];
     const int C = e->dims[s];
     void *a, *b, *c;
-    SRGD_TRY(res_block(x, sw.rb[0], cur, C, nullptr, 0, &a));
+    // want_twin flags (fp8 mode only): true where the tensor is read by a 3x3 convolution later - a: next block + skip,
+    // c: skip (+ the last stage's 3x3 resampler), d: the next stage's first block
+    SRGD_TRY(res_block(x, sw.rb[0], cur, C, nullptr, 0, &a, true));
     if (cur != x0) e->pool.put(cur);
     skips.push_back(a);
     SRGD_TRY(res_block(x, sw.rb[1], a, C, nullptr, 0, &b));
-    SRGD_TRY(attn_block(x, sw.attn, b, &c));
+    SRGD_TRY(attn_block(x, sw.attn, b, &c, true));
     e->pool.put(b);
     skips.push_back(c);
     const ConvW& rs = sw.resample;
     const int Ho = (s < n - 1) ? x.H / 2 : x.H, Wo = (s < n - 1) ? x.W / 2 : x.W;
     void* d = e->pool.get((size_t)x.nb * Ho * Wo * rs.Cout * e->es);
     if (!d) return -1;
-    if (conv_is_q(x, rs, C, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, C, nullptr, 0, x.H, x.W, d, false));
-    else SRGD_TRY(run_conv(x, rs, c, C, nullptr, 0, x.H, x.W, d, nullptr, false));
+    if (conv_is_q(x, rs, C, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, C, nullptr, 0, x.H, x.W, d, false, true));
+    else SRGD_TRY(run_conv(x, rs, c, C, nullptr, 0, x.H, x.W, d, nullptr, false, false, nullptr, true));
     x.H = Ho; x.W = Wo;
     cur = d;
   }
@@ -794,9 +842,9 @@ int unet_body(Ctx& x, void* x0, void** out) {
     const int C = e->dims[n];
     SRGD_TRY(res_block(x, e->mid1, cur, C, nullptr, 0, &a));
     e->pool.put(cur);
-    SRGD_TRY(attn_block(x, e->mid_attn, a, &b));
+    SRGD_TRY(attn_block(x, e->mid_attn, a, &b, true));
     e->pool.put(a);
-    SRGD_TRY(res_block(x, e->mid2, b, C, nullptr, 0, &c));
+    SRGD_TRY(res_block(x, e->mid2, b, C, nullptr, 0, &c, true));
     e->pool.put(b);
     cur = c;
   }
@@ -805,19 +853,19 @@ int unet_body(Ctx& x, void* x0, void** out) {
     const int s = n - 1 - u, din = e->dims[s], dout = e->dims[s + 1];
     void *a, *b, *c;
     void* sk = skips.back(); skips.pop_back();
-    SRGD_TRY(res_block(x, sw.rb[0], cur, dout, sk, din, &a));
+    SRGD_TRY(res_block(x, sw.rb[0], cur, dout, sk, din, &a, true));
     e->pool.put(cur); e->pool.put(sk);
     sk = skips.back(); skips.pop_back();
     SRGD_TRY(res_block(x, sw.rb[1], a, dout, sk, din, &b));
     e->pool.put(a); e->pool.put(sk);
-    SRGD_TRY(attn_block(x, sw.attn, b, &c));
+    SRGD_TRY(attn_block(x, sw.attn, b, &c, u == n - 1));          // only the last stage resamples with a 3x3 convolution
     e->pool.put(b);
     const ConvW& rs = sw.resample;
     const int Ho = (u < n - 1) ? x.H * 2 : x.H, Wo = (u < n - 1) ? x.W * 2 : x.W;
     void* d = e->pool.get((size_t)x.nb * Ho * Wo * din * e->es);
     if (!d) return -1;
-    if (conv_is_q(x, rs, dout, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, dout, nullptr, 0, x.H, x.W, d, false));
-    else SRGD_TRY(run_conv(x, rs, c, dout, nullptr, 0, x.H, x.W, d, nullptr, false));
+    if (conv_is_q(x, rs, dout, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, dout, nullptr, 0, x.H, x.W, d, false, true));
+    else SRGD_TRY(run_conv(x, rs, c, dout, nullptr, 0, x.H, x.W, d, nullptr, false, false, nullptr, true));
     e->pool.put(c);
     x.H = Ho; x.W = Wo;
     cur = d;
@@ -926,6 +974,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   if (const char* v = getenv("SRGD_GN_FUSION_NTILES")) e->gn_fusion_max_ntiles = atoi(v);
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
+  if (const char* v = getenv("SRGD_Q_FUSED")) e->no_twin_fusion = atoi(v) == 0;
   *out = e.release();
   return 0;
 }

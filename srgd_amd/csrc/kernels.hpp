@@ -33,6 +33,11 @@ struct ConvArgs {
   const void* gn_res_src;
   const float* gn_res_a;
   const float* gn_res_b;
+  // optional MX-fp8 twin of the (bf16) output, written by the same epilogue (fp8 mode: the tensor feeds a 3x3 convolution
+  // on the MX matrix cores): e4m3 [.., C] and E8M0 [.., C/32] with C = Cout (pixel-shuffle mode: Cout / 4).  Supported by
+  // conv1x1_bf16 and conv3x3_mxfp8; identical to quant_mxfp8 of the stored bf16 values.
+  void* out_q = nullptr;
+  void* out_s = nullptr;
 };
 int conv_igemm(const ConvArgs& a, bool is_bf16, hipStream_t st);
 int conv_tile_m();
@@ -98,8 +103,9 @@ struct GnFinalizeArgs {
   float* coefB;
 };
 int gn_finalize(const GnFinalizeArgs& a, hipStream_t st);
+// out_q / out_s (nullable, bf16 only): MX-fp8 twin of y written alongside (see ConvArgs::out_q)
 int gn_apply_silu(const void* x, void* y, const void* residual, const float* coefA, const float* coefB,
-                  int B, int hw, int C, bool is_bf16, hipStream_t st);
+                  int B, int hw, int C, bool is_bf16, hipStream_t st, void* out_q = nullptr, void* out_s = nullptr);
 int rms_norm(const void* x, void* y, const void* residual, const float* g, long npix, int C,
              bool is_bf16, hipStream_t st);
 
@@ -122,7 +128,8 @@ void linattn_fused_pack(const float* to_qkv, const float* norm_g, const float* t
                         std::vector<unsigned short>& wkv_img, std::vector<unsigned short>& wq,
                         std::vector<unsigned short>& wout);
 int linattn_fused(const void* x, void* y, int B, int N, const void* wkv_img, const void* wq, const void* wout,
-                  const float* bout, const float* g2_scaled, float* ws, hipStream_t st);
+                  const float* bout, const float* g2_scaled, float* ws, hipStream_t st, void* y_q = nullptr,
+                  void* y_s = nullptr);          // y_q / y_s: optional MX-fp8 twin of y (see ConvArgs::out_q)
 
 // ---------------------------------------------------------------- cond.hip
 // feat[r] = [x, sin(2 pi x w_i), cos(2 pi x w_i)]   (reference model.py:233-238)

@@ -215,6 +215,7 @@ struct La2Args {
   const float* g2;       // [128] = to_out.1.g * sqrt(C)
   const float* ctxn;     // [B*4][32 d][32 e] fp32: normalised context * dh^-0.5
   const float* rinv;     // [B][N] 1/||x_n|| written by la1
+  unsigned char* yq; unsigned char* ys;   // optional MX-fp8 twin of y (fp8 mode: y feeds a 3x3 convolution)
   int tiles_per_wg;
 };
 
@@ -393,7 +394,9 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
       bf16x8 yv;
 #pragma unroll
       for (int e = 0; e < 8; ++e) yv[e] = (bf16)((float)ov[e] + (float)xv[e]);
-      *reinterpret_cast<bf16x8*>(p.y + ((size_t)b * p.N + px0 + row) * 128 + c16 * 8) = yv;
+      const size_t yo = ((size_t)b * p.N + px0 + row) * 128 + c16 * 8;
+      *reinterpret_cast<bf16x8*>(p.y + yo) = yv;
+      if (p.yq) mx_store_twin(yv, p.yq, p.ys, yo, tid & 3);
     }
     // Tile t+1 (issued one iteration ago) must have landed before the next iteration reads it; this iteration's DMA of
     // tile t+2 (5 pieces) and its 4 stores (younger still) stay in flight.
@@ -438,7 +441,7 @@ void linattn_fused_pack(const float* to_qkv /*[384][C]*/, const float* norm_g /*
 }
 
 int linattn_fused(const void* x, void* y, int B, int N, const void* wkv_img, const void* wq, const void* wout,
-                  const float* bout, const float* g2_scaled, float* ws, hipStream_t st) {
+                  const float* bout, const float* g2_scaled, float* ws, hipStream_t st, void* y_q, void* y_s) {
   const int strip = la1_strip(N);
   const int nstrips = cdiv(N, strip);
   const int nch = nstrips;
@@ -462,6 +465,7 @@ int linattn_fused(const void* x, void* y, int B, int N, const void* wkv_img, con
   La2Args a;
   a.x = (const bf16*)x; a.y = (bf16*)y; a.N = N; a.wq = (const bf16*)wq; a.wout = (const bf16*)wout; a.bout = bout;
   a.g2 = g2_scaled; a.ctxn = ctxn; a.rinv = rinv;
+  a.yq = (unsigned char*)y_q; a.ys = (unsigned char*)y_s;
   const int ntiles = N / TM;
   // persistent-ish: enough tiles per workgroup to amortise the register-resident operands (64 + 40 VGPRs of weights, context,
   // bias and gain), enough workgroups to fill 256 CUs x 2-3 resident workgroups

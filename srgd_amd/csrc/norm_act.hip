@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                         const T* __restrict__ res,
                                                         const float* __restrict__ cA,
                                                         const float* __restrict__ cB, long nvec, int vec_per_sample,
-                                                        int vec_per_pixel, int C) {
+                                                        int vec_per_pixel, int C, unsigned char* __restrict__ oq,
+                                                        unsigned char* __restrict__ os) {
   constexpr int N = Vec16<T>::N;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
     const int b = (int)(i / vec_per_sample);
@@ -71,6 +72,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       o.set(j, t);
     }
     reinterpret_cast<Vec16<T>*>(y)[i] = o;
+    if constexpr (sizeof(T) == 2) {
+      if (oq) mx_store_twin(o.v, oq, os, (size_t)i * 8, threadIdx.x & 3);      // MX-fp8 twin of the stored bf16 values
+    }
   }
 }
 
@@ -118,18 +122,19 @@ int gn_finalize(const GnFinalizeArgs& a, hipStream_t st) {
 }
 
 int gn_apply_silu(const void* x, void* y, const void* residual, const float* coefA, const float* coefB, int B,
-                  int hw, int C, bool is_bf16, hipStream_t st) {
+                  int hw, int C, bool is_bf16, hipStream_t st, void* out_q, void* out_s) {
   const int N = is_bf16 ? 8 : 4;
   if (C % N != 0) SRGD_FAIL("gn_apply: C must be a multiple of the 16-byte vector width");
+  if (out_q && (!is_bf16 || !out_s || C % 32 != 0)) SRGD_FAIL("gn_apply: the MX-fp8 twin needs bf16 activations and C % 32 == 0");
   const long nvec = (long)B * hw * C / N;
   const int vps = (int)((long)hw * C / N), vpp = C / N;
   const int grid = (int)std::min<long>((nvec + 255) / 256, 256L * 64);
   if (is_bf16)
     hipLaunchKernelGGL((gn_apply_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y,
-                       (const bf16*)residual, coefA, coefB, nvec, vps, vpp, C);
+                       (const bf16*)residual, coefA, coefB, nvec, vps, vpp, C, (unsigned char*)out_q, (unsigned char*)out_s);
   else
     hipLaunchKernelGGL((gn_apply_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,
-                       (const float*)residual, coefA, coefB, nvec, vps, vpp, C);
+                       (const float*)residual, coefA, coefB, nvec, vps, vpp, C, nullptr, nullptr);
   SRGD_HIP(hipGetLastError());
   return 0;
 }

@@ -34,26 +34,9 @@ __global__ __launch_bounds__(256) void quant_mxfp8_kernel(const bf16* __restrict
 #pragma unroll
       for (int j = 0; j < 8; ++j) y[j] = (float)v[j];
     }
-    float amax = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(y[j]));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));            // the 4 lanes of a 32-channel block are consecutive
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    // floor(log2 amax) = biased exponent - 127 for a normal float; zero / denormal blocks get the smallest scale
-    const int bexp = (int)((__float_as_uint(amax) >> 23) & 0xffu);
-    const int sb = max(bexp - 8, 0);                         // E8M0 byte = (floor(log2 amax) - 8) + 127
-    const float inv = __uint_as_float((unsigned)(254 - sb) << 23);      // 2^(127 - sb)
-    unsigned w0 = 0, w1 = 0;
-    {
-      float t[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = fminf(fmaxf(y[j] * inv, -448.f), 448.f);
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], w0, false);
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], w0, true);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], w1, false);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], w1, true);
-    }
-    reinterpret_cast<uint2*>(q)[i] = make_uint2(w0, w1);
+    int sb;
+    const uint2 w = mx_quant8(y, &sb);
+    reinterpret_cast<uint2*>(q)[i] = w;
     if ((threadIdx.x & 3) == 0) s[i >> 2] = (unsigned char)sb;
   }
 }

@@ -747,3 +747,28 @@ def test_config5_full_geometry_fp8_vs_bf16_parity_report():
     assert outs["fp8"].shape == (1, 3, 1024, 1024)
     assert torch.isfinite(outs["fp8"]).all() and outs["fp8"].min() >= 0 and outs["fp8"].max() <= 1
     assert psnr > 25.0, psnr           # random-init weights, 3 mantissa bits on weights AND activations; tightened to measured - 3 dB
+
+
+def test_fp8_fused_twins_equal_separate_quantisation_passes_bitwise():
+    # fp8 mode: producers write the MX-fp8 twin of a tensor in their own epilogue (conv1x1 variants, GroupNorm2 + residual,
+    # fused LinearAttention, the 3x3 resamplers).  The twin is defined as quant(stored bf16 values), so switching the fusion
+    # off (every conv input quantised by quant_mxfp8 in a pass of its own) must not change a single bit of the result.
+    import os
+    sampler = build_sampler(128)
+    cond = C.synthetic_lr_condition(2, 96, 96).cuda()               # 384^2 -> canvas 768^2, 9 / 4 tiles
+    label = torch.tensor([1]).cuda()
+    outs = {}
+    try:
+        sampler.noise_source = "device"
+        sampler.device_noise_seed = 3
+        for mode in ("1", "0"):
+            os.environ["SRGD_Q_FUSED"] = mode
+            sampler.model._invalidate_engines()                     # the switch is read at engine creation
+            outs[mode] = sampler.tiled_sample(batch_size=9, condition_x=cond, class_label=label, num_sample_steps=4,
+                                              class_cond_scale=1.5, precision="fp8").cpu()
+    finally:
+        os.environ.pop("SRGD_Q_FUSED", None)
+        sampler.model._invalidate_engines()
+        sampler.noise_source = "host"
+    assert torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["1"], outs["0"])
