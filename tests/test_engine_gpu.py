@@ -746,7 +746,7 @@ def test_config5_full_geometry_fp8_vs_bf16_parity_report():
     _report(test="config5_full_1024_fp8_vs_bf16", psnr_db=psnr, max_abs=float(err.max()), mean_abs=float(err.mean()))
     assert outs["fp8"].shape == (1, 3, 1024, 1024)
     assert torch.isfinite(outs["fp8"]).all() and outs["fp8"].min() >= 0 and outs["fp8"].max() <= 1
-    assert psnr > 25.0, psnr           # random-init weights, 3 mantissa bits on weights AND activations; tightened to measured - 3 dB
+    assert psnr > 31.0, psnr           # measured 34.1 dB on MI355X (random-init weights; 3 mantissa bits on weights AND activations)
 
 
 def test_fp8_fused_twins_equal_separate_quantisation_passes_bitwise():
