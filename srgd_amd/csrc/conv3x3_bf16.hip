@@ -52,7 +52,12 @@ struct Conv3Args {
   float* gn_partial; int groups;
   const float* gn_in_a;   // GNIN: y = silu(a[b][c] * x + b[b][c]) applied to the input while it is staged ([B][Cin] fp32)
   int gn_in_b_off;        // byte offset of the shift array from the scale array (same allocation)
+  int stagger;            // > 0: first-wave workgroups that are the SECOND on their CU sleep stagger x 8128 cycles once (see kernel)
+  unsigned long long* stamps;   // diagnostics (SRGD_CONV3_STAMPS=1): per-phase s_memtime deltas summed over workgroups; null otherwise
 };
+
+// phase accumulators of the diagnostic mode: [prologue, main loop, LDS transpose, stores, statistics, total, workgroups]
+__device__ unsigned long long g_conv3_stamps[8];
 
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 // Raw barrier (no vmcnt drain: LDS-DMA prefetches stay in flight) fenced for the instruction scheduler:
@@ -229,6 +234,20 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     }
   };
 
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+  if (p.stamps) t0 = __builtin_amdgcn_s_memtime();
+  // ---- stagger.  The two workgroups of a CU are dispatched together and do identical work, so left alone they run in
+  // lock-step: both in their prologue (DMA latency, no MFMA) and both in their epilogue at the same time, and the matrix pipe
+  // idles for that long every tile (measured: a fixed cost of ~19 K-steps per tile, half the main loop of the 128-channel
+  // layers).  Delaying the second workgroup of each CU by half a tile once, at the start of the launch, puts one workgroup's
+  // overhead beside the other's MFMA phase; the offset persists because every tile of a launch takes the same time.
+  // The second workgroup of a CU is the one whose LDS allocation does not start at 0 (HW_REG_LDS_ALLOC.LDS_BASE).
+  if (p.stagger > 0 && blockIdx.x < 512) {
+    const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6);      // HW_REG_LDS_ALLOC[7:0]
+    if (lds_base != 0)
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
   // ---- prologue: A(0) and B[0], B[1]
   issue_a_piece(0, 0);
   issue_a_piece(0, 1);
@@ -244,6 +263,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   BARRIER();
+  if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
 
   // ---- main loop.  Per K-step: [issue A piece of the next chunk (taps 0..2)] [issue B[s+2]] compute(s)
   //      wait until B[s+1] (and, in order, everything older) has landed, barrier.
@@ -286,6 +306,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // 256-byte channel rows, 16 B per lane - 8 store instructions per thread instead of 64.
   constexpr int EROW = BN3 * 2 + 16;
   BARRIER();                                              // every wave is done reading the operand buffers
+  if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
   constexpr int NI = M16 ? 4 : 2;                         // column blocks per wave (16 or 32 wide)
   float s1[NI], s2[NI];
 #pragma unroll
@@ -331,21 +352,11 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       }
     }
   }
-  __syncthreads();
-  {
-    bf16* obase = p.out + ((size_t)(b * p.H + y0) * p.W + x0) * p.Cout + nt * BN3;
-#pragma unroll
-    for (int i = 0; i < (PH * PW * 16) / NT3; ++i) {
-      const int q = tid + NT3 * i;                        // 16-byte chunk: pixel q/16, channels (q%16)*8..+7
-      const int pix = q >> 4, c16 = q & 15;
-      const int py = pix / PW, px = pix - py * PW;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + pix * EROW + c16 * 16);
-      *reinterpret_cast<bf16x8*>(obase + ((size_t)py * p.W + px) * p.Cout + c16 * 8) = v;
-    }
-  }
+  // the waves' column sums go to the 4 KiB behind the staged tile, so ONE barrier publishes both; nothing below waits for
+  // the output stores (the first version reduced the statistics after the stores, behind a __syncthreads() whose vmcnt(0)
+  // drained them: ~6,000 cycles per tile during which the workgroup held its LDS and registers and issued nothing)
+  float* const cs = reinterpret_cast<float*>(smem + PH * PW * EROW);       // [4 (wm)][128][2] = 4,096 B; 69,632 + 4,096 = LDS_BYTES
   if (STATS) {
-    __syncthreads();                                      // the staged output tile has been read back
-    float* cs = reinterpret_cast<float*>(smem);           // [4 (wm)][128][2]
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       float t1 = s1[ni], t2 = s2[ni];
@@ -361,29 +372,62 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
         cs[(wm * BN3 + cl) * 2 + 1] = t2;
       }
     }
-    __syncthreads();
-    const int cpg = p.Cout / p.groups;                    // multiple of 16, divides or is a multiple of 128
-    const int g_in_tile = cpg >= BN3 ? 1 : BN3 / cpg;
-    if (tid < g_in_tile) {
-      const int span = cpg >= BN3 ? BN3 : cpg;
-      float a1 = 0.f, a2 = 0.f;
-      for (int c = 0; c < span; ++c) {
-        const int cl = tid * span + c;
+  }
+  __syncthreads();                                        // (no global store is outstanding yet: this does not wait for HBM)
+  if (p.stamps) t3 = __builtin_amdgcn_s_memtime();
+  {
+    bf16* obase = p.out + ((size_t)(b * p.H + y0) * p.W + x0) * p.Cout + nt * BN3;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          a1 += cs[(k * BN3 + cl) * 2 + 0];
-          a2 += cs[(k * BN3 + cl) * 2 + 1];
-        }
+    for (int i = 0; i < (PH * PW * 16) / NT3; ++i) {
+      const int q = tid + NT3 * i;                        // 16-byte chunk: pixel q/16, channels (q%16)*8..+7
+      const int pix = q >> 4, c16 = q & 15;
+      const int py = pix / PW, px = pix - py * PW;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + pix * EROW + c16 * 16);
+      *reinterpret_cast<bf16x8*>(obase + ((size_t)py * p.W + px) * p.Cout + c16 * 8) = v;
+    }
+  }
+  if (p.stamps) t4 = __builtin_amdgcn_s_memtime();
+  if (STATS) {
+    // per-(sample, group) sums of this tile: columns summed over the 4 row blocks by 128 threads, then a shuffle tree over the
+    // group's span of columns (the first version let one thread per group walk its columns serially)
+    const int cpg = p.Cout / p.groups;                    // multiple of 16, divides or is a multiple of 128
+    const int span = cpg >= BN3 ? BN3 : cpg;              // columns of this tile that belong to one group: 16, 32, 64 or 128
+    float a1 = 0.f, a2 = 0.f;
+    if (tid < BN3) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a1 += cs[(k * BN3 + tid) * 2 + 0];
+        a2 += cs[(k * BN3 + tid) * 2 + 1];
       }
+      for (int o = 1; o < span && o < 64; o <<= 1) {
+        a1 += __shfl_xor(a1, o, 64);
+        a2 += __shfl_xor(a2, o, 64);
+      }
+    }
+    if (span == BN3) {                                    // a group spans both waves: combine through LDS (uniform branch);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // raw barriers: the output stores stay in flight
+      BARRIER();
+      if (tid < BN3 && lane == 0) { cs[wave * 2 + 0] = a1; cs[wave * 2 + 1] = a2; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      BARRIER();
+      if (tid == 0) { a1 = cs[0] + cs[2]; a2 = cs[1] + cs[3]; }
+    }
+    if (tid < BN3 && (tid % span) == 0) {
       // slot layout: [b][group][m-tile within image (x n-tiles per group when a group spans several)]
       const int tiles_per_group = cpg >= BN3 ? cpg / BN3 : 1;
-      const int g = cpg >= BN3 ? (nt * BN3) / cpg : (nt * BN3) / cpg + tid;
+      const int g = (nt * BN3) / cpg + (cpg >= BN3 ? 0 : tid / span);
       const int nslots = tiles_y * tiles_x * tiles_per_group;
       const int slot = trem * tiles_per_group + (cpg >= BN3 ? nt % tiles_per_group : 0);
       float* dst = p.gn_partial + ((size_t)(b * p.groups + g) * nslots + slot) * 2;
       dst[0] = a1;
       dst[1] = a2;
     }
+  }
+  if (p.stamps && tid == 0) {
+    const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+    atomicAdd(&p.stamps[0], t1 - t0); atomicAdd(&p.stamps[1], t2 - t1); atomicAdd(&p.stamps[2], t3 - t2);
+    atomicAdd(&p.stamps[3], t4 - t3); atomicAdd(&p.stamps[4], t5 - t4); atomicAdd(&p.stamps[5], t5 - t0);
+    atomicAdd(&p.stamps[6], 1ull);
   }
 }
 
@@ -454,7 +498,21 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   p.out = (bf16*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
   p.gn_in_a = gn_in_a;
   p.gn_in_b_off = gnin ? (int)((const char*)gn_in_b - (const char*)gn_in_a) : 0;
+  {
+    // half a tile's main loop: S K-steps x ~1,000 cycles (four waves share a SIMD) / 2, in units of s_sleep(127) = 8,128 cycles
+    static int knob = -2;
+    if (knob == -2) { const char* v = getenv("SRGD_CONV3_STAGGER"); knob = v ? atoi(v) : -1; }
+    const int S = 9 * ((a.C0 + a.C1) / KC);
+    p.stagger = knob >= 0 ? knob * S / 64 : (S * 500) / 8128;      // SRGD_CONV3_STAGGER=0 switches it off; =n scales it (n/64 sleeps per step)
+  }
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
+  static int want_stamps = -1;
+  if (want_stamps < 0) { const char* v = getenv("SRGD_CONV3_STAMPS"); want_stamps = (v && atoi(v)) ? 1 : 0; }
+  p.stamps = nullptr;
+  if (want_stamps) {
+    SRGD_HIP(hipGetSymbolAddress((void**)&p.stamps, HIP_SYMBOL(g_conv3_stamps)));
+    SRGD_HIP(hipMemsetAsync(p.stamps, 0, sizeof(unsigned long long) * 8, st));
+  }
   static bool attr_set[64] = {};
   if (first_use_on_device(attr_set)) {
 #define SRGD_SET(S_, G_, M_)                                                                              \
@@ -475,6 +533,15 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   }
 #undef SRGD_GO
   SRGD_HIP(hipGetLastError());
+  if (want_stamps) {                                    // diagnostic mode: synchronous, prints the mean cycles per workgroup and phase
+    unsigned long long h[8];
+    SRGD_HIP(hipStreamSynchronize(st));
+    SRGD_HIP(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));
+    const double n = h[6] ? (double)h[6] : 1.0;
+    fprintf(stderr, "[conv3x3_bf16 stamps] C %d+%d -> %d @%dx%d grid %d: prologue %.0f  main %.0f  transpose %.0f  stores %.0f  "
+                    "stats %.0f  total %.0f  (s_memtime ticks per workgroup)\n",
+            a.C0, a.C1, a.Cout, a.Hin, a.Win, grid, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n);
+  }
   return 0;
 }
 

@@ -68,6 +68,7 @@ struct ConvQArgs {
   bf16* out;
   float* gn_partial; int groups;
   unsigned char* oq; unsigned char* os;   // optional MX-fp8 twin of the output (ConvArgs::out_q / out_s)
+  int stagger;            // as in conv3x3_bf16.hip: one-time delay (x 8128 cycles) of the second workgroup of every CU
 };
 
 #define QWAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
@@ -252,6 +253,13 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     asm volatile("" : "+v"(c60), "+v"(c61), "+v"(c62), "+v"(c63), "+v"(c70), "+v"(c71), "+v"(c72), "+v"(c73));
   };
 
+  // ---- stagger the two workgroups of a CU by half a tile, once (conv3x3_bf16.hip explains why)
+  if (p.stagger > 0 && blockIdx.x < 512) {
+    const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6);      // HW_REG_LDS_ALLOC[7:0]
+    if (lds_base != 0)
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+
   // ---- prologue: A(0), B[0]
   issue_a(0);
   issue_b(0, 0);
@@ -310,6 +318,24 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     }
   }
 #undef SRGD_QACC
+  // column sums behind the staged tile: one barrier publishes both, and nothing below waits for the output stores
+  // (conv3x3_bf16.hip: reducing after the stores cost ~6,000 cycles per tile behind a vmcnt(0))
+  float* const cs = reinterpret_cast<float*>(smem + QPH * QPW * EROW);      // [2 (wm)][128][2] floats at byte 69,632 (< QLDS)
+  if (STATS) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      float t1 = s1[ni], t2 = s2[ni];
+      t1 += __shfl_xor(t1, 32, 64);
+      t2 += __shfl_xor(t2, 32, 64);
+      t1 += __shfl_xor(t1, 16, 64);
+      t2 += __shfl_xor(t2, 16, 64);
+      if (lane < 16) {
+        const int cl = wn * 64 + ni * 16 + r16;
+        cs[(wm * QBN + cl) * 2 + 0] = t1;
+        cs[(wm * QBN + cl) * 2 + 1] = t2;
+      }
+    }
+  }
   __syncthreads();
   {
     bf16* obase = p.out + ((size_t)(b * p.H + y0) * p.W + x0) * p.Cout + nt * QBN;
@@ -325,37 +351,31 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     }
   }
   if (STATS) {
-    __syncthreads();                                      // the staged output tile has been read back
-    float* cs = reinterpret_cast<float*>(smem);           // [2 (wm)][128][2]
+    const int cpg = p.Cout / p.groups;                    // multiple of 16, divides or is a multiple of 128
+    const int span = cpg >= QBN ? QBN : cpg;              // columns of this tile that belong to one group: 16, 32, 64 or 128
+    float a1 = 0.f, a2 = 0.f;
+    if (tid < QBN) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      float t1 = s1[ni], t2 = s2[ni];
-      t1 += __shfl_xor(t1, 32, 64);
-      t2 += __shfl_xor(t2, 32, 64);
-      t1 += __shfl_xor(t1, 16, 64);
-      t2 += __shfl_xor(t2, 16, 64);
-      if (lane < 16) {
-        const int cl = wn * 64 + ni * 16 + r16;
-        cs[(wm * QBN + cl) * 2 + 0] = t1;
-        cs[(wm * QBN + cl) * 2 + 1] = t2;
+      for (int k = 0; k < 2; ++k) {
+        a1 += cs[(k * QBN + tid) * 2 + 0];
+        a2 += cs[(k * QBN + tid) * 2 + 1];
+      }
+      for (int o = 1; o < span && o < 64; o <<= 1) {
+        a1 += __shfl_xor(a1, o, 64);
+        a2 += __shfl_xor(a2, o, 64);
       }
     }
-    __syncthreads();
-    const int cpg = p.Cout / p.groups;                    // multiple of 16, divides or is a multiple of 128
-    const int g_in_tile = cpg >= QBN ? 1 : QBN / cpg;
-    if (tid < g_in_tile) {
-      const int span = cpg >= QBN ? QBN : cpg;
-      float a1 = 0.f, a2 = 0.f;
-      for (int c = 0; c < span; ++c) {
-        const int cl = tid * span + c;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          a1 += cs[(k * QBN + cl) * 2 + 0];
-          a2 += cs[(k * QBN + cl) * 2 + 1];
-        }
-      }
+    if (span == QBN) {                                    // a group spans both waves: combine through LDS, raw barriers
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      QBARRIER();
+      if (tid < QBN && lane == 0) { cs[wave * 2 + 0] = a1; cs[wave * 2 + 1] = a2; }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      QBARRIER();
+      if (tid == 0) { a1 = cs[0] + cs[2]; a2 = cs[1] + cs[3]; }
+    }
+    if (tid < QBN && (tid % span) == 0) {
       const int tiles_per_group = cpg >= QBN ? cpg / QBN : 1;
-      const int grp = cpg >= QBN ? (nt * QBN) / cpg : (nt * QBN) / cpg + tid;
+      const int grp = (nt * QBN) / cpg + (cpg >= QBN ? 0 : tid / span);
       const int nslots = tiles_y * tiles_x * tiles_per_group;
       const int slot = trem * tiles_per_group + (cpg >= QBN ? nt % tiles_per_group : 0);
       float* dst = p.gn_partial + ((size_t)(b * p.groups + grp) * nslots + slot) * 2;
@@ -454,6 +474,12 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   p.B = a.B; p.H = a.Hin; p.W = a.Win; p.w = (const unsigned char*)packed_w; p.bias = a.bias; p.Cout = a.Cout;
   p.out = (bf16*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
   p.oq = (unsigned char*)a.out_q; p.os = (unsigned char*)a.out_s;
+  {
+    static int knob = -2;
+    if (knob == -2) { const char* v = getenv("SRGD_CONV3_STAGGER"); knob = v ? atoi(v) : -1; }
+    const int S = 9 * ((a.C0 + a.C1) / QKC);
+    p.stagger = knob >= 0 ? knob * S / 16 : (S * 1000) / 8128;     // half of S steps x ~2,000 cycles (two waves share a SIMD)
+  }
   const int grid = a.B * (a.Hin / QPH) * (a.Win / QPW) * (a.Cout / QBN);
   static bool attr_set[64] = {};
   if (first_use_on_device(attr_set)) {

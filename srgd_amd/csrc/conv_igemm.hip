@@ -19,6 +19,15 @@ namespace {
 
 constexpr int BM = 128, BN = 128, NT = 256;
 
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for
+// the output stores issued just before the GroupNorm statistics are reduced (thousands of cycles per tile)
+#define IGEMM_LDS_BARRIER()                                  \
+  do {                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+    __builtin_amdgcn_s_barrier();                            \
+    __builtin_amdgcn_sched_barrier(0);                       \
+  } while (0)
+
 template <typename T> struct Frag;                 // one lane's 16-byte operand fragment
 template <> struct Frag<float> { f32x4 v; };
 template <> struct Frag<bf16> { bf16x8 v; };
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
         }
       }
     }
-    if (p.gn_partial) __syncthreads();                     // staged tile consumed before the statistics reuse LDS
+    if (p.gn_partial) IGEMM_LDS_BARRIER();                 // staged tile consumed before the statistics reuse LDS
   } else {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
@@ -274,18 +283,28 @@ __global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
         cs[(wm * BN + cl) * 2 + 1] = t2;
       }
     }
-    __syncthreads();
-    const int cpg = p.Cout / p.groups;                   // channels per group (<= BN, divides BN)
-    const int g_in_tile = BN / cpg;
-    if (tid < g_in_tile) {
-      const int g = n0 / cpg + tid;
+    IGEMM_LDS_BARRIER();
+    // columns summed over the 2 row blocks by 128 threads, then a shuffle tree over each group's span of columns (a serial
+    // walk by one thread per group cost thousands of cycles per tile: see conv3x3_bf16.hip)
+    const int cpg = p.Cout / p.groups;                   // channels per group (<= BN, divides BN: 16, 32, 64 or 128)
+    float a1 = 0.f, a2 = 0.f;
+    if (tid < BN) {
+      a1 = cs[tid * 2 + 0] + cs[(BN + tid) * 2 + 0];
+      a2 = cs[tid * 2 + 1] + cs[(BN + tid) * 2 + 1];
+      for (int o = 1; o < cpg && o < 64; o <<= 1) {
+        a1 += __shfl_xor(a1, o, 64);
+        a2 += __shfl_xor(a2, o, 64);
+      }
+    }
+    if (cpg == BN) {                                     // the group spans both waves (uniform branch)
+      IGEMM_LDS_BARRIER();
+      if (tid < BN && lane == 0) { cs[wave * 2 + 0] = a1; cs[wave * 2 + 1] = a2; }
+      IGEMM_LDS_BARRIER();
+      if (tid == 0) { a1 = cs[0] + cs[2]; a2 = cs[1] + cs[3]; }
+    }
+    if (tid < BN && (tid % cpg) == 0) {
+      const int g = n0 / cpg + tid / cpg;
       if (g < p.groups) {
-        float a1 = 0.f, a2 = 0.f;
-        for (int c = 0; c < cpg; ++c) {
-          const int cl = tid * cpg + c;
-          a1 += cs[cl * 2 + 0] + cs[(BN + cl) * 2 + 0];
-          a2 += cs[cl * 2 + 1] + cs[(BN + cl) * 2 + 1];
-        }
         float* dst = p.gn_partial + ((size_t)(tb * p.groups + g) * tps + tslot) * 2;
         dst[0] = a1;
         dst[1] = a2;
