@@ -517,13 +517,17 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   if (first_use_on_device(attr_set)) {
 #define SRGD_SET(S_, G_, M_)                                                                              \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_, M_>),           \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     SRGD_SET(true, false, false) SRGD_SET(false, false, false) SRGD_SET(true, true, false) SRGD_SET(false, true, false)
     SRGD_SET(true, false, true) SRGD_SET(false, false, true) SRGD_SET(true, true, true) SRGD_SET(false, true, true)
 #undef SRGD_SET
   }
   const bool stats = a.gn_partial != nullptr;
-#define SRGD_GO(S_, G_, M_) hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_, M_>), dim3(grid), dim3(NT3), LDS_BYTES, st, p)
+  // diagnostic: SRGD_CONV3_ONE_WG=1 pads the LDS request so that only ONE workgroup fits a CU (what a warp-specialised
+  // variant with helper waves would have to live with: at 128 VGPRs the register file holds 16 waves per CU either way)
+  static int lds_req = 0;
+  if (!lds_req) { const char* v = getenv("SRGD_CONV3_ONE_WG"); lds_req = (v && atoi(v)) ? 96 * 1024 : LDS_BYTES; }
+#define SRGD_GO(S_, G_, M_) hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_, M_>), dim3(grid), dim3(NT3), lds_req, st, p)
   if (conv3x3_bf16_m16()) {
     if (stats && gnin) SRGD_GO(true, true, true); else if (stats) SRGD_GO(true, false, true);
     else if (gnin) SRGD_GO(false, true, true); else SRGD_GO(false, false, true);
