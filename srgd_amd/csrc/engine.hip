@@ -251,6 +251,7 @@ struct srgd_engine {
   bool no_gn_fusion = true;
   int gn_fusion_max_ntiles = 1 << 30;   // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile)
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
+  unsigned fp8_bf16_zones = 0;   // SRGD_FP8_BF16_ZONES (bit mask over Ctx::zone): zones whose 3x3 convs stay bf16 in fp8 mode (study knob)
   bool no_twin_fusion = false;   // SRGD_Q_FUSED=0: fp8 mode quantises every conv input in a separate pass (A/B + bit-equality test)
 
   Pool pool;
@@ -372,10 +373,13 @@ int build_topology(srgd_engine* e) {
   if (c.sinus_dim < 2 || c.sinus_dim % 2) SRGD_FAIL("learned_sinusoidal_dim must be even");
   if (c.dim % 16 != 0) SRGD_FAIL("unet_dim must be a multiple of 16");
   if (c.groups < 1 || c.dim % c.groups != 0) SRGD_FAIL("unet_dim must be divisible by resnet_block_groups");
-  if (c.precision < SRGD_PRECISION_FP32 || c.precision > SRGD_PRECISION_FP8) SRGD_FAIL("unknown precision mode");
+  if (c.precision < SRGD_PRECISION_FP32 || c.precision > SRGD_PRECISION_FP8_MIXED) SRGD_FAIL("unknown precision mode");
   e->bf16 = c.precision != SRGD_PRECISION_FP32;
   e->w8 = c.precision == SRGD_PRECISION_BF16_W8;
-  e->fp8 = c.precision == SRGD_PRECISION_FP8;
+  e->fp8 = c.precision == SRGD_PRECISION_FP8 || c.precision == SRGD_PRECISION_FP8_MIXED;
+  // mixed mode: the zones at the tile's own resolution (Ctx::zone 0, 2n, 2n+1) stay on the bf16 3x3 kernel - their
+  // activations carry the finest detail and cost 19 dB of the fp8 mode's error (tools/fp8_zone_study.py)
+  if (c.precision == SRGD_PRECISION_FP8_MIXED) e->fp8_bf16_zones = 1u | (1u << (2 * c.n_stages)) | (1u << (2 * c.n_stages + 1));
   e->es = e->bf16 ? 2 : 4;
   e->dim = c.dim; e->time_dim = 4 * c.dim; e->hid = c.heads * c.dim_head; e->n_stages = c.n_stages;
   e->dims.push_back(c.dim);
@@ -523,6 +527,7 @@ struct Ctx {
   hipStream_t st;
   const int* step_ptr = nullptr;   // sampler: device step counter (row += *step_ptr * step_mul)
   int step_mul = 2;                // conditioning rows per step: 2 (DDPM: label / no label), 4 (EDM: x {sigma_hat, sigma_next})
+  int zone = 0;                    // U-Net zone being evaluated: 0..n-1 down stages, n middle, n+1..2n up stages, 2n+1 final block
 };
 
 // gn_in: the input is a raw conv output whose GroupNorm+SiLU (coefA/coefB) the fast 3x3 kernel applies while
@@ -605,6 +610,7 @@ ConvArgs conv3_args(Ctx& x, const ConvW& c, int C0, int C1, int H, int W, void* 
 bool conv_is_q(Ctx& x, const ConvW& c, int C0, int C1, int H, int W, bool stats) {
   srgd_engine* e = x.e;
   if (!e->fp8 || !c.wq || e->force_generic_conv) return false;
+  if ((e->fp8_bf16_zones >> x.zone) & 1u) return false;            // this zone's 3x3 convolutions stay on the bf16 kernel
   return conv3x3_mxfp8_eligible(conv3_args(x, c, C0, C1, H, W, nullptr, stats));
 }
 int q_alloc(Ctx& x, int C, int hw, QTensor* t) {
@@ -818,6 +824,7 @@ int unet_body(Ctx& x, void* x0, void** out) {
   for (int s = 0; s < n; ++s) {
     const StageW& sw = e->downs[s];
     const int C = e->dims[s];
+    x.zone = s;
     void *a, *b, *c;
     // want_twin flags (fp8 mode only): true where the tensor is read by a 3x3 convolution later - a: next block + skip,
     // c: skip (+ the last stage's 3x3 resampler), d: the next stage's first block
@@ -840,6 +847,7 @@ int unet_body(Ctx& x, void* x0, void** out) {
   {
     void *a, *b, *c;
     const int C = e->dims[n];
+    x.zone = n;
     SRGD_TRY(res_block(x, e->mid1, cur, C, nullptr, 0, &a));
     e->pool.put(cur);
     SRGD_TRY(attn_block(x, e->mid_attn, a, &b, true));
@@ -851,6 +859,7 @@ int unet_body(Ctx& x, void* x0, void** out) {
   for (int u = 0; u < n; ++u) {
     const StageW& sw = e->ups[u];
     const int s = n - 1 - u, din = e->dims[s], dout = e->dims[s + 1];
+    x.zone = n + 1 + u;
     void *a, *b, *c;
     void* sk = skips.back(); skips.pop_back();
     SRGD_TRY(res_block(x, sw.rb[0], cur, dout, sk, din, &a, true));
@@ -872,6 +881,7 @@ int unet_body(Ctx& x, void* x0, void** out) {
   }
   if (x.H != H0 || x.W != W0) SRGD_FAIL("internal: resolution bookkeeping");
   void* fin;
+  x.zone = 2 * n + 1;
   SRGD_TRY(res_block(x, e->final_rb, cur, e->dim, x0, e->dim, &fin));
   e->pool.put(cur);
   *out = fin;
@@ -975,6 +985,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_Q_FUSED")) e->no_twin_fusion = atoi(v) == 0;
+  if (const char* v = getenv("SRGD_FP8_BF16_ZONES")) e->fp8_bf16_zones = (unsigned)strtoul(v, nullptr, 0);
   *out = e.release();
   return 0;
 }

@@ -6,7 +6,7 @@ Differences that are deliberate and documented: torchvision/log
 ``T.Resize`` on a PIL image, ``ToTensor`` and ``ToPILImage`` do; ``pil_to_unit_tensor`` / ``unit_tensor_to_pil`` are
 the host-side equivalents kept for tests); ``--no_amp`` is accepted and, as upstream (whose sampler ignores ``amp`` and
 always computes fp32), changes nothing: the default run reproduces the reference's fp32 numerics.
-Engine-only switches: ``--precision {fp32,bf16,bf16_w8,fp8}`` opts into a throughput mode, ``--device_noise`` switches from
+Engine-only switches: ``--precision {fp32,bf16,bf16_w8,fp8,fp8_mixed}`` opts into a throughput mode, ``--device_noise`` switches from
 the reference-compatible host noise stream to on-device Philox.
 """
 from __future__ import annotations
@@ -49,8 +49,8 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=71)
     p.add_argument("--backend", type=str, default="ddp")
     # engine-only switches (absent upstream)
-    p.add_argument("--precision", choices=["fp32", "bf16", "bf16_w8", "fp8"], default="fp32",
-                   help="fp32 (default): the reference's numerics (<= 1e-3 of its CPU path); bf16 / bf16_w8 / fp8: "
+    p.add_argument("--precision", choices=["fp32", "bf16", "bf16_w8", "fp8", "fp8_mixed"], default="fp32",
+                   help="fp32 (default): the reference's numerics (<= 1e-3 of its CPU path); bf16 / bf16_w8 / fp8 / fp8_mixed: "
                         "throughput modes of the MI355X engine (explicit opt-in)")
     p.add_argument("--device_noise", action="store_true",
                    help="draw DDPM noise on the GPU (Philox) instead of replaying torch's CPU stream")

@@ -329,7 +329,8 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
         self.max_tiles_per_launch = None   # None: use the caller's batch_size as the reference does
         # engine precision: "fp32" (default: the reference's numerics - upstream ignores ``amp`` and always computes fp32,
         # SURVEY App. E), "bf16" (throughput mode), "bf16_w8" (bf16 kernels, fp8-e4m3-rounded conv weights),
-        # "fp8" (MX-fp8 3x3 convolutions, BASELINE configs[4]).  tiled_sample(precision=...) overrides it per call.
+        # "fp8" (MX-fp8 3x3 convolutions, BASELINE configs[4]), "fp8_mixed" (fp8 below the top resolution only: 53 dB vs
+        # bf16 instead of 34 dB).  tiled_sample(precision=...) overrides it per call.
         self.precision = "fp32"
         # set by srgd_amd.parallel.shard_canvas: a torch.distributed group whose ranks share ONE canvas - each rank
         # runs a contiguous slice of every step's tiles and the updated tiles are all-gathered

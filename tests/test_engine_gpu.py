@@ -735,7 +735,7 @@ def test_config5_full_geometry_fp8_vs_bf16_parity_report():
     sampler.noise_source = "device"
     outs = {}
     try:
-        for prec in ("bf16", "fp8"):
+        for prec in ("bf16", "fp8", "fp8_mixed"):
             sampler.device_noise_seed = 71
             outs[prec] = sampler.tiled_sample(batch_size=25, condition_x=cond, class_label=label, class_cond_scale=2.0,
                                               num_sample_steps=100, precision=prec).cpu()
@@ -743,7 +743,12 @@ def test_config5_full_geometry_fp8_vs_bf16_parity_report():
         sampler.noise_source = "host"
     err = (outs["fp8"] - outs["bf16"]).abs()
     psnr = float(10 * np.log10(1.0 / max(float((err ** 2).mean()), 1e-20)))
-    _report(test="config5_full_1024_fp8_vs_bf16", psnr_db=psnr, max_abs=float(err.max()), mean_abs=float(err.mean()))
+    errm = (outs["fp8_mixed"] - outs["bf16"]).abs()
+    psnr_mixed = float(10 * np.log10(1.0 / max(float((errm ** 2).mean()), 1e-20)))
+    _report(test="config5_full_1024_fp8_vs_bf16", psnr_db=psnr, max_abs=float(err.max()), mean_abs=float(err.mean()),
+            mixed_psnr_db=psnr_mixed, mixed_max_abs=float(errm.max()))
+    # fp8 below the top resolution only (the 256x256-resolution zones keep bf16 3x3 convolutions): measured 53.2 dB
+    assert torch.isfinite(outs["fp8_mixed"]).all() and psnr_mixed > 50.0, psnr_mixed
     assert outs["fp8"].shape == (1, 3, 1024, 1024)
     assert torch.isfinite(outs["fp8"]).all() and outs["fp8"].min() >= 0 and outs["fp8"].max() <= 1
     assert psnr > 31.0, psnr           # measured 34.1 dB on MI355X (random-init weights; 3 mantissa bits on weights AND activations)
