@@ -167,7 +167,7 @@ typedef struct srgd_edm_scalars {
   float c_in_next, c_skip_next, c_out_next;     /* ... at sigma_next */
   float ring_sigma;                             /* sigmas[i]: odd-step ring = ring_sigma * z'       (model.py:2448-2452) */
   float clamp;                                  /* != 0: clamp the denoised prediction to [-1, 1]   (model.py:2180) */
-  float pad0, pad1;
+  float dpm_gamma, pad1;                        /* srgd_edm_dpmpp_step only: multistep weight, see there */
 } srgd_edm_scalars;
 
 /* As srgd_sampler_begin; c_noise_host: [2*n_steps] = c_noise(sigma_hat_i), c_noise(sigma_next_i) - the "time" input of
@@ -183,6 +183,18 @@ int srgd_edm_begin(srgd_engine* e, const srgd_sampler_geometry* g, const float* 
 int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start, float* work,
                   const float* noise_canvas, const float* ring_noise_canvas, int passes, int guidance_kind,
                   float guidance_scale, int sub_batch, uint64_t seed, void* stream);
+
+/* One DPM-Solver++(2M) step of the EDM wrapper's un-tiled loop (reference sample_using_dpmpp, model.py:2517-2542) over
+ * every tile of grid (step % 2), one network evaluation, no noise, no ring:
+ *   den   = clamp(c_skip_hat * img + c_out_hat * net(c_in_hat * img, c_noise[2*step]))          (:2528, preconditioning :2140-2183)
+ *   den_d = (1 - dpm_gamma) * den + dpm_gamma * old_denoised                                      (:2533-2539)
+ *   img   = dt * img - half_dt * den_d ;  old_denoised = den ;  x_start (nullable) = den_d         (:2541-2547)
+ * with the step's srgd_edm_scalars read as: *_hat / clamp at sigma_i, dt = sigma_fn(t_next) / sigma_fn(t),
+ * half_dt = expm1(-h), dpm_gamma = -1 / (2 r), or 0 on the first step and on the last (sigma_next == 0) - the host computes
+ * them with the reference's fp32 tensor ops.  old_denoised: device fp32 canvas [n_images,3,Hp,Wp], zero before the first step.
+ * Run between srgd_edm_begin and srgd_sampler_end like srgd_edm_step. */
+int srgd_edm_dpmpp_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start, float* old_denoised,
+                        int passes, int guidance_kind, float guidance_scale, int sub_batch, void* stream);
 
 /* Host helper (no GPU): out[i] = e4m3(in[i] / scale) * scale, round-to-nearest-even, saturating at +-448 (the OCP
  * "fn" variant torch.float8_e4m3fn implements) - the weight rounding of SRGD_PRECISION_BF16_W8, exposed for tests. */

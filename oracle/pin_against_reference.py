@@ -31,9 +31,45 @@ def report(name, got, want, bound):
     return ok
 
 
+def pin_edm_untiled(rm, rc):
+    ok = True
+    # ---- un-tiled EDM entry points: sample -> sample_org (model.py:2196-2306) and sample_using_dpmpp (:2479-2557)
+    def run_edm_untiled(dpmpp, b, steps, ccs=1.0, cs=1.0, label=0, ctor_steps=None, **extra):
+        ctor_steps = ctor_steps or steps
+        sampler, _ = refshim.build_reference_sampler(rm, rc, dim=16, num_sample_steps=ctor_steps, model="conditional_elucidated")
+        sampler.use_dpmpp_solver = dpmpp                                  # what the ctor stores (model.py:2126); read at :2200
+        schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+        sd = synth_state_dict(schema, seed=0)
+        sampler.load_state_dict(sd, strict=True)
+        usd = {k[len("net."):]: v for k, v in sd.items()}
+        g = torch.Generator().manual_seed(4321)
+        cond = torch.rand(b, 3, 256, 256, generator=g)
+        lab = torch.tensor([label]) if label is not None else None
+        torch.manual_seed(71)
+        with torch.inference_mode():
+            want = sampler.sample(batch_size=b, condition_x=cond.clone(), class_label=lab, cond_scale=cs,
+                                  class_cond_scale=ccs, num_sample_steps=steps, **extra)
+        torch.manual_seed(71)
+        fn = O.edm_sample_dpmpp if dpmpp else O.edm_sample
+        with torch.inference_mode():
+            got = fn(usd, O.UnetCfg(dim=16), O.EdmCfg(num_sample_steps=ctor_steps), cond.clone(), lab, num_sample_steps=steps,
+                     cond_scale=cs, class_cond_scale=ccs, **extra)
+        return got, want
+
+    print("[edm un-tiled] dim=16, [B,3,256,256]: Heun (sample_org) and DPM-Solver++ (sample_using_dpmpp)")
+    for kw in (dict(dpmpp=False, b=2, steps=5), dict(dpmpp=False, b=1, steps=6, ccs=2.0, class_guidance_start_steps=2),
+               dict(dpmpp=False, b=1, steps=5, ctor_steps=8, generation_start_steps=1, clamp=False),
+               dict(dpmpp=True, b=2, steps=6), dict(dpmpp=True, b=1, steps=6, cs=1.5, zero_init=True),
+               dict(dpmpp=True, b=1, steps=7, ctor_steps=9, generation_start_steps=2, ccs=2.0)):
+        got, want = run_edm_untiled(**kw)
+        ok &= report("edm un-tiled " + str(kw), got, want, 1e-4)
+    return ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="skip the dim-128 cases")
+    ap.add_argument("--section", choices=["all", "edm_untiled"], default="all", help="run one section only")
     args = ap.parse_args()
     ref = refshim.load_reference()
     if ref is None:
@@ -41,6 +77,10 @@ def main():
         return 0
     rm, rc = ref
     torch.set_num_threads(8)
+    if args.section == "edm_untiled":
+        ok = pin_edm_untiled(rm, rc)
+        print("PINNED" if ok else "MISMATCH")
+        return 0 if ok else 1
     ok = True
 
     print("[geometry] get_coord_and_pad / get_coords / get_area")
@@ -163,6 +203,7 @@ def main():
                dict(h=300, w=300, steps=5, bs=4, ctor_steps=8, generation_start_steps=1)):   # per-call steps != ctor steps
         got, want = run_edm(16, **kw)
         ok &= report("edm final image " + str({k: v for k, v in kw.items() if k not in ("h", "w", "bs")}), got, want, 1e-4)
+    ok &= pin_edm_untiled(rm, rc)
     print("PINNED" if ok else "MISMATCH")
     return 0 if ok else 1
 

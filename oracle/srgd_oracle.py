@@ -531,3 +531,78 @@ def sample(sd, cfg: UnetCfg, condition_x: Tensor, class_label: Optional[Tensor] 
         ccs = class_cond_scale if i >= class_guidance_start_steps else 1.0
         img, _ = predict_and_step(sd, cfg, img, steps[i], steps[i + 1], cond, class_label, cs, ccs, noise)
     return (img.clamp(-1.0, 1.0) + 1) * 0.5                              # :3239-3240
+
+
+# --------------------------------------------------------------------------------------
+# un-tiled EDM sampling: ConditionalElucidatedDiffusionSR.sample -> sample_org (model.py:2196-2306, Heun) or
+# sample_using_dpmpp (model.py:2479-2557, DPM-Solver++(2M)) when the wrapper was built with use_dpmpp_solver
+# --------------------------------------------------------------------------------------
+def _edm_start(e: EdmCfg, cond: Tensor, sigmas: Tensor, generation_start_steps: int, zero_init: bool, noise) -> Tensor:
+    if generation_start_steps > 0:                                       # get_noised_images, ctor schedule (:2186-2194)
+        return cond + edm_sigmas(e, e.num_sample_steps)[generation_start_steps] * noise.randn(cond.shape)
+    if zero_init:
+        return torch.zeros(cond.shape)
+    return sigmas[0] * noise.randn(cond.shape)
+
+
+def edm_sample(sd, cfg: UnetCfg, e: EdmCfg, condition_x: Tensor, class_label: Optional[Tensor] = None, *,
+               num_sample_steps: int = 32, cond_scale: float = 1.0, guidance_start_steps: int = 0,
+               class_cond_scale: float = 1.0, class_guidance_start_steps: int = 0, generation_start_steps: int = 0,
+               clamp: bool = True, zero_init: bool = False, noise: Optional["NoiseSource"] = None) -> Tensor:
+    """sample_org, model.py:2212-2306.  condition_x [B,3,h,w] in [0,1]; one randn over the batch tensor per draw."""
+    noise = noise or NoiseSource()
+    n = num_sample_steps
+    cond = condition_x * 2 - 1                                           # :2223
+    sigmas = edm_sigmas(e, n)
+    gammas = edm_gammas(e, sigmas, n)
+    img = _edm_start(e, cond, sigmas, generation_start_steps, zero_init, noise)
+    for i in range(n):
+        if i < generation_start_steps:
+            continue
+        cs = cond_scale if i >= guidance_start_steps else 1.0
+        ccs = class_cond_scale if i >= class_guidance_start_steps else 1.0
+        sigma, sigma_next, gamma = sigmas[i].item(), sigmas[i + 1].item(), gammas[i].item()
+        eps = e.S_noise * noise.randn(cond.shape)                        # :2269
+        sigma_hat = sigma + gamma * sigma
+        img_hat = img + math.sqrt(sigma_hat ** 2 - sigma ** 2) * eps     # :2272
+        out = edm_denoise(sd, cfg, e, img_hat, sigma_hat, cond, class_label, cs, ccs, clamp)
+        d = (img_hat - out) / sigma_hat                                  # :2276
+        nxt = img_hat + (sigma_next - sigma_hat) * d                     # :2278
+        if sigma_next != 0:                                              # :2282-2286
+            out2 = edm_denoise(sd, cfg, e, nxt, sigma_next, cond, class_label, cs, ccs, clamp)
+            d2 = (nxt - out2) / sigma_next
+            nxt = img_hat + 0.5 * (sigma_next - sigma_hat) * (d + d2)
+        img = nxt
+    return (img.clamp(-1.0, 1.0) + 1) * 0.5                              # :2298, :2306
+
+
+def edm_sample_dpmpp(sd, cfg: UnetCfg, e: EdmCfg, condition_x: Tensor, class_label: Optional[Tensor] = None, *,
+                     num_sample_steps: int = 32, cond_scale: float = 1.0, guidance_start_steps: int = 0,
+                     class_cond_scale: float = 1.0, class_guidance_start_steps: int = 0, generation_start_steps: int = 0,
+                     clamp: bool = True, zero_init: bool = False, noise: Optional["NoiseSource"] = None) -> Tensor:
+    """sample_using_dpmpp, model.py:2479-2557: one U-Net evaluation per step, a two-step multistep update in t = -log sigma."""
+    noise = noise or NoiseSource()
+    n = num_sample_steps
+    cond = condition_x * 2 - 1                                           # :2494
+    sigmas = edm_sigmas(e, n)
+    img = _edm_start(e, cond, sigmas, generation_start_steps, zero_init, noise)
+    t_of = lambda s: s.log().neg()                                       # :2513-2514
+    sigma_of = lambda t: t.neg().exp()
+    old = None
+    for i in range(n):
+        if i < generation_start_steps:
+            continue
+        cs = cond_scale if i >= guidance_start_steps else 1.0
+        ccs = class_cond_scale if i >= class_guidance_start_steps else 1.0
+        den = edm_denoise(sd, cfg, e, img, sigmas[i].item(), cond, class_label, cs, ccs, clamp)   # :2528
+        t, t_next = t_of(sigmas[i]), t_of(sigmas[i + 1])
+        h = t_next - t
+        if old is None or sigmas[i + 1] == 0:                            # :2533
+            den_d = den
+        else:
+            r = (t - t_of(sigmas[i - 1])) / h                            # :2536-2537
+            g = -1 / (2 * r)
+            den_d = (1 - g) * den + g * old                              # :2539
+        img = (sigma_of(t_next) / sigma_of(t)) * img - (-h).expm1() * den_d   # :2541
+        old = den
+    return (img.clamp(-1.0, 1.0) + 1) * 0.5                              # :2549, :2557

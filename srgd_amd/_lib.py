@@ -36,7 +36,7 @@ class StepScalars(C.Structure):
 class EdmScalars(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("s_noise", "hat_coef", "sigma_hat", "sigma_next", "dt", "half_dt", "c_in_hat",
                                          "c_skip_hat", "c_out_hat", "c_in_next", "c_skip_next", "c_out_next", "ring_sigma",
-                                         "clamp", "pad0", "pad1")]
+                                         "clamp", "dpm_gamma", "pad1")]
 
 
 class SamplerGeometry(C.Structure):
@@ -74,6 +74,8 @@ PROTOTYPES = {
                                  C.c_void_p]),
     "srgd_edm_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_int, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_void_p]),
+    "srgd_edm_dpmpp_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_float, C.c_int, C.c_void_p]),
     "srgd_sampler_q_start": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_uint64,
                                        C.c_void_p]),
     "srgd_sampler_end": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1336,6 +1336,63 @@ int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas
   });
 }
 
+// One DPM-Solver++(2M) step (reference sample_using_dpmpp, model.py:2517-2547): one network evaluation per tile at sigma_i,
+// multistep update against the previous step's denoised canvas.  Deterministic (no noise), launched eagerly.
+int srgd_edm_dpmpp_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start, float* old_denoised,
+                        int passes, int guidance_kind, float guidance_scale, int sub_batch, void* stream) {
+  if (!e || !e->run_active || !e->run_is_edm) SRGD_FAIL("srgd_edm_dpmpp_step: call srgd_edm_begin first");
+  if (step < 0 || step >= e->n_steps) SRGD_FAIL("srgd_edm_dpmpp_step: step out of range");
+  if (!img || !cond_canvas || !old_denoised) SRGD_FAIL("srgd_edm_dpmpp_step: null argument");
+  if (passes != 1 && passes != 2) SRGD_FAIL("srgd_edm_dpmpp_step: passes must be 1 or 2");
+  if (passes == 2 && guidance_kind != 1 && guidance_kind != 2) SRGD_FAIL("srgd_edm_dpmpp_step: guidance_kind must be 1 or 2");
+  if (sub_batch < 1) SRGD_FAIL("srgd_edm_dpmpp_step: sub_batch must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  SRGD_HIP(hipSetDevice(e->cfg.device));
+  const srgd_sampler_geometry& g = e->geo;
+  const int parity = step & 1;
+  const int n_local = parity ? g.n_odd : g.n_even;
+  const int n = n_local * g.n_images;
+  const int* tiles = parity ? e->d_tiles_odd : e->d_tiles_even;
+  sub_batch = std::min(sub_batch, n);
+  const size_t canvas_elems = (size_t)3 * g.Hp * g.Wp * g.n_images;
+  e->pool.reset_busy();
+  SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
+  if (!e->d_step) SRGD_HIP(hipMalloc((void**)&e->d_step, sizeof(int)));
+  hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, e->d_step, step);
+  const int row_label = e->run_class >= 0 ? 0 : 1, row_null = 1;
+  const int mask = (passes == 2 && guidance_kind == 2) ? 0x1 : 0x3;
+  for (int first = 0; first < n; first += sub_batch) {
+    const int nt = std::min(sub_batch, n - first);
+    const int nb = nt * passes;
+    TileBatch tb{tiles, first, nt, g.Hp, g.Wp, g.tile, n_local};
+    void* x0 = e->pool.get((size_t)nb * g.tile * g.tile * e->dim * e->es);
+    if (!x0) return -1;
+    {
+      Prof p(e, KC_INIT, st);
+      void* padded = e->pool.get((size_t)nb * (g.tile + 6) * (g.tile + 8) * 8 * e->es);
+      if (!padded) return -1;
+      SRGD_TRY(init_gather_from_canvas_edm(img, nullptr, cond_canvas, tb, passes, mask, e->d_edm, e->d_step, 2, padded,
+                                           e->bf16, st));
+      SRGD_TRY(run_init7(e, padded, nb, g.tile, g.tile, x0, st));
+      e->pool.put(padded);
+    }
+    // conditioning rows of evaluation 0 (c_noise at sigma_i), as in edm_step_launch
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, st, e->d_rows, nb, nt, row_label,
+                       (passes == 2 && guidance_kind == 1) ? row_null : row_label);
+    Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st, e->d_step, 4};
+    void* act = nullptr;
+    SRGD_TRY(unet_body(x, x0, &act));
+    FinalStepArgs fa;
+    fa.act = act; fa.C = e->dim; fa.passes = passes; fa.guidance = guidance_scale;
+    fa.w = e->final_w; fa.bias = e->final_b; fa.img = img; fa.x_start = x_start; fa.noise = nullptr;
+    fa.sc = nullptr; fa.step_ptr = e->d_step;
+    { Prof p(e, KC_FINAL, st); SRGD_TRY(final_step_edm(fa, e->d_edm, old_denoised, canvas_elems, 2, tb, e->bf16, st)); }
+    e->pool.put(act);
+    e->pool.put(x0);
+  }
+  return 0;
+}
+
 // all launches of one DDPM step; step-dependent values come through e->d_step (set by the caller on the stream)
 static int sampler_step_launch(srgd_engine* e, bool last, int parity, int tile_first, int tile_count, bool ring, float* img,
                                const float* cond_canvas, float* x_start, const float* noise_tiles,

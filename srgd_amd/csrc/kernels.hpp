@@ -153,7 +153,7 @@ struct EdmScalars {        // == srgd_edm_scalars (include/srgd_hip.h); fp32 val
   float c_in_next, c_skip_next, c_out_next;
   float ring_sigma;                  // sigmas[i]: odd-step ring = ring_sigma * z'            (model.py:2448-2452)
   float clamp;                       // != 0: clamp the denoised prediction to [-1, 1]
-  float pad0, pad1;
+  float dpm_gamma, pad1;             // srgd_edm_dpmpp_step: multistep weight (dt / half_dt hold its two update coefficients)
 };
 struct TileBatch {
   const int* tile_yx;      // device [n_images * n_local][3] = (y, x, image) of each tile, image-major

@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void init_gather_kernel(InitSrc s, int entries
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           float xv = v[c];
-          if (s.edm_pass == 0) xv = xv + sc.hat_coef * (sc.s_noise * s.z[oz + c * s.plane_stride]);
-          v[c] = (s.edm_pass == 0 ? sc.c_in_hat : sc.c_in_next) * xv;
+          if (s.z) xv = xv + sc.hat_coef * (sc.s_noise * s.z[oz + c * s.plane_stride]);   // pass 0 of the Heun step only
+          v[c] = (s.edm_pass == 1 ? sc.c_in_next : sc.c_in_hat) * xv;
         }
       }
     }
@@ -231,8 +231,18 @@ __global__ __launch_bounds__(256) void final_step_edm_kernel(FinalStepArgs a, co
   const bool last = sc.sigma_next == 0.0f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float xh = a.img[c * plane + o] + sc.hat_coef * (sc.s_noise * a.noise[c * plane + oz]);     // :2389
     const float net = eps[c][threadIdx.x];
+    if (edm_pass == 2) {                      // DPM-Solver++(2M) update of the un-tiled loop (model.py:2528-2547)
+      const float xi = a.img[c * plane + o];
+      float den = sc.c_skip_hat * xi + sc.c_out_hat * net;
+      if (sc.clamp != 0.0f) den = fminf(fmaxf(den, -1.0f), 1.0f);
+      const float den_d = (1.0f - sc.dpm_gamma) * den + sc.dpm_gamma * nxt_c[c * plane + o];     // :2539 (gamma 0: den)
+      a.img[c * plane + o] = sc.dt * xi - sc.half_dt * den_d;                                    // :2541
+      nxt_c[c * plane + o] = den;                                                                // old_denoised :2542
+      if (a.x_start) a.x_start[c * plane + o] = den_d;                                           // :2547
+      continue;
+    }
+    const float xh = a.img[c * plane + o] + sc.hat_coef * (sc.s_noise * a.noise[c * plane + oz]);     // :2389
     if (edm_pass == 0) {
       float den = sc.c_skip_hat * xh + sc.c_out_hat * net;                     // :2149
       if (sc.clamp != 0.0f) den = fminf(fmaxf(den, -1.0f), 1.0f);              // :2180-2181
@@ -463,7 +473,7 @@ int final_step_edm(const FinalStepArgs& a, const EdmScalars* sc, float* work, si
   const int grid = (int)((n + 255) / 256);
   if (a.C % (is_bf16 ? 8 : 4) != 0) SRGD_FAIL("final_step_edm: C must be a multiple of the vector width");
   if (((long)tb.tile * tb.tile) % 256 != 0) SRGD_FAIL("final_step_edm: tile area must be a multiple of 256");
-  if (!sc || !work || !a.noise) SRGD_FAIL("final_step_edm: null argument");
+  if (!sc || !work || (!a.noise && edm_pass != 2)) SRGD_FAIL("final_step_edm: null argument");
   if (is_bf16) hipLaunchKernelGGL((final_step_edm_kernel<bf16>), dim3(grid), dim3(256), 0, st, a, sc, work, canvas_elems, edm_pass, tb);
   else hipLaunchKernelGGL((final_step_edm_kernel<float>), dim3(grid), dim3(256), 0, st, a, sc, work, canvas_elems, edm_pass, tb);
   SRGD_HIP(hipGetLastError());

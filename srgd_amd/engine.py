@@ -177,6 +177,15 @@ class HipEngine:
                                         float(guidance_scale), int(sub_batch), int(seed) & (2 ** 64 - 1),
                                         _stream_ptr(self.device)), "srgd_edm_step")
 
+    def edm_dpmpp_step(self, step: int, img: torch.Tensor, cond_canvas: torch.Tensor, x_start: Optional[torch.Tensor],
+                       old_denoised: torch.Tensor, passes: int, guidance_kind: int, guidance_scale: float,
+                       sub_batch: int) -> None:
+        assert old_denoised.is_contiguous() and old_denoised.dtype == torch.float32 and old_denoised.numel() == img.numel()
+        with torch.cuda.device(self.device):
+            check(self._L.srgd_edm_dpmpp_step(self._h, step, _dev_ptr(img), _dev_ptr(cond_canvas), _dev_ptr(x_start),
+                                              _dev_ptr(old_denoised), passes, guidance_kind, float(guidance_scale),
+                                              int(sub_batch), _stream_ptr(self.device)), "srgd_edm_dpmpp_step")
+
     def sampler_q_start(self, cond01: torch.Tensor, noise_canvas: Optional[torch.Tensor], alpha: float, sigma: float,
                         img: torch.Tensor, seed: int = 0) -> None:
         with torch.cuda.device(self.device):

@@ -557,7 +557,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
     The base class ``denoising_diffusion_pytorch.ElucidatedDiffusion`` (un-vendored, pinned 1.8.15) contributes the
     rho-schedule and the preconditioning coefficients; they are restated here from the published algorithm
     (``sample_schedule`` / ``c_in`` / ``c_skip`` / ``c_out`` / ``c_noise``) with torch fp32 ops, and handed to the engine as
-    per-step scalars.  Inference only; ``sample`` / ``sample_using_dpmpp`` / training are not built."""
+    per-step scalars.  Inference only (``tiled_sample``, ``sample`` -> ``sample_org`` / ``sample_using_dpmpp``)."""
 
     def __init__(self, net, *, image_size, channels=3, num_sample_steps=32, sigma_min=0.002, sigma_max=80, sigma_data=0.5,
                  rho=7, P_mean=-1.2, P_std=1.2, S_churn=80, S_tmin=0.05, S_tmax=50, S_noise=1.003, cond_drop_prob=0.0,
@@ -626,7 +626,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
                 c_in_next=float(self.c_in(sn)), c_skip_next=float(self.c_skip(sn)), c_out_next=float(self.c_out(sn)),
                 # read on odd steps only; upstream indexes its constructor-length schedule there (IndexError beyond it)
                 ring_sigma=float(noised_sigmas[i]) if (i % 2 == 1 or i < len(noised_sigmas)) else 0.0,
-                clamp=1.0 if clamp else 0.0, pad0=0.0, pad1=0.0))
+                clamp=1.0 if clamp else 0.0, dpm_gamma=0.0, pad1=0.0))
             c_noise += [float(self.c_noise(sh)), float(self.c_noise(sn))]
         return sigmas, noised_sigmas, scalars, c_noise
 
@@ -704,11 +704,172 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
             return (out, image_list, x0_image_list) if with_x0_images else (out, image_list)
         return out
 
-    def sample(self, *args, **kwargs):
-        raise NotImplementedError("un-tiled EDM sampling (model.py:2196) is not on the shipped inference path; use tiled_sample")
+    def _dpmpp_tables(self, n: int, clamp: bool):
+        """Per-step scalars of ``sample_using_dpmpp`` (model.py:2513-2541), evaluated with the reference's fp32 tensor ops:
+        preconditioning at sigma_i, update coefficients sigma_fn(t_next)/sigma_fn(t) and expm1(-h), multistep weight gamma."""
+        from ._lib import EdmScalars
+        sigmas = self.sample_schedule(n)
+        t_fn = lambda sigma: sigma.log().neg()
+        sigma_fn = lambda t: t.neg().exp()
+        scalars, c_noise = [], []
+        for i in range(n):
+            si = torch.full((1,), sigmas[i].item())                                             # :2137 fp32 tensor
+            t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+            h = t_next - t
+            scalars.append(EdmScalars(
+                s_noise=0.0, hat_coef=0.0, sigma_hat=float(sigmas[i]), sigma_next=float(sigmas[i + 1]),
+                dt=float(sigma_fn(t_next) / sigma_fn(t)), half_dt=float((-h).expm1()),
+                c_in_hat=float(self.c_in(si)), c_skip_hat=float(self.c_skip(si)), c_out_hat=float(self.c_out(si)),
+                c_in_next=0.0, c_skip_next=0.0, c_out_next=0.0, ring_sigma=0.0, clamp=1.0 if clamp else 0.0,
+                dpm_gamma=0.0, pad1=0.0))                                    # dpm_gamma: set per call (depends on the start step)
+            c_noise += [float(self.c_noise(si)), 0.0]
+        return sigmas, scalars, c_noise
 
-    def sample_using_dpmpp(self, *args, **kwargs):
-        raise NotImplementedError("the DPM++ solver variant (model.py:2478) is not built")
+    @torch.inference_mode()
+    def sample(self, batch_size=16, condition_x=None, class_label=None, cond_scale=1.0, guidance_start_steps=0,
+               class_cond_scale=1.0, class_guidance_start_steps=0, generation_start_steps=0, num_sample_steps=None,
+               clamp=True, with_images=False, with_x0_images=False, zero_init=False, precision=None):
+        """Reference model.py:2196-2209: un-tiled sampling of a ``[B,3,256,256]`` batch - the Heun loop ``sample_org``
+        (:2212-2306), or ``sample_using_dpmpp`` when the wrapper was built with ``use_dpmpp_solver``."""
+        fn = self.sample_using_dpmpp if self.use_dpmpp_solver else self.sample_org
+        return fn(batch_size, condition_x, class_label, cond_scale, guidance_start_steps, class_cond_scale,
+                  class_guidance_start_steps, generation_start_steps, num_sample_steps, clamp, with_images, with_x0_images,
+                  zero_init, precision=precision)
+
+    def _untiled_setup(self, batch_size, condition_x, class_label, cond_scale, class_cond_scale, generation_start_steps,
+                       zero_init, sigma0, precision):
+        """Shared front end of the two un-tiled loops: the batch becomes one canvas of B stacked tiles (``[1,3,B*S,S]``, no
+        padding, empty ring) exactly as in the DDPM wrapper's ``sample``; returns the engine, layout helpers and the start
+        canvas (model.py:2219-2244 / :2490-2503)."""
+        if cond_scale != 1.0 and class_cond_scale != 1.0:
+            raise NotImplementedError("Currently, you cannot specify both cond_scale and class_cond_scale at the same time.")
+        dev = self.device
+        if dev.type != "cuda":
+            raise _lib.SrgdHipError("sample runs on MI355X only (no CPU fallback)")
+        b = int(batch_size)
+        s_ = 256
+        if tuple(condition_x.shape) != (b, self.channels, s_, s_):
+            raise NotImplementedError(f"condition_x must be [{b},{self.channels},{s_},{s_}]: this engine's un-tiled path runs "
+                                      "256 x 256 images (the tile edge of its kernels; the shipped image_size)")
+        if generation_start_steps > 0 and b not in (1, s_):
+            # get_noised_images (model.py:2191-2193) multiplies a [B] sigma vector into a [B,3,h,w] tensor
+            raise RuntimeError(f"The size of tensor a ({b}) must match the size of tensor b ({s_}) at non-singleton dimension 3")
+        eng = self.net.engine(precision or self.precision)
+        to_canvas = lambda t: t.permute(1, 0, 2, 3).reshape(1, 3, b * s_, s_).contiguous()       # [B,3,S,S] -> [1,3,B*S,S]
+        from_canvas = lambda t: t.reshape(3, b, s_, s_).permute(1, 0, 2, 3).contiguous()
+        tiles = [(i * s_, 0) for i in range(b)]
+        geo = SamplerGeometry(H=b * s_, W=s_, Hp=b * s_, Wp=s_, left=0, top=0, inner_l=0, inner_t=0, inner_r=s_, inner_b=b * s_,
+                              tile=s_, n_even=b, n_odd=b, n_images=1)
+        cond01 = to_canvas(condition_x.to(dev, torch.float32))
+        host_noise = self.noise_source == "host"
+        seed = self.device_noise_seed
+
+        def batch_noise(stream_id):
+            if host_noise:
+                return to_canvas(torch.randn(b, 3, s_, s_).to(dev, non_blocking=True))
+            return eng.randn_(torch.empty(1, 3, b * s_, s_, device=dev), seed, stream_id)
+
+        def start(eng_):
+            if generation_start_steps > 0:                               # get_noised_images: the CONSTRUCTOR's schedule
+                img = torch.empty(1, 3, b * s_, s_, device=dev)
+                sig = float(self.sample_schedule(self.num_sample_steps)[generation_start_steps])
+                eng_.sampler_q_start(cond01, batch_noise(1), 1.0, sig, img, seed)
+                return img
+            if zero_init:
+                return torch.zeros(1, 3, b * s_, s_, device=dev)
+            return batch_noise(1) * sigma0
+        return eng, b, s_, dev, geo, tiles, cond01, to_canvas, from_canvas, batch_noise, start, host_noise, seed
+
+    @staticmethod
+    def _guidance(i, cond_scale, guidance_start_steps, class_cond_scale, class_guidance_start_steps):
+        cur_cond_scale = 1.0 if i < guidance_start_steps else cond_scale
+        cur_class_scale = 1.0 if i < class_guidance_start_steps else class_cond_scale
+        if cur_cond_scale != 1.0:
+            return 2, 2, cur_cond_scale
+        if cur_class_scale != 1.0:
+            return 2, 1, cur_class_scale
+        return 1, 0, 1.0
+
+    @torch.inference_mode()
+    def sample_org(self, batch_size=16, condition_x=None, class_label=None, cond_scale=1.0, guidance_start_steps=0,
+                   class_cond_scale=1.0, class_guidance_start_steps=0, generation_start_steps=0, num_sample_steps=None,
+                   clamp=True, with_images=False, with_x0_images=False, zero_init=False, precision=None):
+        """Reference model.py:2212-2306 (stochastic Heun, two network evaluations per step) on the tiled EDM machinery:
+        the same per-step arithmetic as ``tiled_sample`` with one tile per image, per-image noise and no ring."""
+        n = self.num_sample_steps if num_sample_steps is None else num_sample_steps
+        sigmas, _, scalars, c_noise = self._step_tables(n, clamp)
+        (eng, b, s_, dev, geo, tiles, cond01, to_canvas, from_canvas, batch_noise, start, host_noise,
+         seed) = self._untiled_setup(batch_size, condition_x, class_label, cond_scale, class_cond_scale,
+                                     generation_start_steps, zero_init, float(sigmas[0]), precision)
+        cond_canvas = torch.empty(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
+        eng.edm_begin(geo, cond01, cond_canvas, tiles, tiles, scalars, c_noise, _single_class_id(class_label))
+        img = start(eng)
+        x_start = img.clone() if with_x0_images else None
+        image_list = [from_canvas(img).cpu()] if with_images else None
+        x0_image_list = [from_canvas(img).cpu()] if with_x0_images else None
+        work = torch.empty(2, 1, 3, b * s_, s_, device=dev, dtype=torch.float32)
+        for i in range(n):
+            if i < generation_start_steps:
+                continue
+            passes, kind, scale = self._guidance(i, cond_scale, guidance_start_steps, class_cond_scale,
+                                                 class_guidance_start_steps)
+            z = batch_noise(None) if host_noise else None               # eps of the step (:2269)
+            # the ring of this geometry is empty (inner area = the whole canvas): no second draw on odd steps
+            eng.edm_step(i, img, cond_canvas, x_start, work, z, None, passes, kind, scale, self.max_tiles_per_launch or b,
+                         seed=seed)
+            if with_images:
+                image_list.append(from_canvas(img).cpu())
+            if with_x0_images:
+                x0_image_list.append(from_canvas(x_start).cpu())
+        out = torch.empty(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
+        eng.sampler_end(img, out)
+        out = from_canvas(out)
+        if with_images:
+            return (out, image_list, x0_image_list) if with_x0_images else (out, image_list)
+        return out
+
+    @torch.inference_mode()
+    def sample_using_dpmpp(self, batch_size=16, condition_x=None, class_label=None, cond_scale=1.0, guidance_start_steps=0,
+                           class_cond_scale=1.0, class_guidance_start_steps=0, generation_start_steps=0,
+                           num_sample_steps=None, clamp=True, with_images=False, with_x0_images=False, zero_init=False,
+                           precision=None):
+        """Reference model.py:2479-2557: DPM-Solver++(2M) in t = -log sigma, one network evaluation per step
+        (``srgd_edm_dpmpp_step``); deterministic after the start canvas."""
+        n = self.num_sample_steps if num_sample_steps is None else num_sample_steps
+        sigmas, scalars, c_noise = self._dpmpp_tables(n, clamp)
+        t_fn = lambda sigma: sigma.log().neg()
+        for i in range(n):                                               # :2533-2538; old_denoised is None on the first
+            first = i == max(generation_start_steps, 0)                  # executed step, the multistep term is dropped on the last
+            if not first and sigmas[i + 1] != 0 and i > 0:
+                t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+                r = (t - t_fn(sigmas[i - 1])) / (t_next - t)
+                scalars[i].dpm_gamma = float(-1 / (2 * r))
+        (eng, b, s_, dev, geo, tiles, cond01, to_canvas, from_canvas, batch_noise, start, host_noise,
+         seed) = self._untiled_setup(batch_size, condition_x, class_label, cond_scale, class_cond_scale,
+                                     generation_start_steps, zero_init, float(sigmas[0]), precision)
+        cond_canvas = torch.empty(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
+        eng.edm_begin(geo, cond01, cond_canvas, tiles, tiles, scalars, c_noise, _single_class_id(class_label))
+        img = start(eng)
+        x_start = img.clone() if with_x0_images else None
+        image_list = [from_canvas(img).cpu()] if with_images else None
+        x0_image_list = [from_canvas(img).cpu()] if with_x0_images else None
+        old = torch.zeros(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
+        for i in range(n):
+            if i < generation_start_steps:
+                continue
+            passes, kind, scale = self._guidance(i, cond_scale, guidance_start_steps, class_cond_scale,
+                                                 class_guidance_start_steps)
+            eng.edm_dpmpp_step(i, img, cond_canvas, x_start, old, passes, kind, scale, self.max_tiles_per_launch or b)
+            if with_images:
+                image_list.append(from_canvas(img).cpu())
+            if with_x0_images:
+                x0_image_list.append(from_canvas(x_start).cpu())
+        out = torch.empty(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
+        eng.sampler_end(img, out)
+        out = from_canvas(out)
+        if with_images:
+            return (out, image_list, x0_image_list) if with_x0_images else (out, image_list)
+        return out
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError("training is not part of the inference-only release this engine mirrors")

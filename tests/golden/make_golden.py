@@ -141,6 +141,34 @@ def make_edm(only=None):
         print("edm", case["name"], "done", tuple(img.shape), float(img.mean()))
 
 
+def make_edm_untiled(only=None):
+    """Un-tiled EDM fixtures: ``sample`` dispatching to sample_org / sample_using_dpmpp (model.py:2196-2209)."""
+    ref = refshim.load_reference()
+    assert ref is not None, "reference not present"
+    rm, rc = ref
+    torch.set_num_threads(8)
+    for case in C.EDM_UNTILED_CASES:
+        if only and case["name"] not in only:
+            continue
+        sampler, _ = refshim.build_reference_sampler(rm, rc, dim=case["dim"],
+                                                     num_sample_steps=case.get("ctor_steps", case["steps"]),
+                                                     model="conditional_elucidated")
+        sampler.use_dpmpp_solver = case["dpmpp"]         # the constructor argument's attribute (model.py:2126), read at :2200
+        schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+        sd = synth_state_dict(schema, seed=case["weight_seed"])
+        sampler.load_state_dict(sd, strict=True)
+        cond = C.sample_condition(case)
+        label = torch.tensor([case["label"]])
+        torch.manual_seed(case["seed"])
+        with torch.inference_mode():
+            img = sampler.sample(batch_size=case["batch"], condition_x=cond.clone(), class_label=label,
+                                 cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
+                                 num_sample_steps=case["steps"], **C.edm_extra_kwargs(case))
+        np.savez_compressed(os.path.join(HERE, f"sample_edm_untiled_{case['name']}.npz"), image=img.numpy(),
+                            cond_sum=np.float64(cond.double().sum().item()))
+        print("edm un-tiled", case["name"], "done", tuple(img.shape), float(img.mean()))
+
+
 def make_modules():
     """G3: per-module outputs of the reference U-Net's own sub-modules."""
     ref = refshim.load_reference()
@@ -233,8 +261,11 @@ if __name__ == "__main__":
         main(only={"dim16_300x300_lrcfg"})
     elif "--edm-only" in sys.argv:
         make_edm()
+    elif "--edm-untiled-only" in sys.argv:
+        make_edm_untiled()
     else:
         main()
         make_edm()
         make_modules()
         make_sample()
+        make_edm_untiled()

@@ -94,6 +94,7 @@ def test_misuse_returns_errors_and_engine_stays_usable():
     assert "tile range" in _err(L, L.srgd_sampler_step_tiles(h, 0, 1, 1, 1, p_img, p_cc, None, None, None, 1, 0, 1.0, 4, 0, st))
     assert "tile range" in _err(L, L.srgd_sampler_exchange_tiles(h, 0, 0, 2, p_img, p_img, 0, st))
     assert _err(L, L.srgd_edm_step(h, 0, p_img, p_cc, None, p_img, None, None, 1, 0, 1.0, 4, 0, st))      # DDPM run active, not EDM
+    assert "srgd_edm_begin" in _err(L, L.srgd_edm_dpmpp_step(h, 0, p_img, p_cc, None, p_img, 1, 0, 1.0, 4, st))
     # ... and the engine still works: one valid step and the end of the run
     assert L.srgd_sampler_step(h, 0, p_img, p_cc, None, None, None, 1, 0, 1.0, 4, 1, st) == 0, L.srgd_last_error()
     out = torch.empty(1, 3, 256, 256, device="cuda")

@@ -400,6 +400,43 @@ def test_edm_tiled_sample_fp32_matches_reference(case):
     assert err <= 3e-4, err                 # regression guard
 
 
+@pytest.mark.parametrize("case", C.EDM_UNTILED_CASES, ids=lambda c: c["name"])
+def test_edm_untiled_sample_fp32_matches_reference(case):
+    # ConditionalElucidatedDiffusionSR.sample (model.py:2196-2209): the Heun loop sample_org (:2212-2306) or, with
+    # use_dpmpp_solver, sample_using_dpmpp (:2479-2557, srgd_edm_dpmpp_step); [B,3,256,256] batches, per-image noise
+    z = np.load(os.path.join(G, f"sample_edm_untiled_{case['name']}.npz"))
+    sampler = build_edm_sampler(case["dim"], weight_seed=case["weight_seed"])
+    cond = C.sample_condition(case).cuda()
+    assert abs(cond.double().sum().item() - float(z["cond_sum"])) < 1e-6
+    label = torch.tensor([case["label"]]).cuda()
+    ctor_steps, ctor_solver = sampler.num_sample_steps, sampler.use_dpmpp_solver
+    torch.manual_seed(case["seed"])
+    try:
+        sampler.num_sample_steps = case.get("ctor_steps", case["steps"])
+        sampler.use_dpmpp_solver = case["dpmpp"]
+        got, imgs, x0s = sampler.sample(batch_size=case["batch"], condition_x=cond, class_label=label,
+                                        cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
+                                        num_sample_steps=case["steps"], precision="fp32", with_images=True,
+                                        with_x0_images=True, **C.edm_extra_kwargs(case))
+        if case.get("generation_start_steps", 0) == 0:
+            # get_noised_images broadcasts a [B] sigma vector against [B,3,h,w] (model.py:2191-2193): B = 3 fails upstream
+            with pytest.raises(RuntimeError):
+                sampler.sample(batch_size=3, condition_x=torch.rand(3, 3, 256, 256).cuda(), class_label=label,
+                               num_sample_steps=case["steps"], generation_start_steps=1)
+    finally:
+        sampler.num_sample_steps, sampler.use_dpmpp_solver = ctor_steps, ctor_solver
+    got = got.cpu()
+    want = torch.from_numpy(z["image"])
+    err = (got - want).abs().max().item()
+    _report(test="edm_untiled_sample", case=case["name"], precision="fp32", max_abs=err)
+    assert got.shape == want.shape
+    assert err <= 1e-3 and err <= 3e-4, err
+    executed = case["steps"] - case.get("generation_start_steps", 0)
+    assert len(imgs) == len(x0s) == executed + 1 and imgs[-1].shape == want.shape
+    # the last trajectory entry is the un-clamped final image (model.py:2291 / :2545 before :2298 / :2549)
+    assert ((imgs[-1].clamp(-1, 1) + 1) * 0.5 - got).abs().max().item() <= 1e-6
+
+
 def test_edm_bf16_and_device_noise_modes_run():
     case = C.EDM_CASES[0]
     z = np.load(os.path.join(G, f"sample_edm_{case['name']}.npz"))

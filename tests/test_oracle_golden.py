@@ -205,3 +205,21 @@ def test_untiled_sample_matches_reference(case):
                        class_cond_scale=case["class_cond_scale"], **C.sample_extra_kwargs(case))
     assert got.shape == z["image"].shape
     assert np.abs(got.numpy() - z["image"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("case", C.EDM_UNTILED_CASES, ids=lambda c: c["name"])
+def test_edm_untiled_sample_matches_reference(case):
+    # sample -> sample_org (Heun, model.py:2212-2306) / sample_using_dpmpp (DPM-Solver++(2M), :2479-2557)
+    z = np.load(os.path.join(G, f"sample_edm_untiled_{case['name']}.npz"))
+    sd = _edm_state_dict(case["dim"], case["weight_seed"])
+    usd = {k[len("net."):]: v for k, v in sd.items()}
+    cond = C.sample_condition(case)
+    assert abs(cond.double().sum().item() - float(z["cond_sum"])) < 1e-6
+    fn = O.edm_sample_dpmpp if case["dpmpp"] else O.edm_sample
+    torch.manual_seed(case["seed"])
+    with torch.inference_mode():
+        got = fn(usd, O.UnetCfg(dim=case["dim"]), O.EdmCfg(num_sample_steps=case.get("ctor_steps", case["steps"])), cond,
+                 torch.tensor([case["label"]]), num_sample_steps=case["steps"], cond_scale=case["cond_scale"],
+                 class_cond_scale=case["class_cond_scale"], **C.edm_extra_kwargs(case))
+    assert got.shape == z["image"].shape
+    assert np.abs(got.numpy() - z["image"]).max() <= 1e-4
