@@ -134,7 +134,7 @@ struct AttnW {
   int ngi = -1, ogi = -1;
   float *norm_g = nullptr, *out_g = nullptr;
   ConvW qkv, out;
-  // fused LinearAttention block operands (bf16, C = 128): see linattn_fused.hip
+  // fused LinearAttention block operands (bf16, C = 128 / 256): see linattn_fused.hip, linattn_fused256.hip
   void *f_wkv = nullptr, *f_wq = nullptr, *f_wout = nullptr;
   float* f_g2 = nullptr;
 };
@@ -250,6 +250,7 @@ struct srgd_engine {
   bool w8 = false;            // SRGD_PRECISION_BF16_W8: conv weights rounded through fp8 e4m3 (per-output-channel scale)
   bool no_gn_fusion = true;
   int gn_fusion_max_ntiles = 1 << 30;   // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile)
+  bool no_la256 = false;      // SRGD_LA256=0: the C = 256 LinearAttention sites run the unfused chain (A/B switch)
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
   unsigned fp8_bf16_zones = 0;   // SRGD_FP8_BF16_ZONES (bit mask over Ctx::zone): zones whose 3x3 convs stay bf16 in fp8 mode (study knob)
   bool no_twin_fusion = false;   // SRGD_Q_FUSED=0: fp8 mode quantises every conv input in a separate pass (A/B + bit-equality test)
@@ -492,7 +493,7 @@ int pack_attn(srgd_engine* e, AttnW& a) {
   if (a.ogi >= 0) SRGD_TRY(upload_f32(e, a.ogi, &a.out_g));
   SRGD_TRY(pack_conv(e, a.qkv));
   SRGD_TRY(pack_conv(e, a.out));
-  if (!a.full && e->bf16 && a.C == 128 && e->cfg.heads == 4 && e->cfg.dim_head == 32) {
+  if (!a.full && e->bf16 && (a.C == 128 || (a.C == 256 && !e->no_la256)) && e->cfg.heads == 4 && e->cfg.dim_head == 32) {
     std::vector<unsigned short> wkv, wq, wo;
     linattn_fused_pack(e->wt[a.qkv.wi].data.data(), e->wt[a.ngi].data.data(), e->wt[a.out.wi].data.data(), a.C, wkv, wq, wo);
     SRGD_TRY(upload(e, wkv.data(), wkv.size() * 2, &a.f_wkv));
@@ -735,7 +736,7 @@ int attn_block(Ctx& x, const AttnW& a, const void* in, void** out, bool want_twi
     if (linattn_fused_workspace(x.nb, hw) / sizeof(float) > e->la_ws_cap) SRGD_FAIL("internal: fused attention workspace too small");
     QTensor tw;
     if (twin_wanted(e, want_twin, a.C)) SRGD_TRY(twin_alloc(e, (size_t)npix, a.C, &tw));
-    SRGD_TRY(linattn_fused(in, y, x.nb, hw, a.f_wkv, a.f_wq, a.f_wout, a.out.bias, a.f_g2, e->la_ws, x.st, tw.q, tw.s));
+    SRGD_TRY(linattn_fused(in, y, x.nb, hw, a.C, a.f_wkv, a.f_wq, a.f_wout, a.out.bias, a.f_g2, e->la_ws, x.st, tw.q, tw.s));
     if (tw.q) twin_register(e, y, tw);
     *out = y;
     return 0;
@@ -984,6 +985,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   if (const char* v = getenv("SRGD_GN_FUSION_NTILES")) e->gn_fusion_max_ntiles = atoi(v);
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
+  if (const char* v = getenv("SRGD_LA256")) e->no_la256 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_Q_FUSED")) e->no_twin_fusion = atoi(v) == 0;
   if (const char* v = getenv("SRGD_FP8_BF16_ZONES")) e->fp8_bf16_zones = (unsigned)strtoul(v, nullptr, 0);
   *out = e.release();

@@ -137,7 +137,7 @@ int srgd_k_linattn_block_fused(const void* x, void* y, int B, int N, int C, cons
                                const float* norm_g_host, const float* to_out_w_host, const float* to_out_b_host,
                                const float* out_g_host, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (!linattn_fused_eligible(C, 4, 32, N, true)) SRGD_FAIL("linattn_block_fused: needs C = 128, N % 64 == 0");
+  if (!linattn_fused_eligible(C, 4, 32, N, true)) SRGD_FAIL("linattn_block_fused: needs C = 128 or 256, N % 64 == 0");
   std::vector<unsigned short> wkv, wq, wo;
   linattn_fused_pack(to_qkv_host, norm_g_host, to_out_w_host, C, wkv, wq, wo);
   std::vector<float> g2(C);
@@ -150,7 +150,7 @@ int srgd_k_linattn_block_fused(const void* x, void* y, int B, int N, int C, cons
   SRGD_HIP(hipMemcpy(dout.p, wo.data(), wo.size() * 2, hipMemcpyHostToDevice));
   SRGD_HIP(hipMemcpy(db.p, to_out_b_host, C * 4, hipMemcpyHostToDevice));
   SRGD_HIP(hipMemcpy(dg.p, g2.data(), C * 4, hipMemcpyHostToDevice));
-  SRGD_TRY(linattn_fused(x, y, B, N, dkv.p, dq.p, dout.p, (const float*)db.p, (const float*)dg.p, (float*)ws.p, st));
+  SRGD_TRY(linattn_fused(x, y, B, N, C, dkv.p, dq.p, dout.p, (const float*)db.p, (const float*)dg.p, (float*)ws.p, st));
   SRGD_HIP(hipStreamSynchronize(st));
   return 0;
 }

@@ -1,4 +1,4 @@
-// Fused LinearAttention block for gfx950 (bf16 mode, C = 128, 4 heads x 32): the whole of reference
+// Fused LinearAttention block for gfx950 (bf16 mode, C = 128, 4 heads x 32; C = 256: linattn_fused256.hip): the whole of reference
 // model.py:306-324 -
 //     RMSNorm -> to_qkv (1x1) -> q softmax over d / k softmax over ALL positions -> context -> out ->
 //     to_out (1x1 + bias) -> RMSNorm -> (+ x, model.py:703)
@@ -408,6 +408,7 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
 }  // namespace
 
 bool linattn_fused_eligible(int C, int heads, int dh, int N, bool is_bf16) {
+  if (C == 256) return linattn_fused256_eligible(heads, dh, N, is_bf16);
   return is_bf16 && C == 128 && heads == 4 && dh == 32 && N % TM == 0 && (size_t)N * 256 < (1ull << 31);
 }
 
@@ -424,6 +425,7 @@ size_t linattn_fused_workspace(int B, int N) {
 void linattn_fused_pack(const float* to_qkv /*[384][C]*/, const float* norm_g /*[C]*/, const float* to_out /*[C][128]*/,
                         int C, std::vector<unsigned short>& wkv_img, std::vector<unsigned short>& wq,
                         std::vector<unsigned short>& wout) {
+  if (C == 256) return linattn_fused256_pack(to_qkv, norm_g, to_out, wkv_img, wq, wout);
   const float sq = sqrtf((float)C);
   wkv_img.assign(256 * 128, 0);
   wq.assign(128 * 128, 0);
@@ -440,7 +442,7 @@ void linattn_fused_pack(const float* to_qkv /*[384][C]*/, const float* norm_g /*
     for (int k = 0; k < 128; ++k) wout[c * 128 + k] = f32_to_bf16_host(to_out[(size_t)c * 128 + k]);
 }
 
-int linattn_fused(const void* x, void* y, int B, int N, const void* wkv_img, const void* wq, const void* wout,
+int linattn_fused(const void* x, void* y, int B, int N, int C, const void* wkv_img, const void* wq, const void* wout,
                   const float* bout, const float* g2_scaled, float* ws, hipStream_t st, void* y_q, void* y_s) {
   const int strip = la1_strip(N);
   const int nstrips = cdiv(N, strip);
@@ -451,6 +453,9 @@ int linattn_fused(const void* x, void* y, int B, int N, const void* wkv_img, con
   float* pctx = pl + bh * nch * 32;
   float* ctxn = pctx + bh * nch * 1024;
   float* rinv = ctxn + bh * 1024;
+  if (C == 256)
+    return linattn_fused256(x, y, B, N, wkv_img, wq, wout, bout, g2_scaled, pm, pl, pctx, ctxn, rinv, strip, st, y_q, y_s);
+  if (C != 128) SRGD_FAIL("linattn_fused: C must be 128 or 256");
   static bool attr[64] = {};
   const int lds1 = RING * TILE_BYTES + 2 * TM * 4;
   const int lds2 = (RING + 1) * TILE_BYTES + 4 * TM * 4 + RING * 4 * TM * 4;

@@ -308,14 +308,14 @@ def test_conv3x3_bf16_integer_exact():
     assert torch.equal(got, F.conv2d(x, w, b, padding=1).to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("cfg", [(1, 16, 16), (2, 32, 64), (1, 128, 128)], ids=lambda s: "B%d_%dx%d" % s)
-def test_linear_attention_block_fused(cfg):
-    # linattn_fused.hip: RMSNorm -> qkv -> linear attention -> to_out -> RMSNorm -> + x in two kernels,
-    # against the oracle's LinearAttention block on bf16-rounded inputs/weights.
+@pytest.mark.parametrize("C", [128, 256])
+@pytest.mark.parametrize("cfg", [(1, 16, 16), (2, 32, 64), (1, 128, 128), (3, 8, 8)], ids=lambda s: "B%d_%dx%d" % s)
+def test_linear_attention_block_fused(cfg, C):
+    # linattn_fused.hip (C = 128) / linattn_fused256.hip (C = 256): RMSNorm -> qkv -> linear attention -> to_out ->
+    # RMSNorm -> + x in two kernels, against the oracle's LinearAttention block on bf16-rounded inputs/weights.
     B, H, W = cfg
     lib = L().lib()
     g = torch.Generator().manual_seed(21)
-    C = 128
     x = rnd(torch.randn(B, C, H, W, generator=g) * 1.5, True)
     sd = {"a.norm.g": 1 + 0.1 * torch.randn(1, C, 1, 1, generator=g),
           "a.to_qkv.weight": torch.randn(384, C, 1, 1, generator=g) / C ** 0.5,
