@@ -64,6 +64,21 @@ template <bool PRECISE> __device__ __forceinline__ float silu(float x) {
   return x * __frcp_rn(1.0f + __expf(-x));
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane of the row: two quad permutes, then
+// row_half_mirror and row_mirror (after the quad steps a quad is uniform, so the mirrors fetch "the other quad / half").
+// VALU-only - 4 DPP moves instead of 4 ds_bpermute round trips through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);    // row_half_mirror
+  v += dpp_move<0x140>(v);    // row_mirror
+  return v;
+}
+
 // OCP MX-fp8 quantisation of 8 consecutive channels held by this lane; lanes (lane & ~3) .. (lane | 3) hold one 32-channel
 // block and must all be active.  Returns the 8 e4m3 bytes; *scale_byte = E8M0 shared exponent of the block
 // (floor(log2 max|y|) - 8 + 127).  Same arithmetic in every kernel that writes MX-fp8 (quant_mxfp8.hip and the fused

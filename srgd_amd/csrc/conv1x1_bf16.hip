@@ -37,7 +37,7 @@ __device__ __forceinline__ void dma16_1(__amdgpu_buffer_rsrc_t rsrc, char* lds_w
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 
-enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GNTAIL = 2, EPI_PS_SILU = 3 };
+enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GNTAIL = 2, EPI_PS_SILU = 3, EPI_GNTAIL_FINAL = 4 };
 
 struct Conv1Args {
   const bf16* in0; const bf16* in1; int C0, C1;
@@ -53,6 +53,7 @@ struct Conv1Args {
   const bf16* aux;        // EPI_RESIDUAL: tensor added to the output; EPI_GNTAIL: tensor the GroupNorm tail is applied to
   const float* gn_a; const float* gn_b;   // EPI_GNTAIL: [B][Cout] scale / shift
   unsigned char* oq; unsigned char* os;   // optional MX-fp8 twin of the output (ConvArgs::out_q / out_s)
+  float* eps4; const float* fin_w; const float* fin_b;   // EPI_GNTAIL_FINAL (ConvArgs::eps4)
 };
 
 __device__ __forceinline__ int row_swz1(int row) { return (row >> 1) & 3; }
@@ -202,6 +203,17 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
     ps_c0 = col0 - ps_ij * CoutPS;
   }
   obase = (size_t)m0 * p.Cout + col0;
+  // EPI_GNTAIL_FINAL: this lane's 8 channels (c16 = tid & 15 in every iteration) of the three output-convolution rows (the
+  // 16 lanes of a DPP row share a pixel; fp32 sums in a different order than out_conv3_coop's: equal to rounding)
+  float fw0[8], fw1[8], fw2[8];
+  if (EPI == EPI_GNTAIL_FINAL) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      fw0[e] = p.fin_w[(tid & 15) * 8 + e];
+      fw1[e] = p.fin_w[BN1 + (tid & 15) * 8 + e];
+      fw2[e] = p.fin_w[2 * BN1 + (tid & 15) * 8 + e];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < (BM1 * 16) / NT1; ++i) {
     const int q = tid + NT1 * i;
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
         const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.aux + o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rr[e]);
-      } else if (EPI == EPI_GNTAIL) {
+      } else if (EPI == EPI_GNTAIL || EPI == EPI_GNTAIL_FINAL) {
         const bf16x8 hh = *reinterpret_cast<const bf16x8*>(p.aux + o);
         const float* ga = p.gn_a + (size_t)b * p.Cout + col0 + c16 * 8;
         const float* gb = p.gn_b + (size_t)b * p.Cout + col0 + c16 * 8;
@@ -231,6 +243,22 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
           const float ca = e < 4 ? a_lo[e & 3] : a_hi[e & 3], cb = e < 4 ? b_lo[e & 3] : b_hi[e & 3];
           v[e] = (bf16)(silu<false>(ca * (float)hh[e] + cb) + (float)v[e]);
         }
+      }
+      if (EPI == EPI_GNTAIL_FINAL) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xv = (float)v[e];
+          s0 += xv * fw0[e];
+          s1 += xv * fw1[e];
+          s2 += xv * fw2[e];
+        }
+        s0 = row16_sum(s0);
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if (c16 == 0)
+          *reinterpret_cast<f32x4*>(p.eps4 + ((size_t)m0 + pix) * 4) = f32x4{s0 + p.fin_b[0], s1 + p.fin_b[1], s2 + p.fin_b[2], 0.f};
+        continue;
       }
       *reinterpret_cast<bf16x8*>(p.out + o) = v;
       if (p.oq) mx_store_twin(v, p.oq, p.os, o, tid & 3);
@@ -253,6 +281,7 @@ bool conv1x1_bf16_eligible(const ConvArgs& a) {
   if (a.mode == CONV_PIXEL_SHUFFLE_SILU && ((a.Cout / 4) % BN1 || a.residual || a.gn_res_src)) return false;
   if (a.mode != CONV_PLAIN && a.mode != CONV_PIXEL_SHUFFLE_SILU) return false;
   if (a.residual && a.gn_res_src) return false;
+  if (a.eps4 && (!a.gn_res_src || a.Cout != BN1 || !a.fin_w || !a.fin_b || a.out_q)) return false;
   if ((size_t)a.Hin * a.Win * (size_t)std::max(a.ps0, a.ps1) * 2 >= (1ull << 31)) return false;
   if ((size_t)a.KH * a.KW * ((a.C0 + a.C1) / KC1) * (a.Cout / BN1) * B1_BYTES >= (1ull << 31)) return false;
   return true;
@@ -289,6 +318,7 @@ int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st) {
   p.aux = a.gn_res_src ? (const bf16*)a.gn_res_src : (const bf16*)a.residual;
   p.gn_a = a.gn_res_a; p.gn_b = a.gn_res_b;
   p.oq = (unsigned char*)a.out_q; p.os = (unsigned char*)a.out_s;
+  p.eps4 = a.eps4; p.fin_w = a.fin_w; p.fin_b = a.fin_b;
   if ((p.oq != nullptr) != (p.os != nullptr)) SRGD_FAIL("conv1x1_bf16: MX-fp8 twin needs both the element and the scale buffer");
   const long m_tiles = (long)a.B * a.Hout * a.Wout / BM1;
   const long grid = m_tiles * (a.Cout / BN1);
@@ -298,11 +328,12 @@ int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st) {
 #define SRGD_SET1(E_)                                                                                   \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bf16_kernel<E_>),                 \
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));
-    SRGD_SET1(EPI_PLAIN) SRGD_SET1(EPI_RESIDUAL) SRGD_SET1(EPI_GNTAIL) SRGD_SET1(EPI_PS_SILU)
+    SRGD_SET1(EPI_PLAIN) SRGD_SET1(EPI_RESIDUAL) SRGD_SET1(EPI_GNTAIL) SRGD_SET1(EPI_PS_SILU) SRGD_SET1(EPI_GNTAIL_FINAL)
 #undef SRGD_SET1
   }
 #define SRGD_GO1(E_) hipLaunchKernelGGL((conv1x1_bf16_kernel<E_>), dim3((unsigned)grid), dim3(NT1), LDS1_BYTES, st, p)
   if (a.mode == CONV_PIXEL_SHUFFLE_SILU) SRGD_GO1(EPI_PS_SILU);
+  else if (a.gn_res_src && a.eps4) SRGD_GO1(EPI_GNTAIL_FINAL);
   else if (a.gn_res_src) SRGD_GO1(EPI_GNTAIL);
   else if (a.residual) SRGD_GO1(EPI_RESIDUAL);
   else SRGD_GO1(EPI_PLAIN);

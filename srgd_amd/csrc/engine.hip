@@ -250,6 +250,7 @@ struct srgd_engine {
   bool w8 = false;            // SRGD_PRECISION_BF16_W8: conv weights rounded through fp8 e4m3 (per-output-channel scale)
   bool no_gn_fusion = true;
   int gn_fusion_max_ntiles = 1 << 30;   // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile)
+  bool no_final_fusion = false;   // SRGD_FINAL_FUSION=0: the last ResnetBlock stores its output and final_step applies the 1x1 (A/B switch)
   bool no_la256 = false;      // SRGD_LA256=0: the C = 256 LinearAttention sites run the unfused chain (A/B switch)
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
   unsigned fp8_bf16_zones = 0;   // SRGD_FP8_BF16_ZONES (bit mask over Ctx::zone): zones whose 3x3 convs stay bf16 in fp8 mode (study knob)
@@ -529,6 +530,10 @@ struct Ctx {
   const int* step_ptr = nullptr;   // sampler: device step counter (row += *step_ptr * step_mul)
   int step_mul = 2;                // conditioning rows per step: 2 (DDPM: label / no label), 4 (EDM: x {sigma_hat, sigma_next})
   int zone = 0;                    // U-Net zone being evaluated: 0..n-1 down stages, n middle, n+1..2n up stages, 2n+1 final block
+  // Sampler steps: a [nb*H*W][4] fp32 buffer the last ResnetBlock's epilogue may fill with the 1x1 output convolution of its
+  // result (ConvArgs::eps4) instead of storing the block output; eps4_done tells the caller whether that happened.
+  float* eps4 = nullptr;
+  bool eps4_done = false;
 };
 
 // gn_in: the input is a raw conv output whose GroupNorm+SiLU (coefA/coefB) the fast 3x3 kernel applies while
@@ -557,7 +562,8 @@ int twin_alloc(srgd_engine* e, size_t npix, int C, QTensor* t) {
 void twin_register(srgd_engine* e, const void* bf16_buf, const QTensor& t) { e->pool.twins[bf16_buf] = {t.q, t.s}; }
 
 int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, int C1, int Hin, int Win, void* out,
-             const void* residual, bool stats, bool gn_in = false, const void* gn_res_src = nullptr, bool want_twin = false) {
+             const void* residual, bool stats, bool gn_in = false, const void* gn_res_src = nullptr, bool want_twin = false,
+             float* eps4 = nullptr) {
   srgd_engine* e = x.e;
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.ps0 = C0; a.ps1 = C1;
@@ -573,6 +579,11 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
   if (C0 + C1 != c.Cin) SRGD_FAIL("internal: conv input channel mismatch");
   const bool fast = e->bf16 && c.w3 && !e->force_generic_conv && conv3x3_bf16_eligible(a);
   const bool fast1 = !fast && e->bf16 && c.w1 && !e->force_generic_conv && !e->no_conv1x1 && !stats && conv1x1_bf16_eligible(a);
+  if (eps4 && fast1 && !e->no_final_fusion && gn_res_src && c.Cout == 128 && !twin_wanted(e, want_twin, c.Cout)) {
+    a.eps4 = eps4; a.fin_w = e->final_w; a.fin_b = e->final_b;
+    if (conv1x1_bf16_eligible(a)) x.eps4_done = true;
+    else a.eps4 = nullptr;
+  }
   const int fam = fast ? KC_CONV3 : fast1 ? KC_CONV1 : KC_CONV;
   Prof p(e, fam, x.st);
   if (e->prof_on)
@@ -684,7 +695,8 @@ int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_
 }
 
 // ResnetBlock (model.py:261-285); returns a pool buffer [nb,H,W,Cout]
-int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, int C1, void** out, bool want_twin = false) {
+int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, int C1, void** out, bool want_twin = false,
+              float* eps4 = nullptr) {
   srgd_engine* e = x.e;
   const int hw = x.H * x.W;
   const size_t bytes = (size_t)x.nb * hw * r.Cout * e->es;
@@ -711,7 +723,7 @@ int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, i
   if (r.has_res && e->bf16) {
     // GroupNorm2 + SiLU + (+ res_conv(x)) evaluated in the 1x1 res_conv's epilogue, in place over v
     SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, nullptr, true));
-    SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, v, nullptr, false, false, v, want_twin));
+    SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, v, nullptr, false, false, v, want_twin, eps4));
   } else if (r.has_res) {
     SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, u, nullptr, false));   // u is free again: reuse it
     SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, u));
@@ -883,7 +895,8 @@ int unet_body(Ctx& x, void* x0, void** out) {
   if (x.H != H0 || x.W != W0) SRGD_FAIL("internal: resolution bookkeeping");
   void* fin;
   x.zone = 2 * n + 1;
-  SRGD_TRY(res_block(x, e->final_rb, cur, e->dim, x0, e->dim, &fin));
+  x.eps4_done = false;
+  SRGD_TRY(res_block(x, e->final_rb, cur, e->dim, x0, e->dim, &fin, false, x.eps4));
   e->pool.put(cur);
   *out = fin;
   return 0;
@@ -986,6 +999,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_LA256")) e->no_la256 = atoi(v) == 0;
+  if (const char* v = getenv("SRGD_FINAL_FUSION")) e->no_final_fusion = atoi(v) == 0;
   if (const char* v = getenv("SRGD_Q_FUSED")) e->no_twin_fusion = atoi(v) == 0;
   if (const char* v = getenv("SRGD_FP8_BF16_ZONES")) e->fp8_bf16_zones = (unsigned)strtoul(v, nullptr, 0);
   *out = e.release();
@@ -1277,12 +1291,17 @@ static int edm_step_launch(srgd_engine* e, bool last, int parity, float* img, co
                          2 * ep + ((passes == 2 && guidance_kind == 1) ? row_null : row_label));
       Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st, e->d_step, 4};
       void* act = nullptr;
+      float* eps4 = (float*)e->pool.get((size_t)nb * g.tile * g.tile * 16);
+      if (!eps4) return -1;
+      x.eps4 = eps4;
       SRGD_TRY(unet_body(x, x0, &act));
       FinalStepArgs fa;
       fa.act = act; fa.C = e->dim; fa.passes = passes; fa.guidance = guidance_scale;
       fa.w = e->final_w; fa.bias = e->final_b; fa.img = img; fa.x_start = x_start; fa.noise = z;
       fa.sc = nullptr; fa.step_ptr = e->d_step;
+      fa.eps4 = x.eps4_done ? eps4 : nullptr;
       { Prof p(e, KC_FINAL, st); SRGD_TRY(final_step_edm(fa, e->d_edm, work, canvas_elems, ep, tb, e->bf16, st)); }
+      e->pool.put(eps4);
       e->pool.put(act);
       e->pool.put(x0);
     }
@@ -1383,12 +1402,17 @@ int srgd_edm_dpmpp_step(srgd_engine* e, int step, float* img, const float* cond_
                        (passes == 2 && guidance_kind == 1) ? row_null : row_label);
     Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st, e->d_step, 4};
     void* act = nullptr;
+    float* eps4 = (float*)e->pool.get((size_t)nb * g.tile * g.tile * 16);
+    if (!eps4) return -1;
+    x.eps4 = eps4;
     SRGD_TRY(unet_body(x, x0, &act));
     FinalStepArgs fa;
     fa.act = act; fa.C = e->dim; fa.passes = passes; fa.guidance = guidance_scale;
     fa.w = e->final_w; fa.bias = e->final_b; fa.img = img; fa.x_start = x_start; fa.noise = nullptr;
     fa.sc = nullptr; fa.step_ptr = e->d_step;
+    fa.eps4 = x.eps4_done ? eps4 : nullptr;
     { Prof p(e, KC_FINAL, st); SRGD_TRY(final_step_edm(fa, e->d_edm, old_denoised, canvas_elems, 2, tb, e->bf16, st)); }
+    e->pool.put(eps4);
     e->pool.put(act);
     e->pool.put(x0);
   }
@@ -1435,12 +1459,17 @@ static int sampler_step_launch(srgd_engine* e, bool last, int parity, int tile_f
                        (passes == 2 && guidance_kind == 1) ? row_null : row_label);
     Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st, e->d_step};
     void* act = nullptr;
+    float* eps4 = (float*)e->pool.get((size_t)nb * g.tile * g.tile * 16);
+    if (!eps4) return -1;
+    x.eps4 = eps4;
     SRGD_TRY(unet_body(x, x0, &act));
     FinalStepArgs fa;
     fa.act = act; fa.C = e->dim; fa.passes = passes; fa.guidance = guidance_scale;
     fa.w = e->final_w; fa.bias = e->final_b; fa.img = img; fa.x_start = x_start; fa.noise = nz;
     fa.sc = e->d_sc; fa.step_ptr = e->d_step;
+    fa.eps4 = x.eps4_done ? eps4 : nullptr;
     { Prof p(e, KC_FINAL, st); SRGD_TRY(final_step(fa, tb, e->bf16, st)); }
+    e->pool.put(eps4);
     e->pool.put(act);
     e->pool.put(x0);
   }

@@ -38,6 +38,13 @@ struct ConvArgs {
   // conv1x1_bf16 and conv3x3_mxfp8; identical to quant_mxfp8 of the stored bf16 values.
   void* out_q = nullptr;
   void* out_s = nullptr;
+  // optional, conv1x1_bf16 with the GroupNorm tail and Cout == 128 only (the last ResnetBlock of the U-Net): the block's
+  // output is consumed by the 1x1 output convolution alone (model.py:776-777), so the epilogue applies that convolution to
+  // the bf16 values it would have stored and writes eps4[pixel] = (e0, e1, e2, 0) instead of `out` (16 B instead of 256 B
+  // per pixel, and no second pass reading them back).  fin_w: [3][128] fp32, fin_b: [3].
+  float* eps4 = nullptr;
+  const float* fin_w = nullptr;
+  const float* fin_b = nullptr;
 };
 int conv_igemm(const ConvArgs& a, bool is_bf16, hipStream_t st);
 int conv_tile_m();
@@ -198,6 +205,7 @@ struct FinalStepArgs {
   float* img;              // canvas, updated in place
   float* x_start;          // optional canvas
   const float* noise;
+  const float* eps4 = nullptr;   // when set: the output convolution was already applied (ConvArgs::eps4); act / w / bias unused
   const StepScalars* sc;   // device pointer
   const int* step_ptr;     // optional device step counter indexing sc
 };

@@ -154,6 +154,16 @@ __global__ __launch_bounds__(256) void final_step_kernel(FinalStepArgs a, TileBa
   const long p0 = (long)blockIdx.x * 256;                 // per_tile % 256 == 0: the block stays inside one tile
   const int lane16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const T* act = reinterpret_cast<const T*>(a.act);
+  if (a.eps4) {                              // the output convolution ran in the last ResnetBlock's epilogue (ConvArgs::eps4)
+    f32x4 e = *reinterpret_cast<const f32x4*>(a.eps4 + (p0 + threadIdx.x) * 4);
+    if (a.passes == 2) {
+      const f32x4 n = *reinterpret_cast<const f32x4*>(a.eps4 + (p0 + threadIdx.x + per_tile * tb.ntiles) * 4);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) e[c] = n[c] + (e[c] - n[c]) * a.guidance;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) eps[c][threadIdx.x] = e[c];
+  } else {
 #pragma unroll 4
   for (int i = 0; i < 16; ++i) {
     const int q = i * 16 + grp;
@@ -166,6 +176,7 @@ __global__ __launch_bounds__(256) void final_step_kernel(FinalStepArgs a, TileBa
       for (int c = 0; c < 3; ++c) e[c] = n[c] + (e[c] - n[c]) * a.guidance;     // model.py:3150 / :3154
     }
     if (lane16 < 3) eps[lane16][q] = lane16 == 0 ? e[0] : (lane16 == 1 ? e[1] : e[2]);
+  }
   }
   __syncthreads();
   const long p = p0 + threadIdx.x;
@@ -201,6 +212,16 @@ __global__ __launch_bounds__(256) void final_step_edm_kernel(FinalStepArgs a, co
   const long p0 = (long)blockIdx.x * 256;
   const int lane16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const T* act = reinterpret_cast<const T*>(a.act);
+  if (a.eps4) {
+    f32x4 e = *reinterpret_cast<const f32x4*>(a.eps4 + (p0 + threadIdx.x) * 4);
+    if (a.passes == 2) {
+      const f32x4 n = *reinterpret_cast<const f32x4*>(a.eps4 + (p0 + threadIdx.x + per_tile * tb.ntiles) * 4);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) e[c] = n[c] + (e[c] - n[c]) * a.guidance;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) eps[c][threadIdx.x] = e[c];
+  } else {
 #pragma unroll 4
   for (int i = 0; i < 16; ++i) {
     const int q = i * 16 + grp;
@@ -215,6 +236,7 @@ __global__ __launch_bounds__(256) void final_step_edm_kernel(FinalStepArgs a, co
       for (int c = 0; c < 3; ++c) e[c] = n[c] + (e[c] - n[c]) * a.guidance;
     }
     if (lane16 < 3) eps[lane16][q] = lane16 == 0 ? e[0] : (lane16 == 1 ? e[1] : e[2]);
+  }
   }
   __syncthreads();
   const long p = p0 + threadIdx.x;

@@ -227,6 +227,49 @@ def test_hipgraph_replay_is_bitwise_identical_to_eager_launches():
     assert torch.equal(outs["1"], outs["0"])
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp8_mixed"])
+def test_output_conv_fused_into_last_resnet_block_matches_separate_pass(prec):
+    # dim 128: the last ResnetBlock's res_conv epilogue (conv1x1_bf16 EPI_GNTAIL_FINAL) applies the 1x1 output convolution to
+    # the bf16 values it would have stored and hands final_step 16 B per pixel (ConvArgs::eps4).  Same inputs, fp32 sums in a
+    # different order: after ONE step the predicted x0 agrees with the unfused run (SRGD_FINAL_FUSION=0) to fp32 rounding
+    # (x 1/alpha ~ 150 at t = 1); over several steps the bf16 U-Net amplifies that like any other rounding, so the images are
+    # compared by PSNR.  One pass, two passes (class CFG) and the EDM wrapper's Heun pair.
+    import os
+    sampler = build_sampler(128)
+    edm = build_edm_sampler(128)
+    cond = C.synthetic_lr_condition(4, 64, 64).cuda()            # 256x256: one tile
+    label = torch.tensor([1]).cuda()
+    outs = {}
+    try:
+        for smp in (sampler, edm):
+            smp.noise_source = "device"
+            smp.device_noise_seed = 9
+        for mode in ("1", "0"):
+            os.environ["SRGD_FINAL_FUSION"] = mode
+            sampler.model._invalidate_engines()
+            edm.net._invalidate_engines()
+            one = sampler.tiled_sample(batch_size=4, condition_x=cond, class_label=label, num_sample_steps=1, precision=prec,
+                                       with_images=True, with_x0_images=True)[2][-1]
+            outs[mode] = [one.cpu(),
+                          sampler.tiled_sample(batch_size=4, condition_x=cond, class_label=label, num_sample_steps=5, precision=prec).cpu(),
+                          sampler.tiled_sample(batch_size=4, condition_x=cond, class_label=label, num_sample_steps=5,
+                                               class_cond_scale=2.0, precision=prec).cpu(),
+                          edm.tiled_sample(batch_size=4, condition_x=cond, class_label=label, num_sample_steps=4, cond_scale=1.5,
+                                           precision=prec).cpu()]
+    finally:
+        os.environ.pop("SRGD_FINAL_FUSION", None)
+        sampler.model._invalidate_engines()
+        edm.net._invalidate_engines()
+        for smp in (sampler, edm):
+            smp.noise_source = "host"
+    d1 = (outs["1"][0] - outs["0"][0]).abs().max().item()
+    psnrs = [float(10 * np.log10(1.0 / max(float(((a - b) ** 2).mean()), 1e-20))) for a, b in zip(outs["1"][1:], outs["0"][1:])]
+    _report(test="output_conv_fused_vs_separate", precision=prec, x0_after_one_step_max_abs=d1, psnr_db=psnrs)
+    assert all(torch.isfinite(a).all() for a in outs["1"])
+    assert d1 <= 5e-4, d1                                        # measured 2.7e-5
+    assert min(psnrs) > 45.0, psnrs
+
+
 @pytest.mark.parametrize("noise,prec", [("host", "fp32"), ("device", "bf16")])
 def test_lockstep_images_equal_their_solo_runs(noise, prec):
     # [B,3,H,W] condition: B same-sized images advance together, every U-Net launch spanning tiles of all of them.
