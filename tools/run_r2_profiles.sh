@@ -3,12 +3,13 @@
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for MODE in bf16 fp8; do
-  EXTRA=""; [ $MODE = fp8 ] && EXTRA="--precision fp8 --ddpm_steps 100 --class_cond_scale 2.0"
+for MODE in bf16 fp8 fp8_mixed; do
+  EXTRA=""; [ $MODE != bf16 ] && EXTRA="--precision $MODE --ddpm_steps 100 --class_cond_scale 2.0"
   STEPS=5; [ $MODE = fp8 ] && STEPS=5
   rocprofv3 --kernel-trace --stats -d $O/kt_$MODE -o k -- python3 $R/bench.py --steps $STEPS --warmup 0 --no_cpu_baseline --no_profile $EXTRA > $O/kt_$MODE.log 2>&1
   python3 $R/tools/rocprof_db_stats.py $(find $O/kt_$MODE -name "*.db" | head -1) $O/${MODE}_kernel_stats.csv > $O/${MODE}_kernel_stats.txt
   rm -rf $O/kt_$MODE
+  [ $MODE = fp8_mixed ] && continue        # kernel-trace statistics only: its kernels are the bf16 and fp8 ones
   PMCX="--steps 5 --warmup 0 --no_cpu_baseline --no_profile --ddpm_steps 2"; [ $MODE = fp8 ] && PMCX="$PMCX --precision fp8"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf_$MODE -o f -- python3 $R/bench.py $PMCX > $O/pf_$MODE.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw_$MODE -o w -- python3 $R/bench.py $PMCX > $O/pw_$MODE.log 2>&1
@@ -18,4 +19,4 @@ for MODE in bf16 fp8; do
   python3 $R/tools/pmc_sq.py $(find $O/ps_$MODE -name "*.db" | head -1) $O/pmc_sq_$MODE.json > $O/pmc_sq_$MODE.txt
   rm -rf $O/ps_$MODE
 done
-cd $R; head -22 $O/bf16_kernel_stats.csv; head -16 $O/fp8_kernel_stats.csv; cat $O/pmc_traffic_bf16.txt $O/pmc_traffic_fp8.txt; cat $O/pmc_sq_bf16.txt $O/pmc_sq_fp8.txt | head -60
+cd $R; head -22 $O/bf16_kernel_stats.csv; head -16 $O/fp8_kernel_stats.csv; head -16 $O/fp8_mixed_kernel_stats.csv; cat $O/pmc_traffic_bf16.txt $O/pmc_traffic_fp8.txt; cat $O/pmc_sq_bf16.txt $O/pmc_sq_fp8.txt | head -60
