@@ -184,6 +184,15 @@ int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas
                   const float* noise_canvas, const float* ring_noise_canvas, int passes, int guidance_kind,
                   float guidance_scale, int sub_batch, uint64_t seed, void* stream);
 
+/* srgd_edm_step restricted to tiles [tile_first, tile_first + tile_count) of the step's grid (tile_count < 0: to the end) - the
+ * per-rank unit when one canvas is shared by several GPUs, as srgd_sampler_step_tiles is for the DDPM loop (reference tile loop
+ * model.py:2397-2452); do_ring = 0 skips the odd-step ring re-noise.  `work` is touched at those tiles only; exchange the updated
+ * tiles of img / x_start with srgd_sampler_exchange_tiles. */
+int srgd_edm_step_tiles(srgd_engine* e, int step, int tile_first, int tile_count, int do_ring, float* img,
+                        const float* cond_canvas, float* x_start, float* work, const float* noise_canvas,
+                        const float* ring_noise_canvas, int passes, int guidance_kind, float guidance_scale, int sub_batch,
+                        uint64_t seed, void* stream);
+
 /* One DPM-Solver++(2M) step of the EDM wrapper's un-tiled loop (reference sample_using_dpmpp, model.py:2517-2542) over
  * every tile of grid (step % 2), one network evaluation, no noise, no ring:
  *   den   = clamp(c_skip_hat * img + c_out_hat * net(c_in_hat * img, c_noise[2*step]))          (:2528, preconditioning :2140-2183)

@@ -1254,12 +1254,13 @@ int srgd_edm_begin(srgd_engine* e, const srgd_sampler_geometry* g, const float* 
 }
 
 // all launches of one EDM step (model.py:2377-2455); step-dependent values come through e->d_step
-static int edm_step_launch(srgd_engine* e, bool last, int parity, float* img, const float* cond_canvas, float* x_start,
-                           float* work, const float* noise_canvas, const float* ring_noise_canvas, int passes,
-                           int guidance_kind, float guidance_scale, int sub_batch, uint64_t seed, hipStream_t st) {
+static int edm_step_launch(srgd_engine* e, bool last, int parity, int tile_first, int tile_count, bool ring, float* img,
+                           const float* cond_canvas, float* x_start, float* work, const float* noise_canvas,
+                           const float* ring_noise_canvas, int passes, int guidance_kind, float guidance_scale, int sub_batch,
+                           uint64_t seed, hipStream_t st) {
   const srgd_sampler_geometry& g = e->geo;
   const int n_local = parity ? g.n_odd : g.n_even;
-  const int n = n_local * g.n_images;
+  const int n = tile_first + tile_count;               // this call covers tiles [tile_first, n) of the image-major list
   const int* tiles = parity ? e->d_tiles_odd : e->d_tiles_even;
   const size_t canvas1 = (size_t)3 * g.Hp * g.Wp, canvas_elems = canvas1 * g.n_images;
   const float* z = noise_canvas;
@@ -1270,7 +1271,7 @@ static int edm_step_launch(srgd_engine* e, bool last, int parity, float* img, co
   }
   const int row_label = e->run_class >= 0 ? 0 : 1, row_null = 1;
   const int mask = (passes == 2 && guidance_kind == 2) ? 0x1 : 0x3;
-  for (int first = 0; first < n; first += sub_batch) {
+  for (int first = tile_first; first < n; first += sub_batch) {
     const int nt = std::min(sub_batch, n - first);
     const int nb = nt * passes;
     TileBatch tb{tiles, first, nt, g.Hp, g.Wp, g.tile, n_local};
@@ -1306,7 +1307,7 @@ static int edm_step_launch(srgd_engine* e, bool last, int parity, float* img, co
       e->pool.put(x0);
     }
   }
-  if (parity == 1) {
+  if (parity == 1 && ring) {
     Prof p(e, KC_CANVAS, st);
     const float* nc = ring_noise_canvas;
     if (!nc) {
@@ -1324,6 +1325,16 @@ static int edm_step_launch(srgd_engine* e, bool last, int parity, float* img, co
 int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas, float* x_start, float* work,
                   const float* noise_canvas, const float* ring_noise_canvas, int passes, int guidance_kind,
                   float guidance_scale, int sub_batch, uint64_t seed, void* stream) {
+  return srgd_edm_step_tiles(e, step, 0, -1, 1, img, cond_canvas, x_start, work, noise_canvas, ring_noise_canvas, passes,
+                             guidance_kind, guidance_scale, sub_batch, seed, stream);
+}
+
+// The per-rank unit of a canvas shared by several GPUs (as srgd_sampler_step_tiles for the DDPM loop): tiles
+// [tile_first, tile_first + tile_count) of the step's grid; the two scratch canvases in `work` are touched at those tiles only.
+int srgd_edm_step_tiles(srgd_engine* e, int step, int tile_first, int tile_count, int do_ring, float* img,
+                        const float* cond_canvas, float* x_start, float* work, const float* noise_canvas,
+                        const float* ring_noise_canvas, int passes, int guidance_kind, float guidance_scale, int sub_batch,
+                        uint64_t seed, void* stream) {
   if (!e || !e->run_active || !e->run_is_edm) SRGD_FAIL("srgd_edm_step: call srgd_edm_begin first");
   if (step < 0 || step >= e->n_steps) SRGD_FAIL("srgd_edm_step: step out of range");
   if (!img || !cond_canvas || !work) SRGD_FAIL("srgd_edm_step: null argument");
@@ -1336,24 +1347,27 @@ int srgd_edm_step(srgd_engine* e, int step, float* img, const float* cond_canvas
   const int parity = step & 1;
   const int n = (parity ? g.n_odd : g.n_even) * g.n_images;
   const bool last = step == e->n_steps - 1;
-  sub_batch = std::min(sub_batch, n);
+  if (tile_count < 0) tile_count = n - tile_first;
+  if (tile_first < 0 || tile_count < 0 || tile_first + tile_count > n) SRGD_FAIL("srgd_edm_step_tiles: tile range outside the grid");
+  const bool ring = do_ring != 0;
+  sub_batch = std::max(1, std::min(sub_batch, std::max(tile_count, 1)));
   const size_t canvas1 = (size_t)3 * g.Hp * g.Wp;
   e->pool.reset_busy();
   // every allocation happens here, before any capture
   SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
   if (!noise_canvas) SRGD_TRY(ensure(e, &e->rng_tiles, &e->rng_tiles_cap, canvas1));
-  if (!ring_noise_canvas && parity == 1) SRGD_TRY(ensure(e, &e->rng_canvas, &e->rng_canvas_cap, canvas1));
+  if (!ring_noise_canvas && parity == 1 && ring) SRGD_TRY(ensure(e, &e->rng_canvas, &e->rng_canvas_cap, canvas1));
   if (!e->d_step) SRGD_HIP(hipMalloc((void**)&e->d_step, sizeof(int)));
   hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, st, e->d_step, step);
   const bool graphable = e->use_graphs && !e->prof_on && !noise_canvas && !ring_noise_canvas;
   if (!graphable)
-    return edm_step_launch(e, last, parity, img, cond_canvas, x_start, work, noise_canvas, ring_noise_canvas, passes,
-                           guidance_kind, guidance_scale, sub_batch, seed, st);
+    return edm_step_launch(e, last, parity, tile_first, tile_count, ring, img, cond_canvas, x_start, work, noise_canvas,
+                           ring_noise_canvas, passes, guidance_kind, guidance_scale, sub_batch, seed, st);
   const srgd_engine::StepGraph key{parity, passes, guidance_kind, sub_batch, guidance_scale, img, cond_canvas, x_start, seed, last,
-                                   0, n, true, 1, work, 1, nullptr, nullptr};
+                                   tile_first, tile_count, ring, 1, work, 1, nullptr, nullptr};
   return run_step_through_graph(e, key, st, [&](hipStream_t s2) {
-    return edm_step_launch(e, last, parity, img, cond_canvas, x_start, work, nullptr, nullptr, passes, guidance_kind,
-                           guidance_scale, sub_batch, seed, s2);
+    return edm_step_launch(e, last, parity, tile_first, tile_count, ring, img, cond_canvas, x_start, work, nullptr, nullptr,
+                           passes, guidance_kind, guidance_scale, sub_batch, seed, s2);
   });
 }
 

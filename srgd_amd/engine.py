@@ -177,6 +177,18 @@ class HipEngine:
                                         float(guidance_scale), int(sub_batch), int(seed) & (2 ** 64 - 1),
                                         _stream_ptr(self.device)), "srgd_edm_step")
 
+    def edm_step_tiles(self, step: int, tile_first: int, tile_count: int, do_ring: bool, img: torch.Tensor,
+                       cond_canvas: torch.Tensor, x_start: Optional[torch.Tensor], work: torch.Tensor,
+                       noise_canvas: Optional[torch.Tensor], ring_noise_canvas: Optional[torch.Tensor], passes: int,
+                       guidance_kind: int, guidance_scale: float, sub_batch: int, seed: int = 0) -> None:
+        assert work.is_contiguous() and work.dtype == torch.float32 and work.numel() >= 2 * img.numel()
+        with torch.cuda.device(self.device):
+            check(self._L.srgd_edm_step_tiles(self._h, step, int(tile_first), int(tile_count), int(bool(do_ring)), _dev_ptr(img),
+                                              _dev_ptr(cond_canvas), _dev_ptr(x_start), _dev_ptr(work), _dev_ptr(noise_canvas),
+                                              _dev_ptr(ring_noise_canvas), passes, guidance_kind, float(guidance_scale),
+                                              int(sub_batch), int(seed) & (2 ** 64 - 1), _stream_ptr(self.device)),
+                  "srgd_edm_step_tiles")
+
     def edm_dpmpp_step(self, step: int, img: torch.Tensor, cond_canvas: torch.Tensor, x_start: Optional[torch.Tensor],
                        old_denoised: torch.Tensor, passes: int, guidance_kind: int, guidance_scale: float,
                        sub_batch: int) -> None:

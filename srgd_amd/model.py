@@ -577,6 +577,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         self.device_noise_seed = 0
         self.max_tiles_per_launch = None
         self.precision = "fp32"            # as in the DDPM wrapper
+        self.canvas_group = None           # set by srgd_amd.parallel.shard_canvas: tiles of every step split over its ranks
 
     def set_seed(self, seed):
         torch.cuda.manual_seed(seed)
@@ -693,7 +694,13 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
                 passes, kind, scale = 1, 0, 1.0
             z = canvas_noise(None) if host_noise else None              # eps of the step (:2386), before the ring draw
             ring = canvas_noise(None) if (host_noise and i % 2 == 1) else None
-            eng.edm_step(i, img, cond_canvas, x_start, work, z, ring, passes, kind, scale, sub_batch, seed=seed)
+            if self.canvas_group is None:
+                eng.edm_step(i, img, cond_canvas, x_start, work, z, ring, passes, kind, scale, sub_batch, seed=seed)
+            else:
+                from .parallel import sharded_edm_step
+                n_tiles = (len(coords1) if i % 2 else len(coords0)) * batch
+                sharded_edm_step(eng, self.canvas_group, i, n_tiles, img, cond_canvas, x_start, work, z, ring, passes, kind,
+                                 scale, sub_batch, seed)
             if with_images:
                 image_list.append(img.clone().cpu())
             if with_x0_images:

@@ -113,3 +113,24 @@ def sharded_step(eng, group, step: int, n_tiles: int, img, cond_canvas, x_start,
         eng.sampler_exchange_tiles(step & 1, mine.start, len(mine), canvas, packed, to_canvas=False)
         everyone = _all_gather_tiles(packed, group).reshape(world * width, 3, 256, 256)
         eng.sampler_exchange_tiles(step & 1, 0, n_tiles, canvas, everyone, to_canvas=True)
+
+
+def sharded_edm_step(eng, group, step: int, n_tiles: int, img, cond_canvas, x_start, work, noise_canvas, ring_noise_canvas,
+                     passes: int, kind: int, scale: float, sub_batch: int, seed: int) -> None:
+    """One EDM (Heun) step of a canvas shared by the ranks of ``group`` (reference model.py:2379-2463): my slice of the tiles
+    (both network evaluations; the scratch canvases stay rank-local), the odd-step ring on every rank's own canvas, then the
+    same tile exchange as the DDPM loop."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    sl = tile_slices(n_tiles, world)
+    mine, width = sl[rank], len(sl[0])
+    eng.edm_step_tiles(step, mine.start, len(mine), True, img, cond_canvas, x_start, work, noise_canvas, ring_noise_canvas,
+                       passes, kind, scale, sub_batch, seed)
+    if world == 1:
+        return
+    for canvas in (img, x_start):
+        if canvas is None:
+            continue
+        packed = torch.zeros(width, 3, 256, 256, device=img.device, dtype=torch.float32)
+        eng.sampler_exchange_tiles(step & 1, mine.start, len(mine), canvas, packed, to_canvas=False)
+        everyone = _all_gather_tiles(packed, group).reshape(world * width, 3, 256, 256)
+        eng.sampler_exchange_tiles(step & 1, 0, n_tiles, canvas, everyone, to_canvas=True)

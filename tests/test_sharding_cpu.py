@@ -80,6 +80,18 @@ class _FakeEngine:
         if (step & 1) and do_ring:
             img[0, :, :128] = step
 
+    def edm_step_tiles(self, step, first, count, do_ring, img, cond, x_start, work, z, ring, passes, kind, scale, sb, seed):
+        # two evaluations per tile (Heun): the second reads what the first left in the rank-local scratch canvas
+        for t in range(first, first + count):
+            y, x = self.grids[step & 1][t]
+            reg = img[0, :, y:y + 256, x:x + 256]
+            work[0, 0, :, y:y + 256, x:x + 256] = reg * 0.25 + (t + 1) * 0.02
+            reg.copy_(reg * 0.5 + work[0, 0, :, y:y + 256, x:x + 256].mean() + step)
+            if x_start is not None:
+                x_start[0, :, y:y + 256, x:x + 256] = reg * 3
+        if (step & 1) and do_ring:
+            img[0, :, :128] = -step
+
     def sampler_exchange_tiles(self, parity, first, count, canvas, tiles, to_canvas):
         for j in range(count):
             y, x = self.grids[parity][first + j]
@@ -97,15 +109,20 @@ def _canvas_grids():
     return hp, wp, (even, odd)
 
 
-def _run_fake(group, steps=5, with_x0=True):
-    from srgd_amd.parallel import sharded_step
+def _run_fake(group, steps=5, with_x0=True, edm=False):
+    from srgd_amd.parallel import sharded_edm_step, sharded_step
     hp, wp, grids = _canvas_grids()
     eng = _FakeEngine(grids)
     img = torch.linspace(-1, 1, 3 * hp * wp).reshape(1, 3, hp, wp).clone()
     xs = img.clone() if with_x0 else None
+    work = torch.zeros(2, 1, 3, hp, wp)
     for i in range(steps):
         n = len(grids[i & 1])
-        if group is None:
+        if edm and group is None:
+            eng.edm_step_tiles(i, 0, n, True, img, None, xs, work, None, None, 1, 0, 1.0, n, 0)
+        elif edm:
+            sharded_edm_step(eng, group, i, n, img, None, xs, work, None, None, 1, 0, 1.0, n, 0)
+        elif group is None:
             eng.sampler_step_tiles(i, 0, n, True, img, None, xs, None, None, 1, 0, 1.0, n, 0)
         else:
             sharded_step(eng, group, i, n, img, None, xs, None, None, 1, 0, 1.0, n, 0)
@@ -116,7 +133,8 @@ def _canvas_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     img, xs = _run_fake(dist.group.WORLD)
-    torch.save({"img": img, "xs": xs}, os.path.join(out_dir, f"canvas_r{rank}.pt"))
+    eimg, exs = _run_fake(dist.group.WORLD, edm=True)
+    torch.save({"img": img, "xs": xs, "edm_img": eimg, "edm_xs": exs}, os.path.join(out_dir, f"canvas_r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -135,7 +153,10 @@ def test_sharded_canvas_steps_equal_single_rank_world3(tmp_path):
     port = _free_port()
     mp.spawn(_canvas_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
     want_img, want_xs = _run_fake(None)
+    want_eimg, want_exs = _run_fake(None, edm=True)
     for r in range(3):
         got = torch.load(tmp_path / f"canvas_r{r}.pt")
         assert torch.equal(got["img"], want_img), r
         assert torch.equal(got["xs"], want_xs), r
+        assert torch.equal(got["edm_img"], want_eimg), r       # parallel.sharded_edm_step (EDM wrapper's Heun step)
+        assert torch.equal(got["edm_xs"], want_exs), r
