@@ -69,7 +69,7 @@ def pin_edm_untiled(rm, rc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="skip the dim-128 cases")
-    ap.add_argument("--section", choices=["all", "edm_untiled"], default="all", help="run one section only")
+    ap.add_argument("--section", choices=["all", "geometry", "edm_untiled"], default="all", help="run one section only")
     args = ap.parse_args()
     ref = refshim.load_reference()
     if ref is None:
@@ -95,7 +95,19 @@ def main():
         e, o = O.sampling_grids(hp, wp)
         ok &= (c0 == e) and (c1 == o)
         ok &= rm.get_area(c1, hp, wp) == O.grid_bbox(o, hp, wp)
+    import random
+    rng = random.Random(7)
+    for _ in range(500):                                  # random sizes, ragged strides and shifts (tests/test_host_cpu.py mirrors this)
+        h, w = rng.randint(1, 3000), rng.randint(1, 3000)
+        ok &= rm.get_coord_and_pad(h, w) == O.canvas_box_and_pad(h, w)
+        hh, ww, stride, shift = rng.randint(256, 2000), rng.randint(256, 2000), rng.randint(1, 256), rng.choice((0, 128))
+        c = rm.get_coords(hh, ww, 256, stride, diff=shift)
+        ok &= c == O.tile_grid(hh, ww, 256, stride, shift)
+        ok &= rm.get_area(c, hh + 2 * shift, ww + 2 * shift) == O.grid_bbox(c, hh + 2 * shift, ww + 2 * shift)
     print("  ok" if ok else "  BAD")
+    if args.section == "geometry":
+        print("PINNED" if ok else "MISMATCH")
+        return 0 if ok else 1
 
     print("[schedule] beta_linear_log_snr and per-step scalars (bit-exact expected)")
     for n in (10, 50, 100, 250):

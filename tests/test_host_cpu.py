@@ -81,6 +81,30 @@ def test_geometry_helpers_match_golden_tables():
     assert get_coords(600, 256, 256, 200) == [(0, 256, 0, 256), (200, 456, 0, 256), (344, 600, 0, 256)]
 
 
+def test_geometry_helpers_agree_with_the_pinned_oracle_on_random_sizes():
+    # the product's int helpers (re-derived, math.ceil form) against the oracle's restatement - itself pinned 0.0 against the
+    # reference's get_coord_and_pad / get_coords / get_area (oracle/pin_against_reference.py) - on sizes the tables do not hold:
+    # one-pixel images, primes, sizes at and around tile multiples, ragged strides
+    import random
+    from oracle import srgd_oracle as O
+    from srgd_amd.model import get_area, get_coord_and_pad, get_coords
+    rng = random.Random(7)
+    sizes = [(1, 1), (255, 257), (256, 512), (511, 513), (769, 1023), (2047, 31)] + \
+            [(rng.randint(1, 3000), rng.randint(1, 3000)) for _ in range(300)]
+    for (h, w) in sizes:
+        assert get_coord_and_pad(h, w) == O.canvas_box_and_pad(h, w), (h, w)
+        _, pad = get_coord_and_pad(h, w)
+        hp, wp = h + pad[2] + pad[3], w + pad[0] + pad[1]
+        even = get_coords(hp, wp, 256, 256, diff=0)
+        odd = even if (hp <= 256 and wp <= 256) else get_coords(hp - 256, wp - 256, 256, 256, diff=128)
+        oe, oo = O.sampling_grids(hp, wp)
+        assert even == oe and odd == oo, (h, w)
+        assert get_area(odd, hp, wp) == O.grid_bbox(oo, hp, wp), (h, w)
+    for _ in range(200):                                  # ragged strides / shifts (tile_grid is the oracle's get_coords)
+        hh, ww, stride, shift = rng.randint(256, 2000), rng.randint(256, 2000), rng.randint(1, 256), rng.choice((0, 128))
+        assert get_coords(hh, ww, 256, stride, diff=shift) == O.tile_grid(hh, ww, 256, stride, shift), (hh, ww, stride, shift)
+
+
 def test_schedule_scalars_bit_identical_to_oracle():
     from oracle import srgd_oracle as O
     from srgd_amd.model import _schedule
