@@ -48,32 +48,47 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnFinalizeArgs a) {
   }
 }
 
+// One grid row (blockIdx.y) per sample: the vector index inside the sample is a 32-bit int, its channel offset a 32-bit
+// remainder (a mask when C / N is a power of two) and the coefficient rows are block-uniform.  (The first version ran one flat
+// 64-bit index over the batch and paid a 64-bit division + remainder per 16-byte vector: VALU-bound at 5.1 TB/s.)
 template <typename T, bool PRECISE>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                         const T* __restrict__ res,
                                                         const float* __restrict__ cA,
-                                                        const float* __restrict__ cB, long nvec, int vec_per_sample,
+                                                        const float* __restrict__ cB, int vec_per_sample,
                                                         int vec_per_pixel, int C, unsigned char* __restrict__ oq,
                                                         unsigned char* __restrict__ os) {
   constexpr int N = Vec16<T>::N;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int b = (int)(i / vec_per_sample);
-    const int c = (int)(i % vec_per_pixel) * N;
-    Vec16<T> v = reinterpret_cast<const Vec16<T>*>(x)[i];
+  const int b = blockIdx.y;
+  const size_t base = (size_t)b * vec_per_sample;
+  const Vec16<T>* xs = reinterpret_cast<const Vec16<T>*>(x) + base;
+  const Vec16<T>* rs = res ? reinterpret_cast<const Vec16<T>*>(res) + base : nullptr;
+  Vec16<T>* ys = reinterpret_cast<Vec16<T>*>(y) + base;
+  const float* pa0 = cA + (size_t)b * C;
+  const float* pb0 = cB + (size_t)b * C;
+  const bool pow2 = (vec_per_pixel & (vec_per_pixel - 1)) == 0;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)vec_per_sample; i += gridDim.x * 256u) {
+    const int c = (int)(pow2 ? (i & (unsigned)(vec_per_pixel - 1)) : (i % (unsigned)vec_per_pixel)) * N;
+    Vec16<T> v = xs[i];
     Vec16<T> r;
-    if (res) r = reinterpret_cast<const Vec16<T>*>(res)[i];
-    const float* pa = cA + (size_t)b * C + c;
-    const float* pb = cB + (size_t)b * C + c;
+    if (rs) r = rs[i];
+    float ca[N], cb[N];
+#pragma unroll
+    for (int j = 0; j < N; j += 4) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa0 + c + j), b4 = *reinterpret_cast<const f32x4*>(pb0 + c + j);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ca[j + k] = a4[k]; cb[j + k] = b4[k]; }
+    }
     Vec16<T> o;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      float t = silu<PRECISE>(pa[j] * v.get(j) + pb[j]);
-      if (res) t += r.get(j);
+      float t = silu<PRECISE>(ca[j] * v.get(j) + cb[j]);
+      if (rs) t += r.get(j);
       o.set(j, t);
     }
-    reinterpret_cast<Vec16<T>*>(y)[i] = o;
+    ys[i] = o;
     if constexpr (sizeof(T) == 2) {
-      if (oq) mx_store_twin(o.v, oq, os, (size_t)i * 8, threadIdx.x & 3);      // MX-fp8 twin of the stored bf16 values
+      if (oq) mx_store_twin(o.v, oq, os, (base + i) * 8, threadIdx.x & 3);      // MX-fp8 twin of the stored bf16 values
     }
   }
 }
@@ -126,15 +141,16 @@ int gn_apply_silu(const void* x, void* y, const void* residual, const float* coe
   const int N = is_bf16 ? 8 : 4;
   if (C % N != 0) SRGD_FAIL("gn_apply: C must be a multiple of the 16-byte vector width");
   if (out_q && (!is_bf16 || !out_s || C % 32 != 0)) SRGD_FAIL("gn_apply: the MX-fp8 twin needs bf16 activations and C % 32 == 0");
-  const long nvec = (long)B * hw * C / N;
   const int vps = (int)((long)hw * C / N), vpp = C / N;
-  const int grid = (int)std::min<long>((nvec + 255) / 256, 256L * 64);
+  if ((long)hw * C / N >= (1L << 31) || B > 65535) SRGD_FAIL("gn_apply: sample too large for the 32-bit vector index");
+  // ~64 blocks per CU over the whole launch, at least one block per sample
+  const int gx = (int)std::max<long>(1, std::min<long>((vps + 255) / 256, (256L * 64 + B - 1) / B));
   if (is_bf16)
-    hipLaunchKernelGGL((gn_apply_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)y,
-                       (const bf16*)residual, coefA, coefB, nvec, vps, vpp, C, (unsigned char*)out_q, (unsigned char*)out_s);
+    hipLaunchKernelGGL((gn_apply_kernel<bf16, false>), dim3(gx, B), dim3(256), 0, st, (const bf16*)x, (bf16*)y,
+                       (const bf16*)residual, coefA, coefB, vps, vpp, C, (unsigned char*)out_q, (unsigned char*)out_s);
   else
-    hipLaunchKernelGGL((gn_apply_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,
-                       (const float*)residual, coefA, coefB, nvec, vps, vpp, C, nullptr, nullptr);
+    hipLaunchKernelGGL((gn_apply_kernel<float, true>), dim3(gx, B), dim3(256), 0, st, (const float*)x, (float*)y,
+                       (const float*)residual, coefA, coefB, vps, vpp, C, nullptr, nullptr);
   SRGD_HIP(hipGetLastError());
   return 0;
 }

@@ -11,20 +11,28 @@
 namespace srgd {
 namespace {
 
+// One grid row (blockIdx.y) per sample for the GroupNorm variant: 32-bit index arithmetic and block-uniform coefficient rows
+// (a flat 64-bit index costs a 64-bit division + remainder per 16-byte vector and makes the pass VALU-bound).
 template <bool GN>
 __global__ __launch_bounds__(256) void quant_mxfp8_kernel(const bf16* __restrict__ x, unsigned char* __restrict__ q,
-                                                           unsigned char* __restrict__ s, long nvec, int C,
-                                                           int vec_per_sample, const float* __restrict__ cA,
-                                                           const float* __restrict__ cB) {
+                                                           unsigned char* __restrict__ s, int vec_per_sample, int C,
+                                                           const float* __restrict__ cA, const float* __restrict__ cB) {
   const int vec_per_pixel = C >> 3;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
+  const int b = blockIdx.y;
+  const size_t base = (size_t)b * vec_per_sample;
+  const bf16x8* xs = reinterpret_cast<const bf16x8*>(x) + base;
+  uint2* qs = reinterpret_cast<uint2*>(q) + base;
+  unsigned char* ss = s + (base >> 2);
+  const float* pa = GN ? cA + (size_t)b * C : nullptr;
+  const float* pb = GN ? cB + (size_t)b * C : nullptr;
+  const bool pow2 = (vec_per_pixel & (vec_per_pixel - 1)) == 0;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)vec_per_sample; i += gridDim.x * 256u) {
+    const bf16x8 v = xs[i];
     float y[8];
     if (GN) {
-      const int b = (int)(i / vec_per_sample);
-      const int c = (int)(i % vec_per_pixel) * 8;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(cA + (size_t)b * C + c), a1 = *reinterpret_cast<const f32x4*>(cA + (size_t)b * C + c + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(cB + (size_t)b * C + c), b1 = *reinterpret_cast<const f32x4*>(cB + (size_t)b * C + c + 4);
+      const int c = (int)(pow2 ? (i & (unsigned)(vec_per_pixel - 1)) : (i % (unsigned)vec_per_pixel)) * 8;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(pa + c), a1 = *reinterpret_cast<const f32x4*>(pa + c + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(pb + c), b1 = *reinterpret_cast<const f32x4*>(pb + c + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         y[j] = silu<false>(a0[j] * (float)v[j] + b0[j]);
@@ -36,36 +44,45 @@ __global__ __launch_bounds__(256) void quant_mxfp8_kernel(const bf16* __restrict
     }
     int sb;
     const uint2 w = mx_quant8(y, &sb);
-    reinterpret_cast<uint2*>(q)[i] = w;
-    if ((threadIdx.x & 3) == 0) s[i >> 2] = (unsigned char)sb;
+    qs[i] = w;
+    if ((threadIdx.x & 3) == 0) ss[i >> 2] = (unsigned char)sb;
   }
 }
 
 }  // namespace
 
-static int launch_quant(const void* x, void* q, void* s, long npix, int C, int hw, const float* cA, const float* cB,
-                        hipStream_t st) {
+// B samples of hw pixels; the plain variant (no coefficients) treats the whole tensor as ceil(npix / 65536)-pixel "samples"
+static int launch_quant(const void* x, void* q, void* s, int B, long hw, int C, const float* cA, const float* cB, hipStream_t st) {
   if (C % 32 != 0) SRGD_FAIL("quant_mxfp8: C must be a multiple of 32");
-  const long nvec = npix * (C / 8);
-  const int grid = (int)std::min<long>((nvec + 255) / 256, 256L * 64);
+  const long vps = hw * (C / 8);
+  if (vps >= (1L << 31) || B > 65535 || B < 1) SRGD_FAIL("quant_mxfp8: tensor too large for the 32-bit vector index");
+  const int gx = (int)std::max<long>(1, std::min<long>((vps + 255) / 256, (256L * 64 + B - 1) / B));
   if (cA)
-    hipLaunchKernelGGL((quant_mxfp8_kernel<true>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (unsigned char*)q,
-                       (unsigned char*)s, nvec, C, hw * (C / 8), cA, cB);
+    hipLaunchKernelGGL((quant_mxfp8_kernel<true>), dim3(gx, B), dim3(256), 0, st, (const bf16*)x, (unsigned char*)q,
+                       (unsigned char*)s, (int)vps, C, cA, cB);
   else
-    hipLaunchKernelGGL((quant_mxfp8_kernel<false>), dim3(grid), dim3(256), 0, st, (const bf16*)x, (unsigned char*)q,
-                       (unsigned char*)s, nvec, C, hw * (C / 8), nullptr, nullptr);
+    hipLaunchKernelGGL((quant_mxfp8_kernel<false>), dim3(gx, B), dim3(256), 0, st, (const bf16*)x, (unsigned char*)q,
+                       (unsigned char*)s, (int)vps, C, nullptr, nullptr);
   SRGD_HIP(hipGetLastError());
   return 0;
 }
 
 int quant_mxfp8(const void* x_bf16, void* q, void* s, long npix, int C, hipStream_t st) {
-  return launch_quant(x_bf16, q, s, npix, C, 1, nullptr, nullptr, st);
+  if (npix <= 0) return 0;
+  // split into equal "samples" so that the per-sample vector count stays a 32-bit int and the grid's y extent < 65536; the
+  // split must keep every sample's vector count a multiple of 4 (one scale byte per 4 vectors): any whole number of pixels is
+  if (C % 32 != 0) SRGD_FAIL("quant_mxfp8: C must be a multiple of 32");
+  long per = npix;
+  int B = 1;
+  for (int d : {4096, 1024, 256, 64, 16, 4, 2})
+    if (npix % d == 0 && npix / d >= 1024) { B = d; per = npix / d; break; }
+  return launch_quant(x_bf16, q, s, B, per, C, nullptr, nullptr, st);
 }
 
 int gn_apply_silu_mxfp8(const void* x_bf16, void* q, void* s, const float* coefA, const float* coefB, int B, int hw, int C,
                         hipStream_t st) {
   if (!coefA || !coefB) SRGD_FAIL("gn_apply_silu_mxfp8: null coefficients");
-  return launch_quant(x_bf16, q, s, (long)B * hw, C, hw, coefA, coefB, st);
+  return launch_quant(x_bf16, q, s, B, hw, C, coefA, coefB, st);
 }
 
 }  // namespace srgd
