@@ -137,13 +137,13 @@ void linattn_fused_pack(const float* to_qkv, const float* norm_g, const float* t
 int linattn_fused(const void* x, void* y, int B, int N, int C, const void* wkv_img, const void* wq, const void* wout,
                   const float* bout, const float* g2_scaled, float* ws, hipStream_t st, void* y_q = nullptr,
                   void* y_s = nullptr);          // y_q / y_s: optional MX-fp8 twin of y (see ConvArgs::out_q)
-// linattn_fused256.hip: the C = 256 kernels behind the three entry points above
-bool linattn_fused256_eligible(int heads, int dh, int N, bool is_bf16);
-void linattn_fused256_pack(const float* to_qkv, const float* norm_g, const float* to_out, std::vector<unsigned short>& wkv,
+// linattn_fused256.hip: the 32-pixel-tile kernels (C = 256 always; C = 128 when SRGD_LA128_TM32=1) behind the entry points above
+bool linattn_fused256_eligible(int C, int heads, int dh, int N, bool is_bf16);
+void linattn_fused256_pack(const float* to_qkv, const float* norm_g, const float* to_out, int C, std::vector<unsigned short>& wkv,
                            std::vector<unsigned short>& wq, std::vector<unsigned short>& wout);
-int linattn_fused256(const void* x, void* y, int B, int N, const void* wkv, const void* wq, const void* wout, const float* bout,
-                     const float* g2_scaled, float* pm, float* pl, float* pctx, float* ctxn, float* rinv, int strip,
-                     hipStream_t st, void* y_q, void* y_s);
+int linattn_fused256(const void* x, void* y, int B, int N, int C, const void* wkv, const void* wq, const void* wout,
+                     const float* bout, const float* g2_scaled, float* pm, float* pl, float* pctx, float* ctxn, float* rinv,
+                     int strip, hipStream_t st, void* y_q, void* y_s);
 
 // ---------------------------------------------------------------- cond.hip
 // feat[r] = [x, sin(2 pi x w_i), cos(2 pi x w_i)]   (reference model.py:233-238)

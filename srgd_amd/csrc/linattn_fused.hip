@@ -20,6 +20,8 @@
 // CU and their MFMA, exponential and store phases overlap; 1/||x|| is computed once (la1) and handed to la2 (4 B / pixel).
 // bf16-mode only, so exponentials are bare v_exp_f32 in the log2 domain (1/||x|| * log2(e) rides in the argument).
 // The RMSNorm gains g1*sqrt(C) are folded into Wkv'/Wq' on the host.
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace srgd {
@@ -407,8 +409,16 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
 
 }  // namespace
 
+// C = 128 on the 32-pixel-tile kernels of linattn_fused256.hip (3 workgroups per CU) instead of the 64-pixel ones here: A/B switch,
+// read once (the weight images differ, so it must not change between packing and launching)
+static bool la128_tm32() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SRGD_LA128_TM32"); v = (e && atoi(e)) ? 1 : 0; }
+  return v == 1;
+}
+
 bool linattn_fused_eligible(int C, int heads, int dh, int N, bool is_bf16) {
-  if (C == 256) return linattn_fused256_eligible(heads, dh, N, is_bf16);
+  if (C == 256 || (C == 128 && la128_tm32())) return linattn_fused256_eligible(C, heads, dh, N, is_bf16);
   return is_bf16 && C == 128 && heads == 4 && dh == 32 && N % TM == 0 && (size_t)N * 256 < (1ull << 31);
 }
 
@@ -425,7 +435,7 @@ size_t linattn_fused_workspace(int B, int N) {
 void linattn_fused_pack(const float* to_qkv /*[384][C]*/, const float* norm_g /*[C]*/, const float* to_out /*[C][128]*/,
                         int C, std::vector<unsigned short>& wkv_img, std::vector<unsigned short>& wq,
                         std::vector<unsigned short>& wout) {
-  if (C == 256) return linattn_fused256_pack(to_qkv, norm_g, to_out, wkv_img, wq, wout);
+  if (C == 256 || (C == 128 && la128_tm32())) return linattn_fused256_pack(to_qkv, norm_g, to_out, C, wkv_img, wq, wout);
   const float sq = sqrtf((float)C);
   wkv_img.assign(256 * 128, 0);
   wq.assign(128 * 128, 0);
@@ -453,8 +463,8 @@ int linattn_fused(const void* x, void* y, int B, int N, int C, const void* wkv_i
   float* pctx = pl + bh * nch * 32;
   float* ctxn = pctx + bh * nch * 1024;
   float* rinv = ctxn + bh * 1024;
-  if (C == 256)
-    return linattn_fused256(x, y, B, N, wkv_img, wq, wout, bout, g2_scaled, pm, pl, pctx, ctxn, rinv, strip, st, y_q, y_s);
+  if (C == 256 || (C == 128 && la128_tm32()))
+    return linattn_fused256(x, y, B, N, C, wkv_img, wq, wout, bout, g2_scaled, pm, pl, pctx, ctxn, rinv, strip, st, y_q, y_s);
   if (C != 128) SRGD_FAIL("linattn_fused: C must be 128 or 256");
   static bool attr[64] = {};
   const int lds1 = RING * TILE_BYTES + 2 * TM * 4;
