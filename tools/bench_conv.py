@@ -38,6 +38,11 @@ SHAPES = [
     ("1x1 256->384 @128", 256, 0, 384, 128, 1),
     ("1x1 128->256 @128", 128, 0, 256, 128, 1),
     ("1x1 512+256->512 @64", 512, 256, 512, 64, 1),
+    ("1x1 1024+512->1024 @32", 1024, 512, 1024, 32, 1),
+    ("1x1 256->512 @128", 256, 0, 512, 128, 1),
+    ("1x1 512->1024 @64", 512, 0, 1024, 64, 1),
+    ("1x1 512->384 @64", 512, 0, 384, 64, 1),
+    ("1x1 128->512 @64", 128, 0, 512, 64, 1),
 ]
 
 
@@ -90,7 +95,9 @@ def main():
         ds = ((outs[0][1] - outs[1][1]).abs().max().item() / max(1.0, outs[0][1].abs().max().item())) if outs[0][1] is not None else 0.0
         rows.append(dict(shape=name, generic_tflops=round(res[1], 1), engine_tflops=round(res[0], 1),
                          max_abs_diff=d, ref_max=ref, stats_rel_diff=ds))
-        print(f"{name:28s} generic {res[1]:7.1f} TF   engine {res[0]:7.1f} TF   |diff| {d:.3g} (max {ref:.3g})  stats {ds:.2g}", flush=True)
+        gb = 2.0 * B * hw * hw * (c0 + c1 + cout) / 1e9           # bf16 in + out, once
+        ms0 = 2.0 * B * hw * hw * cout * ks * ks * (c0 + c1) / (res[0] * 1e12) * 1e3
+        print(f"{name:28s} generic {res[1]:7.1f} TF   engine {res[0]:7.1f} TF ({ms0:.3f} ms, {gb / ms0:.2f} TB/s in+out)   |diff| {d:.3g} (max {ref:.3g})  stats {ds:.2g}", flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/bench_conv.json", "w") as f:
         json.dump(rows, f, indent=1)
