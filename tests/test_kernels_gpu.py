@@ -169,11 +169,12 @@ def test_pixel_shuffle_upsample(bf16):
 
 
 @pytest.mark.parametrize("bf16", [False, True], ids=["fp32", "bf16"])
-@pytest.mark.parametrize("cfg", [(2, 32, 64, 16, 16), (1, 16, 128, 32, 32), (2, 64, 16, 16, 8)],
-                         ids=lambda s: "B%d_Cin%d_Cout%d_%dx%d" % s)
+@pytest.mark.parametrize("cfg", [(2, 32, 64, 16, 16, 8), (1, 16, 128, 32, 32, 8), (2, 64, 16, 16, 8, 8), (3, 32, 96, 16, 8, 6)],
+                         ids=lambda s: "B%d_Cin%d_Cout%d_%dx%d_g%d" % s)
 def test_conv_groupnorm_scale_shift_silu_residual(bf16, cfg):
+    # (Cout = 96, 6 groups: 12 / 24 vectors per pixel - the GroupNorm-apply kernel's non-power-of-two channel-offset path)
     # Block.forward (model.py:250-259) + the ResnetBlock residual (:285) on top of the conv's fused statistics
-    B, cin, cout, H, W = cfg
+    B, cin, cout, H, W, ngroups = cfg
     lib = L().lib()
     g = torch.Generator().manual_seed(5)
     x = rnd(torch.randn(B, cin, H, W, generator=g) * 2 + 0.5, bf16)
@@ -182,21 +183,21 @@ def test_conv_groupnorm_scale_shift_silu_residual(bf16, cfg):
     gamma, beta = 1 + 0.2 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
     ss = 0.5 * torch.randn(B, 2 * cout, generator=g)
     res = rnd(torch.randn(B, cout, H, W, generator=g), bf16)
-    conv_out, part, nslots = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=bf16, groups=8, want_slots=True)
+    conv_out, part, nslots = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=bf16, groups=ngroups, want_slots=True)
     assert torch.isfinite(part).all(), "conv epilogue did not fill every GroupNorm partial slot"
     ref_conv = F.conv2d(x, w, b, padding=1)
     # statistics must come from the fp32 accumulators
     s1 = part[..., 0].sum(-1).cpu()
-    want_s1 = ref_conv.reshape(B, 8, -1).sum(-1)
+    want_s1 = ref_conv.reshape(B, ngroups, -1).sum(-1)
     assert (s1 - want_s1).abs().max() <= 1e-3 * max(1.0, float(want_s1.abs().max()))
     d = to_dev_nhwc(conv_out, bf16)
     dres = to_dev_nhwc(res, bf16)
     dg, db_, dss = gamma.to(DEV), beta.to(DEV), ss.to(DEV)      # keep the device copies alive across the call
     part = part.contiguous()
-    L().check(lib.srgd_k_groupnorm_silu(ptr(d), ptr(d), ptr(dres), ptr(part), B, H * W, cout, 8, ptr(dg), ptr(db_),
+    L().check(lib.srgd_k_groupnorm_silu(ptr(d), ptr(d), ptr(dres), ptr(part), B, H * W, cout, ngroups, ptr(dg), ptr(db_),
                                         ptr(dss), nslots, int(bf16), stream()), "groupnorm")
     got = from_dev_nhwc(d)
-    y = F.group_norm(conv_out if bf16 else ref_conv, 8, gamma, beta, eps=1e-5)
+    y = F.group_norm(conv_out if bf16 else ref_conv, ngroups, gamma, beta, eps=1e-5)
     y = y * (ss[:, :cout, None, None] + 1) + ss[:, cout:, None, None]
     want = F.silu(y) + res
     assert (got - want).abs().max() <= tol(bf16, want, k=2.0)
