@@ -43,8 +43,8 @@ typedef struct srgd_engine srgd_engine;
                               * U-Net); other 3x3 layers fall back to the bf16 kernels. */
 #define SRGD_PRECISION_FP8_MIXED 4 /* SRGD_PRECISION_FP8 below the top resolution only: the first down stage, the last up stage
                                     * and the final ResnetBlock (everything at the tile's own 256x256 resolution) keep their 3x3
-                                    * convolutions on the bf16 kernel.  Measured on BASELINE configs[4]: 53.2 dB vs the bf16
-                                    * engine (all-fp8: 34.1 dB) at 1.16x its throughput (all-fp8: 1.32x). */
+                                    * convolutions on the bf16 kernel.  Measured on BASELINE configs[4]: 53.5 dB vs the bf16
+                                    * engine (all-fp8: 36.6 dB) at 1.16x its throughput (all-fp8: 1.32x). */
 
 /* Constructor arguments of ConditionalSRUnet (model.py:537-556) as get_model passes them
  * (model.py:3504-3514).  Unsupported combinations are rejected by srgd_create. */

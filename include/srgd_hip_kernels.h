@@ -46,7 +46,8 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
                         const float* gn_tail_b, void* stream);
 
 /* bf16 NHWC [npix][C] -> OCP MX-fp8: q [npix][C] e4m3 bytes + s [npix][C/32] E8M0 bytes (x ~ q * 2^(s-127); one scale per 32
- * consecutive channels = floor(log2 max|x|) - 8, elements clamped to +-448, round-to-nearest-even).  C % 32 == 0.
+ * consecutive channels = floor(log2 max|x|) - 8, + 1 when the block maximum would exceed 448 after scaling; elements clamped to
+ * +-448, round-to-nearest-even).  C % 32 == 0.
  * The activation format of the fp8 mode's 3x3 convolutions (SRGD_PRECISION_FP8). */
 int srgd_k_quant_mxfp8(const void* x_bf16, void* q, void* s, int64_t npix, int C, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution on v_mfma_scale_f32_16x16x128_f8f6f4.  replaces: Block.proj (model.py:246) in fp8 mode.

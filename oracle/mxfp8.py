@@ -1,9 +1,9 @@
 """CPU emulation of OCP Microscaling fp8 (MX-fp8, e4m3 elements + one E8M0 scale per 32 elements) - TEST INFRASTRUCTURE ONLY.
 
 The reference has no fp8 path: BASELINE configs[4] asks for an fp8 compute mode of THIS engine with a parity-vs-bf16
-check.  This file restates the published format (OCP Microscaling Formats v1.0: shared exponent =
-floor(log2(max|x|)) - emax_elem with emax_elem = 8 for e4m3, elements = round-to-nearest-even of x / 2^exp, saturated to
-+-448) so the GPU quantisation kernel (quant_mxfp8.hip), the host weight packing (conv3x3_mxfp8.hip) and the convolution on
+check.  This file restates the published format (OCP Microscaling Formats v1.0: e4m3 elements = round-to-nearest-even of
+x / 2^exp saturated to +-448, one E8M0 exponent per 32 elements) with the engine's scale rule (block_exponent: the recipe's
+floor(log2(max|x|)) - 8, one step up when the block maximum would saturate) so the GPU quantisation kernel (quant_mxfp8.hip), the host weight packing (conv3x3_mxfp8.hip) and the convolution on
 v_mfma_scale_f32_16x16x128_f8f6f4 can be checked bit for bit / to fp32 summation order.  Imported by tests only.
 """
 from __future__ import annotations
@@ -12,10 +12,15 @@ import torch
 
 
 def block_exponent(amax: torch.Tensor) -> torch.Tensor:
-    """E8M0 byte of a block with maximum magnitude `amax` (float32 tensor): floor(log2 amax) - 8 + 127; zero/denormal
-    blocks get byte 0.  Read from the float's exponent field exactly as the kernels do."""
-    bexp = (amax.contiguous().view(torch.int32) >> 23) & 0xFF
-    return (bexp - 8).clamp(min=0).to(torch.uint8)
+    """E8M0 byte of a block with maximum magnitude `amax` (float32 tensor): floor(log2 amax) - 8 + 127, plus one when the
+    maximum's mantissa exceeds 1.75 (it would land above 448 = the e4m3 maximum after scaling): the smallest power-of-two scale
+    that does not saturate the block maximum.  (The OCP conversion recipe stops at floor(log2 amax) - 8 and clamps; the engine's
+    rule keeps the format and trades one bit of resolution in those blocks for an unclipped maximum: +2.5 dB on configs[4].)
+    Zero/denormal blocks get byte 0.  Read from the float's bit fields exactly as the kernels do."""
+    bits = amax.contiguous().view(torch.int32)
+    bexp = (bits >> 23) & 0xFF
+    over = ((bits & 0x7FFFFF) > 0x600000).to(torch.int32)
+    return (bexp - 8 + over).clamp(min=0, max=254).to(torch.uint8)
 
 
 def quantize(x: torch.Tensor, block: int = 32):

@@ -403,12 +403,13 @@ unsigned char e4m3_encode(float x) {
   return sgn | (unsigned char)((e << 3) | mant);
 }
 
-// E8M0 exponent of a block with maximum magnitude amax (OCP MX: floor(log2 amax) - emax(e4m3) with emax = 8), clamped
+// E8M0 exponent of a block with maximum magnitude amax: floor(log2 amax) - emax(e4m3) with emax = 8 (the OCP MX recipe), one step
+// up when the maximum would saturate (mantissa > 1.75 -> above 448 after scaling); the rule of mx_quant8 (common.hpp), clamped
 int mx_block_exponent(float amax) {
   if (!(amax > 0.f)) return -127;
   int ex;
-  (void)std::frexp(amax, &ex);                    // amax = m * 2^ex, m in [0.5, 1) -> floor(log2 amax) = ex - 1
-  int e = ex - 1 - 8;
+  const float m = std::frexp(amax, &ex);          // amax = m * 2^ex, m in [0.5, 1) -> floor(log2 amax) = ex - 1
+  int e = ex - 1 - 8 + (m * 2.0f > 1.75f ? 1 : 0);
   return e < -127 ? -127 : (e > 127 ? 127 : e);
 }
 

@@ -1,8 +1,9 @@
 // bf16 NHWC activations -> OCP MX-fp8 for the block-scaled 3x3 convolution (conv3x3_mxfp8.hip):
 //   q [npix][C]     e4m3 ("fn": bias 7, max 448, no infinity), one byte per element, channels contiguous
 //   s [npix][C/32]  E8M0 shared exponent per 32 consecutive channels: x ~ q * 2^(s - 127)
-// Scale rule (OCP Microscaling spec, e4m3: emax = 8): s - 127 = floor(log2(max |x| over the block)) - 8, elements scaled by
-// 2^-(s-127), clamped to +-448 (a block maximum with mantissa > 1.75 would otherwise overflow) and rounded to nearest-even.
+// Scale rule: s - 127 = floor(log2(max |x| over the block)) - 8 (OCP Microscaling recipe, e4m3: emax = 8), plus one when the block
+// maximum's mantissa exceeds 1.75 - the smallest power of two that does not saturate it (mx_quant8, common.hpp); elements scaled
+// by 2^-(s-127), clamped to +-448 and rounded to nearest-even.
 // Optionally fused in front: y = silu(a[b][c] * x + b[b][c]) - the GroupNorm-apply + SiLU between the two convolutions of a
 // ResnetBlock (reference Block.forward model.py:250-259), so that pass writes 1 byte per element instead of 2.
 // HBM-bound: 2 B read + 1.03 B written per element; 4 lanes share a scale block (16-byte loads, 8-byte stores).

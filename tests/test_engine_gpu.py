@@ -835,7 +835,8 @@ def test_config5_full_geometry_fp8_vs_bf16_parity_report():
     assert torch.isfinite(outs["fp8_mixed"]).all() and psnr_mixed > 50.0, psnr_mixed
     assert outs["fp8"].shape == (1, 3, 1024, 1024)
     assert torch.isfinite(outs["fp8"]).all() and outs["fp8"].min() >= 0 and outs["fp8"].max() <= 1
-    assert psnr > 31.0, psnr           # measured 34.1 dB on MI355X (random-init weights; 3 mantissa bits on weights AND activations)
+    assert psnr > 33.5, psnr           # measured 36.6 dB on MI355X (random-init weights; 3 mantissa bits on weights AND activations;
+                                       # 34.1 dB with the OCP recipe's clamping scale rule)
 
 
 def test_fp8_fused_twins_equal_separate_quantisation_passes_bitwise():

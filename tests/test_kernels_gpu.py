@@ -475,7 +475,7 @@ def test_kernel_chains_match_reference_submodules_fp32():
 
 # ------------------------------------------------------------------ MX-fp8 (BASELINE configs[4] compute path)
 def test_quant_mxfp8_is_bit_exact_with_the_format_emulation():
-    # quant_mxfp8.hip vs oracle/mxfp8.py (OCP MX: E8M0 = floor(log2 amax) - 8, e4m3 RNE, saturation at 448): every byte equal.
+    # quant_mxfp8.hip vs oracle/mxfp8.py (OCP MX format; E8M0 = floor(log2 amax) - 8, + 1 when the block maximum would saturate; e4m3 RNE): every byte equal.
     from oracle import mxfp8 as MX
     lib = L().lib()
     g = torch.Generator().manual_seed(31)
