@@ -32,8 +32,9 @@ def run(prec):
 ref, t_bf = run("bf16")
 print(f"bf16: {t_bf:.2f} s for 5 HR tiles")
 rows = []
-for name, mask in [("fp8 everywhere", 0), ("final block bf16", 1 << 9), ("final + up3 bf16", (1 << 9) | (1 << 8)), ("down0 + final + up3 bf16", 1 | (1 << 9) | (1 << 8)),
-                   ("all 256^2 + 128^2 zones bf16", 1 | 2 | (1 << 7) | (1 << 8) | (1 << 9)), ("only middle+32^2/64^2 fp8", 1 | 2 | (1 << 7) | (1 << 8) | (1 << 9))][:5]:
+extra = [(f"mask {int(m, 0)}", int(m, 0)) for m in os.environ.get("MASKS", "").split(",") if m]
+for name, mask in extra or [("fp8 everywhere", 0), ("final block bf16", 1 << 9), ("final + up3 bf16", (1 << 9) | (1 << 8)), ("down0 + final + up3 bf16", 1 | (1 << 9) | (1 << 8)),
+                   ("all 256^2 + 128^2 zones bf16", 1 | 2 | (1 << 7) | (1 << 8) | (1 << 9)), ("only middle+32^2/64^2 fp8", 1 | 2 | (1 << 7) | (1 << 8) | (1 << 9))][:len(extra) or 5]:
     os.environ["SRGD_FP8_BF16_ZONES"] = str(mask)
     sampler.model._invalidate_engines()
     out, t = run("fp8")
@@ -42,4 +43,4 @@ for name, mask in [("fp8 everywhere", 0), ("final block bf16", 1 << 9), ("final 
     rows.append(dict(zones_bf16=name, mask=mask, psnr_db_vs_bf16=round(psnr, 2), seconds_5_hr_tiles=round(t, 2), speedup_vs_bf16=round(t_bf / t, 3)))
     print(rows[-1], flush=True)
 os.environ.pop("SRGD_FP8_BF16_ZONES", None)
-json.dump(dict(bf16_seconds=t_bf, rows=rows), open(os.path.join(ROOT, "gpurun_out", "fp8_zone_study.json"), "w"), indent=1)
+json.dump(dict(bf16_seconds=t_bf, rows=rows), open(os.path.join(ROOT, "gpurun_out", "fp8_zone_study_extra.json" if extra else "fp8_zone_study.json"), "w"), indent=1)
