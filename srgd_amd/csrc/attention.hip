@@ -35,13 +35,11 @@ __global__ __launch_bounds__(256) void la_partial_kernel(const T* __restrict__ q
   const T* vp = kp + hid;
 
   float m = -INFINITY;
-#pragma unroll 8
   for (int n = h; n < cnt; n += 2) m = fmaxf(m, to_f32<T>(kp[(size_t)n * C3]));
   m = fmaxf(m, __shfl_xor(m, 32, 64));
 
   f32x16 acc = 0;
   float l = 0.f;
-#pragma unroll 4
   for (int n = 0; n < cnt; n += 2) {
     const bool ok = n + h < cnt;
     const size_t o = (size_t)(ok ? n + h : 0) * C3;

@@ -105,7 +105,6 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   const int y0 = ty * PH, x0 = tx * PW;
   const int Cin = p.C0 + p.C1;
   const int CC = Cin / KC;
-  const int S = CC * 9;
 
   // ---- A staging: 24 wave-instructions per chunk; wave w issues pieces w, w+8, w+16 (pieces >= 22 are all-zero).
   // Per-lane pixel offset (y*W+x) or -1 and source chunk (0..3) of its three pieces, as NAMED scalars (indexed
