@@ -223,3 +223,28 @@ def test_edm_untiled_sample_matches_reference(case):
                  class_cond_scale=case["class_cond_scale"], **C.edm_extra_kwargs(case))
     assert got.shape == z["image"].shape
     assert np.abs(got.numpy() - z["image"]).max() <= 1e-4
+
+
+def test_mxfp8_emulation_scale_rule_and_round_trip():
+    # oracle/mxfp8.py (the format emulation the GPU quantiser is checked against bit for bit): known answers of the scale rule -
+    # floor(log2 amax) - 8, one step up exactly when the block maximum would land above 448 - and round-trip properties
+    from oracle import mxfp8 as M
+    be = lambda v: int(M.block_exponent(torch.tensor([v], dtype=torch.float32))[0])
+    assert be(448.0) == 127 and be(449.0) == 128            # 448 = 1.75 * 2^8 still fits, 449 does not
+    assert be(1.0) == 119 and be(1.75) == 119 and be(1.76) == 120
+    assert be(0.0) == 0 and be(1e-40) == 0                  # zero / denormal blocks: smallest scale
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 128, generator=g) * torch.logspace(-3, 3, 64).unsqueeze(1)      # rows over six decades
+    q, s, deq = M.quantize(x)
+    assert q.shape == x.shape and s.shape == (64, 4) and q.dtype == torch.uint8 and s.dtype == torch.uint8
+    blocks = x.reshape(64, 4, 32)
+    scale = torch.ldexp(torch.ones(64, 4), s.int() - 127)
+    # never saturates: the block maximum is representable (<= 448 after scaling), and the scale is the smallest such power of two
+    assert float((blocks.abs().amax(-1) / scale).max()) <= 448.0
+    assert float((blocks.abs().amax(-1) / (scale / 2)).min()) > 448.0
+    # e4m3 carries 3 mantissa bits: relative error of a normal element <= 2^-4; dequantise -> requantise is idempotent
+    rel = ((deq - x).abs() / x.abs().clamp(min=1e-30)).reshape(64, 4, 32)
+    big = blocks.abs() >= blocks.abs().amax(-1, keepdim=True) / 64       # elements within 6 binades of the block maximum
+    assert float(rel[big].max()) <= 2.0 ** -4 + 1e-6
+    # (as values: a maximum that rounded down onto mantissa 1.75 is re-encoded one scale step lower with the same value)
+    assert torch.equal(M.quantize(deq)[2], deq)
