@@ -785,7 +785,9 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
             if zero_init:
                 return torch.zeros(1, 3, b * s_, s_, device=dev)
             return batch_noise(1) * sigma0
-        return eng, b, s_, dev, geo, tiles, cond01, to_canvas, from_canvas, batch_noise, start, host_noise, seed
+        from types import SimpleNamespace
+        return SimpleNamespace(eng=eng, b=b, s=s_, dev=dev, geo=geo, tiles=tiles, cond01=cond01, from_canvas=from_canvas,
+                               batch_noise=batch_noise, start=start, host_noise=host_noise, seed=seed)
 
     @staticmethod
     def _guidance(i, cond_scale, guidance_start_steps, class_cond_scale, class_guidance_start_steps):
@@ -805,32 +807,32 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         the same per-step arithmetic as ``tiled_sample`` with one tile per image, per-image noise and no ring."""
         n = self.num_sample_steps if num_sample_steps is None else num_sample_steps
         sigmas, _, scalars, c_noise = self._step_tables(n, clamp)
-        (eng, b, s_, dev, geo, tiles, cond01, to_canvas, from_canvas, batch_noise, start, host_noise,
-         seed) = self._untiled_setup(batch_size, condition_x, class_label, cond_scale, class_cond_scale,
-                                     generation_start_steps, zero_init, float(sigmas[0]), precision)
+        u = self._untiled_setup(batch_size, condition_x, class_label, cond_scale, class_cond_scale, generation_start_steps,
+                                zero_init, float(sigmas[0]), precision)
+        eng, b, s_, dev = u.eng, u.b, u.s, u.dev
         cond_canvas = torch.empty(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
-        eng.edm_begin(geo, cond01, cond_canvas, tiles, tiles, scalars, c_noise, _single_class_id(class_label))
-        img = start(eng)
+        eng.edm_begin(u.geo, u.cond01, cond_canvas, u.tiles, u.tiles, scalars, c_noise, _single_class_id(class_label))
+        img = u.start(eng)
         x_start = img.clone() if with_x0_images else None
-        image_list = [from_canvas(img).cpu()] if with_images else None
-        x0_image_list = [from_canvas(img).cpu()] if with_x0_images else None
+        image_list = [u.from_canvas(img).cpu()] if with_images else None
+        x0_image_list = [u.from_canvas(img).cpu()] if with_x0_images else None
         work = torch.empty(2, 1, 3, b * s_, s_, device=dev, dtype=torch.float32)
         for i in range(n):
             if i < generation_start_steps:
                 continue
             passes, kind, scale = self._guidance(i, cond_scale, guidance_start_steps, class_cond_scale,
                                                  class_guidance_start_steps)
-            z = batch_noise(None) if host_noise else None               # eps of the step (:2269)
+            z = u.batch_noise(None) if u.host_noise else None           # eps of the step (:2269)
             # the ring of this geometry is empty (inner area = the whole canvas): no second draw on odd steps
             eng.edm_step(i, img, cond_canvas, x_start, work, z, None, passes, kind, scale, self.max_tiles_per_launch or b,
-                         seed=seed)
+                         seed=u.seed)
             if with_images:
-                image_list.append(from_canvas(img).cpu())
+                image_list.append(u.from_canvas(img).cpu())
             if with_x0_images:
-                x0_image_list.append(from_canvas(x_start).cpu())
+                x0_image_list.append(u.from_canvas(x_start).cpu())
         out = torch.empty(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
         eng.sampler_end(img, out)
-        out = from_canvas(out)
+        out = u.from_canvas(out)
         if with_images:
             return (out, image_list, x0_image_list) if with_x0_images else (out, image_list)
         return out
@@ -851,15 +853,15 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
                 t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
                 r = (t - t_fn(sigmas[i - 1])) / (t_next - t)
                 scalars[i].dpm_gamma = float(-1 / (2 * r))
-        (eng, b, s_, dev, geo, tiles, cond01, to_canvas, from_canvas, batch_noise, start, host_noise,
-         seed) = self._untiled_setup(batch_size, condition_x, class_label, cond_scale, class_cond_scale,
-                                     generation_start_steps, zero_init, float(sigmas[0]), precision)
+        u = self._untiled_setup(batch_size, condition_x, class_label, cond_scale, class_cond_scale, generation_start_steps,
+                                zero_init, float(sigmas[0]), precision)
+        eng, b, s_, dev = u.eng, u.b, u.s, u.dev
         cond_canvas = torch.empty(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
-        eng.edm_begin(geo, cond01, cond_canvas, tiles, tiles, scalars, c_noise, _single_class_id(class_label))
-        img = start(eng)
+        eng.edm_begin(u.geo, u.cond01, cond_canvas, u.tiles, u.tiles, scalars, c_noise, _single_class_id(class_label))
+        img = u.start(eng)
         x_start = img.clone() if with_x0_images else None
-        image_list = [from_canvas(img).cpu()] if with_images else None
-        x0_image_list = [from_canvas(img).cpu()] if with_x0_images else None
+        image_list = [u.from_canvas(img).cpu()] if with_images else None
+        x0_image_list = [u.from_canvas(img).cpu()] if with_x0_images else None
         old = torch.zeros(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
         for i in range(n):
             if i < generation_start_steps:
@@ -868,12 +870,12 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
                                                  class_guidance_start_steps)
             eng.edm_dpmpp_step(i, img, cond_canvas, x_start, old, passes, kind, scale, self.max_tiles_per_launch or b)
             if with_images:
-                image_list.append(from_canvas(img).cpu())
+                image_list.append(u.from_canvas(img).cpu())
             if with_x0_images:
-                x0_image_list.append(from_canvas(x_start).cpu())
+                x0_image_list.append(u.from_canvas(x_start).cpu())
         out = torch.empty(1, 3, b * s_, s_, device=dev, dtype=torch.float32)
         eng.sampler_end(img, out)
-        out = from_canvas(out)
+        out = u.from_canvas(out)
         if with_images:
             return (out, image_list, x0_image_list) if with_x0_images else (out, image_list)
         return out
