@@ -54,6 +54,9 @@ def parse_args(argv=None):
                         "throughput modes of the MI355X engine (explicit opt-in)")
     p.add_argument("--device_noise", action="store_true",
                    help="draw DDPM noise on the GPU (Philox) instead of replaying torch's CPU stream")
+    p.add_argument("--lockstep", type=int, default=1,
+                   help="sample up to N consecutive same-sized images together (their tiles share U-Net launches, "
+                        "--batch_size tiles per image and launch); every image comes out bit-identical to its solo run")
     return p.parse_args(argv)
 
 
@@ -138,6 +141,30 @@ def sr_target_image(image, sr_model, scale=4, batch_size=8, test_label=2, cond_s
     return sr_img
 
 
+def sr_target_images(images, sr_model, scale=4, batch_size=8, test_label=2, cond_scale=1.0, guidance_start_steps=0,
+                     class_cond_scale=1.0, class_guidance_start_steps=0, generation_start_steps=0,
+                     num_sample_steps=250, enable_amp=False, interpolation="bicubic", seed=71):
+    """``sr_target_image`` for several same-sized images in lock-step (engine extension): one ``tiled_sample`` call on a
+    ``[B,3,H,W]`` condition.  Each image is sampled exactly as it would be alone after the reference's per-image
+    ``seed_everything(seed)`` (inference.py:73) - bit-identical outputs - while their tiles fill the U-Net launches."""
+    assert len({im.size for im in images}) == 1, "lock-step images must have the same size"
+    width, height = images[0].size
+    condition_x = torch.cat([upsample_bicubic_on_device(im, scale, sr_model.device) for im in images], 0)
+    label = torch.LongTensor([test_label]).to(sr_model.device) if test_label is not None else None
+    seed_everything(seed)
+    sr_model.device_noise_seed = seed
+    with torch.inference_mode():
+        output = sr_model.tiled_sample(batch_size=batch_size * len(images), condition_x=condition_x, class_label=label,
+                                       cond_scale=cond_scale, guidance_start_steps=guidance_start_steps,
+                                       class_cond_scale=class_cond_scale,
+                                       class_guidance_start_steps=class_guidance_start_steps,
+                                       generation_start_steps=generation_start_steps,
+                                       num_sample_steps=num_sample_steps, amp=enable_amp)
+    outs = [unit_tensor_to_pil_on_device(o) for o in output]
+    assert all(o.size == (width * 4, height * 4) for o in outs)
+    return outs
+
+
 def try_open_image(image_path):
     try:
         return Image.open(image_path).convert("RGB")
@@ -148,25 +175,45 @@ def try_open_image(image_path):
 def batch_sr_target_images(input_dir, output_dir, sr_model, scale=4, batch_size=8, test_label=2, cond_scale=1.0,
                            guidance_start_steps=0, class_cond_scale=1.0, class_guidance_start_steps=0,
                            generation_start_steps=0, num_sample_steps=250, start_index=0, end_index=None,
-                           enable_amp=False, interpolation="bicubic", seed=71):
+                           enable_amp=False, interpolation="bicubic", seed=71, lockstep=1):
     print(f"save images at: {output_dir}")
     os.makedirs(output_dir, exist_ok=True)
-    for filename in sorted(glob.glob(f"{input_dir}/*"))[start_index:end_index]:
-        save_path = os.path.join(output_dir, os.path.basename(filename).replace(".png", "_out.png"))
-        if os.path.exists(save_path):
-            print("skip")
-            continue
-        image = try_open_image(filename)
-        if image is None:
-            print("Invalid image or unable to open image:", filename)
-            continue
-        sr = sr_target_image(image, sr_model, scale=scale, batch_size=batch_size, test_label=test_label,
-                             cond_scale=cond_scale, guidance_start_steps=guidance_start_steps,
-                             class_cond_scale=class_cond_scale,
-                             class_guidance_start_steps=class_guidance_start_steps,
-                             generation_start_steps=generation_start_steps, num_sample_steps=num_sample_steps,
-                             enable_amp=enable_amp, interpolation=interpolation, seed=seed)
-        sr.save(save_path)
+    kw = dict(scale=scale, batch_size=batch_size, test_label=test_label, cond_scale=cond_scale,
+              guidance_start_steps=guidance_start_steps, class_cond_scale=class_cond_scale,
+              class_guidance_start_steps=class_guidance_start_steps, generation_start_steps=generation_start_steps,
+              num_sample_steps=num_sample_steps, enable_amp=enable_amp, interpolation=interpolation, seed=seed)
+    from concurrent.futures import ThreadPoolExecutor
+    pending, saves = [], []                              # (image, save_path) of the current lock-step group; PNG writers
+
+    with ThreadPoolExecutor(max_workers=2) as pool:      # PNG encoding overlaps the next group's sampling
+        def flush():
+            if not pending:
+                return
+            if len(pending) == 1:
+                outs = [sr_target_image(pending[0][0], sr_model, **kw)]
+            else:
+                outs = sr_target_images([im for im, _ in pending], sr_model, **kw)
+            for (_, path), sr in zip(pending, outs):
+                saves.append(pool.submit(sr.save, path))
+            pending.clear()
+
+        for filename in sorted(glob.glob(f"{input_dir}/*"))[start_index:end_index]:
+            save_path = os.path.join(output_dir, os.path.basename(filename).replace(".png", "_out.png"))
+            if os.path.exists(save_path):
+                print("skip")
+                continue
+            image = try_open_image(filename)
+            if image is None:
+                print("Invalid image or unable to open image:", filename)
+                continue
+            if pending and (len(pending) >= max(1, lockstep) or pending[0][0].size != image.size):
+                flush()
+            pending.append((image, save_path))
+            if len(pending) >= max(1, lockstep):
+                flush()
+        flush()
+        for f in saves:
+            f.result()                                   # surface write errors
 
 
 def main(argv=None):
@@ -190,7 +237,7 @@ def main(argv=None):
                            generation_start_steps=args.generation_start_steps,
                            num_sample_steps=args.num_sample_steps, start_index=args.start_index,
                            end_index=args.end_index, enable_amp=args.amp, interpolation=args.interpolation,
-                           seed=args.seed)
+                           seed=args.seed, lockstep=args.lockstep)
 
 
 if __name__ == "__main__":

@@ -66,3 +66,30 @@ def test_inference_cli_writes_out_pngs_and_matches_the_oracle_pipeline(tmp_path)
     bf = np.asarray(Image.open(out_bf / "a_out.png").convert("RGB")).astype(np.float64)
     mse = ((bf - got.astype(np.float64)) ** 2).mean() / 255.0 ** 2
     assert 10 * np.log10(1.0 / max(mse, 1e-20)) > 40.0
+
+
+def test_inference_cli_lockstep_groups_equal_one_image_at_a_time(tmp_path):
+    # --lockstep N (engine extension): consecutive same-sized images sampled together, each bit-identical to its solo run (the
+    # reference reseeds per image, inference.py:73); a differently sized image closes the group
+    dim, steps = 16, 3
+    conf_src = open(os.path.join(ROOT, "conf", "conditional_continuous_linear_df8kost_dim128.yaml")).read()
+    conf = tmp_path / "dim16.yaml"
+    conf.write_text(conf_src.replace("unet_dim: 128", f"unet_dim: {dim}"))
+    ckpt = tmp_path / "ckpt.pth"
+    torch.save({"ema_model": synth_state_dict(_schema(dim), seed=3), "epoch": 300}, ckpt)
+    indir = tmp_path / "in"
+    indir.mkdir()
+    rng = np.random.default_rng(9)
+    for name, (h, w) in (("a", (40, 56)), ("b", (40, 56)), ("c", (40, 56)), ("d", (72, 64)), ("e", (40, 56))):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB").save(indir / f"{name}.png")
+    outs = {}
+    for tag, extra in (("solo", []), ("lock", ["--lockstep", "2"])):
+        outdir = tmp_path / f"out_{tag}"
+        cmd = [sys.executable, os.path.join(ROOT, "inference.py"), "-c", str(conf), "-m", str(ckpt), "--input_dir", str(indir),
+               "--output_dir", str(outdir), "--num_sample_steps", str(steps), "--test_label", "0", "--batch_size", "4"] + extra
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[tag] = {n: np.asarray(Image.open(outdir / f"{n}_out.png").convert("RGB")) for n in "abcde"}
+    for n in "abcde":
+        assert outs["solo"][n].shape == outs["lock"][n].shape
+        assert np.array_equal(outs["solo"][n], outs["lock"][n]), n
