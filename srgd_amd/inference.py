@@ -216,6 +216,18 @@ def batch_sr_target_images(input_dir, output_dir, sr_model, scale=4, batch_size=
             f.result()                                   # surface write errors
 
 
+def rank_file_range(n_files, start_index, end_index, rank, world):
+    """The reference parallelises by hand: one process per GPU with its own ``--start_index/--end_index`` (inference.py:36-37,
+    :120).  Under a launcher that sets RANK / WORLD_SIZE (``torchrun --nproc-per-node 8 inference.py ...``) the selected range
+    ``[start_index:end_index]`` is cut into ``world`` contiguous slices instead - contiguous, so that ``--lockstep`` groups of
+    neighbouring same-sized images survive - and this returns rank's ``(start, end)``.  No collective is involved."""
+    lo, hi, _ = slice(start_index, end_index).indices(n_files)
+    n = max(0, hi - lo)
+    per, rem = divmod(n, world)
+    a = lo + rank * per + min(rank, rem)
+    return a, a + per + (1 if rank < rem else 0)
+
+
 def main(argv=None):
     logging.basicConfig(level=logging.INFO, format="[%(levelname)s %(asctime)s] %(message)s")
     args = parse_args(argv)
@@ -225,7 +237,13 @@ def main(argv=None):
     ema_model = get_model(conf, logger)
     if not torch.cuda.is_available():
         raise SystemExit("srgd_amd needs an MI355X: no GPU visible and there is no CPU fallback")
-    sr_model = ema_model.module.eval().to(torch.device("cuda"))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:                                        # one process per GPU, each with its own slice of the input files
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        n_files = len(glob.glob(f"{args.input_dir}/*"))
+        args.start_index, args.end_index = rank_file_range(n_files, args.start_index, args.end_index, rank, world)
+        print(f"rank {rank}/{world}: files [{args.start_index}:{args.end_index}] of {n_files}")
+    sr_model = ema_model.module.eval().to(torch.device("cuda", torch.cuda.current_device()))
     sr_model.noise_source = "device" if args.device_noise else "host"
     sr_model.precision = args.precision
     print(f"engine precision: {args.precision} (noise: {sr_model.noise_source})")

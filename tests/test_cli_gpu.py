@@ -93,3 +93,14 @@ def test_inference_cli_lockstep_groups_equal_one_image_at_a_time(tmp_path):
     for n in "abcde":
         assert outs["solo"][n].shape == outs["lock"][n].shape
         assert np.array_equal(outs["solo"][n], outs["lock"][n]), n
+    # under a launcher (RANK / WORLD_SIZE set): every rank takes a contiguous slice of the files - here two ranks sharing cuda:0 -
+    # and together they produce the same five images (the automatic form of the reference's --start_index/--end_index per process)
+    outdir = tmp_path / "out_2ranks"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(ROOT, "inference.py"), "-c", str(conf), "-m", str(ckpt), "--input_dir", str(indir),
+           "--output_dir", str(outdir), "--num_sample_steps", str(steps), "--test_label", "0", "--batch_size", "4"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "rank 0/2: files [0:3] of 5" in r.stdout and "rank 1/2: files [3:5] of 5" in r.stdout
+    for n in "abcde":
+        assert np.array_equal(np.asarray(Image.open(outdir / f"{n}_out.png").convert("RGB")), outs["solo"][n]), n

@@ -211,3 +211,21 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
                        timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and "{" not in r.stdout
+
+
+def test_cli_rank_file_ranges_partition_the_selected_files():
+    # inference.py under a launcher (RANK / WORLD_SIZE): contiguous per-rank slices of [start_index:end_index], the automatic
+    # form of the reference's hand-set --start_index/--end_index per process (inference.py:36-37, :120)
+    from srgd_amd.inference import rank_file_range
+    for n in (0, 1, 7, 8, 64, 1000):
+        for (s0, e0) in ((0, None), (3, None), (0, 5), (2, 50), (10, 4)):
+            want = list(range(n))[s0:e0]
+            for world in (1, 2, 3, 8):
+                got = []
+                sizes = []
+                for r in range(world):
+                    a, b = rank_file_range(n, s0, e0, r, world)
+                    got += list(range(n))[a:b]
+                    sizes.append(b - a)
+                assert got == want, (n, s0, e0, world)
+                assert max(sizes) - min(sizes) <= 1
