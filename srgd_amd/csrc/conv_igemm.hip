@@ -44,8 +44,10 @@ __device__ __forceinline__ void mma(f32x16& acc, const Frag<float>& a, const Fra
   for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
 }
 
+// fp32 with 16-channel chunks: capped at 128 registers (115 used, no spills) so that four workgroups share a CU - the LDS ring
+// (40,960 B) allows exactly four; left alone the compiler takes 93 VGPRs + 64 AGPRs and only three fit
 template <typename T, int BKC, bool PRECISE>
-__global__ __launch_bounds__(NT) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(NT, (sizeof(T) == 4 && BKC == 16) ? 4 : 1) void conv_igemm_kernel(ConvArgs p) {
   constexpr int ROWB = BKC * (int)sizeof(T);       // bytes of K per tile row: 32 / 64 / 128
   constexpr int CPR = ROWB / 16;                   // 16-byte chunks per row
   constexpr int STRIDE = ROWB + 16;                // padded LDS row stride
