@@ -814,7 +814,8 @@ int run_init7(srgd_engine* e, const void* padded, int entries, int H, int W, voi
   a.gn_res_src = nullptr; a.gn_res_a = a.gn_res_b = nullptr;
   if (e->bf16 && e->init7_w1 && !e->no_conv1x1 && !e->force_generic_conv && conv1x1_bf16_eligible(a)) {
     QTensor tw;                                    // fp8 mode: x0 feeds the first and the last ResnetBlock's 3x3 convolutions
-    if (twin_wanted(e, true, e->dim)) {
+    const bool x0q = e->fp8 && (!((e->fp8_bf16_zones >> 0) & 1u) || !((e->fp8_bf16_zones >> (2 * e->n_stages + 1)) & 1u));
+    if (twin_wanted(e, x0q, e->dim)) {
       SRGD_TRY(twin_alloc(e, (size_t)entries * H * W, e->dim, &tw));
       a.out_q = tw.q; a.out_s = tw.s;
     }
@@ -824,6 +825,10 @@ int run_init7(srgd_engine* e, const void* padded, int entries, int H, int W, voi
   }
   return conv_igemm(a, e->bf16, st);
 }
+
+// fp8 modes: do the 3x3 convolutions of U-Net zone `zone` run on the MX kernel?  A producer writes a tensor's MX-fp8 twin only
+// when one of the tensor's consumers does (in fp8_mixed mode the 256x256 zones read bf16: their inputs need no twin)
+static bool zone_is_q(const srgd_engine* e, int zone) { return e->fp8 && !((e->fp8_bf16_zones >> zone) & 1u); }
 
 // The U-Net between init_conv and final_conv.  x0: [nb,H,W,dim] (kept alive by the caller).
 int unet_body(Ctx& x, void* x0, void** out) {
@@ -841,19 +846,22 @@ int unet_body(Ctx& x, void* x0, void** out) {
     void *a, *b, *c;
     // want_twin flags (fp8 mode only): true where the tensor is read by a 3x3 convolution later - a: next block + skip,
     // c: skip (+ the last stage's 3x3 resampler), d: the next stage's first block
-    SRGD_TRY(res_block(x, sw.rb[0], cur, C, nullptr, 0, &a, true));
+    // consumers: a -> the stage's second block (zone s) and the skip (up-stage zone 2n - s); c -> the skip and, in the last
+    // stage, the 3x3 resampler; d -> the next stage (zone s + 1; s + 1 == n: the middle)
+    SRGD_TRY(res_block(x, sw.rb[0], cur, C, nullptr, 0, &a, zone_is_q(e, s) || zone_is_q(e, 2 * n - s)));
     if (cur != x0) e->pool.put(cur);
     skips.push_back(a);
     SRGD_TRY(res_block(x, sw.rb[1], a, C, nullptr, 0, &b));
-    SRGD_TRY(attn_block(x, sw.attn, b, &c, true));
+    SRGD_TRY(attn_block(x, sw.attn, b, &c, zone_is_q(e, 2 * n - s) || (s == n - 1 && zone_is_q(e, s))));
     e->pool.put(b);
     skips.push_back(c);
     const ConvW& rs = sw.resample;
     const int Ho = (s < n - 1) ? x.H / 2 : x.H, Wo = (s < n - 1) ? x.W / 2 : x.W;
     void* d = e->pool.get((size_t)x.nb * Ho * Wo * rs.Cout * e->es);
     if (!d) return -1;
-    if (conv_is_q(x, rs, C, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, C, nullptr, 0, x.H, x.W, d, false, true));
-    else SRGD_TRY(run_conv(x, rs, c, C, nullptr, 0, x.H, x.W, d, nullptr, false, false, nullptr, true));
+    const bool dq = zone_is_q(e, s + 1);
+    if (conv_is_q(x, rs, C, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, C, nullptr, 0, x.H, x.W, d, false, dq));
+    else SRGD_TRY(run_conv(x, rs, c, C, nullptr, 0, x.H, x.W, d, nullptr, false, false, nullptr, dq));
     x.H = Ho; x.W = Wo;
     cur = d;
   }
@@ -863,9 +871,9 @@ int unet_body(Ctx& x, void* x0, void** out) {
     x.zone = n;
     SRGD_TRY(res_block(x, e->mid1, cur, C, nullptr, 0, &a));
     e->pool.put(cur);
-    SRGD_TRY(attn_block(x, e->mid_attn, a, &b, true));
+    SRGD_TRY(attn_block(x, e->mid_attn, a, &b, zone_is_q(e, n)));
     e->pool.put(a);
-    SRGD_TRY(res_block(x, e->mid2, b, C, nullptr, 0, &c, true));
+    SRGD_TRY(res_block(x, e->mid2, b, C, nullptr, 0, &c, zone_is_q(e, n + 1)));
     e->pool.put(b);
     cur = c;
   }
@@ -875,19 +883,21 @@ int unet_body(Ctx& x, void* x0, void** out) {
     x.zone = n + 1 + u;
     void *a, *b, *c;
     void* sk = skips.back(); skips.pop_back();
-    SRGD_TRY(res_block(x, sw.rb[0], cur, dout, sk, din, &a, true));
+    const bool zq = zone_is_q(e, n + 1 + u);
+    SRGD_TRY(res_block(x, sw.rb[0], cur, dout, sk, din, &a, zq));
     e->pool.put(cur); e->pool.put(sk);
     sk = skips.back(); skips.pop_back();
     SRGD_TRY(res_block(x, sw.rb[1], a, dout, sk, din, &b));
     e->pool.put(a); e->pool.put(sk);
-    SRGD_TRY(attn_block(x, sw.attn, b, &c, u == n - 1));          // only the last stage resamples with a 3x3 convolution
+    SRGD_TRY(attn_block(x, sw.attn, b, &c, u == n - 1 && zq));    // only the last stage resamples with a 3x3 convolution
     e->pool.put(b);
     const ConvW& rs = sw.resample;
     const int Ho = (u < n - 1) ? x.H * 2 : x.H, Wo = (u < n - 1) ? x.W * 2 : x.W;
     void* d = e->pool.get((size_t)x.nb * Ho * Wo * din * e->es);
     if (!d) return -1;
-    if (conv_is_q(x, rs, dout, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, dout, nullptr, 0, x.H, x.W, d, false, true));
-    else SRGD_TRY(run_conv(x, rs, c, dout, nullptr, 0, x.H, x.W, d, nullptr, false, false, nullptr, true));
+    const bool dq = zone_is_q(e, n + 2 + u);                      // the next up stage, or the final block (zone 2n + 1)
+    if (conv_is_q(x, rs, dout, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, dout, nullptr, 0, x.H, x.W, d, false, dq));
+    else SRGD_TRY(run_conv(x, rs, c, dout, nullptr, 0, x.H, x.W, d, nullptr, false, false, nullptr, dq));
     e->pool.put(c);
     x.H = Ho; x.W = Wo;
     cur = d;

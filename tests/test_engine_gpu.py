@@ -830,6 +830,21 @@ def test_fp8_mode_uses_the_mxfp8_kernels():
     # every tensor a 3x3 convolution reads gets its MX-fp8 twin from its producer's epilogue (conv1x1 variants, GroupNorm2 +
     # residual, both fused LinearAttention kernels, the 3x3 resamplers): no stand-alone quantisation pass is left
     assert prof["launches"]["quantize_mxfp8"] == 0
+    # fp8_mixed: the 11 convolutions at the tile's own resolution (first down stage 4, last up stage 4 + its 3x3 resampler, final
+    # block 2) stay on the bf16 kernel, the other 29 run MX-fp8; twins are written only for tensors an MX convolution reads, and
+    # still no stand-alone quantisation pass is needed
+    eng = sampler.model.engine("fp8_mixed")
+    sampler.noise_source = "device"
+    try:
+        eng.profile_begin()
+        out = sampler.tiled_sample(batch_size=4, condition_x=cond, class_label=torch.tensor([0]).cuda(), num_sample_steps=2,
+                                   precision="fp8_mixed")
+        prof = eng.profile_end()
+    finally:
+        sampler.noise_source = "host"
+    assert torch.isfinite(out).all() and out.min() >= 0 and out.max() <= 1
+    assert prof["launches"]["conv3x3_mxfp8"] == 2 * 29 and prof["launches"]["conv3x3_bf16"] == 2 * 11
+    assert prof["launches"]["quantize_mxfp8"] == 0
 
 
 def test_config5_full_geometry_fp8_vs_bf16_parity_report():
