@@ -504,6 +504,36 @@ def test_edm_untiled_sample_fp32_matches_reference(case):
     assert ((imgs[-1].clamp(-1, 1) + 1) * 0.5 - got).abs().max().item() <= 1e-6
 
 
+def test_untiled_entry_points_bf16_dim128_close_to_fp32_engine():
+    # the un-tiled loops (DDPM sample, EDM sample_org / sample_using_dpmpp) on the production kernels: dim 128, batch of two
+    # 256^2 images as stacked tiles, bf16 against the fp32 engine on the same host noise
+    ddpm, edm = build_sampler(128), build_edm_sampler(128)
+    cond = torch.cat([C.synthetic_lr_condition(i, 64, 64) for i in (0, 1)]).cuda()
+    label = torch.tensor([1]).cuda()
+    ctor_solver = edm.use_dpmpp_solver
+    res = {}
+    try:
+        for name, fn in (("ddpm_sample", lambda p: ddpm.sample(batch_size=2, condition_x=cond, class_label=label, num_sample_steps=6,
+                                                                class_cond_scale=1.5, precision=p)),
+                         ("edm_heun", lambda p: edm.sample(batch_size=2, condition_x=cond, class_label=label, num_sample_steps=5,
+                                                           precision=p)),
+                         ("edm_dpmpp", lambda p: edm.sample(batch_size=2, condition_x=cond, class_label=label, num_sample_steps=6,
+                                                            cond_scale=1.5, precision=p))):
+            edm.use_dpmpp_solver = name == "edm_dpmpp"
+            outs = {}
+            for prec in ("fp32", "bf16"):
+                torch.manual_seed(11)
+                outs[prec] = fn(prec).cpu()
+            mse = float(((outs["bf16"] - outs["fp32"]) ** 2).mean())
+            res[name] = float(10 * np.log10(1.0 / max(mse, 1e-20)))
+            assert outs["bf16"].shape == (2, 3, 256, 256) and torch.isfinite(outs["bf16"]).all()
+            assert outs["bf16"].min() >= 0 and outs["bf16"].max() <= 1
+    finally:
+        edm.use_dpmpp_solver = ctor_solver
+    _report(test="untiled_bf16_vs_fp32_engine_dim128", psnr_db=res)
+    assert min(res.values()) > 48.0, res          # measured 51.5 / 55.3 / 55.8 dB
+
+
 def test_edm_bf16_and_device_noise_modes_run():
     case = C.EDM_CASES[0]
     z = np.load(os.path.join(G, f"sample_edm_{case['name']}.npz"))
