@@ -504,6 +504,34 @@ def test_edm_untiled_sample_fp32_matches_reference(case):
     assert ((imgs[-1].clamp(-1, 1) + 1) * 0.5 - got).abs().max().item() <= 1e-6
 
 
+def test_noised_starts_in_device_noise_mode_are_deterministic():
+    # generation_start_steps > 0 (q_sample of the condition, model.py:3305-3310) and start_white_noise=False (:3311-3315) with the
+    # in-engine Philox generator: finite, in range, bit-repeatable per seed, seed-sensitive, different from the white-noise start;
+    # same for the EDM wrapper's noised start (get_noised_images, :2186-2194)
+    ddpm, edm = build_sampler(16), build_edm_sampler(16)
+    cond = C.synthetic_lr_condition(2, 75, 75).cuda()           # 300 x 300 -> 768^2 canvas
+    label = torch.tensor([0]).cuda()
+    try:
+        for smp in (ddpm, edm):
+            smp.noise_source = "device"
+
+        def run(smp, seed, **kw):
+            smp.device_noise_seed = seed
+            return smp.tiled_sample(batch_size=9, condition_x=cond, class_label=label, num_sample_steps=6, precision="bf16", **kw).cpu()
+
+        base = run(ddpm, 5)
+        for kw in (dict(generation_start_steps=2), dict(start_white_noise=False)):
+            a, b, c = run(ddpm, 5, **kw), run(ddpm, 5, **kw), run(ddpm, 6, **kw)
+            assert torch.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
+            assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, base), kw
+        ebase = run(edm, 5)
+        a, b, c = run(edm, 5, generation_start_steps=2), run(edm, 5, generation_start_steps=2), run(edm, 6, generation_start_steps=2)
+        assert torch.isfinite(a).all() and torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, ebase)
+    finally:
+        for smp in (ddpm, edm):
+            smp.noise_source = "host"
+
+
 def test_untiled_entry_points_bf16_dim128_close_to_fp32_engine():
     # the un-tiled loops (DDPM sample, EDM sample_org / sample_using_dpmpp) on the production kernels: dim 128, batch of two
     # 256^2 images as stacked tiles, bf16 against the fp32 engine on the same host noise
