@@ -229,3 +229,15 @@ def test_cli_rank_file_ranges_partition_the_selected_files():
                     sizes.append(b - a)
                 assert got == want, (n, s0, e0, world)
                 assert max(sizes) - min(sizes) <= 1
+
+
+def test_reflect_padding_larger_than_the_image_is_refused_like_upstream():
+    # F.pad(mode="reflect") at model.py:3303 raises when a pad is >= the dimension it mirrors; the product raises the same
+    # RuntimeError before touching the GPU (srgd_amd/model.py::_tiling), e.g. a 60-pixel-high image padded to 256 rows
+    from srgd_amd.model import _tiling
+    with pytest.raises(RuntimeError, match="Padding size should be less than the corresponding input dimension"):
+        _tiling(60, 300, 256, 256)
+    with pytest.raises(RuntimeError):
+        _tiling(300, 100, 256, 256)
+    (left, top, right, bottom), (hp, wp), even, odd, inner = _tiling(200, 200, 256, 256)     # 28-pixel pads: fine
+    assert (hp, wp) == (256, 256) and len(even) == 1 and len(odd) == 1 and (right - left, bottom - top) == (200, 200)
