@@ -86,13 +86,16 @@ def self_launch(args):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; without it RCCL's intra-node transport
+    # setup (and any cross-process device-memory sharing) fails with `hipIpcGetMemHandle: invalid argument`.  The image and
+    # the GPU boxes export it already; it is only defaulted here so that a scrubbed environment still works
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     return subprocess.run(cmd, env=env).returncode
 
 
-def build_sampler(dim, device, world, rank):
+def build_sampler(dim, device, use_dist, rank):
     from srgd_amd.config import load_config
     from srgd_amd.model import get_model
     from srgd_amd.synth import synth_state_dict
@@ -101,7 +104,7 @@ def build_sampler(dim, device, world, rank):
     conf.num_sample_steps = 50
     sampler = get_model(conf, logging.getLogger("bench")).module
     schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
-    if world > 1:
+    if use_dist:
         # rank 0 owns the checkpoint; everyone else receives it over RCCL/xGMI as one flat buffer
         from srgd_amd.parallel import broadcast_state_dict
         sd = broadcast_state_dict(schema, synth_state_dict(schema, seed=0) if rank == 0 else None, src=0, device=device)
@@ -165,6 +168,16 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    # SRGD_FORCE_DIST=1: take the distributed code path even at world size 1 - init_process_group("nccl"), the device-side
+    # weight broadcast, the uint8 output gather, max-over-ranks, and (canvas workload) the per-step all_gather_into_tensor -
+    # so that RCCL and every collective of the N > 1 run execute on a 1-GPU box (tests/test_bench_multirank_gpu.py)
+    force_dist = os.environ.get("SRGD_FORCE_DIST", "0") == "1"
+    if force_dist and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); refusing to mislabel the run")
@@ -178,7 +191,7 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -188,7 +201,7 @@ def main():
     assert n_ranks == args.gpus
 
     from srgd_amd.synth import synthetic_lr_condition
-    sampler, sd = build_sampler(args.dim, device, world, rank)
+    sampler, sd = build_sampler(args.dim, device, dist is not None, rank)
     sampler.noise_source = "device"
     sampler.precision = args.precision
     label = torch.tensor([0], device=device)
@@ -197,25 +210,34 @@ def main():
     canvas_mode = args.workload == "canvas"
     if canvas_mode:
         args.images = 1
-        if world > 1:
+        if dist:
             from srgd_amd.parallel import shard_canvas
-            shard_canvas(sampler)
-    # canvas mode: every rank works on the SAME image; tiles mode: every rank has its own images
-    conds = [synthetic_lr_condition((0 if canvas_mode else rank * total) + i, args.lr_size, args.lr_size).to(device)
+            shard_canvas(sampler, always_exchange=force_dist)
+    # canvas mode: every rank works on the SAME image; tiles mode: item j of 0..world*total-1 belongs to rank j % world
+    # (srgd_amd.parallel.shard_indices), so rank r's k-th image is item r + k*world
+    conds = [synthetic_lr_condition(i if canvas_mode else rank + i * world, args.lr_size, args.lr_size).to(device)
              for i in range(total)]
     n_even = ((4 * args.lr_size + 255) // 256 + 1) ** 2 if args.lr_size * 4 > 256 else 1
 
-    def run(lo, hi):
-        """HR tiles [lo, hi) in lock-step groups of --images (each image sampled exactly as it would be alone)."""
-        res = []
-        for a in range(lo, hi, args.images):
-            b = min(a + args.images, hi)
-            sampler.device_noise_seed = 71
-            res.append(sampler.tiled_sample(batch_size=args.sub_batch or min(125, n_even * (b - a)),
-                                            condition_x=torch.cat(conds[a:b], 0), class_label=label,
-                                            class_cond_scale=args.class_cond_scale, num_sample_steps=args.ddpm_steps,
-                                            precision=args.precision))
-        return res
+    def sample_local(idx):
+        """The local images ``idx`` in ONE lock-step tiled_sample call (each image sampled exactly as it would be alone)."""
+        sampler.device_noise_seed = 71
+        return sampler.tiled_sample(batch_size=args.sub_batch or min(125, n_even * len(idx)),
+                                    condition_x=torch.cat([conds[k] for k in idx], 0), class_label=label,
+                                    class_cond_scale=args.class_cond_scale, num_sample_steps=args.ddpm_steps,
+                                    precision=args.precision)
+
+    def run(lo, hi, gather=False):
+        """Local HR tiles [lo, hi) in lock-step groups of --images; with ``gather`` the HR outputs travel to rank 0 as uint8
+        HWC images (3.1 MB each) and rank 0 gets them back in item order (srgd_amd.parallel.sample_images_sharded)."""
+        if hi <= lo:
+            return [], None
+        if canvas_mode or not dist:
+            return [sample_local(list(range(a, min(a + args.images, hi)))) for a in range(lo, hi, args.images)], None
+        from srgd_amd.parallel import sample_images_sharded
+        local, ordered = sample_images_sharded(lambda items: sample_local([lo + (j - rank) // world for j in items]),
+                                               (hi - lo) * world, args.images, rank, world, dst=0, gather=gather)
+        return [local], ordered
 
     run(0, args.warmup)
     torch.cuda.synchronize()
@@ -223,10 +245,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    outs = run(args.warmup, total)
-    if dist and not canvas_mode:
-        from srgd_amd.parallel import gather_outputs_u8
-        gathered = gather_outputs_u8(torch.cat(outs, 0), dst=0)       # HR tiles -> rank 0 as uint8 HWC (3.1 MB each)
+    outs, gathered = run(args.warmup, total, gather=True)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -235,6 +254,8 @@ def main():
     if dist:
         from srgd_amd.parallel import max_over_ranks
         dt = max_over_ranks(dt, device)
+    if dist and not canvas_mode and rank == 0:
+        assert gathered is not None and len(gathered) == args.steps * world and all(g is not None for g in gathered)
     assert all(torch.isfinite(o).all() for o in outs)
 
     if rank == 0 and canvas_mode:
@@ -254,6 +275,7 @@ def main():
             "config": {"workload": f"one {args.lr_size}x{args.lr_size} LR image x4, canvas {hp}x{hp}, {ne}/{no} tiles per "
                                    f"even/odd step, tiles sharded over {world} rank(s), per-step tile all-gather",
                        "tile_forwards_per_step": tf, "parallelism": f"canvas-sharded x{world}"},
+            "forced_dist": force_dist, "tile_allgathers": sampler.canvas_group.exchanges if sampler.canvas_group else 0,
             "hr_tile_equivalents_per_s": args.steps * tf / dt / TILE_FORWARDS_PER_HR_TILE,
             "tflops_effective": args.steps * tf / dt * 0.7938}), flush=True)
     elif rank == 0:
@@ -261,7 +283,8 @@ def main():
         value = tiles / dt
         line = {
             "metric": "HR tiles/sec (256->1024 x4, 50 steps, CFG=1.0)", "value": value, "unit": "HR tiles/s",
-            "n_gpus": n_ranks, "rccl_ranks": n_ranks, "dist_backend": backend if dist else None,
+            "n_gpus": n_ranks, "rccl_ranks": n_ranks, "dist_backend": backend if dist else None, "forced_dist": force_dist,
+            "gathered_hr_tiles": len(gathered) if gathered else 0,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (seeded LR images, seeded weights with the reference state_dict schema)",
@@ -286,7 +309,7 @@ def main():
         if not args.no_profile:
             eng = sampler.model.engine(args.precision)
             eng.profile_begin()
-            run(args.warmup, args.warmup + min(args.images, args.steps))
+            sample_local(list(range(args.warmup, args.warmup + min(args.images, args.steps))))
             prof = eng.profile_end()
             # the dominant kernel: conv3x3_bf16_kernel in bf16 mode, conv3x3_mxfp8_kernel in fp8 mode, the generic implicit
             # GEMM in fp32 mode - whichever convolution family took the most time in the profiled pass

@@ -607,7 +607,11 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         sigmas = (self.sigma_max ** inv_rho + steps / (n - 1) * (self.sigma_min ** inv_rho - self.sigma_max ** inv_rho)) ** self.rho
         return torch.nn.functional.pad(sigmas, (0, 1), value=0.0)
 
-    def _step_tables(self, n: int, clamp: bool):
+    def _step_tables(self, n: int, clamp: bool, with_ring: bool = True):
+        """Per-step scalars of the Heun loops.  ``with_ring``: the tiled loop re-noises the ring on odd steps from the
+        CONSTRUCTOR's schedule (below); the un-tiled ``sample_org`` never does (model.py:2212-2306 has no get_noised_images
+        call per step) and so runs with any per-call step count.  Odd steps beyond the constructor's schedule get
+        ``ring_sigma = nan`` here; ``tiled_sample`` raises upstream's IndexError when the loop reaches the first of them."""
         from ._lib import EdmScalars
         sigmas = self.sample_schedule(n)
         # get_noised_images (model.py:2186-2189) is called without num_sample_steps at :2342 and :2457, so the
@@ -625,8 +629,8 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
                 sigma_next=sigma_next, dt=sigma_next - sigma_hat, half_dt=0.5 * (sigma_next - sigma_hat),
                 c_in_hat=float(self.c_in(sh)), c_skip_hat=float(self.c_skip(sh)), c_out_hat=float(self.c_out(sh)),
                 c_in_next=float(self.c_in(sn)), c_skip_next=float(self.c_skip(sn)), c_out_next=float(self.c_out(sn)),
-                # read on odd steps only; upstream indexes its constructor-length schedule there (IndexError beyond it)
-                ring_sigma=float(noised_sigmas[i]) if (i % 2 == 1 or i < len(noised_sigmas)) else 0.0,
+                # read on odd steps of the tiled loop only; upstream indexes its constructor-length schedule there
+                ring_sigma=(float(noised_sigmas[i]) if i < len(noised_sigmas) else math.nan) if (with_ring and i % 2 == 1) else 0.0,
                 clamp=1.0 if clamp else 0.0, dpm_gamma=0.0, pad1=0.0))
             c_noise += [float(self.c_noise(sh)), float(self.c_noise(sn))]
         return sigmas, noised_sigmas, scalars, c_noise
@@ -692,6 +696,9 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
                 passes, kind, scale = 2, 1, cur_class_scale
             else:
                 passes, kind, scale = 1, 0, 1.0
+            if i % 2 == 1 and i >= len(noised_sigmas):
+                # upstream fails here too, mid-loop: get_noised_images(images, i) indexes the constructor's schedule (:2457 -> :2187)
+                raise IndexError(f"index {i} is out of bounds for dimension 0 with size {len(noised_sigmas)}")
             z = canvas_noise(None) if host_noise else None              # eps of the step (:2386), before the ring draw
             ring = canvas_noise(None) if (host_noise and i % 2 == 1) else None
             if self.canvas_group is None:
@@ -806,7 +813,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         """Reference model.py:2212-2306 (stochastic Heun, two network evaluations per step) on the tiled EDM machinery:
         the same per-step arithmetic as ``tiled_sample`` with one tile per image, per-image noise and no ring."""
         n = self.num_sample_steps if num_sample_steps is None else num_sample_steps
-        sigmas, _, scalars, c_noise = self._step_tables(n, clamp)
+        sigmas, _, scalars, c_noise = self._step_tables(n, clamp, with_ring=False)
         u = self._untiled_setup(batch_size, condition_x, class_label, cond_scale, class_cond_scale, generation_start_steps,
                                 zero_init, float(sigmas[0]), precision)
         eng, b, s_, dev = u.eng, u.b, u.s, u.dev

@@ -60,6 +60,31 @@ def gather_outputs_u8(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.
     return gather_outputs(local, dst=dst)
 
 
+def sample_images_sharded(sample_group, n_items: int, lockstep: int, rank: int, world: int, dst: int = 0, gather: bool = True):
+    """Independent images over ranks (BASELINE configs[2]; the reference's manual ``--start_index/--end_index`` sharding,
+    inference.py:36-37,120, automated): item ``j`` of ``0..n_items-1`` belongs to rank ``j % world``; every rank samples its
+    items in lock-step groups of ``lockstep`` through ``sample_group(list_of_item_ids) -> [k,3,H,W]`` and the HR outputs are
+    gathered to ``dst`` as the uint8 HWC images the pipeline emits.  ``n_items`` must be a multiple of ``world`` (equal-sized
+    gathers).  Returns ``(local_outputs, ordered)``: ``ordered`` is the list of all ``n_items`` uint8 images in item order on
+    ``dst`` (None elsewhere, and None when ``gather`` is False or there is no process group)."""
+    assert n_items % world == 0, "equal shares per rank (the gather moves equally-shaped stacks)"
+    mine = shard_indices(n_items, rank, world)
+    outs = []
+    for a in range(0, len(mine), lockstep):
+        outs.append(sample_group(mine[a:a + lockstep]))
+    local = torch.cat(outs, 0)
+    if not gather or not dist.is_initialized():
+        return local, None
+    bucket = gather_outputs_u8(local, dst=dst)
+    if bucket is None:
+        return local, None
+    ordered = [None] * n_items
+    for r, stack in enumerate(bucket):
+        for k, j in enumerate(shard_indices(n_items, r, world)):
+            ordered[j] = stack[k]
+    return local, ordered
+
+
 def max_over_ranks(seconds: float, device: torch.device) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -77,60 +102,88 @@ def tile_slices(n_tiles: int, world: int) -> List[range]:
     return [range(min(n_tiles, r * w), min(n_tiles, (r + 1) * w)) for r in range(world)]
 
 
-def shard_canvas(sampler, group=None):
+class CanvasShard:
+    """State of one canvas shared by the ranks of ``group``: the group plus the exchange buffers of the per-step tile
+    all-gather, allocated ONCE per (grid width, device) and reused by every step of every run (round 3: the per-step
+    ``torch.zeros`` + receive-buffer allocations are gone, so a sharded step allocates nothing and the caching allocator
+    never has to synchronise mid-run).
+
+    Payload: the fp32 canvas tiles themselves (x_t is fp32 state in the reference, model.py:3381-3393); rounding them to
+    bf16 for transport would make the sharded run differ from the single-GPU run, which is the property the sharded path is
+    tested by (bit-identical at any world size).  Every tile of a step's grid changes in that step, so "only the changed
+    tiles" is what already travels: 856 MB per step at 8448^2, ~3 ms of RCCL all-gather against ~110 ms of compute per rank.
+
+    ``always_exchange``: run the pack -> all-gather -> unpack round trip even at world size 1 (bench.py's SRGD_FORCE_DIST
+    hook: it puts ``all_gather_into_tensor`` on RCCL through its paces on a 1-GPU box; the result is unchanged)."""
+
+    def __init__(self, group, always_exchange: bool = False):
+        self.group = group
+        self.always_exchange = always_exchange
+        self._bufs = {}
+        self.exchanges = 0                      # tile all-gathers issued so far (tests / bench report it)
+
+    def buffers(self, width: int, world: int, device, tile: int = 256):
+        """(packed [width,3,T,T], everyone [world*width,3,T,T]) views of buffers sized for the widest grid seen so far."""
+        key = (str(device), tile)
+        need = world * width
+        have = self._bufs.get(key)
+        if have is None or have[1].shape[0] < need or have[0].shape[0] < width:
+            packed = torch.zeros(width, 3, tile, tile, device=device, dtype=torch.float32)
+            everyone = torch.empty(need, 3, tile, tile, device=device, dtype=torch.float32)
+            self._bufs[key] = have = (packed, everyone)
+        return have[0][:width], have[1][:need]
+
+
+def shard_canvas(sampler, group=None, always_exchange: bool = False):
     """Make ``sampler.tiled_sample`` split every step's tile list over the ranks of ``group`` (default: WORLD).
     All ranks must call tiled_sample with identical arguments (and, in host-noise mode, identical torch seeds);
     all of them return the full image.  Results are bit-identical to the single-GPU run: tiles are independent
     within a step (model.py:3361-3380) and the noise of a tile depends only on its index in the grid."""
-    sampler.canvas_group = group if group is not None else dist.group.WORLD
+    sampler.canvas_group = CanvasShard(group if group is not None else dist.group.WORLD, always_exchange)
     return sampler
 
 
-def _all_gather_tiles(mine: torch.Tensor, group) -> torch.Tensor:
-    world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+def _all_gather_tiles(out: torch.Tensor, mine: torch.Tensor, group) -> None:
+    """``out`` [world*width, ...] <- every rank's ``mine`` [width, ...] in rank order (both preallocated, contiguous)."""
     if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(out, mine, group=group)       # one RCCL all-gather, no staging copies
     else:
-        dist.all_gather(list(out.unbind(0)), mine, group=group)
-    return out
+        dist.all_gather(list(out.split(mine.shape[0], 0)), mine, group=group)
 
 
-def sharded_step(eng, group, step: int, n_tiles: int, img, cond_canvas, x_start, noise_tiles, noise_canvas,
+def _exchange(eng, shard: CanvasShard, step: int, n_tiles: int, mine: range, width: int, canvases) -> None:
+    world = dist.get_world_size(shard.group)
+    if world == 1 and not shard.always_exchange:
+        return
+    for canvas in canvases:
+        if canvas is None:
+            continue
+        packed, everyone = shard.buffers(width, world, canvas.device)
+        eng.sampler_exchange_tiles(step & 1, mine.start, len(mine), canvas, packed, to_canvas=False)
+        _all_gather_tiles(everyone, packed, shard.group)
+        shard.exchanges += 1
+        eng.sampler_exchange_tiles(step & 1, 0, n_tiles, canvas, everyone, to_canvas=True)
+
+
+def sharded_step(eng, shard: CanvasShard, step: int, n_tiles: int, img, cond_canvas, x_start, noise_tiles, noise_canvas,
                  passes: int, kind: int, scale: float, sub_batch: int, seed: int) -> None:
-    """One DDPM step of a canvas shared by the ranks of ``group``: my slice of the tiles, then exchange."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    """One DDPM step of a canvas shared by the ranks of ``shard.group``: my slice of the tiles, then exchange."""
+    rank, world = dist.get_rank(shard.group), dist.get_world_size(shard.group)
     sl = tile_slices(n_tiles, world)
     mine, width = sl[rank], len(sl[0])
     eng.sampler_step_tiles(step, mine.start, len(mine), True, img, cond_canvas, x_start, noise_tiles, noise_canvas,
                            passes, kind, scale, sub_batch, seed)
-    if world == 1:
-        return
-    for canvas in (img, x_start):
-        if canvas is None:
-            continue
-        packed = torch.zeros(width, 3, 256, 256, device=img.device, dtype=torch.float32)
-        eng.sampler_exchange_tiles(step & 1, mine.start, len(mine), canvas, packed, to_canvas=False)
-        everyone = _all_gather_tiles(packed, group).reshape(world * width, 3, 256, 256)
-        eng.sampler_exchange_tiles(step & 1, 0, n_tiles, canvas, everyone, to_canvas=True)
+    _exchange(eng, shard, step, n_tiles, mine, width, (img, x_start))
 
 
-def sharded_edm_step(eng, group, step: int, n_tiles: int, img, cond_canvas, x_start, work, noise_canvas, ring_noise_canvas,
-                     passes: int, kind: int, scale: float, sub_batch: int, seed: int) -> None:
-    """One EDM (Heun) step of a canvas shared by the ranks of ``group`` (reference model.py:2379-2463): my slice of the tiles
-    (both network evaluations; the scratch canvases stay rank-local), the odd-step ring on every rank's own canvas, then the
-    same tile exchange as the DDPM loop."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+def sharded_edm_step(eng, shard: CanvasShard, step: int, n_tiles: int, img, cond_canvas, x_start, work, noise_canvas,
+                     ring_noise_canvas, passes: int, kind: int, scale: float, sub_batch: int, seed: int) -> None:
+    """One EDM (Heun) step of a canvas shared by the ranks of ``shard.group`` (reference model.py:2379-2463): my slice of the
+    tiles (both network evaluations; the scratch canvases stay rank-local), the odd-step ring on every rank's own canvas, then
+    the same tile exchange as the DDPM loop."""
+    rank, world = dist.get_rank(shard.group), dist.get_world_size(shard.group)
     sl = tile_slices(n_tiles, world)
     mine, width = sl[rank], len(sl[0])
     eng.edm_step_tiles(step, mine.start, len(mine), True, img, cond_canvas, x_start, work, noise_canvas, ring_noise_canvas,
                        passes, kind, scale, sub_batch, seed)
-    if world == 1:
-        return
-    for canvas in (img, x_start):
-        if canvas is None:
-            continue
-        packed = torch.zeros(width, 3, 256, 256, device=img.device, dtype=torch.float32)
-        eng.sampler_exchange_tiles(step & 1, mine.start, len(mine), canvas, packed, to_canvas=False)
-        everyone = _all_gather_tiles(packed, group).reshape(world * width, 3, 256, 256)
-        eng.sampler_exchange_tiles(step & 1, 0, n_tiles, canvas, everyone, to_canvas=True)
+    _exchange(eng, shard, step, n_tiles, mine, width, (img, x_start))

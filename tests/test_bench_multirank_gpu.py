@@ -54,3 +54,37 @@ def test_bare_gpus2_self_launches_two_ranks():
 def test_bare_gpus2_canvas_workload_self_launches_two_ranks():
     d = _run_bare(["--workload", "canvas", "--lr_size", "128"])        # 512^2 image, canvas 768^2, 9/4 tiles over 2 ranks
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+
+
+# ---- RCCL itself, on the real GPU: SRGD_FORCE_DIST=1 takes the N > 1 code path at world size 1 with the nccl backend -
+# init_process_group("nccl", device_id=...), the device-side weight broadcast, the uint8 gather, the max-over-ranks all-reduce,
+# the barriers and (canvas workload) all_gather_into_tensor - the calls the driver's 8-GPU run makes first
+def _run_forced(extra, timeout=600):
+    env = dict(os.environ, SRGD_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SRGD_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no_cpu_baseline", "--no_profile", *extra]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_forced_dist_world1_runs_the_image_sharded_path_on_rccl():
+    d = _run_forced(["--steps", "2", "--warmup", "1", "--images", "2", "--ddpm_steps", "4", "--dim", "16"])
+    assert d["dist_backend"] == "nccl" and d["rccl_ranks"] == 1 and d["n_gpus"] == 1 and d["forced_dist"] is True
+    assert d["gathered_hr_tiles"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_forced_dist_world1_broadcasts_the_dim128_checkpoint_on_rccl():
+    # the 550 MB flat fp32 weight buffer through dist.broadcast on the device, then load_state_dict + per-rank packing
+    d = _run_forced(["--steps", "1", "--warmup", "0", "--images", "1", "--ddpm_steps", "2", "--dim", "128"])
+    assert d["dist_backend"] == "nccl" and d["rccl_ranks"] == 1 and d["gathered_hr_tiles"] == 1 and d["value"] > 0
+
+
+def test_forced_dist_world1_runs_the_canvas_all_gather_on_rccl():
+    d = _run_forced(["--workload", "canvas", "--lr_size", "128", "--steps", "2", "--warmup", "1", "--ddpm_steps", "4",
+                     "--dim", "16"])
+    assert d["dist_backend"] == "nccl" and d["rccl_ranks"] == 1 and d["forced_dist"] is True and d["scaling"] == "strong"
+    assert d["tile_allgathers"] == 3 * 4 and d["value"] > 0        # all_gather_into_tensor once per step of 3 runs

@@ -241,3 +241,28 @@ def test_reflect_padding_larger_than_the_image_is_refused_like_upstream():
         _tiling(300, 100, 256, 256)
     (left, top, right, bottom), (hp, wp), even, odd, inner = _tiling(200, 200, 256, 256)     # 28-pixel pads: fine
     assert (hp, wp) == (256, 256) and len(even) == 1 and len(odd) == 1 and (right - left, bottom - top) == (200, 200)
+
+
+def test_edm_step_tables_accept_more_call_steps_than_constructor_steps():
+    # sample_org (model.py:2212-2306) never re-noises a ring, so a per-call step count beyond the constructor's
+    # schedule must build its tables; the tiled loop (model.py:2457 -> :2187) indexes the constructor's schedule on odd steps
+    # and fails mid-loop at the first odd step beyond it - the table marks those steps (nan) instead of failing up front
+    import math
+    from srgd_amd.model import ConditionalElucidatedDiffusionSR, ConditionalSRUnet
+    unet = ConditionalSRUnet(dim=16, dim_mults=(1, 2, 4, 8), full_attn=(False, False, False, True), num_classes=3,
+                             learned_sinusoidal_cond=True, pixel_shuffle_upsample=True)
+    edm = ConditionalElucidatedDiffusionSR(unet, image_size=256, num_sample_steps=8)
+    for n in (10, 12, 32):
+        sigmas, noised, scalars, c_noise = edm._step_tables(n, True, with_ring=False)
+        assert len(scalars) == n and len(c_noise) == 2 * n and all(s.ring_sigma == 0.0 for s in scalars)
+        _, noised, scalars, _ = edm._step_tables(n, True)                  # tiled: no failure at table build either
+        assert len(noised) == 9
+        for i, s in enumerate(scalars):
+            if i % 2 == 0:
+                assert s.ring_sigma == 0.0
+            elif i < 9:
+                assert s.ring_sigma == pytest.approx(float(noised[i]))
+            else:
+                assert math.isnan(s.ring_sigma)                            # tiled_sample raises IndexError at this step
+    _, _, scalars, _ = edm._step_tables(8, True)                            # in range: every odd step carries its sigma
+    assert all(s.ring_sigma > 0 for s in scalars[1::2])

@@ -4,6 +4,7 @@ import json
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -109,8 +110,12 @@ def _canvas_grids():
     return hp, wp, (even, odd)
 
 
-def _run_fake(group, steps=5, with_x0=True, edm=False):
-    from srgd_amd.parallel import sharded_edm_step, sharded_step
+def _run_fake(group, steps=5, with_x0=True, edm=False, always_exchange=False, shard_out=None):
+    from srgd_amd.parallel import CanvasShard, sharded_edm_step, sharded_step
+    if group is not None:
+        group = CanvasShard(group, always_exchange=always_exchange)
+        if shard_out is not None:
+            shard_out.append(group)
     hp, wp, grids = _canvas_grids()
     eng = _FakeEngine(grids)
     img = torch.linspace(-1, 1, 3 * hp * wp).reshape(1, 3, hp, wp).clone()
@@ -149,14 +154,81 @@ def test_tile_slices_partition_the_grid():
             assert all(r.start == min(n, k * w) for k, r in enumerate(sl)) and all(len(r) <= w for r in sl)
 
 
-def test_sharded_canvas_steps_equal_single_rank_world3(tmp_path):
+# world 3: uneven slices; world 8 (BASELINE configs[3]'s rank count): 16 / 9 tiles over 8 ranks = slices of 2 with empty
+# ranks on the odd grid (9 tiles -> widths 2,2,2,2,1,0,0,0)
+@pytest.mark.parametrize("world", [3, 8])
+def test_sharded_canvas_steps_equal_single_rank(tmp_path, world):
     port = _free_port()
-    mp.spawn(_canvas_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    mp.spawn(_canvas_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     want_img, want_xs = _run_fake(None)
     want_eimg, want_exs = _run_fake(None, edm=True)
-    for r in range(3):
+    for r in range(world):
         got = torch.load(tmp_path / f"canvas_r{r}.pt")
         assert torch.equal(got["img"], want_img), r
         assert torch.equal(got["xs"], want_xs), r
         assert torch.equal(got["edm_img"], want_eimg), r       # parallel.sharded_edm_step (EDM wrapper's Heun step)
         assert torch.equal(got["edm_xs"], want_exs), r
+
+
+def _world1_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shards = []
+    img, xs = _run_fake(dist.group.WORLD, always_exchange=True, shard_out=shards)
+    quiet = []
+    img2, _ = _run_fake(dist.group.WORLD, always_exchange=False, shard_out=quiet)
+    bufs = next(iter(shards[0]._bufs.values()))
+    torch.save({"img": img, "xs": xs, "img2": img2, "exchanges": shards[0].exchanges, "quiet": quiet[0].exchanges,
+                "n_buffers": len(shards[0]._bufs), "packed": tuple(bufs[0].shape), "everyone": tuple(bufs[1].shape)},
+               os.path.join(out_dir, "w1.pt"))
+    dist.destroy_process_group()
+
+
+def test_forced_exchange_at_world_size_one_is_a_no_op_on_the_result(tmp_path):
+    # bench.py's SRGD_FORCE_DIST hook: pack -> all-gather -> unpack runs even with one rank (RCCL on a 1-GPU box) and must not
+    # change anything; the exchange buffers are allocated once for the widest grid (16 tiles) and reused by all 5 steps
+    mp.spawn(_world1_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = torch.load(tmp_path / "w1.pt")
+    want_img, want_xs = _run_fake(None)
+    assert torch.equal(got["img"], want_img) and torch.equal(got["xs"], want_xs) and torch.equal(got["img2"], want_img)
+    assert got["exchanges"] == 5 * 2 and got["quiet"] == 0          # img + x_start canvases, five steps
+    assert got["n_buffers"] == 1 and got["packed"] == (16, 3, 256, 256) and got["everyone"] == (16, 3, 256, 256)
+
+
+# ---------------------------------------------------------------------------------------------
+# independent images over ranks (BASELINE configs[2]): parallel.sample_images_sharded
+# ---------------------------------------------------------------------------------------------
+def _fake_image(j):
+    return torch.full((1, 3, 8, 8), (j % 200) / 255.0 + 1e-4)
+
+
+def _images_worker(rank, world, port, out_dir, n_items, lockstep):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from srgd_amd.parallel import sample_images_sharded
+    groups = []
+
+    def sample_group(items):
+        groups.append(list(items))
+        return torch.cat([_fake_image(j) for j in items], 0)
+
+    local, ordered = sample_images_sharded(sample_group, n_items, lockstep, rank, world, dst=0)
+    torch.save({"groups": groups, "local": local, "ordered": ordered}, os.path.join(out_dir, f"img_r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_64_images_over_8_ranks_come_back_in_item_order(tmp_path):
+    # configs[2]'s partitioning: 64 independent tiles, 8 per rank (item j -> rank j % 8), lock-step groups of 5 (5 + 3)
+    world, n = 8, 64
+    mp.spawn(_images_worker, args=(world, _free_port(), str(tmp_path), n, 5), nprocs=world, join=True)
+    for r in range(world):
+        got = torch.load(tmp_path / f"img_r{r}.pt")
+        assert got["groups"] == [[r + k * world for k in range(5)], [r + k * world for k in range(5, 8)]]
+        assert got["local"].shape == (8, 3, 8, 8)
+        if r == 0:
+            assert len(got["ordered"]) == n
+            for j, img in enumerate(got["ordered"]):
+                assert img.dtype == torch.uint8 and img.shape == (8, 8, 3) and int(img[0, 0, 0]) == j % 200, j
+        else:
+            assert got["ordered"] is None
