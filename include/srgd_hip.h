@@ -230,6 +230,9 @@ int srgd_randn(srgd_engine* e, float* dst, size_t n, uint64_t seed, uint64_t str
  * convolution families) the algorithmic FLOPs issued (2*M*Cout*K).  Family names: srgd_profile_family_name(i). */
 int srgd_profile_begin(srgd_engine* e);
 int srgd_profile_end(srgd_engine* e, double* ms, int64_t* launches, double* flops, int n_families);
+/* Algorithmic HBM bytes per family of the interval the last srgd_profile_begin/end pair bracketed: every operand read once
+ * and every result written once (the roofline numerator of the HBM-bound kernels; bench.py divides by the event time). */
+int srgd_profile_bytes(const srgd_engine* e, double* bytes, int n_families);
 int srgd_profile_num_families(void);
 const char* srgd_profile_family_name(int i);
 int64_t srgd_device_bytes_in_use(const srgd_engine* e);

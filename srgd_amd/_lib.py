@@ -88,6 +88,7 @@ PROTOTYPES = {
     "srgd_profile_begin": (C.c_int, [C.c_void_p]),
     "srgd_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                    C.c_int]),
+    "srgd_profile_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "srgd_profile_num_families": (C.c_int, []),
     "srgd_profile_family_name": (C.c_char_p, [C.c_int]),
     "srgd_device_bytes_in_use": (C.c_int64, [C.c_void_p]),

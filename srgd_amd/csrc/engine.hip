@@ -293,6 +293,7 @@ struct srgd_engine {
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> ev_free;
   double fam_flops[KC_COUNT] = {};   // algorithmic FLOPs issued per family while profiling (conv families only)
+  double fam_bytes[KC_COUNT] = {};   // algorithmic HBM bytes (operands read once + results written once) per family while profiling
 
   int reg(const std::string& name, std::vector<int64_t> shape) {
     HostTensor t;
@@ -536,6 +537,14 @@ struct Ctx {
   bool eps4_done = false;
 };
 
+// The last ResnetBlock can emit the 1x1 output convolution of its result (16 B of eps per pixel) from its res_conv epilogue only
+// on the bf16 streaming-GEMM route at dim 128; everywhere else (fp32 mode, other widths, the A/B switches) the eps4 scratch
+// (nb * 256^2 * 16 B: 131 MB at 125 tiles) is not taken from the pool at all.
+bool final_fusion_possible(const srgd_engine* e) {
+  return e->bf16 && !e->no_final_fusion && !e->no_conv1x1 && !e->force_generic_conv && e->dim == 128 && e->final_rb.has_res &&
+         e->final_rb.res.w1 != nullptr;
+}
+
 // gn_in: the input is a raw conv output whose GroupNorm+SiLU (coefA/coefB) the fast 3x3 kernel applies while
 // staging; *gn_in_done tells the caller whether that happened (otherwise it must run gn_apply first).
 bool conv_can_fuse_gn_in(srgd_engine* e, const ConvW& c, int nb, int H, int W) {
@@ -586,8 +595,18 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
   }
   const int fam = fast ? KC_CONV3 : fast1 ? KC_CONV1 : KC_CONV;
   Prof p(e, fam, x.st);
-  if (e->prof_on)
+  if (e->prof_on) {
     e->fam_flops[fam] += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
+    // algorithmic bytes: every input pixel row once, the weights once, the result once (+ the in-place GroupNorm2 tail operand,
+    // the residual, the MX-fp8 twin); with the fused output convolution 16 B of eps per pixel replace the result row
+    const double npi = (double)x.nb * Hin * Win, npo = (double)x.nb * a.Hout * a.Wout;
+    double by = npi * c.Cin * e->es + (double)c.KS * c.KS * c.Cin * c.Cout * e->es;
+    by += a.eps4 ? npo * 16.0 : npo * c.Cout * e->es;
+    if (gn_res_src) by += npo * c.Cout * e->es;
+    if (residual) by += npo * c.Cout * e->es;
+    if (fast1 && twin_wanted(e, want_twin, c.mode == CONV_PIXEL_SHUFFLE_SILU ? c.Cout / 4 : c.Cout)) by += npo * c.Cout * (1.0 + 1.0 / 32);
+    e->fam_bytes[fam] += by;
+  }
   if (fast1) {
     const bool ps = c.mode == CONV_PIXEL_SHUFFLE_SILU;
     const int Cq = ps ? c.Cout / 4 : c.Cout;
@@ -647,6 +666,7 @@ int q_twin(Ctx& x, const void* src, int C, int hw, QTensor* t) {
   SRGD_TRY(q_alloc(x, C, hw, t));
   pool.twins[src] = {t->q, t->s};
   Prof p(x.e, KC_QUANT, x.st);
+  if (x.e->prof_on) x.e->fam_bytes[KC_QUANT] += (double)x.nb * hw * C * (2.0 + 1.0 + 1.0 / 32);
   return quant_mxfp8(src, t->q, t->s, (long)x.nb * hw, C, x.st);
 }
 int run_conv_q(Ctx& x, const ConvW& c, const QTensor& in0, int C0, const QTensor& in1, int C1, int H, int W, void* out,
@@ -660,7 +680,12 @@ int run_conv_q(Ctx& x, const ConvW& c, const QTensor& in0, int C0, const QTensor
     a.out_q = tw.q; a.out_s = tw.s;
   }
   Prof p(e, KC_CONVQ, x.st);
-  if (e->prof_on) e->fam_flops[KC_CONVQ] += 2.0 * (double)x.nb * H * W * c.Cout * (double)(9 * c.Cin);
+  if (e->prof_on) {
+    e->fam_flops[KC_CONVQ] += 2.0 * (double)x.nb * H * W * c.Cout * (double)(9 * c.Cin);
+    const double np = (double)x.nb * H * W;
+    e->fam_bytes[KC_CONVQ] += np * c.Cin * (1.0 + 1.0 / 32) + 9.0 * c.Cin * c.Cout * (1.0 + 1.0 / 32) + np * c.Cout * 2.0 +
+                              (tw.q ? np * c.Cout * (1.0 + 1.0 / 32) : 0.0);
+  }
   if (stats) e->stats_slots = conv3x3_mxfp8_stats_slots(a);
   SRGD_TRY(conv3x3_mxfp8(a, in0.q, in0.s, in1.q, in1.s, c.wq, x.st));
   if (tw.q) twin_register(e, out, tw);
@@ -689,6 +714,8 @@ int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_
   if (finalize_only) return 0;                     // the consumer conv applies y = silu(A x + B) while staging
   QTensor tw;
   if (twin_wanted(e, want_twin, C)) SRGD_TRY(twin_alloc(e, (size_t)x.nb * hw, C, &tw));
+  if (e->prof_on)      // one read + one write of the tensor (+ the identity residual, + the MX-fp8 twin)
+    e->fam_bytes[KC_GN] += (double)x.nb * hw * C * (e->es * (residual ? 3.0 : 2.0) + (tw.q ? 1.0 + 1.0 / 32 : 0.0));
   SRGD_TRY(gn_apply_silu(buf, buf, residual, e->coefA, e->coefB, x.nb, hw, C, e->bf16, x.st, tw.q, tw.s));
   if (tw.q) twin_register(e, buf, tw);
   return 0;
@@ -711,6 +738,7 @@ int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, i
     QTensor qu;
     SRGD_TRY(q_alloc(x, r.Cout, hw, &qu));
     { Prof p(e, KC_GN, x.st);
+      if (e->prof_on) e->fam_bytes[KC_GN] += (double)x.nb * hw * r.Cout * (2.0 + 1.0 + 1.0 / 32);
       SRGD_TRY(gn_apply_silu_mxfp8(u, qu.q, qu.s, e->coefA, e->coefB, x.nb, hw, r.Cout, x.st)); }
     SRGD_TRY(run_conv_q(x, r.c2, qu, r.Cout, QTensor{}, 0, x.H, x.W, v, true));
     q_free(x, qu);
@@ -748,6 +776,8 @@ int attn_block(Ctx& x, const AttnW& a, const void* in, void** out, bool want_twi
     if (linattn_fused_workspace(x.nb, hw) / sizeof(float) > e->la_ws_cap) SRGD_FAIL("internal: fused attention workspace too small");
     QTensor tw;
     if (twin_wanted(e, want_twin, a.C)) SRGD_TRY(twin_alloc(e, (size_t)npix, a.C, &tw));
+    // la1 reads x once, la2 reads x again and writes y: three passes over a C-channel tensor (+ the twin)
+    if (e->prof_on) e->fam_bytes[KC_LINATTN] += (double)npix * a.C * (3.0 * e->es + (tw.q ? 1.0 + 1.0 / 32 : 0.0));
     SRGD_TRY(linattn_fused(in, y, x.nb, hw, a.C, a.f_wkv, a.f_wq, a.f_wout, a.out.bias, a.f_g2, e->la_ws, x.st, tw.q, tw.s));
     if (tw.q) twin_register(e, y, tw);
     *out = y;
@@ -757,15 +787,19 @@ int attn_block(Ctx& x, const AttnW& a, const void* in, void** out, bool want_twi
   void* qkv = e->pool.get((size_t)npix * 3 * e->hid * e->es);
   void* att = e->pool.get((size_t)npix * e->hid * e->es);
   if (!nrm || !qkv || !att) return -1;
-  { Prof p(e, KC_RMS, x.st); SRGD_TRY(rms_norm(in, nrm, nullptr, a.norm_g, npix, a.C, e->bf16, x.st)); }
+  { Prof p(e, KC_RMS, x.st);
+    if (e->prof_on) e->fam_bytes[KC_RMS] += (double)npix * a.C * e->es * 2.0;
+    SRGD_TRY(rms_norm(in, nrm, nullptr, a.norm_g, npix, a.C, e->bf16, x.st)); }
   SRGD_TRY(run_conv(x, a.qkv, nrm, a.C, nullptr, 0, x.H, x.W, qkv, nullptr, false));
   if (a.full) {
     Prof p(e, KC_FULLATTN, x.st);
+    if (e->prof_on) e->fam_bytes[KC_FULLATTN] += (double)npix * e->hid * e->es * 4.0;      // q, k, v read, o written
     SRGD_TRY(full_attention(qkv, att, x.nb, hw, e->cfg.heads, e->cfg.dim_head, e->bf16, x.st));
   } else {
     Prof p(e, KC_LINATTN, x.st);
     const size_t need = linear_attention_workspace(x.nb, hw, e->cfg.heads, e->cfg.dim_head) / sizeof(float);
     if (need > e->la_ws_cap) SRGD_FAIL("internal: linear attention workspace too small");
+    if (e->prof_on) e->fam_bytes[KC_LINATTN] += (double)npix * e->hid * e->es * 6.0;       // k, v read; q, k-stats read; o written (two passes)
     SRGD_TRY(linear_attention(qkv, att, x.nb, hw, e->cfg.heads, e->cfg.dim_head, e->la_ws, e->bf16, x.st));
   }
   e->pool.put(qkv);
@@ -774,6 +808,7 @@ int attn_block(Ctx& x, const AttnW& a, const void* in, void** out, bool want_twi
   } else {
     SRGD_TRY(run_conv(x, a.out, att, e->hid, nullptr, 0, x.H, x.W, nrm, nullptr, false));
     Prof p(e, KC_RMS, x.st);
+    if (e->prof_on) e->fam_bytes[KC_RMS] += (double)npix * a.C * e->es * 3.0;
     SRGD_TRY(rms_norm(nrm, nrm, in, a.out_g, npix, a.C, e->bf16, x.st));                     // RMSNorm then + x
   }
   e->pool.put(att);
@@ -1302,8 +1337,8 @@ static int edm_step_launch(srgd_engine* e, bool last, int parity, int tile_first
                          2 * ep + ((passes == 2 && guidance_kind == 1) ? row_null : row_label));
       Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st, e->d_step, 4};
       void* act = nullptr;
-      float* eps4 = (float*)e->pool.get((size_t)nb * g.tile * g.tile * 16);
-      if (!eps4) return -1;
+      float* eps4 = final_fusion_possible(e) ? (float*)e->pool.get((size_t)nb * g.tile * g.tile * 16) : nullptr;
+      if (final_fusion_possible(e) && !eps4) return -1;
       x.eps4 = eps4;
       SRGD_TRY(unet_body(x, x0, &act));
       FinalStepArgs fa;
@@ -1312,7 +1347,7 @@ static int edm_step_launch(srgd_engine* e, bool last, int parity, int tile_first
       fa.sc = nullptr; fa.step_ptr = e->d_step;
       fa.eps4 = x.eps4_done ? eps4 : nullptr;
       { Prof p(e, KC_FINAL, st); SRGD_TRY(final_step_edm(fa, e->d_edm, work, canvas_elems, ep, tb, e->bf16, st)); }
-      e->pool.put(eps4);
+      if (eps4) e->pool.put(eps4);
       e->pool.put(act);
       e->pool.put(x0);
     }
@@ -1426,8 +1461,8 @@ int srgd_edm_dpmpp_step(srgd_engine* e, int step, float* img, const float* cond_
                        (passes == 2 && guidance_kind == 1) ? row_null : row_label);
     Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st, e->d_step, 4};
     void* act = nullptr;
-    float* eps4 = (float*)e->pool.get((size_t)nb * g.tile * g.tile * 16);
-    if (!eps4) return -1;
+    float* eps4 = final_fusion_possible(e) ? (float*)e->pool.get((size_t)nb * g.tile * g.tile * 16) : nullptr;
+    if (final_fusion_possible(e) && !eps4) return -1;
     x.eps4 = eps4;
     SRGD_TRY(unet_body(x, x0, &act));
     FinalStepArgs fa;
@@ -1436,7 +1471,7 @@ int srgd_edm_dpmpp_step(srgd_engine* e, int step, float* img, const float* cond_
     fa.sc = nullptr; fa.step_ptr = e->d_step;
     fa.eps4 = x.eps4_done ? eps4 : nullptr;
     { Prof p(e, KC_FINAL, st); SRGD_TRY(final_step_edm(fa, e->d_edm, old_denoised, canvas_elems, 2, tb, e->bf16, st)); }
-    e->pool.put(eps4);
+    if (eps4) e->pool.put(eps4);
     e->pool.put(act);
     e->pool.put(x0);
   }
@@ -1483,8 +1518,8 @@ static int sampler_step_launch(srgd_engine* e, bool last, int parity, int tile_f
                        (passes == 2 && guidance_kind == 1) ? row_null : row_label);
     Ctx x{e, nb, g.tile, g.tile, e->d_rows, e->ct_sampler.table, st, e->d_step};
     void* act = nullptr;
-    float* eps4 = (float*)e->pool.get((size_t)nb * g.tile * g.tile * 16);
-    if (!eps4) return -1;
+    float* eps4 = final_fusion_possible(e) ? (float*)e->pool.get((size_t)nb * g.tile * g.tile * 16) : nullptr;
+    if (final_fusion_possible(e) && !eps4) return -1;
     x.eps4 = eps4;
     SRGD_TRY(unet_body(x, x0, &act));
     FinalStepArgs fa;
@@ -1492,8 +1527,13 @@ static int sampler_step_launch(srgd_engine* e, bool last, int parity, int tile_f
     fa.w = e->final_w; fa.bias = e->final_b; fa.img = img; fa.x_start = x_start; fa.noise = nz;
     fa.sc = e->d_sc; fa.step_ptr = e->d_step;
     fa.eps4 = x.eps4_done ? eps4 : nullptr;
-    { Prof p(e, KC_FINAL, st); SRGD_TRY(final_step(fa, tb, e->bf16, st)); }
-    e->pool.put(eps4);
+    { Prof p(e, KC_FINAL, st);
+      if (e->prof_on) {
+        const double px = (double)nt * g.tile * g.tile;
+        e->fam_bytes[KC_FINAL] += px * passes * (fa.eps4 ? 16.0 : (double)e->dim * e->es) + px * 12.0 * (3.0 + (x_start ? 1.0 : 0.0));
+      }
+      SRGD_TRY(final_step(fa, tb, e->bf16, st)); }
+    if (eps4) e->pool.put(eps4);
     e->pool.put(act);
     e->pool.put(x0);
   }
@@ -1618,6 +1658,7 @@ int srgd_profile_begin(srgd_engine* e) {
   for (auto& r : e->prof) { e->ev_free.push_back(r.a); e->ev_free.push_back(r.b); }
   e->prof.clear();
   for (double& f : e->fam_flops) f = 0.0;
+  for (double& f : e->fam_bytes) f = 0.0;
   e->prof_on = true;
   return 0;
 }
@@ -1645,6 +1686,12 @@ int srgd_quantize_e4m3(const float* in, float* out, size_t n, float scale) {
   if (!in || !out) SRGD_FAIL("srgd_quantize_e4m3: null argument");
   if (!(scale > 0.f)) SRGD_FAIL("srgd_quantize_e4m3: scale must be positive");
   for (size_t i = 0; i < n; ++i) out[i] = round_through_e4m3(in[i] / scale) * scale;
+  return 0;
+}
+
+int srgd_profile_bytes(const srgd_engine* e, double* bytes, int n_families) {
+  if (!e || !bytes) SRGD_FAIL("srgd_profile_bytes: null argument");
+  for (int i = 0; i < n_families && i < KC_COUNT; ++i) bytes[i] = e->fam_bytes[i];
   return 0;
 }
 

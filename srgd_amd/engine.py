@@ -226,9 +226,11 @@ class HipEngine:
         cnt = (C.c_int64 * n)()
         fl = (C.c_double * n)()
         check(self._L.srgd_profile_end(self._h, ms, cnt, fl, n), "srgd_profile_end")
+        by = (C.c_double * n)()
+        check(self._L.srgd_profile_bytes(self._h, by, n), "srgd_profile_bytes")
         names = [self._L.srgd_profile_family_name(i).decode() for i in range(n)]
         return {"ms": {names[i]: ms[i] for i in range(n)}, "launches": {names[i]: int(cnt[i]) for i in range(n)},
-                "flops": {names[i]: fl[i] for i in range(n)}}
+                "flops": {names[i]: fl[i] for i in range(n)}, "bytes": {names[i]: by[i] for i in range(n)}}
 
     def bytes_in_use(self) -> int:
         return int(self._L.srgd_device_bytes_in_use(self._h))

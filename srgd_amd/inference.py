@@ -247,6 +247,16 @@ def main(argv=None):
     sr_model.noise_source = "device" if args.device_noise else "host"
     sr_model.precision = args.precision
     print(f"engine precision: {args.precision} (noise: {sr_model.noise_source})")
+    if args.amp and args.precision == "fp32":
+        # callers of earlier builds got bf16 from amp=True; upstream's sampler ignores amp and so does this one
+        print("note: amp is accepted and ignored as upstream (the sampler always computes fp32, ~9x slower than the bf16 "
+              "engine); pass --precision bf16 for the throughput mode")
+    import time
+    t_pack = time.perf_counter()
+    unet = getattr(sr_model, "model", None) or sr_model.net
+    unet.engine(args.precision)                         # pack + upload the weights now, not inside the first image
+    torch.cuda.synchronize()
+    print(f"engine ready: {len(sr_model.state_dict())} tensors packed and uploaded in {time.perf_counter() - t_pack:.2f} s")
     print(args)
     batch_sr_target_images(args.input_dir, args.output_dir, sr_model, scale=4, batch_size=args.batch_size,
                            test_label=args.test_label, cond_scale=args.cond_scale,

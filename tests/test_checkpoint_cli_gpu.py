@@ -1,0 +1,93 @@
+"""SURVEY 8(f)2, as far as this container allows (the published 550 MB checkpoint is a Git-LFS pointer): a checkpoint of the
+REAL size and schema - dim-128 U-Net, 280 tensors, 137.6 M parameters, `{'ema_model': state_dict}` written by torch.save -
+through the command line, loaded the way the reference loads it (model.py:3659-3664: `torch.load(..., weights_only=True)`,
+`load_state_dict(ckpt['ema_model'], strict=conf.load_strict)`).  The weights are the seeded ones the committed reference fixture
+`sample_dim128_config1.npz` was generated with (BASELINE configs[0]: one 64x64 LR tile, 10 DDPM steps, CFG off, fp32), so the
+PNG the CLI writes must be the reference's own output image after ToPILImage's truncation."""
+import os
+import pickle
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from srgd_amd.synth import synth_state_dict
+from tests.golden import cases as C
+from tests.test_engine_gpu import _schema
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(os.path.dirname(__file__), "golden")
+CONF = os.path.join(ROOT, "conf", "conditional_continuous_linear_df8kost_dim128.yaml")
+
+
+def _cli(conf, ckpt, indir, outdir, case, extra=()):
+    cmd = [sys.executable, os.path.join(ROOT, "inference.py"), "-c", str(conf), "-m", str(ckpt), "--input_dir", str(indir),
+           "--output_dir", str(outdir), "--num_sample_steps", str(case["steps"]), "--test_label", str(case["label"]),
+           "--seed", str(case["seed"]), "--batch_size", str(case["batch_size"]), *extra]
+    return subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+
+
+def test_dim128_checkpoint_file_through_the_cli_reproduces_the_reference_image(tmp_path):
+    case = next(c for c in C.SAMPLER_CASES if c["name"] == "dim128_config1")
+    z = np.load(os.path.join(G, f"sample_{case['name']}.npz"))
+    sd = synth_state_dict(_schema(128), seed=case["weight_seed"])
+    assert len(sd) == 280 and sum(v.numel() for v in sd.values()) == 137_569_939
+    ckpt = tmp_path / "srgd_dim128.pth"
+    torch.save({"ema_model": sd, "epoch": 300}, ckpt)
+    assert os.path.getsize(ckpt) > 540e6                                   # the published file is 550 MB
+    indir, outdir = tmp_path / "in", tmp_path / "out"
+    indir.mkdir()
+    g = torch.Generator().manual_seed(case["cond_seed"])                    # the LR image behind the fixture's condition
+    lr = torch.randint(0, 256, (case["h"] // 4, case["w"] // 4, 3), dtype=torch.uint8, generator=g).numpy()
+    Image.fromarray(lr, "RGB").save(indir / "tile.png")
+    r = _cli(CONF, ckpt, indir, outdir, case)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "engine precision: fp32" in r.stdout and "check: <All keys matched successfully>" in r.stderr + r.stdout
+    m = re.search(r"engine ready: 280 tensors packed and uploaded in ([0-9.]+) s", r.stdout)
+    assert m, r.stdout[-2000:]
+    assert float(m.group(1)) < 5.0                                          # 0.35 s (fp32) / 0.68 s (bf16) measured
+    got = np.asarray(Image.open(outdir / "tile_out.png").convert("RGB"))
+    want = (torch.from_numpy(z["image"])[0] * 255).to(torch.uint8).permute(1, 2, 0).numpy()      # ToPILImage: truncation
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert got.shape == (256, 256, 3)
+    assert diff.max() <= 1 and (diff > 0).mean() < 5e-3, (diff.max(), (diff > 0).mean())   # fp32 engine 7.8e-6 from the reference
+
+    # strict=True (the shipped YAML's load_strict): a checkpoint with one tensor missing must be refused ...
+    short = dict(sd)
+    missing = "model.final_conv.bias"
+    del short[missing]
+    bad = tmp_path / "missing_key.pth"
+    torch.save({"ema_model": short}, bad)
+    r2 = _cli(CONF, bad, indir, tmp_path / "out2", case)
+    assert r2.returncode != 0 and "Missing key(s) in state_dict" in r2.stderr and missing in r2.stderr
+    # ... and accepted with load_strict: false (config.py:121, default True), as upstream's strict=conf.load_strict: the missing
+    # tensor keeps its init value
+    loose = tmp_path / "loose.yaml"
+    loose.write_text(open(CONF).read() + "\nload_strict: false\n")
+    r3 = _cli(loose, bad, indir, tmp_path / "out3", case)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    assert "missing_keys=['model.final_conv.bias']" in r3.stderr + r3.stdout
+    assert (tmp_path / "out3" / "tile_out.png").exists()
+
+
+class _NotATensor:
+    pass
+
+
+def test_checkpoint_load_is_weights_only(tmp_path):
+    # weights_only=True (model.py:3659): a pickle that carries an arbitrary Python object is refused, not executed
+    from srgd_amd.config import load_config
+    from srgd_amd.model import get_model
+    import logging
+    evil = tmp_path / "evil.pth"
+    torch.save({"ema_model": {"x": torch.zeros(1)}, "extra": _NotATensor()}, evil)
+    conf = load_config(CONF)
+    conf.unet_dim = 16
+    conf.ckpt_path = str(evil)
+    with pytest.raises(pickle.UnpicklingError, match="[Ww]eights.only"):
+        get_model(conf, logging.getLogger("test"))

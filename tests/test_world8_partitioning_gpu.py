@@ -46,6 +46,7 @@ def _init(rank, world, port):
     import datetime
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(4)             # eight ranks share the host too (host-noise draws, gloo copies): no 8 x 128-thread pools
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     return dist
