@@ -36,8 +36,8 @@ _MODELS = {}
 
 
 # MX-fp8 modes vs the REFERENCE's fixtures: gates 3 dB under the MI355X measurements (profiles/r3_parity_report.jsonl)
-FP8_CONFIG5_GATE_DB, FP8_MIXED_CONFIG5_GATE_DB = 20.0, 30.0          # provisional until measured
-FP8_CONFIG2_GATE_DB, FP8_MIXED_CONFIG2_GATE_DB = 20.0, 30.0
+FP8_CONFIG5_GATE_DB, FP8_MIXED_CONFIG5_GATE_DB = 34.0, 50.3          # measured 36.99 / 53.29 dB (configs[4], one tile, 100 steps, CFG 2.0)
+FP8_CONFIG2_GATE_DB, FP8_MIXED_CONFIG2_GATE_DB = 25.4, 37.3          # measured 28.43 / 40.31 dB (configs[1] geometry, 2 steps from noise; bf16: 43.5)
 
 
 def build_sampler(dim, steps=50, weight_seed=0):
