@@ -513,7 +513,7 @@ int full_attention(const void* qkv, void* out, int B, int N, int heads, int dh, 
   if (is_bf16 && N % FA_QB == 0 && N <= 1024) {            // bf16 MFMA kernel, K / V^T resident in LDS (production: N = 1024)
     const int lds = N * 64 + DH * (N * 2 + 16);
     static bool attr_set[64] = {};
-    if (first_use_on_device(attr_set)) {
+    if (DeviceSetup once(attr_set); once.need) {
       SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_attn_bf16_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 64 + DH * (1024 * 2 + 16)));
     }

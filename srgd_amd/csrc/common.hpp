@@ -2,6 +2,8 @@
 // Written for MI355X (CDNA4, wave64) only - no portability layer.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -155,12 +157,32 @@ enum KClass {
 
 // One-time per-device setup guard (kernel attributes such as the dynamic-LDS limit are per device): returns true the first
 // time it is called for `flags` on the current HIP device.  Engines are one-per-device and single-threaded per device.
-inline bool first_use_on_device(bool (&flags)[64]) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;      // unknown device: redo the setup
-  if (flags[dev]) return false;
-  flags[dev] = true;
-  return true;
-}
+// One-time per-device setup of a kernel family (hipFuncSetAttribute for > 64 KiB of dynamic LDS), safe when several host threads
+// drive engines of their own: `if (DeviceSetup once(flags); once.need) { ...setup... }` - the first caller on a device runs the
+// block under a process-wide mutex and the flag is published (release) only when the block is left, so no other thread can
+// launch the kernel before its attribute is set; afterwards the check is one acquire load.
+struct DeviceSetup {
+  bool need = false;
+  explicit DeviceSetup(bool (&flags)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { need = true; return; }   // unknown device: redo the setup
+    flag_ = &flags[dev];
+    if (__atomic_load_n(flag_, __ATOMIC_ACQUIRE)) return;
+    mutex().lock();
+    locked_ = true;
+    need = !__atomic_load_n(flag_, __ATOMIC_ACQUIRE);
+  }
+  ~DeviceSetup() {
+    if (need && flag_) __atomic_store_n(flag_, true, __ATOMIC_RELEASE);
+    if (locked_) mutex().unlock();
+  }
+  DeviceSetup(const DeviceSetup&) = delete;
+  DeviceSetup& operator=(const DeviceSetup&) = delete;
+
+ private:
+  static std::mutex& mutex() { static std::mutex m; return m; }
+  bool* flag_ = nullptr;
+  bool locked_ = false;
+};
 
 }  // namespace srgd

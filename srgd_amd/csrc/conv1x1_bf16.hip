@@ -324,7 +324,7 @@ int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st) {
   const long grid = m_tiles * (a.Cout / BN1);
   if (grid <= 0 || grid > 0x7fffffffL) SRGD_FAIL("conv1x1_bf16: bad grid");
   static bool attr_set[64] = {};
-  if (first_use_on_device(attr_set)) {
+  if (DeviceSetup once(attr_set); once.need) {
 #define SRGD_SET1(E_)                                                                                   \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bf16_kernel<E_>),                 \
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));

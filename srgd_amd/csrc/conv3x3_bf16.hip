@@ -580,7 +580,7 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
     SRGD_HIP(hipMemsetAsync(p.stamps, 0, sizeof(unsigned long long) * 8, st));
   }
   static bool attr_set[64] = {};
-  if (first_use_on_device(attr_set)) {
+  if (DeviceSetup once(attr_set); once.need) {
 #define SRGD_SET(S_, G_, M_)                                                                              \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_, M_>),           \
                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

@@ -42,7 +42,7 @@ constexpr int QA_PIECES = 11;                    // 1 KiB LDS-DMA pieces per wav
 constexpr int QA_BYTES = 4 * QA_PIECES * 1024;   // 44 KiB (340 px * 128 B = 43,520 used)
 constexpr int QAS_BYTES = 2048;                  // activation scales: 4 B per halo pixel (1,360 used), 2 dword pieces per wave
 constexpr int QB_TILE = QBN * QKC;               // 16 KiB of e4m3 weights per K-step
-constexpr int QB_BYTES = QB_TILE + 512;          // + [128 n][4 g] scale bytes: one 16.5 KiB unit per (tap, chunk, n-tile)
+constexpr int QB_BYTES = QB_TILE + 512;          // + 512 scale bytes ([wn][r16][g][J]): one 16.5 KiB unit per (tap, chunk, n-tile)
 constexpr int QRING = 2;
 constexpr int QLDS = QA_BYTES + QAS_BYTES + QRING * QB_BYTES;   // 80,896 B: two workgroups per CU (<= 81,920)
 
@@ -70,6 +70,13 @@ struct ConvQArgs {
   unsigned char* oq; unsigned char* os;   // optional MX-fp8 twin of the output (ConvArgs::out_q / out_s)
   int stagger;            // as in conv3x3_bf16.hip: one-time delay (x 8128 cycles) of the second workgroup of every CU
 };
+
+// lane id from v_mbcnt, as volatile asm: never hoisted or CSE'd, so no VGPR carries it (or the thread id) across the K loop
+__device__ __forceinline__ int lane_id_opaque() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 
 #define QWAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define QBARRIER()                       \
@@ -136,12 +143,12 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     const bool first = cc < CC0;
     const int Cs = first ? p.C0 : p.C1;
     const int ccl = first ? cc : cc - CC0;
-    int opq_a = 0;
-    asm volatile("" : "+v"(opq_a));               // per-chunk recomputation of the 13 staging offsets (they are invariant
-                                                  // across chunks, and hoisted out of the K loop they cost 26 long-lived VGPRs)
+    // per-chunk recomputation of the 13 staging offsets from a freshly derived lane id (they are invariant across chunks, and
+    // hoisted out of the K loop they cost 26 long-lived VGPRs; so would a copy of the lane id kept for this purpose alone)
+    const int opq_a = lane_id_opaque();
 #pragma unroll
     for (int j = 0; j < QA_PIECES; ++j) {
-      const int idx = (wave + 4 * j) * 64 + lane + opq_a;
+      const int idx = (wave + 4 * j) * 64 + opq_a;
       const int P = idx >> 3;
       const int pix = halo_pix(P);
       const int sub = (idx & 7) ^ (P & 6);
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     const int Cs32 = Cs / 32;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {                 // scale dwords of halo pixels (wave + 4k)*64 .. +63
-      const int pix = halo_pix((wave + 4 * k) * 64 + lane + opq_a);
+      const int pix = halo_pix((wave + 4 * k) * 64 + opq_a);
       const int voff = pix >= 0 ? pix * Cs32 + ccl * 4 : 0x7ffffff0;
       if (first) dma4(rs0, sAs + (wave + 4 * k) * 256, voff); else dma4(rs1, sAs + (wave + 4 * k) * 256, voff);
     }
@@ -184,7 +191,10 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   const int asb = lanepix * 4 + g;                                  // scale byte of (pixel, channel block g)
   // B: n = 64 wn + 16 J + r16 -> n & 6 = r16 & 6
   const int bb = (wn * 64 + r16) * 128 + ((g ^ (r16 & 6)) << 4);
-  const int bsb = QB_TILE + (wn * 64 + r16) * 4 + g;
+  // weight scales: the unit's 512 scale bytes are laid out [wn][r16][g][J] (pack_conv3x3_mxfp8), so ONE dword per lane holds the
+  // scales of its four column blocks J for K block g, and the MFMA's opsel picks byte J: 1 ds_read_b32 and 1 VGPR per tap instead
+  // of 4 ds_read_u8 and 4 VGPRs (the kernel lives at the 256-register budget)
+  const int bsb = QB_TILE + ((wn * 16 + r16) * 4 + g) * 4;
 
   // One K-step: the 4 weight fragments (64 output channels of this wave) stay in registers, the 8 pixel fragments stream
   // through one at a time - 24 ds_read_b128 per 32 MFMAs, and 128 + 32 + 16 operand/accumulator registers.
@@ -197,13 +207,12 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     int r7t = r7;
     asm volatile("" : "+v"(r7t));
     v8i b0, b1, b2, b3;
-    int sb0, sb1, sb2, sb3;
+    const int sbw = *reinterpret_cast<const int*>(Bt + bsb);
 #define SRGD_QLOAD_B(J)                                                              \
     {                                                                                \
       const v4i lo = *reinterpret_cast<const v4i*>(Bt + bb + J * 2048);              \
       const v4i hi = *reinterpret_cast<const v4i*>(Bt + (bb ^ 64) + J * 2048);       \
       b##J = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};            \
-      sb##J = *reinterpret_cast<const unsigned char*>(Bt + bsb + J * 64);            \
     }
     SRGD_QLOAD_B(0) SRGD_QLOAD_B(1) SRGD_QLOAD_B(2) SRGD_QLOAD_B(3)
 #undef SRGD_QLOAD_B
@@ -217,40 +226,66 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
       a##I = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};            \
       sa##I = *reinterpret_cast<const unsigned char*>(sAs + asb + Pc * 4);           \
     }
-#define SRGD_QMM(C_, A_, SA_, B_, SB_) C_ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A_, B_, C_, 0, 0, 0, SA_, 0, SB_)
+    // The MFMA goes out as inline asm with the accumulator tied (D = C, "+v"): through the builtin hipcc picks a fresh
+    // destination for every scaled MFMA (this LLVM has no tied form of v_mfma_scale), so the 128 accumulators migrate through the
+    // register file during a tap and the allocator - at 256 registers - spills loop-carried addresses into the K loop (the
+    // reload sat behind s_waitcnt vmcnt(0), i.e. behind the weight DMA just issued).  Volatile asm also keeps each tap's MFMAs
+    // in their tap: left to itself hipcc SINKS the register-only chains of all nine taps below the chunk's last barrier.
+    // Hazards the compiler no longer sees: the operand fragments are overwritten by ds_reads no sooner than four MFMAs
+    // (>= 128 cycles) later, the accumulators are next touched by MFMAs with the same D (interlocked) or by the epilogue behind
+    // a barrier, and the inputs come from LDS reads whose lgkmcnt waits the compiler still inserts.
+    // opsel of the weight scale (byte J of sbw): bit 0 -> op_sel[1], bit 1 -> op_sel_hi[1]
+#define SRGD_QMM_OPSEL_0 "op_sel_hi:[0,0,0]"
+#define SRGD_QMM_OPSEL_1 "op_sel:[0,1,0] op_sel_hi:[0,0,0]"
+#define SRGD_QMM_OPSEL_2 "op_sel_hi:[0,1,0]"
+#define SRGD_QMM_OPSEL_3 "op_sel:[0,1,0] op_sel_hi:[0,1,0]"
+#define SRGD_QMM(C_, A_, SA_, B_, J_)                                                                      \
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " SRGD_QMM_OPSEL_##J_            \
+                 : "+v"(C_) : "v"(A_), "v"(B_), "v"(SA_), "v"(sbw))
 #define SRGD_QROW(I)                                                                 \
-    SRGD_QMM(c##I##0, a##I, sa##I, b0, sb0); SRGD_QMM(c##I##1, a##I, sa##I, b1, sb1);  \
-    SRGD_QMM(c##I##2, a##I, sa##I, b2, sb2); SRGD_QMM(c##I##3, a##I, sa##I, b3, sb3);
+    SRGD_QMM(c##I##0, a##I, sa##I, b0, 0); SRGD_QMM(c##I##1, a##I, sa##I, b1, 1);    \
+    SRGD_QMM(c##I##2, a##I, sa##I, b2, 2); SRGD_QMM(c##I##3, a##I, sa##I, b3, 3);
     // software pipeline over the pixel fragments, fenced for the scheduler (left alone it hoists all eight fragment loads to
     // the top of the step and spills ~130 registers into the loop): the loads of fragment i+1 are issued ahead of the 4 MFMAs
     // (128 cycles of matrix pipe) of fragment i; two fragments live at a time
     SRGD_QLOAD_A(0)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(1) SRGD_QROW(0)
+    SRGD_QLOAD_A(1)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(2) SRGD_QROW(1)
+    SRGD_QROW(0)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(3) SRGD_QROW(2)
+    SRGD_QLOAD_A(2)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(4) SRGD_QROW(3)
+    SRGD_QROW(1)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(5) SRGD_QROW(4)
+    SRGD_QLOAD_A(3)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(6) SRGD_QROW(5)
+    SRGD_QROW(2)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(7) SRGD_QROW(6)
+    SRGD_QLOAD_A(4)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QROW(3)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QLOAD_A(5)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QROW(4)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QLOAD_A(6)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QROW(5)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QLOAD_A(7)
+    __builtin_amdgcn_sched_barrier(0);
+    SRGD_QROW(6)
     __builtin_amdgcn_sched_barrier(0);
     SRGD_QROW(7)
 #undef SRGD_QROW
 #undef SRGD_QMM
+#undef SRGD_QMM_OPSEL_0
+#undef SRGD_QMM_OPSEL_1
+#undef SRGD_QMM_OPSEL_2
+#undef SRGD_QMM_OPSEL_3
 #undef SRGD_QLOAD_A
-    // Pin the accumulators here: hipcc otherwise SINKS the (register-only) MFMA chains of all nine taps below the chunk's last
-    // barrier and carries every tap's operand fragments there through scratch (617 spilled VGPRs); s_setprio brackets
-    // (cdna_hip_programming.md T5) did not hold them.  Empty asm, no instruction emitted.
-    asm volatile("" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
-    asm volatile("" : "+v"(c20), "+v"(c21), "+v"(c22), "+v"(c23), "+v"(c30), "+v"(c31), "+v"(c32), "+v"(c33));
-    asm volatile("" : "+v"(c40), "+v"(c41), "+v"(c42), "+v"(c43), "+v"(c50), "+v"(c51), "+v"(c52), "+v"(c53));
-    asm volatile("" : "+v"(c60), "+v"(c61), "+v"(c62), "+v"(c63), "+v"(c70), "+v"(c71), "+v"(c72), "+v"(c73));
   };
 
   // ---- stagger the two workgroups of a CU by half a tile, once (conv3x3_bf16.hip explains why)
@@ -288,24 +323,36 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     }
   }
   QWAIT_VM(0);                                     // (nothing is in flight here; kept next to the epilogue's reuse of the ring)
+  // The MFMAs are inline asm (compute()): the compiler does not know that the accumulators were written by the matrix pipe and
+  // inserts none of the wait states a VALU read of an XDL result needs (<= 18 for a 16-pass MFMA).  The accumulators are
+  // threaded through these statements, so every epilogue read comes after >= 32 wait states behind the last MFMA.
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
+  asm volatile("" : "+v"(c20), "+v"(c21), "+v"(c22), "+v"(c23), "+v"(c30), "+v"(c31), "+v"(c32), "+v"(c33));
+  asm volatile("" : "+v"(c40), "+v"(c41), "+v"(c42), "+v"(c43), "+v"(c50), "+v"(c51), "+v"(c52), "+v"(c53));
+  asm volatile("" : "+v"(c60), "+v"(c61), "+v"(c62), "+v"(c63), "+v"(c70), "+v"(c71), "+v"(c72), "+v"(c73));
 
   // ------------------------------- epilogue -------------------------------------------
   // tile transposed through LDS ([256 pixels][128 ch] bf16, rows padded to 272 B), stored as whole 256-byte channel rows
   constexpr int EROW = QBN * 2 + 16;
+  // Per-lane epilogue addresses come from a lane id re-derived HERE (v_mbcnt, opaque to the optimiser): derived from `tid` they are
+  // computed ahead of the K loop and carried through it - in registers this kernel does not have (256-VGPR budget): the <STATS>
+  // instance spilled 6 of them, and the reload of one at the top of every chunk put an s_waitcnt vmcnt(0) right behind the
+  // weight DMA of tap 0 (one exposed L2 round trip per chunk = per tile on the 128-channel layers).
+  const int laneE = lane_id_opaque(), tidE = wave * 64 + laneE, r16E = laneE & 15, gE = laneE >> 4;
   float s1[4], s2[4];                                     // (the loop's last barrier retired every operand read)
 #define SRGD_QACC(MI, NI) (NI == 0 ? c##MI##0 : NI == 1 ? c##MI##1 : NI == 2 ? c##MI##2 : c##MI##3)
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
     s1[ni] = 0.f;
     s2[ni] = 0.f;
-    const int cl = wn * 64 + ni * 16 + r16;               // column inside the tile
+    const int cl = wn * 64 + ni * 16 + r16E;               // column inside the tile
     const float bias = p.bias ? p.bias[nt * QBN + cl] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
       const f32x4 av = mi == 0 ? SRGD_QACC(0, ni) : mi == 1 ? SRGD_QACC(1, ni) : mi == 2 ? SRGD_QACC(2, ni) : mi == 3 ? SRGD_QACC(3, ni)
                      : mi == 4 ? SRGD_QACC(4, ni) : mi == 5 ? SRGD_QACC(5, ni) : mi == 6 ? SRGD_QACC(6, ni) : SRGD_QACC(7, ni);
-      // D map: column = lane & 15, row = (lane >> 4) * 4 + reg -> pixel (patch row 4 wm + (mi >> 1), x = 16 (mi & 1) + 4 g + reg)
-      char* trow = smem + ((4 * wm + (mi >> 1)) * QPW + (mi & 1) * 16 + g * 4) * EROW + cl * 2;
+      // D map: column = laneE & 15, row = (laneE >> 4) * 4 + reg -> pixel (patch row 4 wm + (mi >> 1), x = 16 (mi & 1) + 4 gE + reg)
+      char* trow = smem + ((4 * wm + (mi >> 1)) * QPW + (mi & 1) * 16 + gE * 4) * EROW + cl * 2;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const float v = av[reg] + bias;
@@ -329,8 +376,8 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
       t2 += __shfl_xor(t2, 32, 64);
       t1 += __shfl_xor(t1, 16, 64);
       t2 += __shfl_xor(t2, 16, 64);
-      if (lane < 16) {
-        const int cl = wn * 64 + ni * 16 + r16;
+      if (laneE < 16) {
+        const int cl = wn * 64 + ni * 16 + r16E;
         cs[(wm * QBN + cl) * 2 + 0] = t1;
         cs[(wm * QBN + cl) * 2 + 1] = t2;
       }
@@ -341,24 +388,24 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     bf16* obase = p.out + ((size_t)(b * p.H + y0) * p.W + x0) * p.Cout + nt * QBN;
 #pragma unroll
     for (int i = 0; i < (QPH * QPW * 16) / QNT; ++i) {
-      const int q = tid + QNT * i;                        // 16-byte chunk: pixel q/16, channels (q%16)*8..+7
+      const int q = tidE + QNT * i;                        // 16-byte chunk: pixel q/16, channels (q%16)*8..+7
       const int pix = q >> 4, c16 = q & 15;
       const int py = pix / QPW, px = pix - py * QPW;
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + pix * EROW + c16 * 16);
       const size_t oo = ((size_t)py * p.W + px) * p.Cout + c16 * 8;
       *reinterpret_cast<bf16x8*>(obase + oo) = v;
-      if (p.oq) mx_store_twin(v, p.oq, p.os, (size_t)(obase - p.out) + oo, tid & 3);
+      if (p.oq) mx_store_twin(v, p.oq, p.os, (size_t)(obase - p.out) + oo, tidE & 3);
     }
   }
   if (STATS) {
     const int cpg = p.Cout / p.groups;                    // multiple of 16, divides or is a multiple of 128
     const int span = cpg >= QBN ? QBN : cpg;              // columns of this tile that belong to one group: 16, 32, 64 or 128
     float a1 = 0.f, a2 = 0.f;
-    if (tid < QBN) {
+    if (tidE < QBN) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        a1 += cs[(k * QBN + tid) * 2 + 0];
-        a2 += cs[(k * QBN + tid) * 2 + 1];
+        a1 += cs[(k * QBN + tidE) * 2 + 0];
+        a2 += cs[(k * QBN + tidE) * 2 + 1];
       }
       for (int o = 1; o < span && o < 64; o <<= 1) {
         a1 += __shfl_xor(a1, o, 64);
@@ -368,14 +415,14 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     if (span == QBN) {                                    // a group spans both waves: combine through LDS, raw barriers
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       QBARRIER();
-      if (tid < QBN && lane == 0) { cs[wave * 2 + 0] = a1; cs[wave * 2 + 1] = a2; }
+      if (tidE < QBN && laneE == 0) { cs[wave * 2 + 0] = a1; cs[wave * 2 + 1] = a2; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       QBARRIER();
-      if (tid == 0) { a1 = cs[0] + cs[2]; a2 = cs[1] + cs[3]; }
+      if (tidE == 0) { a1 = cs[0] + cs[2]; a2 = cs[1] + cs[3]; }
     }
-    if (tid < QBN && (tid % span) == 0) {
+    if (tidE < QBN && (tidE % span) == 0) {
       const int tiles_per_group = cpg >= QBN ? cpg / QBN : 1;
-      const int grp = (nt * QBN) / cpg + (cpg >= QBN ? 0 : tid / span);
+      const int grp = (nt * QBN) / cpg + (cpg >= QBN ? 0 : tidE / span);
       const int nslots = tiles_y * tiles_x * tiles_per_group;
       const int slot = trem * tiles_per_group + (cpg >= QBN ? nt % tiles_per_group : 0);
       float* dst = p.gn_partial + ((size_t)(b * p.groups + grp) * nslots + slot) * 2;
@@ -433,7 +480,7 @@ int conv3x3_mxfp8_stats_slots(const ConvArgs& a) {
   return (a.Hin / QPH) * (a.Win / QPW) * (cpg >= QBN ? cpg / QBN : 1);
 }
 
-// OIHW fp32 -> [tap][cc][ntile][16.5 KiB]: 128 rows x 128 B of e4m3 (swizzled LDS image) + [128][4] E8M0 bytes.
+// OIHW fp32 -> [tap][cc][ntile][16.5 KiB]: 128 rows x 128 B of e4m3 (swizzled LDS image) + 512 E8M0 bytes [wn][r16][blk][J].
 // One scale per (output channel, tap, 32 input channels): w = q * 2^(byte - 127).
 void pack_conv3x3_mxfp8(const float* src_oihw, int Cin, int Cout, std::vector<unsigned char>& out) {
   const int CC = Cin / QKC, NTL = Cout / QBN;
@@ -451,7 +498,8 @@ void pack_conv3x3_mxfp8(const float* src_oihw, int Cin, int Cout, std::vector<un
               amax = std::max(amax, std::fabs(src_oihw[(((size_t)o * Cin + ci) * 3 + tap / 3) * 3 + tap % 3]));
             }
             const int ex = mx_block_exponent(amax);
-            unit[QB_TILE + n * 4 + blk] = (unsigned char)(ex + 127);
+            // scale bytes as [wn = n / 64][r16 = n % 16][blk][J = (n / 16) % 4]: see the kernel's `bsb`
+            unit[QB_TILE + (((n >> 6) * 16 + (n & 15)) * 4 + blk) * 4 + ((n >> 4) & 3)] = (unsigned char)(ex + 127);
             const float inv = std::ldexp(1.0f, -ex);
             for (int e = 0; e < 32; ++e) {
               const int k = blk * 32 + e;                      // channel inside the chunk = K index
@@ -483,7 +531,7 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   }
   const int grid = a.B * (a.Hin / QPH) * (a.Win / QPW) * (a.Cout / QBN);
   static bool attr_set[64] = {};
-  if (first_use_on_device(attr_set)) {
+  if (DeviceSetup once(attr_set); once.need) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<false>),

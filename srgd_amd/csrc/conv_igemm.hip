@@ -325,7 +325,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
   if (sizeof(T) == 2) lds = std::max(lds, (size_t)BM * (BN * 2 + 16));     // bf16 epilogue staging tile
   const int grid = a.B * cdiv(a.Hout * a.Wout, BM) * (a.CoutPad / BN);
   static bool attr_set[64] = {};
-  if (first_use_on_device(attr_set)) {
+  if (DeviceSetup once(attr_set); once.need) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BKC, PRECISE>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }

@@ -469,7 +469,7 @@ int linattn_fused(const void* x, void* y, int B, int N, int C, const void* wkv_i
   static bool attr[64] = {};
   const int lds1 = RING * TILE_BYTES + 2 * TM * 4;
   const int lds2 = (RING + 1) * TILE_BYTES + 4 * TM * 4 + RING * 4 * TM * 4;
-  if (first_use_on_device(attr)) {
+  if (DeviceSetup once(attr); once.need) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
   }

@@ -415,7 +415,7 @@ static int launch_la_t(const void* x, void* y, int B, int N, const void* wkv, co
   static bool attr[64] = {};
   const int lds1 = RING2 * LaDims<C>::TILE + 2 * TM2 * 4;
   const int lds2 = RING2 * LaDims<C>::TILE + ATT2 + 4 * TM2 * 4 + RING2 * 4 * 64 * 4 + 2 * C * 4;
-  if (first_use_on_device(attr)) {
+  if (DeviceSetup once(attr); once.need) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la1_t_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la2_t_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
   }

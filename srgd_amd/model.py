@@ -32,6 +32,11 @@ __all__ = ["get_coord_and_pad", "get_coords", "get_area", "beta_linear_log_snr",
 # ---------------------------------------------------------------------------------------------
 # tiling geometry (pure ints; reference model.py:116-179)
 # ---------------------------------------------------------------------------------------------
+def _host_randn(generator, *shape):
+    """Host-noise draw: ``torch.randn`` on the CPU generator the reference draws from (global unless one is given)."""
+    return torch.randn(*shape, generator=generator)
+
+
 def get_coord_and_pad(height: int, width: int, tile_size: int = 256):
     """Canvas size and placement of an ``height x width`` image: one tile if it fits, otherwise the
     size rounded up to whole tiles plus one extra tile (half a tile of margin per side)."""
@@ -325,6 +330,8 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
         self.loss_type = loss_type
         # engine knobs (not part of the reference surface)
         self.noise_source = "host"     # "host": torch CPU generator in the reference's draw order; "device": Philox
+        self.host_generator = None     # host-noise draws: None = torch's global CPU generator (what seed_everything seeds, as the
+                                       # reference); a torch.Generator makes a run independent of other threads' draws
         self.device_noise_seed = 0
         self.max_tiles_per_launch = None   # None: use the caller's batch_size as the reference does
         # engine precision: "fp32" (default: the reference's numerics - upstream ignores ``amp`` and always computes fp32,
@@ -402,10 +409,10 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
                 else torch.tensor(1.0)
             ls0 = beta_linear_log_snr(t0)
             img = torch.empty(batch, 3, hp, wp, device=dev)
-            eng.sampler_q_start(cond01, torch.randn(1, 3, hp, wp).to(dev) if host_noise else None,
+            eng.sampler_q_start(cond01, _host_randn(self.host_generator, 1, 3, hp, wp).to(dev) if host_noise else None,
                                 float(ls0.sigmoid().sqrt()), float((-ls0).sigmoid().sqrt()), img, self.device_noise_seed)
         elif host_noise:
-            img = torch.randn(1, 3, hp, wp).to(dev).repeat(batch, 1, 1, 1)   # reference draw #1 (model.py:3311)
+            img = _host_randn(self.host_generator, 1, 3, hp, wp).to(dev).repeat(batch, 1, 1, 1)   # reference draw #1 (model.py:3311)
         else:
             img = eng.randn_(torch.empty(1, 3, hp, wp, device=dev), self.device_noise_seed, 0).repeat(batch, 1, 1, 1)
         x_start = img.clone() if with_x0_images else None
@@ -432,9 +439,9 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
                 # identical to the reference's per-minibatch randn_like draws (SURVEY Appendix D:
                 # 16-element block property makes one contiguous draw equal to the minibatch draws)
                 if not last:
-                    noise_tiles = torch.randn(n_tiles, 3, tile_size, tile_size).to(dev, non_blocking=True)
+                    noise_tiles = _host_randn(self.host_generator, n_tiles, 3, tile_size, tile_size).to(dev, non_blocking=True)
                 if i % 2 == 1:
-                    noise_canvas = torch.randn(1, 3, hp, wp).to(dev, non_blocking=True)
+                    noise_canvas = _host_randn(self.host_generator, 1, 3, hp, wp).to(dev, non_blocking=True)
             if self.canvas_group is None:
                 eng.sampler_step(i, img, cond_canvas, x_start, noise_tiles, noise_canvas, passes, kind, scale, sub_batch,
                                  seed=self.device_noise_seed)
@@ -491,10 +498,10 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
         if generation_start_steps > 0:                                   # q_sample(condition, t_start) :3198-3201
             ls0 = beta_linear_log_snr(1.0 - torch.tensor(generation_start_steps / num_sample_steps))
             img = torch.empty(1, 3, b * s_, s_, device=dev)
-            nz = to_canvas(torch.randn(b, 3, s_, s_).to(dev)) if host_noise else None
+            nz = to_canvas(_host_randn(self.host_generator, b, 3, s_, s_).to(dev)) if host_noise else None
             eng.sampler_q_start(cond01, nz, float(ls0.sigmoid().sqrt()), float((-ls0).sigmoid().sqrt()), img, seed)
         elif host_noise:
-            img = to_canvas(torch.randn(b, 3, s_, s_).to(dev))           # :3203
+            img = to_canvas(_host_randn(self.host_generator, b, 3, s_, s_).to(dev))           # :3203
         else:
             img = eng.randn_(torch.empty(1, 3, b * s_, s_, device=dev), seed, 0)
         x_start = img.clone() if with_x0_images else None
@@ -512,7 +519,7 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
             else:
                 passes, kind, scale = 1, 0, 1.0
             last = i == num_sample_steps - 1
-            noise_tiles = torch.randn(b, 3, s_, s_).to(dev, non_blocking=True) if (host_noise and not last) else None
+            noise_tiles = _host_randn(self.host_generator, b, 3, s_, s_).to(dev, non_blocking=True) if (host_noise and not last) else None
             # no ring re-noise in the un-tiled loop: run the step over all tiles with do_ring = False
             eng.sampler_step_tiles(i, 0, b, False, img, cond_canvas, x_start, noise_tiles, None, passes, kind, scale,
                                    self.max_tiles_per_launch or b, seed=seed)
@@ -574,6 +581,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         self.use_dpmpp_solver, self.loss_type = use_dpmpp_solver, loss_type
         # engine knobs (not part of the reference surface)
         self.noise_source = "host"
+        self.host_generator = None         # as in the DDPM wrapper: None = torch's global CPU generator
         self.device_noise_seed = 0
         self.max_tiles_per_launch = None
         self.precision = "fp32"            # as in the DDPM wrapper
@@ -670,7 +678,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
 
         def canvas_noise(stream_id):
             if host_noise:
-                return torch.randn(1, 3, hp, wp).to(dev, non_blocking=True)
+                return _host_randn(self.host_generator, 1, 3, hp, wp).to(dev, non_blocking=True)
             return eng.randn_(torch.empty(1, 3, hp, wp, device=dev), seed, stream_id)
 
         if generation_start_steps > 0:                                  # get_noised_images(condition, step) :2340, :2185
@@ -780,7 +788,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
 
         def batch_noise(stream_id):
             if host_noise:
-                return to_canvas(torch.randn(b, 3, s_, s_).to(dev, non_blocking=True))
+                return to_canvas(_host_randn(self.host_generator, b, 3, s_, s_).to(dev, non_blocking=True))
             return eng.randn_(torch.empty(1, 3, b * s_, s_, device=dev), seed, stream_id)
 
         def start(eng_):

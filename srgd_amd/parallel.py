@@ -18,19 +18,73 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_items, world))
 
 
+class TorchComm:
+    """The communicator the product runs on: a ``torch.distributed`` process group (``nccl`` = RCCL on the GPU box, ``gloo`` in
+    the CPU tests).  The sharding code below talks to this small interface only - rank, world, backend and the four collectives
+    the path needs - so that a test can stand eight ranks up as eight THREADS of one process (``tests/thread_comm.py``): a
+    one-GPU box admits at most six processes on its card, and the 8-rank partitionings of BASELINE configs[2]/[3] have to be
+    exercised on it."""
+
+    def __init__(self, group=None):
+        self.group = group if group is not None else dist.group.WORLD
+
+    @property
+    def rank(self) -> int:
+        return dist.get_rank(self.group)
+
+    @property
+    def world(self) -> int:
+        return dist.get_world_size(self.group)
+
+    @property
+    def backend(self) -> str:
+        return dist.get_backend(self.group)
+
+    def all_gather_tiles(self, out: torch.Tensor, mine: torch.Tensor) -> None:
+        """``out`` [world*width, ...] <- every rank's ``mine`` [width, ...] in rank order (both preallocated, contiguous)."""
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(out, mine, group=self.group)       # one RCCL all-gather, no staging copies
+        else:
+            dist.all_gather(list(out.split(mine.shape[0], 0)), mine, group=self.group)
+
+    def gather(self, local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
+        if self.backend != "nccl" and local.is_cuda:
+            local = local.cpu()
+        bucket = [torch.empty_like(local) for _ in range(self.world)] if self.rank == dst else None
+        dist.gather(local, bucket, dst=dst, group=self.group)
+        return bucket
+
+    def broadcast(self, flat: torch.Tensor, src: int = 0) -> None:
+        dist.broadcast(flat, src=src, group=self.group)
+
+    def all_reduce_max(self, t: torch.Tensor) -> None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
+    def barrier(self) -> None:
+        dist.barrier(group=self.group)
+
+
+def _comm(comm=None):
+    """``comm`` itself, or the WORLD group's communicator; None when no process group exists (single-process runs)."""
+    if comm is not None:
+        return comm
+    return TorchComm() if dist.is_initialized() else None
+
+
 def broadcast_state_dict(schema: Mapping[str, Sequence[int]], state_dict: Optional[Dict[str, torch.Tensor]],
-                         src: int = 0, device: torch.device = torch.device("cpu")) -> Dict[str, torch.Tensor]:
+                         src: int = 0, device: torch.device = torch.device("cpu"), comm=None) -> Dict[str, torch.Tensor]:
     """Rank ``src`` owns the checkpoint; every rank returns an identical CPU fp32 state_dict.  The tensors
     travel as ONE flat buffer (550 MB fp32 for the dim-128 model): a single broadcast instead of 280."""
+    comm = _comm(comm)
     keys = list(schema.keys())
     sizes = [int(torch.Size(schema[k]).numel()) for k in keys]
-    if dist.get_backend() != "nccl":
+    if comm.backend != "nccl":
         device = torch.device("cpu")                 # gloo (CPU tests, shared-GPU test hook): stage through host memory
     flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
-    if dist.get_rank() == src:
+    if comm.rank == src:
         assert state_dict is not None
         flat.copy_(torch.cat([state_dict[k].reshape(-1).float() for k in keys]))
-    dist.broadcast(flat, src=src)
+    comm.broadcast(flat, src=src)
     host = flat.cpu()
     out, o = {}, 0
     for k, n in zip(keys, sizes):
@@ -39,17 +93,12 @@ def broadcast_state_dict(schema: Mapping[str, Sequence[int]], state_dict: Option
     return out
 
 
-def gather_outputs(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
+def gather_outputs(local: torch.Tensor, dst: int = 0, comm=None) -> Optional[List[torch.Tensor]]:
     """Gather equally-shaped per-rank output stacks to ``dst`` (returns the list there, None elsewhere)."""
-    world = dist.get_world_size()
-    if dist.get_backend() != "nccl" and local.is_cuda:
-        local = local.cpu()
-    bucket = [torch.empty_like(local) for _ in range(world)] if dist.get_rank() == dst else None
-    dist.gather(local, bucket, dst=dst)
-    return bucket
+    return _comm(comm).gather(local, dst=dst)
 
 
-def gather_outputs_u8(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
+def gather_outputs_u8(local: torch.Tensor, dst: int = 0, comm=None) -> Optional[List[torch.Tensor]]:
     """Gather the HR outputs the way they leave the pipeline (``ToPILImage``: uint8 HWC, inference.py:93): each rank converts
     its ``[n,3,H,W]`` fp32 stack on the GPU and 3.1 MB per 1024^2 tile travel instead of 12.6 MB."""
     if local.is_cuda:
@@ -57,25 +106,28 @@ def gather_outputs_u8(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.
         local = torch.stack([unit_tensor_to_u8_on_device(img) for img in local], 0)
     else:                                            # CPU tests (gloo): same arithmetic, torch ops
         local = local.mul(255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
-    return gather_outputs(local, dst=dst)
+    return gather_outputs(local, dst=dst, comm=comm)
 
 
-def sample_images_sharded(sample_group, n_items: int, lockstep: int, rank: int, world: int, dst: int = 0, gather: bool = True):
+def sample_images_sharded(sample_group, n_items: int, lockstep: int, rank: int, world: int, dst: int = 0, gather: bool = True,
+                          comm=None):
     """Independent images over ranks (BASELINE configs[2]; the reference's manual ``--start_index/--end_index`` sharding,
     inference.py:36-37,120, automated): item ``j`` of ``0..n_items-1`` belongs to rank ``j % world``; every rank samples its
     items in lock-step groups of ``lockstep`` through ``sample_group(list_of_item_ids) -> [k,3,H,W]`` and the HR outputs are
     gathered to ``dst`` as the uint8 HWC images the pipeline emits.  ``n_items`` must be a multiple of ``world`` (equal-sized
     gathers).  Returns ``(local_outputs, ordered)``: ``ordered`` is the list of all ``n_items`` uint8 images in item order on
-    ``dst`` (None elsewhere, and None when ``gather`` is False or there is no process group)."""
+    ``dst`` (None elsewhere, and None when ``gather`` is False or there is no process group).  ``comm``: the communicator
+    (default: the WORLD process group)."""
     assert n_items % world == 0, "equal shares per rank (the gather moves equally-shaped stacks)"
     mine = shard_indices(n_items, rank, world)
     outs = []
     for a in range(0, len(mine), lockstep):
         outs.append(sample_group(mine[a:a + lockstep]))
     local = torch.cat(outs, 0)
-    if not gather or not dist.is_initialized():
+    comm = _comm(comm)
+    if not gather or comm is None:
         return local, None
-    bucket = gather_outputs_u8(local, dst=dst)
+    bucket = gather_outputs_u8(local, dst=dst, comm=comm)
     if bucket is None:
         return local, None
     ordered = [None] * n_items
@@ -85,9 +137,10 @@ def sample_images_sharded(sample_group, n_items: int, lockstep: int, rank: int, 
     return local, ordered
 
 
-def max_over_ranks(seconds: float, device: torch.device) -> float:
-    t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+def max_over_ranks(seconds: float, device: torch.device, comm=None) -> float:
+    comm = _comm(comm)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if comm.backend == "nccl" else "cpu")
+    comm.all_reduce_max(t)
     return float(t.item())
 
 
@@ -103,7 +156,7 @@ def tile_slices(n_tiles: int, world: int) -> List[range]:
 
 
 class CanvasShard:
-    """State of one canvas shared by the ranks of ``group``: the group plus the exchange buffers of the per-step tile
+    """State of one canvas shared by the ranks of ``comm``: the communicator plus the exchange buffers of the per-step tile
     all-gather, allocated ONCE per (grid width, device) and reused by every step of every run (round 3: the per-step
     ``torch.zeros`` + receive-buffer allocations are gone, so a sharded step allocates nothing and the caching allocator
     never has to synchronise mid-run).
@@ -116,8 +169,8 @@ class CanvasShard:
     ``always_exchange``: run the pack -> all-gather -> unpack round trip even at world size 1 (bench.py's SRGD_FORCE_DIST
     hook: it puts ``all_gather_into_tensor`` on RCCL through its paces on a 1-GPU box; the result is unchanged)."""
 
-    def __init__(self, group, always_exchange: bool = False):
-        self.group = group
+    def __init__(self, comm, always_exchange: bool = False):
+        self.comm = comm
         self.always_exchange = always_exchange
         self._bufs = {}
         self.exchanges = 0                      # tile all-gathers issued so far (tests / bench report it)
@@ -134,25 +187,18 @@ class CanvasShard:
         return have[0][:width], have[1][:need]
 
 
-def shard_canvas(sampler, group=None, always_exchange: bool = False):
-    """Make ``sampler.tiled_sample`` split every step's tile list over the ranks of ``group`` (default: WORLD).
+def shard_canvas(sampler, group=None, always_exchange: bool = False, comm=None):
+    """Make ``sampler.tiled_sample`` split every step's tile list over the ranks of ``group`` (default: WORLD; or of an explicit
+    communicator ``comm``).
     All ranks must call tiled_sample with identical arguments (and, in host-noise mode, identical torch seeds);
     all of them return the full image.  Results are bit-identical to the single-GPU run: tiles are independent
     within a step (model.py:3361-3380) and the noise of a tile depends only on its index in the grid."""
-    sampler.canvas_group = CanvasShard(group if group is not None else dist.group.WORLD, always_exchange)
+    sampler.canvas_group = CanvasShard(comm if comm is not None else TorchComm(group), always_exchange)
     return sampler
 
 
-def _all_gather_tiles(out: torch.Tensor, mine: torch.Tensor, group) -> None:
-    """``out`` [world*width, ...] <- every rank's ``mine`` [width, ...] in rank order (both preallocated, contiguous)."""
-    if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(out, mine, group=group)       # one RCCL all-gather, no staging copies
-    else:
-        dist.all_gather(list(out.split(mine.shape[0], 0)), mine, group=group)
-
-
 def _exchange(eng, shard: CanvasShard, step: int, n_tiles: int, mine: range, width: int, canvases) -> None:
-    world = dist.get_world_size(shard.group)
+    world = shard.comm.world
     if world == 1 and not shard.always_exchange:
         return
     for canvas in canvases:
@@ -160,15 +206,15 @@ def _exchange(eng, shard: CanvasShard, step: int, n_tiles: int, mine: range, wid
             continue
         packed, everyone = shard.buffers(width, world, canvas.device)
         eng.sampler_exchange_tiles(step & 1, mine.start, len(mine), canvas, packed, to_canvas=False)
-        _all_gather_tiles(everyone, packed, shard.group)
+        shard.comm.all_gather_tiles(everyone, packed)
         shard.exchanges += 1
         eng.sampler_exchange_tiles(step & 1, 0, n_tiles, canvas, everyone, to_canvas=True)
 
 
 def sharded_step(eng, shard: CanvasShard, step: int, n_tiles: int, img, cond_canvas, x_start, noise_tiles, noise_canvas,
                  passes: int, kind: int, scale: float, sub_batch: int, seed: int) -> None:
-    """One DDPM step of a canvas shared by the ranks of ``shard.group``: my slice of the tiles, then exchange."""
-    rank, world = dist.get_rank(shard.group), dist.get_world_size(shard.group)
+    """One DDPM step of a canvas shared by the ranks of ``shard.comm``: my slice of the tiles, then exchange."""
+    rank, world = shard.comm.rank, shard.comm.world
     sl = tile_slices(n_tiles, world)
     mine, width = sl[rank], len(sl[0])
     eng.sampler_step_tiles(step, mine.start, len(mine), True, img, cond_canvas, x_start, noise_tiles, noise_canvas,
@@ -178,10 +224,10 @@ def sharded_step(eng, shard: CanvasShard, step: int, n_tiles: int, img, cond_can
 
 def sharded_edm_step(eng, shard: CanvasShard, step: int, n_tiles: int, img, cond_canvas, x_start, work, noise_canvas,
                      ring_noise_canvas, passes: int, kind: int, scale: float, sub_batch: int, seed: int) -> None:
-    """One EDM (Heun) step of a canvas shared by the ranks of ``shard.group`` (reference model.py:2379-2463): my slice of the
+    """One EDM (Heun) step of a canvas shared by the ranks of ``shard.comm`` (reference model.py:2379-2463): my slice of the
     tiles (both network evaluations; the scratch canvases stay rank-local), the odd-step ring on every rank's own canvas, then
     the same tile exchange as the DDPM loop."""
-    rank, world = dist.get_rank(shard.group), dist.get_world_size(shard.group)
+    rank, world = shard.comm.rank, shard.comm.world
     sl = tile_slices(n_tiles, world)
     mine, width = sl[rank], len(sl[0])
     eng.edm_step_tiles(step, mine.start, len(mine), True, img, cond_canvas, x_start, work, noise_canvas, ring_noise_canvas,

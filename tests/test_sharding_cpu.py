@@ -111,9 +111,9 @@ def _canvas_grids():
 
 
 def _run_fake(group, steps=5, with_x0=True, edm=False, always_exchange=False, shard_out=None):
-    from srgd_amd.parallel import CanvasShard, sharded_edm_step, sharded_step
+    from srgd_amd.parallel import CanvasShard, TorchComm, sharded_edm_step, sharded_step
     if group is not None:
-        group = CanvasShard(group, always_exchange=always_exchange)
+        group = CanvasShard(group if hasattr(group, "all_gather_tiles") else TorchComm(group), always_exchange=always_exchange)
         if shard_out is not None:
             shard_out.append(group)
     hp, wp, grids = _canvas_grids()

@@ -1,6 +1,9 @@
-"""BASELINE configs[2] / configs[3] on their real 8-rank partitioning.  The box has one GPU, so the eight
-ranks are eight processes that share cuda:0 and talk over gloo; the driver's 8-GPU runs execute the same Python
-(`srgd_amd.parallel`) with nccl (= RCCL).  dim-16 U-Net, few steps: the property under test is the partitioning -
+"""BASELINE configs[2] / configs[3] on their real 8-rank partitioning.  The box has one GPU and its process
+guard admits at most six processes on the card, so the eight ranks are eight THREADS of this process (`tests/thread_comm.py`:
+the communicator interface of `srgd_amd.parallel` with barrier-and-copy collectives), each with its own sampler and engine; the
+driver's 8-GPU runs execute the same Python (`srgd_amd.parallel`) on `TorchComm` with nccl (= RCCL), which
+`tests/test_bench_multirank_gpu.py` exercises at world size 1 and `tests/test_canvas_shard_gpu.py` / `test_sharding_cpu.py` at
+world 2-3 over gloo.  dim-16 U-Net, few steps: the property under test is the partitioning -
 
 * configs[2]-shaped: 64 independent images, 8 per rank (item j -> rank j % 8), lock-step groups of 5 + 3, gathered to rank 0
   as uint8 HWC in item order: must equal the 1-rank run image for image;
@@ -8,48 +11,14 @@ ranks are eight processes that share cuda:0 and talk over gloo; the driver's 8-G
   slices of 4,4,4,4,4,4,1,0 and 2 x 8) and 1280 x 1792 (35 / 24 tiles: 5 x 7 + 0 and 3 x 8), i.e. short and EMPTY slices -
   DDPM and EDM, host-noise fp32 and device-noise bf16: every rank must return the single-process image bit for bit.
 """
-import os
-import socket
-
 import pytest
 import torch
-import torch.multiprocessing as mp
 
 from tests.golden import cases as C
+from tests.thread_comm import ThreadWorld
 
 pytestmark = pytest.mark.gpu
 WORLD = 8
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def _spawn(target, args, timeout=600):
-    ctx = mp.get_context("spawn")
-    port = _free_port()
-    procs = [ctx.Process(target=target, args=(r, WORLD, port, *args)) for r in range(WORLD)]
-    for pr in procs:
-        pr.start()
-    for pr in procs:
-        pr.join(timeout=timeout)
-    hung = [pr for pr in procs if pr.is_alive()]
-    for pr in hung:
-        pr.terminate()
-    assert not hung, f"{len(hung)} rank(s) did not finish within {timeout} s"
-    assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
-
-
-def _init(rank, world, port):
-    import datetime
-    import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.set_num_threads(4)             # eight ranks share the host too (host-noise draws, gloo copies): no 8 x 128-thread pools
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
-    return dist
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -66,8 +35,7 @@ def _sample_items(sampler, items):
                                 precision="fp32")
 
 
-def _images_worker(rank, world, port, out_dir):
-    dist = _init(rank, world, port)
+def _images_worker(comm):
     from srgd_amd.parallel import sample_images_sharded
     from tests.test_engine_gpu import build_sampler
     sampler = build_sampler(16)
@@ -77,29 +45,27 @@ def _images_worker(rank, world, port, out_dir):
         groups.append(list(items))
         return _sample_items(sampler, items)
 
-    local, ordered = sample_images_sharded(sample_group, N_ITEMS, LOCKSTEP, rank, world, dst=0)
-    torch.save({"groups": groups, "ordered": ordered}, os.path.join(out_dir, f"img_r{rank}.pt"))
-    dist.barrier()
-    dist.destroy_process_group()
+    local, ordered = sample_images_sharded(sample_group, N_ITEMS, LOCKSTEP, comm.rank, comm.world, dst=0, comm=comm)
+    return {"groups": groups, "ordered": ordered}
 
 
-def test_configs2_shape_64_images_over_8_ranks_equal_the_one_rank_run(tmp_path):
+def test_configs2_shape_64_images_over_8_ranks_equal_the_one_rank_run():
     from srgd_amd.inference import unit_tensor_to_u8_on_device
     from tests.test_engine_gpu import build_sampler
     sampler = build_sampler(16)
     # the 1-rank run: every image sampled alone (lock-step images are bit-identical to solo runs, so the grouping is free)
     want = [unit_tensor_to_u8_on_device(_sample_items(sampler, [j])[0]).cpu() for j in range(N_ITEMS)]
     assert len({w.numpy().tobytes() for w in want}) == N_ITEMS, "the images must differ for the order check to mean something"
-    _spawn(_images_worker, (str(tmp_path),))
+    res = ThreadWorld(WORLD).run(_images_worker)
     for r in range(WORLD):
-        got = torch.load(tmp_path / f"img_r{r}.pt")
+        got = res[r]
         assert got["groups"] == [[r + k * WORLD for k in range(5)], [r + k * WORLD for k in range(5, 8)]]
         if r:
             assert got["ordered"] is None
             continue
         assert len(got["ordered"]) == N_ITEMS
         for j in range(N_ITEMS):
-            assert got["ordered"][j].shape == (4 * LR, 4 * LR, 3) and torch.equal(got["ordered"][j], want[j]), j
+            assert got["ordered"][j].shape == (4 * LR, 4 * LR, 3) and torch.equal(got["ordered"][j].cpu(), want[j]), j
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -116,31 +82,29 @@ def _run_canvas(sampler, name, edm):
     for noise, prec in (("host", "fp32"), ("device", "bf16")):
         sampler.noise_source = noise
         sampler.device_noise_seed = 29
-        torch.manual_seed(11)
+        sampler.host_generator = torch.Generator().manual_seed(11)     # per rank: eight threads must not share the global one
         o, imgs, x0s = sampler.tiled_sample(batch_size=8, condition_x=cond, class_label=label, num_sample_steps=steps,
                                             class_cond_scale=1.3, precision=prec, with_images=True, with_x0_images=True)
         out[f"{noise}_{prec}"] = o.cpu()
         out[f"{noise}_{prec}_x0"] = x0s[-1]
     sampler.noise_source = "host"
+    sampler.host_generator = None
     return out
 
 
-def _canvas_worker(rank, world, port, out_dir, name, edm):
-    dist = _init(rank, world, port)
+def _canvas_worker(comm, name, edm):
     from srgd_amd.parallel import shard_canvas
     from tests.test_engine_gpu import build_edm_sampler, build_sampler
-    sampler = shard_canvas(build_edm_sampler(16) if edm else build_sampler(16))
+    sampler = shard_canvas(build_edm_sampler(16) if edm else build_sampler(16), comm=comm)
     res = _run_canvas(sampler, name, edm)
     res["exchanges"] = sampler.canvas_group.exchanges
     res["buffers"] = {k: (tuple(v[0].shape), tuple(v[1].shape)) for k, v in sampler.canvas_group._bufs.items()}
-    torch.save(res, os.path.join(out_dir, f"canvas_r{rank}.pt"))
-    dist.barrier()
-    dist.destroy_process_group()
+    return res
 
 
 @pytest.mark.parametrize("edm", [False, True], ids=["ddpm", "edm"])
 @pytest.mark.parametrize("name", list(CANVASES))
-def test_configs3_shape_canvas_over_8_ranks_equals_the_single_process_run(tmp_path, name, edm):
+def test_configs3_shape_canvas_over_8_ranks_equals_the_single_process_run(name, edm):
     from srgd_amd.model import _tiling
     from tests.test_engine_gpu import build_edm_sampler, build_sampler
     sampler = build_edm_sampler(16) if edm else build_sampler(16)
@@ -149,10 +113,10 @@ def test_configs3_shape_canvas_over_8_ranks_equals_the_single_process_run(tmp_pa
     _, (hp, wp), even, odd, _ = _tiling(hh, ww, 256, 256)
     assert f"{hp}x{wp}" == name and (len(even), len(odd)) == ((25, 16) if name == "1280x1280" else (35, 24))
     want = _run_canvas(sampler, name, edm)
-    _spawn(_canvas_worker, (str(tmp_path), name, edm))
+    res = ThreadWorld(WORLD).run(_canvas_worker, name, edm)
     width = -(-len(even) // WORLD)
     for r in range(WORLD):
-        got = torch.load(tmp_path / f"canvas_r{r}.pt")
+        got = res[r]
         for k in want:
             assert torch.equal(got[k], want[k]), (r, k)
         # two runs x 3 steps x (img + x_start) exchanges, through ONE preallocated buffer pair sized for the even grid
