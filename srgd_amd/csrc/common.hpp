@@ -104,7 +104,12 @@ __device__ __forceinline__ uint2 mx_quant8(const float (&y)[8], int* scale_byte)
   const float inv = __uint_as_float((unsigned)(254 - sb) << 23);      // 2^(127 - sb)
   float t[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) t[j] = fminf(fmaxf(y[j] * inv, -448.f), 448.f);
+  for (int j = 0; j < 8; ++j) {
+    // saturate, but let a NaN through (fmaxf / fminf return the other operand): it becomes the e4m3 NaN byte 0x7f and the
+    // MFMA carries it on - a numerical blow-up stays visible in fp8 mode instead of turning into a finite -448
+    const float u = y[j] * inv;
+    t[j] = (u != u) ? u : fminf(fmaxf(u, -448.f), 448.f);
+  }
   unsigned w0 = 0, w1 = 0;
   w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], w0, false);
   w0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], w0, true);

@@ -53,7 +53,6 @@ struct Conv3Args {
   float* gn_partial; int groups;
   const float* gn_in_a;   // GNIN: y = silu(a[b][c] * x + b[b][c]) applied to the input while it is staged ([B][Cin] fp32)
   int gn_in_b_off;        // byte offset of the shift array from the scale array (same allocation)
-  int stagger;            // > 0: first-wave workgroups that are the SECOND on their CU sleep stagger x 8128 cycles once (see kernel)
   unsigned long long* stamps;   // diagnostics (SRGD_CONV3_STAMPS=1): per-phase s_memtime deltas summed over workgroups; null otherwise
 };
 
@@ -289,18 +288,6 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
 
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
   if (p.stamps) t0 = __builtin_amdgcn_s_memtime();
-  // ---- stagger.  The two workgroups of a CU are dispatched together and do identical work, so left alone they run in
-  // lock-step: both in their prologue (DMA latency, no MFMA) and both in their epilogue at the same time, and the matrix pipe
-  // idles for that long every tile (measured: a fixed cost of ~19 K-steps per tile, half the main loop of the 128-channel
-  // layers).  Delaying the second workgroup of each CU by half a tile once, at the start of the launch, puts one workgroup's
-  // overhead beside the other's MFMA phase; the offset persists because every tile of a launch takes the same time.
-  // The second workgroup of a CU is the one whose LDS allocation does not start at 0 (HW_REG_LDS_ALLOC.LDS_BASE).
-  if (p.stagger > 0 && blockIdx.x < 512) {
-    const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6);      // HW_REG_LDS_ALLOC[7:0]
-    if (lds_base != 0)
-      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-
   // ---- prologue: A(0) and B[0], B[1]
   if (GNIN) coef_dma(0);
   issue_a_piece(0, 0);
@@ -564,13 +551,6 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   p.out = (bf16*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
   p.gn_in_a = gn_in_a;
   p.gn_in_b_off = gnin ? (int)((const char*)gn_in_b - (const char*)gn_in_a) : 0;
-  {
-    // half a tile's main loop: S K-steps x ~1,000 cycles (four waves share a SIMD) / 2, in units of s_sleep(127) = 8,128 cycles
-    static int knob = -2;
-    if (knob == -2) { const char* v = getenv("SRGD_CONV3_STAGGER"); knob = v ? atoi(v) : -1; }
-    const int S = 9 * ((a.C0 + a.C1) / KC);
-    p.stagger = knob >= 0 ? knob * S / 64 : (S * 500) / 8128;      // SRGD_CONV3_STAGGER=0 switches it off; =n scales it (n/64 sleeps per step)
-  }
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
   static int want_stamps = -1;
   if (want_stamps < 0) { const char* v = getenv("SRGD_CONV3_STAMPS"); want_stamps = (v && atoi(v)) ? 1 : 0; }

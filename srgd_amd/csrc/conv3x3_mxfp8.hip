@@ -68,7 +68,6 @@ struct ConvQArgs {
   bf16* out;
   float* gn_partial; int groups;
   unsigned char* oq; unsigned char* os;   // optional MX-fp8 twin of the output (ConvArgs::out_q / out_s)
-  int stagger;            // as in conv3x3_bf16.hip: one-time delay (x 8128 cycles) of the second workgroup of every CU
 };
 
 // lane id from v_mbcnt, as volatile asm: never hoisted or CSE'd, so no VGPR carries it (or the thread id) across the K loop
@@ -216,8 +215,14 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     }
     SRGD_QLOAD_B(0) SRGD_QLOAD_B(1) SRGD_QLOAD_B(2) SRGD_QLOAD_B(3)
 #undef SRGD_QLOAD_B
+    // SRGD_MXFP8_DIAG_NOLDS (timing-only diagnostic build, wrong results): fragments 1..7 are register copies of fragment 0 -
+    // 2/3 of the step's ds_read traffic gone - to price the kernel's LDS-bandwidth limit (tools/build_variant.py)
+#ifndef SRGD_MXFP8_DIAG_NOLDS
+#define SRGD_MXFP8_DIAG_NOLDS 0
+#endif
 #define SRGD_QLOAD_A(I)                                                              \
     v8i a##I; int sa##I;                                                             \
+    if (SRGD_MXFP8_DIAG_NOLDS && (I) > 0) { a##I = a0; sa##I = sa0; } else           \
     {                                                                                \
       const int Pc = ((I >> 1) + dy) * QWP + (I & 1) * 16 + dx;                      \
       const int o = apix + ((g ^ (((Pc & 7) + r7t) & 6)) << 4);                      \
@@ -287,13 +292,6 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
 #undef SRGD_QMM_OPSEL_3
 #undef SRGD_QLOAD_A
   };
-
-  // ---- stagger the two workgroups of a CU by half a tile, once (conv3x3_bf16.hip explains why)
-  if (p.stagger > 0 && blockIdx.x < 512) {
-    const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6);      // HW_REG_LDS_ALLOC[7:0]
-    if (lds_base != 0)
-      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
 
   // ---- prologue: A(0), B[0]
   issue_a(0);
@@ -523,12 +521,6 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   p.B = a.B; p.H = a.Hin; p.W = a.Win; p.w = (const unsigned char*)packed_w; p.bias = a.bias; p.Cout = a.Cout;
   p.out = (bf16*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
   p.oq = (unsigned char*)a.out_q; p.os = (unsigned char*)a.out_s;
-  {
-    static int knob = -2;
-    if (knob == -2) { const char* v = getenv("SRGD_CONV3_STAGGER"); knob = v ? atoi(v) : -1; }
-    const int S = 9 * ((a.C0 + a.C1) / QKC);
-    p.stagger = knob >= 0 ? knob * S / 16 : (S * 1000) / 8128;     // half of S steps x ~2,000 cycles (two waves share a SIMD)
-  }
   const int grid = a.B * (a.Hin / QPH) * (a.Win / QPW) * (a.Cout / QBN);
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {

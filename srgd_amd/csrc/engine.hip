@@ -243,13 +243,15 @@ struct srgd_engine {
   int stats_slots = 0;          // slots per (sample, group) the last conv wrote into gn_partial
   bool force_generic_conv = false;
   bool force_unfused_attn = false;
-  // conv3x3_bf16 can apply the producer's GroupNorm+SiLU while staging its input (GNIN).  Measured on MI355X it
-  // LOSES: the 16 transcendentals per 16-byte chunk sit on the barrier-paced critical path of an MFMA-bound kernel
-  // (+0.137 s of conv vs -0.055 s of gn_apply per HR tile), so it is off; kept for a staggered-schedule retry.
+  // conv3x3_bf16 can apply the producer's GroupNorm+SiLU while staging its input (GNIN): the separate gn_apply pass over that
+  // tensor (2 B read + 2 B written per element) disappears, the MFMA-bound convolution pays ~13 VALU cycles per staged element.
+  // Round 3, on the spill-free K loop (profiles/r3/gnin_ab.txt, same box): on for the layers with ONE 128-channel output tile
+  // (+1.7 % HR tiles/s: GroupNorm share 10.1 -> 5.9 %, conv3x3 1304 -> 1249 TFLOP/s), off above (the transform is repeated per
+  // n-tile: two tiles +1.3 %, all layers -0.7 %).  SRGD_GN_FUSION=0 switches it off, SRGD_GN_FUSION_NTILES=n moves the limit.
   bool fp8 = false;           // SRGD_PRECISION_FP8: 3x3 convolutions on the block-scaled MX-fp8 matrix cores, the rest as bf16
   bool w8 = false;            // SRGD_PRECISION_BF16_W8: conv weights rounded through fp8 e4m3 (per-output-channel scale)
-  bool no_gn_fusion = true;
-  int gn_fusion_max_ntiles = 1 << 30;   // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile)
+  bool no_gn_fusion = false;
+  int gn_fusion_max_ntiles = 1;         // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile)
   bool no_final_fusion = false;   // SRGD_FINAL_FUSION=0: the last ResnetBlock stores its output and final_step applies the 1x1 (A/B switch)
   bool no_la256 = false;      // SRGD_LA256=0: the C = 256 LinearAttention sites run the unfused chain (A/B switch)
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)

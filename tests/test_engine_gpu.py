@@ -40,9 +40,10 @@ FP8_CONFIG5_GATE_DB, FP8_MIXED_CONFIG5_GATE_DB = 34.0, 50.3          # measured 
 FP8_CONFIG2_GATE_DB, FP8_MIXED_CONFIG2_GATE_DB = 25.4, 37.3          # measured 28.43 / 40.31 dB (configs[1] geometry, 2 steps from noise; bf16: 43.5)
 
 
-def build_sampler(dim, steps=50, weight_seed=0):
-    """The product objects, built exactly as inference.py does (get_model -> .module.eval().to(cuda))."""
-    key = (dim, weight_seed)
+def build_sampler(dim, steps=50, weight_seed=0, fresh=False):
+    """The product objects, built exactly as inference.py does (get_model -> .module.eval().to(cuda)).  ``fresh``: a sampler
+    (and engine) of the caller's own instead of the cached one - ranks-as-threads tests need one per thread."""
+    key = (dim, weight_seed) if not fresh else (dim, weight_seed, object())
     if key not in _MODELS:
         import logging
         from srgd_amd.config import load_config
@@ -53,7 +54,7 @@ def build_sampler(dim, steps=50, weight_seed=0):
         ema = get_model(conf, logging.getLogger("test"))
         ema.module.load_state_dict(synth_state_dict(_schema(dim), seed=weight_seed), strict=True)
         _MODELS[key] = ema.module.eval().to(torch.device("cuda"))
-    return _MODELS[key]
+    return _MODELS.pop(key) if fresh else _MODELS[key]
 
 
 def test_library_is_loaded_in_process():
@@ -430,8 +431,8 @@ def test_groupnorm_fused_into_conv_staging_matches_separate_pass():
 _EDM_MODELS = {}
 
 
-def build_edm_sampler(dim, steps=32, weight_seed=0):
-    key = (dim, weight_seed)
+def build_edm_sampler(dim, steps=32, weight_seed=0, fresh=False):
+    key = (dim, weight_seed) if not fresh else (dim, weight_seed, object())
     if key not in _EDM_MODELS:
         import logging
         from srgd_amd.config import load_config
@@ -445,7 +446,7 @@ def build_edm_sampler(dim, steps=32, weight_seed=0):
         assert list(ema.module.state_dict().keys()) == list(schema.keys())
         ema.module.load_state_dict(synth_state_dict(schema, seed=weight_seed), strict=True)
         _EDM_MODELS[key] = ema.module.eval().to(torch.device("cuda"))
-    return _EDM_MODELS[key]
+    return _EDM_MODELS.pop(key) if fresh else _EDM_MODELS[key]
 
 
 @pytest.mark.parametrize("case", C.EDM_CASES, ids=lambda c: c["name"])

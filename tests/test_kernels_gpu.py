@@ -496,6 +496,36 @@ def test_quant_mxfp8_is_bit_exact_with_the_format_emulation():
     assert torch.equal(q.cpu(), wq)
 
 
+def test_quant_mxfp8_keeps_a_nan_visible():
+    # a NaN activation must not become a finite e4m3 value (the convolution consumes the fp8 twin, so the blow-up would
+    # vanish): it is stored as the e4m3 NaN byte (0x7f / 0xff), its block's scale comes from the finite elements, and an
+    # infinity saturates to +-448 like any out-of-range value.
+    from oracle import mxfp8 as MX
+    lib = L().lib()
+    g = torch.Generator().manual_seed(32)
+    npix, C = 64, 64
+    x = torch.randn(npix, C, generator=g).to(torch.bfloat16)
+    x[3, 5] = float("nan")
+    x[9, 40] = float("inf")
+    d = x.to(DEV)
+    q = torch.empty(npix, C, dtype=torch.uint8, device=DEV)
+    s = torch.empty(npix, C // 32, dtype=torch.uint8, device=DEV)
+    L().check(lib.srgd_k_quant_mxfp8(ptr(d), ptr(q), ptr(s), npix, C, stream()), "quant")
+    torch.cuda.synchronize()
+    q, s = q.cpu(), s.cpu()
+    assert (int(q[3, 5]) & 0x7f) == 0x7f
+    clean = x.float().clone()
+    clean[3, 5] = 0.0
+    wq, ws, _ = MX.quantize(clean)
+    keep = torch.ones(npix, C, dtype=torch.bool)
+    keep[3, 5] = False
+    keep[9, 32:] = False                                   # the infinity's block: its scale byte saturates, checked below
+    assert torch.equal(s[:, 0], ws[:, 0]) and torch.equal(s[torch.arange(npix) != 9, 1], ws[torch.arange(npix) != 9, 1])
+    assert torch.equal(q[keep], wq[keep])
+    assert q[9, 40] == 0x7e                                # +448, the largest finite e4m3 value
+    assert torch.isfinite(q.view(torch.float8_e4m3fn).float()[keep]).all()
+
+
 def _mx_conv_reference(x0, x1, w, b):
     """The fp8 convolution's arithmetic on the CPU: MX-quantised activations (per pixel, per 32 channels) and weights (per
     output channel, tap, 32 input channels), exact products, fp32 sums; each source quantised on its own as the engine does."""

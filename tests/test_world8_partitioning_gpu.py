@@ -38,7 +38,7 @@ def _sample_items(sampler, items):
 def _images_worker(comm):
     from srgd_amd.parallel import sample_images_sharded
     from tests.test_engine_gpu import build_sampler
-    sampler = build_sampler(16)
+    sampler = build_sampler(16, fresh=True)        # one sampler + engine per rank (thread)
     groups = []
 
     def sample_group(items):
@@ -95,7 +95,7 @@ def _run_canvas(sampler, name, edm):
 def _canvas_worker(comm, name, edm):
     from srgd_amd.parallel import shard_canvas
     from tests.test_engine_gpu import build_edm_sampler, build_sampler
-    sampler = shard_canvas(build_edm_sampler(16) if edm else build_sampler(16), comm=comm)
+    sampler = shard_canvas(build_edm_sampler(16, fresh=True) if edm else build_sampler(16, fresh=True), comm=comm)
     res = _run_canvas(sampler, name, edm)
     res["exchanges"] = sampler.canvas_group.exchanges
     res["buffers"] = {k: (tuple(v[0].shape), tuple(v[1].shape)) for k, v in sampler.canvas_group._bufs.items()}

@@ -1,7 +1,6 @@
-# Round-2 profile collection on the GPU box (gpurun): kernel-trace stats and separate PMC passes, as MI355X_MICROARCH.md prescribes
+# Profile collection on the GPU box (gpurun): kernel-trace stats and separate PMC passes, as MI355X_MICROARCH.md prescribes
 # (FETCH_SIZE and WRITE_SIZE in passes of their own, never combined with sys/hip tracing).
-set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2prof; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r3}; O=$R/gpurun_out/${TAG}prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for MODE in bf16 fp8 fp8_mixed; do
   EXTRA=""; [ $MODE != bf16 ] && EXTRA="--precision $MODE --ddpm_steps 100 --class_cond_scale 2.0"
@@ -19,4 +18,8 @@ for MODE in bf16 fp8 fp8_mixed; do
   python3 $R/tools/pmc_sq.py $(find $O/ps_$MODE -name "*.db" | head -1) $O/pmc_sq_$MODE.json > $O/pmc_sq_$MODE.txt
   rm -rf $O/ps_$MODE
 done
+SRGD_GRAPHS=0 rocprofv3 --kernel-trace --stats -d $O/kt_nograph -o k -- python3 $R/bench.py --steps 5 --warmup 0 --no_cpu_baseline --no_profile > $O/kt_nograph.log 2>&1
+python3 $R/tools/rocprof_db_stats.py $(find $O/kt_nograph -name "*.db" | head -1) $O/bf16_nograph_kernel_stats.csv > $O/bf16_nograph_kernel_stats.txt
+rm -rf $O/kt_nograph
+grep -h copyBuffer $O/bf16_kernel_stats.csv $O/bf16_nograph_kernel_stats.csv
 cd $R; head -22 $O/bf16_kernel_stats.csv; head -16 $O/fp8_kernel_stats.csv; head -16 $O/fp8_mixed_kernel_stats.csv; cat $O/pmc_traffic_bf16.txt $O/pmc_traffic_fp8.txt; cat $O/pmc_sq_bf16.txt $O/pmc_sq_fp8.txt | head -60

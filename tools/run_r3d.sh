@@ -1,20 +1,19 @@
-# round 3, GPU job c: full GPU suite, MX-fp8 conv A/B (tied inline-asm MFMAs vs the round-2 kernel), GroupNorm-in-staging (GNIN) A/B on the
-# spill-free K loops, workgroup-stagger A/B, kernel-trace of the default bench
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3c; mkdir -p $O; cd $R
-(time timeout -k 10 1000 python -m pytest tests -m gpu -x -q --durations=12) > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
-cp gpurun_out/parity_report.jsonl $O/ 2>/dev/null
-tail -4 $O/pytest_gpu.log
-grep -q "rc=0" $O/pytest_gpu.log || exit 1
-timeout -k 10 200 python tools/bench_conv_fp8.py --batch 125 --iters 10 --out $O/conv_fp8_new.json > $O/conv_fp8_new.txt 2>&1 &&
+# round 3, GPU job d: world-8 thread tests + MX-fp8 kernel tests first, then the A/B runs of job c (the suite itself passed 156/157 there)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3d; mkdir -p $O; cd $R
+(time timeout -k 10 900 python -m pytest tests/test_world8_partitioning_gpu.py tests/test_kernels_gpu.py -m gpu -x -q --durations=8) > $O/pytest_sel.log 2>&1; echo "rc=$?" >> $O/pytest_sel.log
+tail -4 $O/pytest_sel.log
+grep -q "rc=0" $O/pytest_sel.log || exit 1
+timeout -k 10 200 python tools/bench_conv_fp8.py --batch 125 --iters 10 --out $O/conv_fp8_pipe.json > $O/conv_fp8_pipe.txt 2>&1 &&
+SRGD_HIP_LIB=$R/srgd_amd/variants/libsrgd_hip_r3tied.so timeout -k 10 200 python tools/bench_conv_fp8.py --batch 125 --iters 10 --out $O/conv_fp8_tied.json > $O/conv_fp8_tied.txt 2>&1 &&
 SRGD_HIP_LIB=$R/srgd_amd/variants/libsrgd_hip_r3base.so timeout -k 10 200 python tools/bench_conv_fp8.py --batch 125 --iters 10 --out $O/conv_fp8_base.json > $O/conv_fp8_base.txt 2>&1 &&
-SRGD_CONV3_STAGGER=0 timeout -k 10 200 python tools/bench_conv_fp8.py --batch 125 --iters 10 --out $O/conv_fp8_new_nostagger.json > $O/conv_fp8_new_nostagger.txt 2>&1
+SRGD_CONV3_STAGGER=0 timeout -k 10 200 python tools/bench_conv_fp8.py --batch 125 --iters 10 --out $O/conv_fp8_pipe_nostagger.json > $O/conv_fp8_pipe_nostagger.txt 2>&1
 python - $O <<'PY'
 import json,sys
 O=sys.argv[1]
-L=lambda n:{r['shape']:r for r in json.load(open(f"{O}/{n}.json"))} if True else None
+L=lambda n:{r['shape']:r for r in json.load(open(f"{O}/{n}.json"))}
 try:
-    a,b,c=L('conv_fp8_base'),L('conv_fp8_new'),L('conv_fp8_new_nostagger')
-    for k in b: print(f"{k:28s} base {a[k]['mxfp8_tflops']:7.1f}  new {b[k]['mxfp8_tflops']:7.1f}  new/nostagger {c[k]['mxfp8_tflops']:7.1f}  bf16 {b[k]['bf16_tflops']:7.1f}")
+    a,t,b,c=L('conv_fp8_base'),L('conv_fp8_tied'),L('conv_fp8_pipe'),L('conv_fp8_pipe_nostagger')
+    for k in b: print(f"{k:28s} r2 {a[k]['mxfp8_tflops']:7.1f}  tied {t[k]['mxfp8_tflops']:7.1f}  pipe {b[k]['mxfp8_tflops']:7.1f}  pipe/nostagger {c[k]['mxfp8_tflops']:7.1f}  bf16 {b[k]['bf16_tflops']:7.1f} nostag {c[k]['bf16_tflops']:7.1f}")
 except Exception as e: print('fp8 table ERR', e)
 PY
 B="timeout -k 10 300 python bench.py --steps 5 --warmup 5 --no_cpu_baseline"
