@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 TFLOP_PER_HR_TILE = 813.6          # BASELINE.md section 3 (1,025 tile-forwards x 793.8 GFLOP)
 TILE_FORWARDS_PER_HR_TILE = 1025
-PMC_TRAFFIC_FILE = "r2_pmc_traffic.json"     # newest committed PMC summary (tools/pmc_traffic.py)
+PMC_TRAFFIC_FILE = "r3_pmc_traffic.json"     # newest committed PMC summary (tools/pmc_traffic.py)
 # MI355X_MICROARCH.md: dense MFMA peaks of the dominant kernel's instruction (fp8 = block-scaled MX e4m3, 2x the bf16 rate)
 PEAK_TFLOPS = {"conv3x3_bf16": 2500.0, "conv3x3_mxfp8": 5000.0, "conv_igemm:bf16": 2500.0, "conv_igemm:fp32": 157.3}
 KERNEL_OF = {"conv3x3_bf16": "conv3x3_bf16_kernel", "conv3x3_mxfp8": "conv3x3_mxfp8_kernel", "conv_igemm": "conv_igemm_kernel"}
@@ -411,7 +411,7 @@ def main():
                                 "avg_launch_ms": conv_ms / max(n_launch, 1),
                                 "algorithmic_gflop_per_launch": fl / max(n_launch, 1) / 1e9,
                                 "family_time_share": conv_ms / sum(prof["ms"].values())}
-            conv_fams = ("conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "conv3x3_mxfp8")
+            conv_fams = ("conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "conv3x3_mxfp8", "conv1x1_mxfp8")
             all_conv_ms = sum(prof["ms"].get(k, 0.0) for k in conv_fams)
             line["conv_all_tflops"] = sum(prof["flops"].get(k, 0.0) for k in conv_fams) / (all_conv_ms * 1e-3) / 1e12
             tot = sum(prof["ms"].values())
@@ -420,7 +420,7 @@ def main():
             # SURVEY 8(d) secondary check: the HBM-bound kernel families, algorithmic bytes (every operand read once, every
             # result written once; summed by the engine per launch) / HIP-event time, against the 8 TB/s HBM3E peak
             hbm = {}
-            for k in ("groupnorm_silu", "rmsnorm", "linear_attention", "conv1x1_bf16", "final_conv_ddpm_step", "quantize_mxfp8"):
+            for k in ("groupnorm_silu", "rmsnorm", "linear_attention", "conv1x1_bf16", "conv1x1_mxfp8", "final_conv_ddpm_step", "quantize_mxfp8"):
                 if prof["ms"].get(k, 0.0) > 0 and prof["bytes"].get(k, 0.0) > 0:
                     gbps = prof["bytes"][k] / (prof["ms"][k] * 1e-3) / 1e9
                     hbm[k] = {"achieved": round(gbps, 1), "unit": "GB/s", "peak": 8000.0, "frac": round(gbps / 8000.0, 4),

@@ -157,11 +157,10 @@ enum KClass {
   KC_COND,         // conditioning MLPs
   KC_CONVQ,        // conv3x3_mxfp8_kernel: block-scaled MX-fp8 3x3 convolution (fp8 mode)
   KC_QUANT,        // bf16 -> MX-fp8 quantisation passes (fp8 mode)
+  KC_CONV1Q,       // conv1x1_mxfp8_kernel: pointwise layers on the MX matrix cores (fp8 mode)
   KC_COUNT
 };
 
-// One-time per-device setup guard (kernel attributes such as the dynamic-LDS limit are per device): returns true the first
-// time it is called for `flags` on the current HIP device.  Engines are one-per-device and single-threaded per device.
 // One-time per-device setup of a kernel family (hipFuncSetAttribute for > 64 KiB of dynamic LDS), safe when several host threads
 // drive engines of their own: `if (DeviceSetup once(flags); once.need) { ...setup... }` - the first caller on a device runs the
 // block under a process-wide mutex and the flag is published (release) only when the block is left, so no other thread can

@@ -13,7 +13,7 @@
 //   * the accumulators are transposed through LDS and leave as 16-byte channel-contiguous stores; the epilogue
 //     variants (residual add, GroupNorm tail, pixel-shuffle scatter + SiLU) read/write 16 B per lane as well;
 //   * workgroup ids are renumbered so that the n-tiles of one m-tile run back to back on one XCD (A re-read from L2).
-#include "kernels.hpp"
+#include "conv1x1_epilogue.hpp"
 
 namespace srgd {
 namespace {
@@ -23,8 +23,8 @@ constexpr int A1_BYTES = BM1 * KC1 * 2;            // 16 KiB
 constexpr int B1_BYTES = BN1 * KC1 * 2;            // 8 KiB
 constexpr int STAGE1 = A1_BYTES + B1_BYTES;        // 24 KiB
 constexpr int RING1 = 3;
-constexpr int EROW1 = BN1 * 2 + 16;                // transposed output row (272 B: conflict-free 2-byte column writes)
-constexpr int LDS1_BYTES = RING1 * STAGE1;         // 73,728 >= 256 * 272 = 69,632 (epilogue staging)
+constexpr int LDS1_BYTES = RING1 * STAGE1;         // 73,728 >= EPI_LDS_BYTES = 69,632 (epilogue staging)
+static_assert(LDS1_BYTES >= EPI_LDS_BYTES && BM1 == EPI_BM && BN1 == EPI_BN && NT1 == EPI_NT, "conv1x1_epilogue.hpp tile shape");
 
 typedef __attribute__((address_space(3))) void* lds_ptr1;
 __device__ __forceinline__ void dma16_1(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset) {
@@ -36,8 +36,6 @@ __device__ __forceinline__ void dma16_1(__amdgpu_buffer_rsrc_t rsrc, char* lds_w
     __builtin_amdgcn_s_barrier();        \
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
-
-enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GNTAIL = 2, EPI_PS_SILU = 3, EPI_GNTAIL_FINAL = 4 };
 
 struct Conv1Args {
   const bf16* in0; const bf16* in1; int C0, C1;
@@ -171,99 +169,8 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
     BARRIER1();
   }
 
-  // ---- epilogue: transpose through LDS, then 16-byte channel-contiguous traffic only
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int cl = wn * 64 + ni * 16 + r16;
-    const float bias = p.bias ? p.bias[nt * BN1 + cl] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const f32x4 av = mi == 0 ? (ni == 0 ? c00 : ni == 1 ? c01 : ni == 2 ? c02 : c03)
-                     : mi == 1 ? (ni == 0 ? c10 : ni == 1 ? c11 : ni == 2 ? c12 : c13)
-                     : mi == 2 ? (ni == 0 ? c20 : ni == 1 ? c21 : ni == 2 ? c22 : c23)
-                               : (ni == 0 ? c30 : ni == 1 ? c31 : ni == 2 ? c32 : c33);
-      char* trow = smem + (wm * 64 + mi * 16 + q16 * 4) * EROW1 + cl * 2;      // C layout: row = (lane >> 4) * 4 + reg
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        float v = av[reg] + bias;
-        if (EPI == EPI_PS_SILU) v = silu<false>(v);
-        // staged in bf16 (LDS budget): with a residual / GroupNorm-tail add the conv term is rounded once here and the
-        // sum once more at the store
-        *reinterpret_cast<bf16*>(trow + reg * EROW1) = (bf16)v;
-      }
-    }
-  }
-  __syncthreads();
-  const int col0 = nt * BN1;
-  size_t obase;                                      // element offset of (tile pixel 0, channel col0) for plain layouts
-  int CoutPS = 0, ps_ij = 0, ps_c0 = 0;
-  if (EPI == EPI_PS_SILU) {
-    CoutPS = p.Cout >> 2;
-    ps_ij = col0 / CoutPS;
-    ps_c0 = col0 - ps_ij * CoutPS;
-  }
-  obase = (size_t)m0 * p.Cout + col0;
-  // EPI_GNTAIL_FINAL: this lane's 8 channels (c16 = tid & 15 in every iteration) of the three output-convolution rows (the
-  // 16 lanes of a DPP row share a pixel; fp32 sums in a different order than out_conv3_coop's: equal to rounding)
-  float fw0[8], fw1[8], fw2[8];
-  if (EPI == EPI_GNTAIL_FINAL) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      fw0[e] = p.fin_w[(tid & 15) * 8 + e];
-      fw1[e] = p.fin_w[BN1 + (tid & 15) * 8 + e];
-      fw2[e] = p.fin_w[2 * BN1 + (tid & 15) * 8 + e];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < (BM1 * 16) / NT1; ++i) {
-    const int q = tid + NT1 * i;
-    const int pix = q >> 4, c16 = q & 15;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + pix * EROW1 + c16 * 16);
-    if (EPI == EPI_PS_SILU) {
-      const int op = p0 + pix;
-      const int oy = op / p.Wout, ox = op - oy * p.Wout;
-      const size_t o = ((size_t)(b * 2 * p.Hout + 2 * oy + (ps_ij >> 1)) * (2 * p.Wout) + 2 * ox + (ps_ij & 1)) * CoutPS +
-                       ps_c0 + c16 * 8;
-      *reinterpret_cast<bf16x8*>(p.out + o) = v;
-      if (p.oq) mx_store_twin(v, p.oq, p.os, o, tid & 3);
-    } else {
-      const size_t o = obase + (size_t)pix * p.Cout + c16 * 8;
-      if (EPI == EPI_RESIDUAL) {
-        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.aux + o);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rr[e]);
-      } else if (EPI == EPI_GNTAIL || EPI == EPI_GNTAIL_FINAL) {
-        const bf16x8 hh = *reinterpret_cast<const bf16x8*>(p.aux + o);
-        const float* ga = p.gn_a + (size_t)b * p.Cout + col0 + c16 * 8;
-        const float* gb = p.gn_b + (size_t)b * p.Cout + col0 + c16 * 8;
-        const f32x4 a_lo = *reinterpret_cast<const f32x4*>(ga), a_hi = *reinterpret_cast<const f32x4*>(ga + 4);
-        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(gb), b_hi = *reinterpret_cast<const f32x4*>(gb + 4);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float ca = e < 4 ? a_lo[e & 3] : a_hi[e & 3], cb = e < 4 ? b_lo[e & 3] : b_hi[e & 3];
-          v[e] = (bf16)(silu<false>(ca * (float)hh[e] + cb) + (float)v[e]);
-        }
-      }
-      if (EPI == EPI_GNTAIL_FINAL) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xv = (float)v[e];
-          s0 += xv * fw0[e];
-          s1 += xv * fw1[e];
-          s2 += xv * fw2[e];
-        }
-        s0 = row16_sum(s0);
-        s1 = row16_sum(s1);
-        s2 = row16_sum(s2);
-        if (c16 == 0)
-          *reinterpret_cast<f32x4*>(p.eps4 + ((size_t)m0 + pix) * 4) = f32x4{s0 + p.fin_b[0], s1 + p.fin_b[1], s2 + p.fin_b[2], 0.f};
-        continue;
-      }
-      *reinterpret_cast<bf16x8*>(p.out + o) = v;
-      if (p.oq) mx_store_twin(v, p.oq, p.os, o, tid & 3);
-    }
-  }
+  // ---- epilogue (conv1x1_epilogue.hpp): transpose through LDS, then 16-byte channel-contiguous traffic only
+  conv1x1_epilogue<EPI>(p, smem, tid, nt, m0, b, p0, c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33);
 }
 
 }  // namespace

@@ -1,0 +1,127 @@
+// Epilogue shared by the pointwise streaming GEMMs (conv1x1_bf16.hip and conv1x1_mxfp8.hip): both end with the same 16 x 16
+// accumulator blocks per wave (8 waves = 4 along M x 2 along N, wave tile 64 x 64, D layout row = 4 * (lane >> 4) + reg,
+// column = lane & 15) of a 256-pixel x 128-channel tile, so the output side - + bias, LDS transpose, 16-byte channel-contiguous
+// stores, residual add, the ResnetBlock's GroupNorm2 + SiLU tail (reference model.py:250-259, :285), PixelShuffle scatter + SiLU
+// (:70-98), the fused 1x1 output convolution (:776-777), the optional MX-fp8 twin - is written once.
+#pragma once
+#include "kernels.hpp"
+
+namespace srgd {
+namespace {
+
+enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GNTAIL = 2, EPI_PS_SILU = 3, EPI_GNTAIL_FINAL = 4 };
+constexpr int EPI_BM = 256, EPI_BN = 128, EPI_NT = 512;
+constexpr int EPI_ROW = EPI_BN * 2 + 16;           // transposed output row (272 B: conflict-free 2-byte column writes)
+constexpr int EPI_LDS_BYTES = EPI_BM * EPI_ROW;    // 69,632 B of staging (every caller's operand ring is larger)
+
+// `Args` supplies: Hout, Wout, Cout, bias, out, aux, gn_a, gn_b, oq, os, eps4, fin_w, fin_b (Conv1Args / Conv1QArgs).
+// m0: first output pixel of the tile (global), b: its image, p0: pixel offset inside the image, nt: 128-channel tile index.
+// Must be entered by all 512 threads AFTER a barrier that retired every read of the operand buffers in `smem`.
+template <int EPI, class Args>
+__device__ __forceinline__ void conv1x1_epilogue(const Args& p, char* smem, const int tid, const int nt, const long m0, const int b,
+                                                 const int p0, const f32x4& c00, const f32x4& c01, const f32x4& c02, const f32x4& c03,
+                                                 const f32x4& c10, const f32x4& c11, const f32x4& c12, const f32x4& c13,
+                                                 const f32x4& c20, const f32x4& c21, const f32x4& c22, const f32x4& c23,
+                                                 const f32x4& c30, const f32x4& c31, const f32x4& c32, const f32x4& c33) {
+  constexpr int BM1 = EPI_BM, BN1 = EPI_BN, NT1 = EPI_NT, EROW1 = EPI_ROW;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, q16 = lane >> 4;
+  // ---- epilogue: transpose through LDS, then 16-byte channel-contiguous traffic only
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int cl = wn * 64 + ni * 16 + r16;
+    const float bias = p.bias ? p.bias[nt * BN1 + cl] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const f32x4 av = mi == 0 ? (ni == 0 ? c00 : ni == 1 ? c01 : ni == 2 ? c02 : c03)
+                     : mi == 1 ? (ni == 0 ? c10 : ni == 1 ? c11 : ni == 2 ? c12 : c13)
+                     : mi == 2 ? (ni == 0 ? c20 : ni == 1 ? c21 : ni == 2 ? c22 : c23)
+                               : (ni == 0 ? c30 : ni == 1 ? c31 : ni == 2 ? c32 : c33);
+      char* trow = smem + (wm * 64 + mi * 16 + q16 * 4) * EROW1 + cl * 2;      // C layout: row = (lane >> 4) * 4 + reg
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        float v = av[reg] + bias;
+        if (EPI == EPI_PS_SILU) v = silu<false>(v);
+        // staged in bf16 (LDS budget): with a residual / GroupNorm-tail add the conv term is rounded once here and the
+        // sum once more at the store
+        *reinterpret_cast<bf16*>(trow + reg * EROW1) = (bf16)v;
+      }
+    }
+  }
+  __syncthreads();
+  const int col0 = nt * BN1;
+  size_t obase;                                      // element offset of (tile pixel 0, channel col0) for plain layouts
+  int CoutPS = 0, ps_ij = 0, ps_c0 = 0;
+  if (EPI == EPI_PS_SILU) {
+    CoutPS = p.Cout >> 2;
+    ps_ij = col0 / CoutPS;
+    ps_c0 = col0 - ps_ij * CoutPS;
+  }
+  obase = (size_t)m0 * p.Cout + col0;
+  // EPI_GNTAIL_FINAL: this lane's 8 channels (c16 = tid & 15 in every iteration) of the three output-convolution rows (the
+  // 16 lanes of a DPP row share a pixel; fp32 sums in a different order than out_conv3_coop's: equal to rounding)
+  float fw0[8], fw1[8], fw2[8];
+  if (EPI == EPI_GNTAIL_FINAL) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      fw0[e] = p.fin_w[(tid & 15) * 8 + e];
+      fw1[e] = p.fin_w[BN1 + (tid & 15) * 8 + e];
+      fw2[e] = p.fin_w[2 * BN1 + (tid & 15) * 8 + e];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < (BM1 * 16) / NT1; ++i) {
+    const int q = tid + NT1 * i;
+    const int pix = q >> 4, c16 = q & 15;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + pix * EROW1 + c16 * 16);
+    if (EPI == EPI_PS_SILU) {
+      const int op = p0 + pix;
+      const int oy = op / p.Wout, ox = op - oy * p.Wout;
+      const size_t o = ((size_t)(b * 2 * p.Hout + 2 * oy + (ps_ij >> 1)) * (2 * p.Wout) + 2 * ox + (ps_ij & 1)) * CoutPS +
+                       ps_c0 + c16 * 8;
+      *reinterpret_cast<bf16x8*>(p.out + o) = v;
+      if (p.oq) mx_store_twin(v, p.oq, p.os, o, tid & 3);
+    } else {
+      const size_t o = obase + (size_t)pix * p.Cout + c16 * 8;
+      if (EPI == EPI_RESIDUAL) {
+        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.aux + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rr[e]);
+      } else if (EPI == EPI_GNTAIL || EPI == EPI_GNTAIL_FINAL) {
+        const bf16x8 hh = *reinterpret_cast<const bf16x8*>(p.aux + o);
+        const float* ga = p.gn_a + (size_t)b * p.Cout + col0 + c16 * 8;
+        const float* gb = p.gn_b + (size_t)b * p.Cout + col0 + c16 * 8;
+        const f32x4 a_lo = *reinterpret_cast<const f32x4*>(ga), a_hi = *reinterpret_cast<const f32x4*>(ga + 4);
+        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(gb), b_hi = *reinterpret_cast<const f32x4*>(gb + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float ca = e < 4 ? a_lo[e & 3] : a_hi[e & 3], cb = e < 4 ? b_lo[e & 3] : b_hi[e & 3];
+          v[e] = (bf16)(silu<false>(ca * (float)hh[e] + cb) + (float)v[e]);
+        }
+      }
+      if (EPI == EPI_GNTAIL_FINAL) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xv = (float)v[e];
+          s0 += xv * fw0[e];
+          s1 += xv * fw1[e];
+          s2 += xv * fw2[e];
+        }
+        s0 = row16_sum(s0);
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if (c16 == 0)
+          *reinterpret_cast<f32x4*>(p.eps4 + ((size_t)m0 + pix) * 4) = f32x4{s0 + p.fin_b[0], s1 + p.fin_b[1], s2 + p.fin_b[2], 0.f};
+        continue;
+      }
+      *reinterpret_cast<bf16x8*>(p.out + o) = v;
+      if (p.oq) mx_store_twin(v, p.oq, p.os, o, tid & 3);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace srgd

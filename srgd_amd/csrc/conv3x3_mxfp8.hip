@@ -311,7 +311,11 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
       const int s = cc * 9 + tap;
       issue_b(min(s + 1, S - 1), (s + 1) % QRING);   // (the last step re-fetches its own unit into the idle slot)
       compute(tap, s);
+#ifdef SRGD_MXFP8_DIAG_LATE_WAIT           // timing-only diagnostic (wrong results): the step does not wait for its weight DMA -
+      QWAIT_VM(10);                        // two more steps' worth may stay in flight - to price the DMA latency on the critical path
+#else
       QWAIT_VM(0);
+#endif
       QBARRIER();
     }
     if (cc + 1 < CC) {

@@ -113,6 +113,7 @@ struct ConvW {
   void* w3 = nullptr;         // conv3x3_bf16 fast-path packing (bf16 mode, eligible channel counts)
   void* w1 = nullptr;         // conv1x1_bf16 packing (bf16 mode: 1x1 / pixel-shuffle / space-to-depth layers)
   void* wq = nullptr;         // conv3x3_mxfp8 packing (fp8 mode: e4m3 weights + E8M0 block scales)
+  void* wq1 = nullptr;        // conv1x1_mxfp8 packing (fp8 mode: the pointwise layers whose inputs have MX-fp8 twins)
   float* bias = nullptr;
 };
 struct Lin {
@@ -210,7 +211,7 @@ struct ProfRec { int kc; hipEvent_t a, b; };
 
 const char* kFamilyNames[KC_COUNT] = {"conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "init_conv7x7", "groupnorm_silu", "rmsnorm", "linear_attention",
                                       "full_attention", "final_conv_ddpm_step", "canvas_rng", "conditioning", "conv3x3_mxfp8",
-                                      "quantize_mxfp8"};
+                                      "quantize_mxfp8", "conv1x1_mxfp8"};
 
 }  // namespace
 }  // namespace srgd
@@ -255,6 +256,7 @@ struct srgd_engine {
   bool no_final_fusion = false;   // SRGD_FINAL_FUSION=0: the last ResnetBlock stores its output and final_step applies the 1x1 (A/B switch)
   bool no_la256 = false;      // SRGD_LA256=0: the C = 256 LinearAttention sites run the unfused chain (A/B switch)
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
+  bool no_mx1x1 = false;      // SRGD_MX1X1=0: fp8 modes keep the pointwise layers on conv1x1_bf16 (A/B switch)
   unsigned fp8_bf16_zones = 0;   // SRGD_FP8_BF16_ZONES (bit mask over Ctx::zone): zones whose 3x3 convs stay bf16 in fp8 mode (study knob)
   bool no_twin_fusion = false;   // SRGD_Q_FUSED=0: fp8 mode quantises every conv input in a separate pass (A/B + bit-equality test)
 
@@ -472,6 +474,11 @@ int pack_conv(srgd_engine* e, ConvW& c) {
     std::vector<unsigned short> p1;
     pack_conv1x1_bf16(reinterpret_cast<const float*>(f32p.data()), c.KS * c.KS, c.Cin, c.Cout, p1, f32_to_bf16_host);
     SRGD_TRY(upload(e, p1.data(), p1.size() * 2, &c.w1));
+    if (e->fp8 && !e->no_mx1x1 && c.Cin % 128 == 0) {
+      std::vector<unsigned char> pq1;
+      pack_conv1x1_mxfp8(reinterpret_cast<const float*>(f32p.data()), c.KS * c.KS, c.Cin, c.Cout, pq1);
+      SRGD_TRY(upload(e, pq1.data(), pq1.size(), &c.wq1));
+    }
   }
   return 0;
 }
@@ -572,9 +579,15 @@ int twin_alloc(srgd_engine* e, size_t npix, int C, QTensor* t) {
 }
 void twin_register(srgd_engine* e, const void* bf16_buf, const QTensor& t) { e->pool.twins[bf16_buf] = {t.q, t.s}; }
 
+int q_twin(Ctx& x, const void* src, int C, int hw, QTensor* t);
+
+// mx_in (fp8 modes): the caller states that the inputs of this pointwise layer are tensors a 3x3 convolution of an fp8 zone
+// reads as well, i.e. tensors that have (or, with SRGD_Q_FUSED=0, get on first use) an MX-fp8 twin - the layer may then run on
+// the MX matrix cores (conv1x1_mxfp8).  The routing depends on this static statement only, never on whether a twin happens to
+// exist yet, so the fused-twin and the separate-quantisation builds take the same path (bit-identical, tested).
 int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, int C1, int Hin, int Win, void* out,
              const void* residual, bool stats, bool gn_in = false, const void* gn_res_src = nullptr, bool want_twin = false,
-             float* eps4 = nullptr) {
+             float* eps4 = nullptr, bool mx_in = false) {
   srgd_engine* e = x.e;
   ConvArgs a;
   a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.ps0 = C0; a.ps1 = C1;
@@ -595,14 +608,23 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
     if (conv1x1_bf16_eligible(a)) x.eps4_done = true;
     else a.eps4 = nullptr;
   }
-  const int fam = fast ? KC_CONV3 : fast1 ? KC_CONV1 : KC_CONV;
+  // fp8 modes: a pointwise layer of an fp8 zone whose inputs are twinned tensors runs on the MX matrix cores (conv1x1_mxfp8)
+  const bool fastq1 = fast1 && mx_in && e->fp8 && c.wq1 && !e->no_mx1x1 && !((e->fp8_bf16_zones >> x.zone) & 1u) &&
+                      conv1x1_mxfp8_eligible(a);
+  QTensor mq0, mq1;
+  if (fastq1) {                                   // (a twin that does not exist yet is quantised here, as for the 3x3 convolutions)
+    SRGD_TRY(q_twin(x, in0, C0, Hin * Win, &mq0));
+    if (in1) SRGD_TRY(q_twin(x, in1, C1, Hin * Win, &mq1));
+  }
+  const int fam = fast ? KC_CONV3 : fastq1 ? KC_CONV1Q : fast1 ? KC_CONV1 : KC_CONV;
   Prof p(e, fam, x.st);
   if (e->prof_on) {
     e->fam_flops[fam] += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
     // algorithmic bytes: every input pixel row once, the weights once, the result once (+ the in-place GroupNorm2 tail operand,
     // the residual, the MX-fp8 twin); with the fused output convolution 16 B of eps per pixel replace the result row
     const double npi = (double)x.nb * Hin * Win, npo = (double)x.nb * a.Hout * a.Wout;
-    double by = npi * c.Cin * e->es + (double)c.KS * c.KS * c.Cin * c.Cout * e->es;
+    const double in_es = fastq1 ? 1.0 + 1.0 / 32 : (double)e->es;       // MX route: 1 B per element + 1 scale byte per 32
+    double by = npi * c.Cin * in_es + (double)c.KS * c.KS * c.Cin * c.Cout * in_es;
     by += a.eps4 ? npo * 16.0 : npo * c.Cout * e->es;
     if (gn_res_src) by += npo * c.Cout * e->es;
     if (residual) by += npo * c.Cout * e->es;
@@ -617,7 +639,8 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
       SRGD_TRY(twin_alloc(e, (size_t)x.nb * a.Hout * a.Wout * (ps ? 4 : 1), Cq, &tw));
       a.out_q = tw.q; a.out_s = tw.s;
     }
-    SRGD_TRY(conv1x1_bf16(a, c.w1, x.st));
+    if (fastq1) SRGD_TRY(conv1x1_mxfp8(a, mq0.q, mq0.s, mq1.q, mq1.s, c.wq1, x.st));
+    else SRGD_TRY(conv1x1_bf16(a, c.w1, x.st));
     if (tw.q) twin_register(e, out, tw);
     return 0;
   }
@@ -753,7 +776,7 @@ int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, i
   if (r.has_res && e->bf16) {
     // GroupNorm2 + SiLU + (+ res_conv(x)) evaluated in the 1x1 res_conv's epilogue, in place over v
     SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, nullptr, true));
-    SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, v, nullptr, false, false, v, want_twin, eps4));
+    SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, v, nullptr, false, false, v, want_twin, eps4, true));
   } else if (r.has_res) {
     SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, u, nullptr, false));   // u is free again: reuse it
     SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, u));
@@ -889,7 +912,8 @@ int unet_body(Ctx& x, void* x0, void** out) {
     if (cur != x0) e->pool.put(cur);
     skips.push_back(a);
     SRGD_TRY(res_block(x, sw.rb[1], a, C, nullptr, 0, &b));
-    SRGD_TRY(attn_block(x, sw.attn, b, &c, zone_is_q(e, 2 * n - s) || (s == n - 1 && zone_is_q(e, s))));
+    const bool cq = zone_is_q(e, 2 * n - s) || (s == n - 1 && zone_is_q(e, s));      // c is read by 3x3 convolutions of fp8 zones
+    SRGD_TRY(attn_block(x, sw.attn, b, &c, cq));
     e->pool.put(b);
     skips.push_back(c);
     const ConvW& rs = sw.resample;
@@ -898,7 +922,7 @@ int unet_body(Ctx& x, void* x0, void** out) {
     if (!d) return -1;
     const bool dq = zone_is_q(e, s + 1);
     if (conv_is_q(x, rs, C, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, C, nullptr, 0, x.H, x.W, d, false, dq));
-    else SRGD_TRY(run_conv(x, rs, c, C, nullptr, 0, x.H, x.W, d, nullptr, false, false, nullptr, dq));
+    else SRGD_TRY(run_conv(x, rs, c, C, nullptr, 0, x.H, x.W, d, nullptr, false, false, nullptr, dq, nullptr, cq));
     x.H = Ho; x.W = Wo;
     cur = d;
   }
@@ -926,7 +950,10 @@ int unet_body(Ctx& x, void* x0, void** out) {
     sk = skips.back(); skips.pop_back();
     SRGD_TRY(res_block(x, sw.rb[1], a, dout, sk, din, &b));
     e->pool.put(a); e->pool.put(sk);
-    SRGD_TRY(attn_block(x, sw.attn, b, &c, u == n - 1 && zq));    // only the last stage resamples with a 3x3 convolution
+    // a twin of the attention output: the last stage resamples with a 3x3 convolution; a softmax-attention stage (to_out's
+    // epilogue writes the twin for 1 B per element) feeds its K-heavy PixelShuffle 1x1 on the MX matrix cores
+    const bool psq = zq && !e->no_mx1x1 && sw.attn.full && sw.resample.wq1 != nullptr;
+    SRGD_TRY(attn_block(x, sw.attn, b, &c, (u == n - 1 && zq) || psq));
     e->pool.put(b);
     const ConvW& rs = sw.resample;
     const int Ho = (u < n - 1) ? x.H * 2 : x.H, Wo = (u < n - 1) ? x.W * 2 : x.W;
@@ -934,7 +961,7 @@ int unet_body(Ctx& x, void* x0, void** out) {
     if (!d) return -1;
     const bool dq = zone_is_q(e, n + 2 + u);                      // the next up stage, or the final block (zone 2n + 1)
     if (conv_is_q(x, rs, dout, 0, x.H, x.W, false)) SRGD_TRY(run_conv_q_from_bf16(x, rs, c, dout, nullptr, 0, x.H, x.W, d, false, dq));
-    else SRGD_TRY(run_conv(x, rs, c, dout, nullptr, 0, x.H, x.W, d, nullptr, false, false, nullptr, dq));
+    else SRGD_TRY(run_conv(x, rs, c, dout, nullptr, 0, x.H, x.W, d, nullptr, false, false, nullptr, dq, nullptr, psq));
     e->pool.put(c);
     x.H = Ho; x.W = Wo;
     cur = d;
@@ -1045,6 +1072,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   if (const char* v = getenv("SRGD_GN_FUSION_NTILES")) e->gn_fusion_max_ntiles = atoi(v);
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
+  if (const char* v = getenv("SRGD_MX1X1")) e->no_mx1x1 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_LA256")) e->no_la256 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_FINAL_FUSION")) e->no_final_fusion = atoi(v) == 0;
   if (const char* v = getenv("SRGD_Q_FUSED")) e->no_twin_fusion = atoi(v) == 0;

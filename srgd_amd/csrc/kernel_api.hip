@@ -62,6 +62,25 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
     SRGD_TRY(dw1.alloc(p1.size() * 2));
     SRGD_HIP(hipMemcpy(dw1.p, p1.data(), p1.size() * 2, hipMemcpyHostToDevice));
   }
+  // impl 4: the pointwise layer on the MX matrix cores (conv1x1_mxfp8.hip); the bf16 sources are quantised here
+  const bool fastq1 = impl == 4;
+  DevBuf dwq1, q0, s0, q1, s1;
+  if (fastq1) {
+    if (!is_bf16 || !conv1x1_mxfp8_eligible(a)) SRGD_FAIL("srgd_k_conv2d: the conv1x1_mxfp8 path does not cover this shape");
+    std::vector<unsigned char> f32p, pq1;
+    std::vector<float> unused;
+    pack_conv_weights(weight_oihw_host, bias_host, kind, Cin, Cout, CoutPad, KS, false, f32p, unused);
+    pack_conv1x1_mxfp8(reinterpret_cast<const float*>(f32p.data()), KS * KS, Cin, Cout, pq1);
+    SRGD_TRY(dwq1.alloc(pq1.size()));
+    SRGD_HIP(hipMemcpy(dwq1.p, pq1.data(), pq1.size(), hipMemcpyHostToDevice));
+    const size_t npix = (size_t)B * Hin * Win;
+    SRGD_TRY(q0.alloc(npix * C0)); SRGD_TRY(s0.alloc(npix * (C0 / 32)));
+    SRGD_TRY(quant_mxfp8(in0, q0.p, s0.p, (long)npix, C0, st));
+    if (C1) {
+      SRGD_TRY(q1.alloc(npix * C1)); SRGD_TRY(s1.alloc(npix * (C1 / 32)));
+      SRGD_TRY(quant_mxfp8(in1, q1.p, s1.p, (long)npix, C1, st));
+    }
+  }
   if (fast) {
     std::vector<unsigned short> p3;
     pack_conv3x3_bf16(weight_oihw_host, Cin, Cout, p3, f32_to_bf16_host);
@@ -70,6 +89,7 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   }
   if (stats_slots) *stats_slots = fast ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
   auto run = [&]() -> int {
+    if (fastq1) return conv1x1_mxfp8(a, q0.p, s0.p, q1.p, s1.p, dwq1.p, st);
     return fast ? conv3x3_bf16(a, dw3.p, nullptr, nullptr, st) : fast1 ? conv1x1_bf16(a, dw1.p, st) : conv_igemm(a, is_bf16 != 0, st);
   };
   SRGD_TRY(run());

@@ -84,6 +84,12 @@ int conv3x3_mxfp8_stats_slots(const ConvArgs& a);
 void pack_conv3x3_mxfp8(const float* src_oihw, int Cin, int Cout, std::vector<unsigned char>& out);
 int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void* q1, const void* s1, const void* packed_w,
                   hipStream_t st);
+// conv1x1_mxfp8.hip: the pointwise layers on the same matrix cores (same ConvArgs as conv1x1_bf16 incl. every epilogue;
+// inputs as MX-fp8 twins; weights from pack_conv1x1_mxfp8, which takes the generic path's fp32 [tap][Cout][Cin] order)
+bool conv1x1_mxfp8_eligible(const ConvArgs& a);
+void pack_conv1x1_mxfp8(const float* src_tap_o_i, int taps, int Cin, int Cout, std::vector<unsigned char>& out);
+int conv1x1_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void* q1, const void* s1, const void* packed_w,
+                  hipStream_t st);
 unsigned char e4m3_encode(float x);
 int mx_block_exponent(float amax);
 float round_through_e4m3(float x);

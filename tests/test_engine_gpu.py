@@ -910,6 +910,11 @@ def test_fp8_mode_uses_the_mxfp8_kernels():
     # every tensor a 3x3 convolution reads gets its MX-fp8 twin from its producer's epilogue (conv1x1 variants, GroupNorm2 +
     # residual, both fused LinearAttention kernels, the 3x3 resamplers): no stand-alone quantisation pass is left
     assert prof["launches"]["quantize_mxfp8"] == 0
+    # pointwise layers on the MX matrix cores wherever the input tensors already have twins: the 8 res_convs of
+    # the up stages + the final block's (with the fused output convolution), the 3 Downsample 1x1s, the PixelShuffle 1x1 behind the
+    # first up stage's softmax attention = 13 of the 32 pointwise launches per forward; to_qkv / to_out of the unfused attention
+    # sites (inputs come out of RMSNorm / the attention core, no twin) and the input convolution stay on conv1x1_bf16
+    assert prof["launches"]["conv1x1_mxfp8"] == 2 * 13, prof["launches"]
     # fp8_mixed: the 11 convolutions at the tile's own resolution (first down stage 4, last up stage 4 + its 3x3 resampler, final
     # block 2) stay on the bf16 kernel, the other 29 run MX-fp8; twins are written only for tensors an MX convolution reads, and
     # still no stand-alone quantisation pass is needed
@@ -925,6 +930,7 @@ def test_fp8_mode_uses_the_mxfp8_kernels():
     assert torch.isfinite(out).all() and out.min() >= 0 and out.max() <= 1
     assert prof["launches"]["conv3x3_mxfp8"] == 2 * 29 and prof["launches"]["conv3x3_bf16"] == 2 * 11
     assert prof["launches"]["quantize_mxfp8"] == 0
+    assert prof["launches"]["conv1x1_mxfp8"] == 2 * 9, prof["launches"]      # the 256^2 zones' pointwise layers stay bf16 too
 
 
 def test_config5_full_geometry_fp8_vs_bf16_parity_report():

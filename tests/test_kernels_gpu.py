@@ -587,3 +587,92 @@ def test_conv3x3_mxfp8_matches_the_quantised_reference(shape):
     wsq = (want.double() ** 2).reshape(B, 8, -1).sum(-1).float()
     assert torch.allclose(p[..., 0], wsum, rtol=2e-3, atol=2e-2 * float(wsq.max()) ** 0.5)
     assert torch.allclose(p[..., 1], wsq, rtol=2e-3)
+
+
+# ------------------------------------------------------------------ MX-fp8 pointwise layers (conv1x1_mxfp8.hip, impl 4)
+def _mx_pointwise_reference(x0, x1, w_oi, b, taps=1):
+    """conv1x1_mxfp8's arithmetic on the CPU: MX-quantised activations (per pixel, per 32 channels of each source) and weights
+    (per output channel, tap, 32 input channels), exact products, fp32 sums.  taps = 4: 2x2 / stride-2 gather (Downsample)."""
+    from oracle import mxfp8 as MX
+    qs = []
+    for t in (x0, x1):
+        if t is not None:
+            _, _, deq = MX.quantize(t.permute(0, 2, 3, 1).contiguous())
+            qs.append(deq.permute(0, 3, 1, 2))
+    xq = torch.cat(qs, 1)
+    if taps == 1:
+        _, _, wq = MX.quantize(w_oi.reshape(w_oi.shape[0], -1))
+        return F.conv2d(xq.double(), wq.reshape(*w_oi.shape[:2], 1, 1).double(), b.double()).float()
+    # Downsample: rearrange 'b c (h p1) (w p2) -> b (c p1 p2) h w' then 1x1 over 4c channels (reference model.py:106-110); the
+    # engine walks it tap-major (tap = p1 * 2 + p2, c inside), one weight scale per (output channel, tap, 32 channels)
+    cout, c4 = w_oi.shape[:2]
+    c = c4 // 4
+    w4 = w_oi.reshape(cout, c, 2, 2).permute(0, 2, 3, 1).contiguous()          # [o, p1, p2, c]
+    _, _, w4q = MX.quantize(w4)
+    return F.conv2d(xq.double(), w4q.permute(0, 3, 1, 2).double(), b.double(), stride=2).float()
+
+
+def test_conv1x1_mxfp8_exact_small_integers():
+    # small integers are exact in e4m3 with power-of-two block scales: bit-identical to torch after the bf16 store; catches the
+    # A / B swizzles, both scale layouts (bytes per pixel, one dword per lane for the weights), the two-source K walk (128 + 256
+    # channels = 3 K-steps through the 3-deep ring) and the shared transposed epilogue.  M = 2*16*32 = 1024 rows, 2 n-tiles.
+    g = torch.Generator().manual_seed(21)
+    x0 = torch.randint(-3, 4, (2, 128, 16, 32), generator=g).float()
+    x1 = torch.randint(-3, 4, (2, 256, 16, 32), generator=g).float()
+    w = torch.randint(-2, 3, (256, 384, 1, 1), generator=g).float()
+    b = torch.randint(-4, 5, (256,), generator=g).float()
+    got, _ = run_conv(x0, x1, w, b, ks=1, stride=1, pad=0, kind=0, bf16=True, impl=4)
+    want = F.conv2d(torch.cat((x0, x1), 1), w, b).to(torch.bfloat16).float()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("variant", ["plain", "residual", "gn_tail", "pixel_shuffle", "unshuffle", "k_heavy"])
+def test_conv1x1_mxfp8_matches_the_quantised_reference(variant):
+    # random data: conv(dequant(MX(x)), dequant(MX(w))) up to fp32 summation order and the bf16 store, through every epilogue the
+    # engine uses; the distance to the bf16 kernel's result is reported (the price of e4m3, not a kernel property)
+    g = torch.Generator().manual_seed(22)
+    B, H, W = 2, 16, 32
+    kw = dict(ks=1, stride=1, pad=0, kind=0, bf16=True)
+    x1 = None
+    if variant == "pixel_shuffle":
+        x0 = rnd(torch.randn(B, 128, H, W, generator=g), True)
+        w = torch.randn(512, 128, 1, 1, generator=g) / 11
+        b = torch.randn(512, generator=g)
+        kw["kind"] = 2
+        pre = _mx_pointwise_reference(x0, None, w[:, :, 0, 0], b)
+        want = F.pixel_shuffle(F.silu(pre), 2)
+    elif variant == "unshuffle":
+        x0 = rnd(torch.randn(B, 128, 2 * H, 2 * W, generator=g), True)
+        w = torch.randn(128, 512, 1, 1, generator=g) / 22
+        b = torch.randn(128, generator=g)
+        kw.update(ks=2, stride=2, kind=1)
+        want = _mx_pointwise_reference(x0, None, w[:, :, 0, 0], b, taps=4)
+    elif variant == "k_heavy":
+        x0 = rnd(torch.randn(1, 1024, H, W, generator=g) * torch.exp(torch.randn(1, 1, H, W, generator=g)), True)
+        x1 = rnd(torch.randn(1, 512, H, W, generator=g), True)
+        w = torch.randn(1024, 1536, 1, 1, generator=g) / 39
+        b = torch.randn(1024, generator=g)
+        want = _mx_pointwise_reference(x0, x1, w[:, :, 0, 0], b)
+    else:
+        x0 = rnd(torch.randn(B, 128, H, W, generator=g), True)
+        x1 = rnd(torch.randn(B, 128, H, W, generator=g), True)
+        w = torch.randn(128, 256, 1, 1, generator=g) / 16
+        b = torch.randn(128, generator=g)
+        want = _mx_pointwise_reference(x0, x1, w[:, :, 0, 0], b)
+        if variant == "residual":
+            kw["residual"] = rnd(torch.randn(B, 128, H, W, generator=g), True)
+            want = want.to(torch.bfloat16).float() + kw["residual"]
+        if variant == "gn_tail":
+            h = rnd(torch.randn(B, 128, H, W, generator=g), True)
+            ca, cb = 1 + 0.3 * torch.randn(B, 128, generator=g), 0.5 * torch.randn(B, 128, generator=g)
+            kw["gn_tail"] = (h, ca, cb)
+            want = F.silu(ca[:, :, None, None] * h + cb[:, :, None, None]) + want.to(torch.bfloat16).float()
+    got, _ = run_conv(x0, x1, w, b, impl=4, **kw)
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    err = (got - want).abs().max().item()
+    assert err <= 2.0 ** -7 * scale + 1e-5, (variant, err, scale)          # bf16 staging + store, fp32 summation order
+    bf, _ = run_conv(x0, x1, rnd(w, True), b, impl=3, **kw)
+    rel = float(((got - bf) ** 2).mean().sqrt() / (bf ** 2).mean().sqrt())
+    _report_k(test="conv1x1_mxfp8_vs_bf16_kernel", variant=variant, rel_rms=rel)
+    assert rel < 0.08
