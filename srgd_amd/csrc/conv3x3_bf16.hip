@@ -38,9 +38,9 @@ constexpr int CONV3_M16_DEFAULT = 1;     // 16x16x32 measured +1..2 % over 32x32
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset) {
-  // LDS destination = wave-uniform base + lane * 16
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)lds_wave_base, 16, voffset, 0, 0, 0);
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset, int soffset = 0) {
+  // LDS destination = wave-uniform base + lane * 16; voffset per lane (VGPR), soffset wave-uniform (SGPR)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
 struct Conv3Args {
@@ -206,10 +206,13 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     else dma16(rs1, dst, voff);
   };
 #define issue_a_piece(CCV, J) issue_a(CCV, J, (J) == 0 ? a_pix0 : ((J) == 1 ? a_pix1 : a_pix2))
-  auto issue_b = [&](int s) {               // K-step s = cc*9 + tap  ->  weight tile (tap, cc)
-    const int cc = s / 9, tap = s - cc * 9;
-    const int voff = (int)((size_t)(tap * CC + cc) * w_tile_stride) + tid * 16;
-    dma16(rsw, sB0 + (s % 3) * B_BYTES + wave * 1024, voff);
+  // K-step (cc, tap) -> weight tile (tap, cc) into ring slot (cc * 9 + tap) % 3 = tap % 3.  Called with compile-time `tap`
+  // (0..10: the unrolled tap loop asks for "two steps ahead"; 9 and 10 mean taps 0 and 1 of the next chunk), so the tile offset is
+  // one scalar multiply-add - round 2's issue_b(s) divided the runtime step index by 9 and by 3: ~20 SALU instructions per tap.
+  const int w_tap_stride = (int)(CC * w_tile_stride);
+  auto issue_b = [&](int cc, int tap) {
+    if (tap >= 9) { tap -= 9; cc += 1; }
+    dma16(rsw, sB0 + (tap % 3) * B_BYTES + wave * 1024, tid * 16, tap * w_tap_stride + cc * (int)w_tile_stride);
   };
 
   // ---- accumulators: 64 fp32 per lane in both shapes
@@ -225,15 +228,28 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // column block rides in the ds_read offset field)
   const int b_base = (M16 ? wn * 64 + r16 : wn * 64 + r) * 64 + (((M16 ? q16 : h) ^ row_swz<M16>(M16 ? r16 : r)) << 4);
   auto b_addr = [&](int j) { return b_base + j * (M16 ? 16 : 32) * 64; };
+  // 16x16 (round 3): halo pixel P = lp + Pc with lp = 2 wm WP + r16 (per lane) and Pc a compile-time constant per (tap, block):
+  // P * 64 splits into lp * 64 (one per-lane base) + Pc * 64 (the ds_read's immediate offset), and the swizzle term
+  // ((P >> 1) & 3) << 4 = ((P << 3) & 0x30) comes from lp8 = lp << 3: THREE VALU instructions per fragment address (add3 with
+  // the opaque zero, and-xor, add) instead of six - the K loop carried ~28 address instructions per 16 MFMAs on the port the
+  // MFMAs issue through.
+  const int lp = 2 * wm * WP + r16, lp8 = lp << 3, lp64 = lp * 64, q16s = q16 << 4;
   auto a_addr = [&](int tap, int i) {        // 32x32: i = patch row of the wave (0/1); 16x16: i = 16-pixel block (0..3)
     const int dy = tap / 3, dx = tap - dy * 3;
-    const int P = M16 ? (2 * wm + (i >> 1) + dy) * WP + (i & 1) * 16 + r16 + dx + opq
-                      : (2 * wm + i + dy) * WP + r + dx + opq;
-    return P * 64 + (((M16 ? q16 : h) ^ row_swz<M16>(P)) << 4);
+    if constexpr (M16 && !GNIN) {
+      const int Pc = ((i >> 1) + dy) * WP + (i & 1) * 16 + dx;
+      return lp64 + (((lp8 + Pc * 8 + opq) & 0x30) ^ q16s) + Pc * 64;
+    } else {
+      // (the GNIN instances keep round 2's form: they refresh `opq` every tap so that NO address part survives a tap in a
+      // register - with the split form the eight swizzle terms of a chunk stay live and 33 registers spill into the K loop)
+      const int P = M16 ? (2 * wm + (i >> 1) + dy) * WP + (i & 1) * 16 + r16 + dx + opq
+                        : (2 * wm + i + dy) * WP + r + dx + opq;
+      return P * 64 + (((M16 ? q16 : h) ^ row_swz<M16>(P)) << 4);
+    }
   };
   auto compute = [&](int cc, int tap, int s) {
     const char* A = sA0 + (cc & 1) * A_BYTES;
-    const char* Bt = sB0 + (s % 3) * B_BYTES;
+    const char* Bt = sB0 + (tap % 3) * B_BYTES;          // (cc * 9 + tap) % 3
     if constexpr (M16 && GNIN) {
       // GNIN carries ~13 more long-lived registers (piece offsets, coefficient addressing): the pixel fragments come in two
       // pairs here - 24 operand registers at a time instead of 32 - so that nothing spills into the K loop (a scratch reload
@@ -293,8 +309,8 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   issue_a_piece(0, 0);
   issue_a_piece(0, 1);
   issue_a_piece(0, 2);
-  issue_b(0);
-  issue_b(1);                                    // S >= 9 always
+  issue_b(0, 0);
+  issue_b(0, 1);                                 // S >= 9 always
   WAIT_VM(1);
   if (GNIN) {
     BARRIER();                                   // coefficient slot visible; this wave's A(0) pieces have landed
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       // by tap 0's barrier, read from tap 2 on
       if (GNIN && tap == 0) coef_dma(cc + 1);
       if (tap < 3) issue_a_piece(cc + 1, tap);
-      issue_b(s + 2);                            // always < S here (cc < CC-1)
+      issue_b(cc, tap + 2);                      // always < S here (cc < CC-1)
       // a wave rewrites only the pieces it DMA'd itself: piece issued at tap t has landed after the wait of tap t+1;
       // six half-piece transforms spread over taps 2..7 (j = 0, 0, 1, 1, 2, 2)
       if (GNIN && tap >= 2 && tap < 8) {
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int s = cc * 9 + tap;
-      if (tap < 7) issue_b(s + 2);
+      if (tap < 7) issue_b(cc, tap + 2);
       compute(cc, tap, s);
       if (tap < 7) WAIT_VM(1); else WAIT_VM(0);
       if (tap < 8) BARRIER();

@@ -206,6 +206,10 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     int r7t = r7;
     asm volatile("" : "+v"(r7t));
     v8i b0, b1, b2, b3;
+#ifdef SRGD_MXFP8_DIAG_NOB                  // timing-only diagnostic (wrong results): weight fragments made up in registers
+    const int sbw = r7t;
+#define SRGD_QLOAD_B(J) b##J = v8i{r7t, lane, r7t + J, lane, r7t, lane + J, r7t, lane};
+#else
     const int sbw = *reinterpret_cast<const int*>(Bt + bsb);
 #define SRGD_QLOAD_B(J)                                                              \
     {                                                                                \
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
       const v4i hi = *reinterpret_cast<const v4i*>(Bt + (bb ^ 64) + J * 2048);       \
       b##J = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};            \
     }
+#endif
     SRGD_QLOAD_B(0) SRGD_QLOAD_B(1) SRGD_QLOAD_B(2) SRGD_QLOAD_B(3)
 #undef SRGD_QLOAD_B
     // SRGD_MXFP8_DIAG_NOLDS (timing-only diagnostic build, wrong results): fragments 1..7 are register copies of fragment 0 -
@@ -309,14 +314,18 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int s = cc * 9 + tap;
+#ifndef SRGD_MXFP8_DIAG_NODMA              // timing-only diagnostic (wrong results): no weight DMA inside the K loop
       issue_b(min(s + 1, S - 1), (s + 1) % QRING);   // (the last step re-fetches its own unit into the idle slot)
+#endif
       compute(tap, s);
 #ifdef SRGD_MXFP8_DIAG_LATE_WAIT           // timing-only diagnostic (wrong results): the step does not wait for its weight DMA -
       QWAIT_VM(10);                        // two more steps' worth may stay in flight - to price the DMA latency on the critical path
 #else
       QWAIT_VM(0);
 #endif
+#ifndef SRGD_MXFP8_DIAG_NO_BARRIER         // timing-only diagnostic (wrong results): no per-step workgroup barrier
       QBARRIER();
+#endif
     }
     if (cc + 1 < CC) {
       issue_a(cc + 1);                             // every wave passed the barrier above: the old patch is dead

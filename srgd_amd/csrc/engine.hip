@@ -257,6 +257,7 @@ struct srgd_engine {
   bool no_la256 = false;      // SRGD_LA256=0: the C = 256 LinearAttention sites run the unfused chain (A/B switch)
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
   bool no_mx1x1 = false;      // SRGD_MX1X1=0: fp8 modes keep the pointwise layers on conv1x1_bf16 (A/B switch)
+  int mx1x1_min_cin = 0;      // SRGD_MX1X1_MIN_CIN: pointwise layers with fewer input channels stay on conv1x1_bf16
   unsigned fp8_bf16_zones = 0;   // SRGD_FP8_BF16_ZONES (bit mask over Ctx::zone): zones whose 3x3 convs stay bf16 in fp8 mode (study knob)
   bool no_twin_fusion = false;   // SRGD_Q_FUSED=0: fp8 mode quantises every conv input in a separate pass (A/B + bit-equality test)
 
@@ -609,8 +610,8 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
     else a.eps4 = nullptr;
   }
   // fp8 modes: a pointwise layer of an fp8 zone whose inputs are twinned tensors runs on the MX matrix cores (conv1x1_mxfp8)
-  const bool fastq1 = fast1 && mx_in && e->fp8 && c.wq1 && !e->no_mx1x1 && !((e->fp8_bf16_zones >> x.zone) & 1u) &&
-                      conv1x1_mxfp8_eligible(a);
+  const bool fastq1 = fast1 && mx_in && e->fp8 && c.wq1 && !e->no_mx1x1 && c.KS * c.KS * c.Cin >= e->mx1x1_min_cin &&
+                      !((e->fp8_bf16_zones >> x.zone) & 1u) && conv1x1_mxfp8_eligible(a);
   QTensor mq0, mq1;
   if (fastq1) {                                   // (a twin that does not exist yet is quantised here, as for the 3x3 convolutions)
     SRGD_TRY(q_twin(x, in0, C0, Hin * Win, &mq0));
@@ -1073,6 +1074,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_MX1X1")) e->no_mx1x1 = atoi(v) == 0;
+  if (const char* v = getenv("SRGD_MX1X1_MIN_CIN")) e->mx1x1_min_cin = atoi(v);
   if (const char* v = getenv("SRGD_LA256")) e->no_la256 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_FINAL_FUSION")) e->no_final_fusion = atoi(v) == 0;
   if (const char* v = getenv("SRGD_Q_FUSED")) e->no_twin_fusion = atoi(v) == 0;
