@@ -27,8 +27,9 @@ constexpr int LDS1_BYTES = RING1 * STAGE1;         // 73,728 >= EPI_LDS_BYTES = 
 static_assert(LDS1_BYTES >= EPI_LDS_BYTES && BM1 == EPI_BM && BN1 == EPI_BN && NT1 == EPI_NT, "conv1x1_epilogue.hpp tile shape");
 
 typedef __attribute__((address_space(3))) void* lds_ptr1;
-__device__ __forceinline__ void dma16_1(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr1)lds_wave_base, 16, voffset, 0, 0, 0);
+// voffset: per-lane byte offset (VGPR); soffset: wave-uniform byte offset (SGPR)
+__device__ __forceinline__ void dma16_1(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr1)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 #define WAIT_VM1(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define BARRIER1()                       \
@@ -81,19 +82,22 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
   const int CC = Cin / KC1;
   const int S = p.KH * p.KW * CC;
 
-  // ---- A staging: 16 wave-instructions per stage, wave w issues pieces w and w+8.  Per-lane input pixel (inside the
-  // image, tap (0,0)) and source chunk of its two pieces.
+  // ---- A staging: 16 wave-instructions per stage, wave w issues pieces w and w+8.  Per-lane BYTE offset of its two pieces
+  // inside each source at tap (0,0), channel chunk 0: input pixel * pixel stride + swizzled 16-byte chunk.  Everything that
+  // changes from K-step to K-step (tap offset, channel chunk, ring slot, weight tile) is wave-uniform and rides in SGPRs - the
+  // buffer instruction's scalar offset and M0.  Round 2 recomputed the per-lane offsets every step from a runtime s / CC and
+  // tap / KW (66 SALU + 17 VALU instructions, two of them v_mul_lo, per 16 MFMAs).
 #define SRGD_A1_DECL(J)                                                      \
-  int a_pix##J, a_sub##J;                                                    \
+  int a_b0##J, a_b1##J;                                                      \
   {                                                                          \
     const int g = (wave + 8 * J) * 64 + lane;                                \
     const int P = g >> 2;                                                    \
     const int op = p0 + P;                                                   \
-    {                                                                        \
-      const int oy = op / p.Wout, ox = op - oy * p.Wout;                     \
-      a_pix##J = oy * p.stride * p.Win + ox * p.stride;                      \
-    }                                                                        \
-    a_sub##J = (g & 3) ^ row_swz1(P);                                        \
+    const int oy = op / p.Wout, ox = op - oy * p.Wout;                       \
+    const int pix = oy * p.stride * p.Win + ox * p.stride;                   \
+    const int sub = (g & 3) ^ row_swz1(P);                                   \
+    a_b0##J = (pix * p.ps0 + sub * 8) * 2;                                   \
+    a_b1##J = (pix * p.ps1 + sub * 8) * 2;                                   \
   }
   SRGD_A1_DECL(0) SRGD_A1_DECL(1)
 #undef SRGD_A1_DECL
@@ -106,25 +110,31 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)p.w + (size_t)nt * B1_BYTES), 0, (int)((size_t)(S - 1) * w_tile_stride + B1_BYTES), 0x00020000);
 
-  auto issue = [&](int s) {                        // K-step s = tap * CC + cc
-    const int tap = s / CC, cc = s - tap * CC;
-    const int c = cc * KC1;
+  // issue stream: the next K-step to request - tap (ty, tx), channel chunk, ring slot, weight offset - advanced incrementally
+  int i_ty = 0, i_tx = 0, i_cc = 0, i_slot = 0, i_w = 0;
+  const int tid16 = tid * 16;
+  auto issue = [&]() __attribute__((always_inline)) {
+    const int c = i_cc * KC1;
     const bool first = c < p.C0;
-    const int Cs = first ? p.ps0 : p.ps1;
-    const int coff = first ? c : c - p.C0;
-    const int tdy = tap / p.KW;
-    const int toff = tdy * p.Win + (tap - tdy * p.KW);
-    char* st = smem + (s % RING1) * STAGE1;
-    const int v0 = ((a_pix0 + toff) * Cs + coff + a_sub0 * 8) * 2;
-    const int v1 = ((a_pix1 + toff) * Cs + coff + a_sub1 * 8) * 2;
+    const int soff = first ? ((i_ty * p.Win + i_tx) * p.ps0 + c) * 2 : ((i_ty * p.Win + i_tx) * p.ps1 + c - p.C0) * 2;
+    char* st = smem + i_slot * STAGE1;
+    // (the per-lane offsets are selected with v_cndmask on purpose: written as two branches hipcc merges them into a select of
+    // ADDRESSES of the two candidates and parks those in scratch - a flat load behind s_waitcnt vmcnt(0) in every K-step)
+    const int vo0 = first ? a_b00 : a_b10, vo1 = first ? a_b01 : a_b11;
     if (first) {
-      dma16_1(rs0, st + wave * 1024, v0);
-      dma16_1(rs0, st + (wave + 8) * 1024, v1);
+      dma16_1(rs0, st + wave * 1024, vo0, soff);
+      dma16_1(rs0, st + (wave + 8) * 1024, vo1, soff);
     } else {
-      dma16_1(rs1, st + wave * 1024, v0);
-      dma16_1(rs1, st + (wave + 8) * 1024, v1);
+      dma16_1(rs1, st + wave * 1024, vo0, soff);
+      dma16_1(rs1, st + (wave + 8) * 1024, vo1, soff);
     }
-    dma16_1(rsw, st + A1_BYTES + wave * 1024, (int)((size_t)s * w_tile_stride) + tid * 16);
+    dma16_1(rsw, st + A1_BYTES + wave * 1024, tid16, i_w);
+    i_w += (int)w_tile_stride;
+    i_slot = i_slot == RING1 - 1 ? 0 : i_slot + 1;
+    if (++i_cc == CC) {
+      i_cc = 0;
+      if (++i_tx == p.KW) { i_tx = 0; ++i_ty; }
+    }
   };
 
   f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c10 = 0, c11 = 0, c12 = 0, c13 = 0,
@@ -139,8 +149,10 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
   };
   const int aa0 = a_addr(0), aa1 = a_addr(1), aa2 = a_addr(2), aa3 = a_addr(3);
   const int ba0 = b_addr(0), ba1 = b_addr(1), ba2 = b_addr(2), ba3 = b_addr(3);
-  auto compute = [&](int s) {
-    const char* st = smem + (s % RING1) * STAGE1;
+  int c_slot = 0;                                  // ring slot of the K-step being consumed
+  auto compute = [&]() __attribute__((always_inline)) {
+    const char* st = smem + c_slot * STAGE1;
+    c_slot = c_slot == RING1 - 1 ? 0 : c_slot + 1;
     const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + aa0);
     const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(st + aa1);
     const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(st + aa2);
@@ -158,13 +170,13 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
   };
 
   // ---- pipeline: stages s+1 and s+2 in flight while stage s is consumed (3 DMA instructions per wave and stage)
-  issue(0);
-  if (S > 1) issue(1);
+  issue();
+  if (S > 1) issue();
   if (S > 1) WAIT_VM1(3); else WAIT_VM1(0);
   BARRIER1();
   for (int s = 0; s < S; ++s) {
-    if (s + 2 < S) issue(s + 2);
-    compute(s);
+    if (s + 2 < S) issue();
+    compute();
     if (s + 2 < S) WAIT_VM1(3); else WAIT_VM1(0);   // stage s+1 has landed (this wave's part; the barrier covers the rest)
     BARRIER1();
   }

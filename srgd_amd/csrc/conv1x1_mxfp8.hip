@@ -90,60 +90,63 @@ __global__ __launch_bounds__(NTQ, 2) void conv1x1_mxfp8_kernel(Conv1QArgs p) {
   // of piece j fills stored chunk l & 7 of row P = j * 8 + (l >> 3) with logical chunk (l & 7) ^ (P & 6); (j * 8) & 6 == 0, so the
   // source chunk is the same for the four pieces.  Scales: 4 B per pixel, one dword per lane, waves 0..3 cover the 256 pixels
   // (waves 4..7 repeat them: identical bytes, and every wave issues the same eight instructions).
+  // Per-lane byte offsets (tap (0,0), channel chunk 0) per source; everything that changes from K-step to K-step (tap offset,
+  // channel chunk, ring slot, weight unit) is wave-uniform and rides in SGPRs (scalar buffer offset, M0), advanced incrementally.
   const int a_sub = (lane & 7) ^ ((lane >> 3) & 6);
   auto in_pix = [&](int P) {                        // input pixel offset (tap (0,0)) of output pixel p0 + P
     const int op = p0 + P;
     const int oy = op / p.Wout, ox = op - oy * p.Wout;
     return oy * p.stride * p.Win + ox * p.stride;
   };
-  const int a_pix0 = in_pix(wave * 8 + (lane >> 3)), a_pix1 = in_pix((wave + 8) * 8 + (lane >> 3)),
-            a_pix2 = in_pix((wave + 16) * 8 + (lane >> 3)), a_pix3 = in_pix((wave + 24) * 8 + (lane >> 3));
+  const int pix0 = in_pix(wave * 8 + (lane >> 3)), pix1 = in_pix((wave + 8) * 8 + (lane >> 3)),
+            pix2 = in_pix((wave + 16) * 8 + (lane >> 3)), pix3 = in_pix((wave + 24) * 8 + (lane >> 3));
   const int s_pix = in_pix((wave & 3) * 64 + lane);
+  const int a00 = pix0 * p.C0 + a_sub * 16, a01 = pix1 * p.C0 + a_sub * 16, a02 = pix2 * p.C0 + a_sub * 16, a03 = pix3 * p.C0 + a_sub * 16;
+  // source 1 as a per-lane DIFFERENCE to source 0: offset = a0x + (d1x & mask) with a wave-uniform mask - written as a select
+  // between two sets of registers hipcc selects between their ADDRESSES and parks both sets in scratch
+  const int d10 = pix0 * (p.C1 - p.C0), d11 = pix1 * (p.C1 - p.C0), d12 = pix2 * (p.C1 - p.C0), d13 = pix3 * (p.C1 - p.C0);
+  const int as0 = s_pix * (p.C0 / 32), ds1 = s_pix * ((p.C1 - p.C0) / 32);
   const size_t npix = (size_t)p.Hin * p.Win;
-  const __amdgpu_buffer_rsrc_t rq0 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.q0 + (size_t)b * npix * p.C0), 0, (int)(npix * p.C0), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs0 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.s0 + (size_t)b * npix * (p.C0 / 32)), 0, (int)(npix * (p.C0 / 32)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rq1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.q1 ? p.q1 + (size_t)b * npix * p.C1 : p.q0), 0, p.q1 ? (int)(npix * p.C1) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.s1 ? p.s1 + (size_t)b * npix * (p.C1 / 32) : p.s0), 0, p.s1 ? (int)(npix * (p.C1 / 32)) : 0, 0x00020000);
+  // per-source base pointers and sizes; the buffer descriptor of a K-step's source is BUILT from a scalar select of these (a
+  // select between two ready-made descriptors goes through scratch memory and a waterfall loop in hipcc's hands)
+  const unsigned char* const qb0 = p.q0 + (size_t)b * npix * p.C0;
+  const unsigned char* const sb0 = p.s0 + (size_t)b * npix * (p.C0 / 32);
+  const unsigned char* const qb1 = p.q1 ? p.q1 + (size_t)b * npix * p.C1 : qb0;
+  const unsigned char* const sb1 = p.s1 ? p.s1 + (size_t)b * npix * (p.C1 / 32) : sb0;
+  const int qn0 = (int)(npix * p.C0), qn1 = p.q1 ? (int)(npix * p.C1) : 0;
   const size_t w_step_stride = (size_t)n_tiles * BQ_BYTES;
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.w + (size_t)nt * BQ_BYTES), 0, (int)((size_t)(S - 1) * w_step_stride + BQ_BYTES), 0x00020000);
 
-  auto issue = [&](int s) {                        // K-step s = tap * CC + cc
-    const int tap = s / CC, cc = s - tap * CC;
-    const bool first = cc < CC0;
-    const int Cs = first ? p.C0 : p.C1;
-    const int ccl = first ? cc : cc - CC0;
-    const int tdy = tap / p.KW;
-    const int toff = tdy * p.Win + (tap - tdy * p.KW);
-    char* st = smem + (s % RINGQ) * STAGEQ;
-    const int cb = ccl * KQ + a_sub * 16;
-    const int v0 = (a_pix0 + toff) * Cs + cb, v1 = (a_pix1 + toff) * Cs + cb, v2 = (a_pix2 + toff) * Cs + cb,
-              v3 = (a_pix3 + toff) * Cs + cb;
-    const int vs = (s_pix + toff) * (Cs / 32) + ccl * 4;
-    const int wbase = (int)((size_t)s * w_step_stride);
+  int i_ty = 0, i_tx = 0, i_cc = 0, i_slot = 0, i_w = 0;       // issue stream: the next K-step to request
+  const int lane16 = lane * 16, lane4 = lane * 4;
+  auto issue = [&]() __attribute__((always_inline)) {
+    const bool first = i_cc < CC0;
+    const int toff = i_ty * p.Win + i_tx;
+    const int soff = first ? toff * p.C0 + i_cc * KQ : toff * p.C1 + (i_cc - CC0) * KQ;
+    const int ssoff = first ? toff * (p.C0 / 32) + i_cc * 4 : toff * (p.C1 / 32) + (i_cc - CC0) * 4;
+    char* st = smem + i_slot * STAGEQ;
+    const int m1 = first ? 0 : -1;
+    const int v0 = a00 + (d10 & m1), v1 = a01 + (d11 & m1), v2 = a02 + (d12 & m1), v3 = a03 + (d13 & m1), vs = as0 + (ds1 & m1);
 #define SRGD_DMAQ(RS_, DST_, VO_, SO_, SZ_) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_, (lds_ptrq)(DST_), SZ_, VO_, SO_, 0, 0)
-    if (first) {
-      SRGD_DMAQ(rq0, st + wave * 1024, v0, 0, 16);
-      SRGD_DMAQ(rq0, st + (wave + 8) * 1024, v1, 0, 16);
-      SRGD_DMAQ(rq0, st + (wave + 16) * 1024, v2, 0, 16);
-      SRGD_DMAQ(rq0, st + (wave + 24) * 1024, v3, 0, 16);
-      SRGD_DMAQ(rs0, st + AQ_BYTES + (wave & 3) * 256, vs, 0, 4);
-    } else {
-      SRGD_DMAQ(rq1, st + wave * 1024, v0, 0, 16);
-      SRGD_DMAQ(rq1, st + (wave + 8) * 1024, v1, 0, 16);
-      SRGD_DMAQ(rq1, st + (wave + 16) * 1024, v2, 0, 16);
-      SRGD_DMAQ(rq1, st + (wave + 24) * 1024, v3, 0, 16);
-      SRGD_DMAQ(rs1, st + AQ_BYTES + (wave & 3) * 256, vs, 0, 4);
-    }
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? qb0 : qb1), 0, first ? qn0 : qn1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? sb0 : sb1), 0, (first ? qn0 : qn1) >> 5, 0x00020000);
+    SRGD_DMAQ(rq, st + wave * 1024, v0, soff, 16);
+    SRGD_DMAQ(rq, st + (wave + 8) * 1024, v1, soff, 16);
+    SRGD_DMAQ(rq, st + (wave + 16) * 1024, v2, soff, 16);
+    SRGD_DMAQ(rq, st + (wave + 24) * 1024, v3, soff, 16);
+    SRGD_DMAQ(rs, st + AQ_BYTES + (wave & 3) * 256, vs, ssoff, 4);
     char* sb = st + AQ_BYTES + ASQ_BYTES;
-    SRGD_DMAQ(rsw, sb + wave * 1024, lane * 16, wbase + wave * 1024, 16);
-    SRGD_DMAQ(rsw, sb + (wave + 8) * 1024, lane * 16, wbase + (wave + 8) * 1024, 16);
-    SRGD_DMAQ(rsw, sb + BQ_TILE + (wave & 1) * 256, lane * 4, wbase + BQ_TILE + (wave & 1) * 256, 4);
+    SRGD_DMAQ(rsw, sb + wave * 1024, lane16, i_w + wave * 1024, 16);
+    SRGD_DMAQ(rsw, sb + (wave + 8) * 1024, lane16, i_w + (wave + 8) * 1024, 16);
+    SRGD_DMAQ(rsw, sb + BQ_TILE + (wave & 1) * 256, lane4, i_w + BQ_TILE + (wave & 1) * 256, 4);
 #undef SRGD_DMAQ
+    i_w += (int)w_step_stride;
+    i_slot = i_slot == RINGQ - 1 ? 0 : i_slot + 1;
+    if (++i_cc == CC) {
+      i_cc = 0;
+      if (++i_tx == p.KW) { i_tx = 0; ++i_ty; }
+    }
   };
 
   f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c10 = 0, c11 = 0, c12 = 0, c13 = 0,
@@ -155,8 +158,10 @@ __global__ __launch_bounds__(NTQ, 2) void conv1x1_mxfp8_kernel(Conv1QArgs p) {
   const int asb = AQ_BYTES + (wm * 64 + r16) * 4 + g;
   const int bb = AQ_BYTES + ASQ_BYTES + (wn * 64 + r16) * 128 + sw;
   const int bsb = AQ_BYTES + ASQ_BYTES + BQ_TILE + ((wn * 16 + r16) * 4 + g) * 4;
-  auto compute = [&](int s) {
-    const char* st = smem + (s % RINGQ) * STAGEQ;
+  int c_slot = 0;                                  // ring slot of the K-step being consumed
+  auto compute = [&]() __attribute__((always_inline)) {
+    const char* st = smem + c_slot * STAGEQ;
+    c_slot = c_slot == RINGQ - 1 ? 0 : c_slot + 1;
     v8iq a0, a1, a2, a3, b0, b1, b2, b3;
     int sa0, sa1, sa2, sa3;
 #define SRGD_LOADQ(DST_, BASE_, I_)                                                     \
@@ -193,13 +198,13 @@ __global__ __launch_bounds__(NTQ, 2) void conv1x1_mxfp8_kernel(Conv1QArgs p) {
   };
 
   // ---- pipeline: stages s+1 and s+2 in flight while stage s is consumed (8 DMA instructions per wave and stage)
-  issue(0);
-  if (S > 1) issue(1);
+  issue();
+  if (S > 1) issue();
   if (S > 1) WAIT_VMQ(8); else WAIT_VMQ(0);
   BARRIERQ();
   for (int s = 0; s < S; ++s) {
-    if (s + 2 < S) issue(s + 2);
-    compute(s);
+    if (s + 2 < S) issue();
+    compute();
     if (s + 2 < S) WAIT_VMQ(8); else WAIT_VMQ(0);   // stage s+1 has landed (this wave's part; the barrier covers the rest)
     BARRIERQ();
   }

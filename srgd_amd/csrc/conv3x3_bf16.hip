@@ -239,12 +239,16 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     if constexpr (M16 && !GNIN) {
       const int Pc = ((i >> 1) + dy) * WP + (i & 1) * 16 + dx;
       return lp64 + (((lp8 + Pc * 8 + opq) & 0x30) ^ q16s) + Pc * 64;
+    } else if constexpr (M16) {
+      // the GNIN instances refresh `opq` every tap so that NO address part survives a tap in a register (they carry ~13 more
+      // long-lived registers; with the split form above the eight swizzle terms of a chunk stay live and 33 registers spill into
+      // the K loop): P * 8 once, then P * 64 and the swizzle term from it - four VALU instructions per address instead of six
+      const int Pc = ((i >> 1) + dy) * WP + (i & 1) * 16 + dx;
+      const int t = lp8 + Pc * 8 + opq;
+      return (t << 3) + ((t & 0x30) ^ q16s);
     } else {
-      // (the GNIN instances keep round 2's form: they refresh `opq` every tap so that NO address part survives a tap in a
-      // register - with the split form the eight swizzle terms of a chunk stay live and 33 registers spill into the K loop)
-      const int P = M16 ? (2 * wm + (i >> 1) + dy) * WP + (i & 1) * 16 + r16 + dx + opq
-                        : (2 * wm + i + dy) * WP + r + dx + opq;
-      return P * 64 + (((M16 ? q16 : h) ^ row_swz<M16>(P)) << 4);
+      const int P = (2 * wm + i + dy) * WP + r + dx + opq;
+      return P * 64 + ((h ^ row_swz<M16>(P)) << 4);
     }
   };
   auto compute = [&](int cc, int tap, int s) {

@@ -113,7 +113,6 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
   const int y0 = ty * QPH, x0 = tx * QPW;
   const int CC0 = p.C0 / QKC, CC = (p.C0 + p.C1) / QKC;
-  const int S = CC * 9;
 
   // ---- A staging: 44 pieces of 1 KiB per chunk, wave w issues pieces w, w+4, ..., w+40; 16-byte chunk index in the LDS image
   // = piece*64 + lane -> pixel P = idx >> 3, stored position idx & 7 holds logical chunk (idx & 7) ^ (P & 6).
@@ -163,9 +162,12 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
       if (first) dma4(rs0, sAs + (wave + 4 * k) * 256, voff); else dma4(rs1, sAs + (wave + 4 * k) * 256, voff);
     }
   };
-  auto issue_b = [&](int s, int slot) {           // K-step s = cc*9 + tap -> weight unit (tap, cc) into ring slot `slot`
-    const int cc = s / 9, tap = s - cc * 9;
-    const int base = (int)((size_t)(tap * CC + cc) * w_step_stride);
+  // weight unit (tap, cc) into ring slot `slot`.  `tap` is a compile-time constant at every call site (unrolled tap loop), so the
+  // unit's offset is one scalar multiply-add (round 2 divided the runtime step index by 9: ~30 SALU instructions per step on
+  // the issue path of a wave that should be feeding the matrix pipe).
+  const int w_tap_stride = (int)(CC * w_step_stride);
+  auto issue_b = [&](int cc, int tap, int slot) {
+    const int base = tap * w_tap_stride + cc * (int)w_step_stride;
     char* dst = sB0 + slot * QB_BYTES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) dma16(rsw, dst + (wave + 4 * j) * 1024, lane * 16, base + (wave + 4 * j) * 1024);
@@ -187,6 +189,12 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   const int lanepix = 4 * wm * QWP + r16;
   const int apix = lanepix * 128;                                   // byte offset of the lane's pixel row (before Pc)
   const int r7 = r16 & 7;
+  // the eight swizzled per-lane bases (one per value of Pc & 7) and their (address ^ 64) partners: 16 registers, and NO address
+  // arithmetic in the K loop (round 2 recomputed them per fragment - 4-5 VALU instructions x 8 fragments per step - because the
+  // kernel had no registers to spare; the tied MFMAs freed 54)
+#define SRGD_QABASE(K) const int ab##K = apix + ((g ^ (((K) + r7) & 6)) << 4), ac##K = ab##K ^ 64;
+  SRGD_QABASE(0) SRGD_QABASE(1) SRGD_QABASE(2) SRGD_QABASE(3) SRGD_QABASE(4) SRGD_QABASE(5) SRGD_QABASE(6) SRGD_QABASE(7)
+#undef SRGD_QABASE
   const int asb = lanepix * 4 + g;                                  // scale byte of (pixel, channel block g)
   // B: n = 64 wn + 16 J + r16 -> n & 6 = r16 & 6
   const int bb = (wn * 64 + r16) * 128 + ((g ^ (r16 & 6)) << 4);
@@ -197,18 +205,13 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
 
   // One K-step: the 4 weight fragments (64 output channels of this wave) stay in registers, the 8 pixel fragments stream
   // through one at a time - 24 ds_read_b128 per 32 MFMAs, and 128 + 32 + 16 operand/accumulator registers.
-  auto compute = [&](int tap, int s) {
-    const char* Bt = sB0 + (s % QRING) * QB_BYTES;
+  auto compute = [&](int tap, int slot) {
+    const char* Bt = sB0 + slot * QB_BYTES;
     const int dy = tap / 3, dx = tap - dy * 3;
-    // The swizzle term of a fragment, ((Pc & 7) + r7) & 6) ^ g, costs 3 VALU instructions from the opaque copy of r7
-    // (refreshed per tap) + 1 for the second chunk at (address ^ 64): 32 per tap.  Kept as 16 per-lane bases instead it
-    // would need no arithmetic at all, but those registers do not exist next to 128 accumulators (26 spills, measured).
-    int r7t = r7;
-    asm volatile("" : "+v"(r7t));
     v8i b0, b1, b2, b3;
 #ifdef SRGD_MXFP8_DIAG_NOB                  // timing-only diagnostic (wrong results): weight fragments made up in registers
-    const int sbw = r7t;
-#define SRGD_QLOAD_B(J) b##J = v8i{r7t, lane, r7t + J, lane, r7t, lane + J, r7t, lane};
+    const int sbw = r7;
+#define SRGD_QLOAD_B(J) b##J = v8i{r7, lane, r7 + J, lane, r7, lane + J, r7, lane};
 #else
     const int sbw = *reinterpret_cast<const int*>(Bt + bsb);
 #define SRGD_QLOAD_B(J)                                                              \
@@ -230,9 +233,11 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     if (SRGD_MXFP8_DIAG_NOLDS && (I) > 0) { a##I = a0; sa##I = sa0; } else           \
     {                                                                                \
       const int Pc = ((I >> 1) + dy) * QWP + (I & 1) * 16 + dx;                      \
-      const int o = apix + ((g ^ (((Pc & 7) + r7t) & 6)) << 4);                      \
+      const int k7 = Pc & 7;                                                         \
+      const int o = k7 == 0 ? ab0 : k7 == 1 ? ab1 : k7 == 2 ? ab2 : k7 == 3 ? ab3 : k7 == 4 ? ab4 : k7 == 5 ? ab5 : k7 == 6 ? ab6 : ab7; \
+      const int o2 = k7 == 0 ? ac0 : k7 == 1 ? ac1 : k7 == 2 ? ac2 : k7 == 3 ? ac3 : k7 == 4 ? ac4 : k7 == 5 ? ac5 : k7 == 6 ? ac6 : ac7; \
       const v4i lo = *reinterpret_cast<const v4i*>(sA + o + Pc * 128);               \
-      const v4i hi = *reinterpret_cast<const v4i*>(sA + (o ^ 64) + Pc * 128);        \
+      const v4i hi = *reinterpret_cast<const v4i*>(sA + o2 + Pc * 128);              \
       a##I = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};            \
       sa##I = *reinterpret_cast<const unsigned char*>(sAs + asb + Pc * 4);           \
     }
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
 
   // ---- prologue: A(0), B[0]
   issue_a(0);
-  issue_b(0, 0);
+  issue_b(0, 0, 0);
   QWAIT_VM(0);
   QBARRIER();
 
@@ -313,11 +318,12 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   for (int cc = 0; cc < CC; ++cc) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int s = cc * 9 + tap;
+      const int slot = (cc + tap) & 1;               // step s = cc * 9 + tap lives in ring slot s % 2
 #ifndef SRGD_MXFP8_DIAG_NODMA              // timing-only diagnostic (wrong results): no weight DMA inside the K loop
-      issue_b(min(s + 1, S - 1), (s + 1) % QRING);   // (the last step re-fetches its own unit into the idle slot)
+      if (tap < 8) issue_b(cc, tap + 1, slot ^ 1);
+      else issue_b(min(cc + 1, CC - 1), cc + 1 < CC ? 0 : 8, slot ^ 1);   // (the last step re-fetches its own unit into the idle slot)
 #endif
-      compute(tap, s);
+      compute(tap, slot);
 #ifdef SRGD_MXFP8_DIAG_LATE_WAIT           // timing-only diagnostic (wrong results): the step does not wait for its weight DMA -
       QWAIT_VM(10);                        // two more steps' worth may stay in flight - to price the DMA latency on the critical path
 #else
