@@ -1,4 +1,4 @@
-# round 3, GPU job m: full GPU suite on the final defaults, default bench with its cpu_baseline leg, then tools/run_profiles.sh
+# One gpurun job (about 9 minutes of box time): full GPU suite on the final defaults, default bench with its cpu_baseline leg, then tools/run_profiles.sh
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3m; mkdir -p $O; cd $R
 (time timeout -k 10 1100 python -m pytest tests -m gpu -x -q --durations=12) > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log
 cp gpurun_out/parity_report.jsonl $O/ 2>/dev/null
