@@ -37,7 +37,7 @@ constexpr int QPH = 8, QPW = 32;                 // output patch
 constexpr int QHP = QPH + 2, QWP = QPW + 2;      // halo patch: 10 x 34 = 340 pixels
 constexpr int QKC = 128;                         // channels per chunk = K of one MFMA
 constexpr int QBN = 128;
-constexpr int QNT = 256;
+constexpr int QNW_DEFAULT = 4;                   // waves per workgroup of the shipped instance (kernel template parameter NW; 8 measured 3-7 % slower)
 constexpr int QA_PIECES = 11;                    // 1 KiB LDS-DMA pieces per wave and chunk
 constexpr int QA_BYTES = 4 * QA_PIECES * 1024;   // 44 KiB (340 px * 128 B = 43,520 used)
 constexpr int QAS_BYTES = 2048;                  // activation scales: 4 B per halo pixel (1,360 used), 2 dword pieces per wave
@@ -84,8 +84,20 @@ __device__ __forceinline__ int lane_id_opaque() {
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 
-template <bool STATS>
-__global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
+// NW = waves per workgroup.  4 (round 2): 2 x 2 waves, wave tile 128 x 64 (128 accumulators, <= 256 VGPRs), two waves per SIMD.
+// 8 (round 3): 4 x 2 waves, wave tile 64 x 64 (64 accumulators, <= 128 VGPRs), FOUR waves per SIMD at the same two workgroups per
+// CU - the bf16 kernel's shape.  Round 3's diagnostics showed the 4-wave kernel is bound by neither LDS, DMA nor
+// barriers; the hypothesis behind this shape - a wave's MFMA stream has gaps and with two waves per SIMD nothing fills them while
+// the co-resident workgroup is in its prologue, epilogue or a chunk-boundary patch reload - did not hold: correct (same tests),
+// and 3-7 % SLOWER on all twelve shapes (profiles/r3/conv3x3_mxfp8_w8_ab.txt; 33 % more ds_read bytes per FLOP, pixel fragments
+// single-buffered to fit 64 VGPRs next to 64 accumulator AGPRs).  Kept as an A/B switch (SRGD_MXFP8_WAVES=8); 4 ships.
+template <bool STATS, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
+  constexpr int NT = NW * 64;               // threads
+  constexpr int NWM = NW / 2;               // wave rows (along pixels); 2 wave columns (along channels)
+  constexpr int RPW = QPH / NWM;            // patch rows per wave: 4 or 2
+  constexpr int NM = RPW * 2;               // 16-pixel fragments per wave: 8 or 4
+  constexpr int A_PIECES = (4 * QA_PIECES + NW - 1) / NW;      // 1 KiB halo-patch pieces per wave and chunk: 11 or 6
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sA = smem;
   char* const sAs = smem + QA_BYTES;
@@ -137,7 +149,7 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.w + (size_t)nt * QB_BYTES), 0, (int)((size_t)(9 * CC - 1) * w_step_stride + QB_BYTES), 0x00020000);
 
-  auto issue_a = [&](int cc) {                    // 11 + 2 DMA instructions per wave
+  auto issue_a = [&](int cc) {                    // 11 + 2 (NW = 4) or <= 6 + 1 (NW = 8) DMA instructions per wave
     const bool first = cc < CC0;
     const int Cs = first ? p.C0 : p.C1;
     const int ccl = first ? cc : cc - CC0;
@@ -145,21 +157,22 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     // hoisted out of the K loop they cost 26 long-lived VGPRs; so would a copy of the lane id kept for this purpose alone)
     const int opq_a = lane_id_opaque();
 #pragma unroll
-    for (int j = 0; j < QA_PIECES; ++j) {
-      const int idx = (wave + 4 * j) * 64 + opq_a;
+    for (int j = 0; j < A_PIECES; ++j) {
+      if (NW * j + wave >= 4 * QA_PIECES) break;  // (NW = 8: 44 pieces over 8 waves - the last round only has waves 0..3; uniform)
+      const int idx = (wave + NW * j) * 64 + opq_a;
       const int P = idx >> 3;
       const int pix = halo_pix(P);
       const int sub = (idx & 7) ^ (P & 6);
       const int voff = pix >= 0 ? pix * Cs + ccl * QKC + sub * 16 : 0x7ffffff0;
-      char* dst = sA + (wave + 4 * j) * 1024;
+      char* dst = sA + (wave + NW * j) * 1024;
       if (first) dma16(rq0, dst, voff); else dma16(rq1, dst, voff);
     }
     const int Cs32 = Cs / 32;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {                 // scale dwords of halo pixels (wave + 4k)*64 .. +63
-      const int pix = halo_pix((wave + 4 * k) * 64 + opq_a);
+    for (int k = 0; k < 8 / NW; ++k) {            // scale dwords of halo pixels (wave + NW k)*64 .. +63 (8 pieces cover 512 >= 340)
+      const int pix = halo_pix((wave + NW * k) * 64 + opq_a);
       const int voff = pix >= 0 ? pix * Cs32 + ccl * 4 : 0x7ffffff0;
-      if (first) dma4(rs0, sAs + (wave + 4 * k) * 256, voff); else dma4(rs1, sAs + (wave + 4 * k) * 256, voff);
+      if (first) dma4(rs0, sAs + (wave + NW * k) * 256, voff); else dma4(rs1, sAs + (wave + NW * k) * 256, voff);
     }
   };
   // weight unit (tap, cc) into ring slot `slot`.  `tap` is a compile-time constant at every call site (unrolled tap loop), so the
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     const int base = tap * w_tap_stride + cc * (int)w_step_stride;
     char* dst = sB0 + slot * QB_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma16(rsw, dst + (wave + 4 * j) * 1024, lane * 16, base + (wave + 4 * j) * 1024);
+    for (int j = 0; j < 16 / NW; ++j) dma16(rsw, dst + (wave + NW * j) * 1024, lane * 16, base + (wave + NW * j) * 1024);
     // the 512 scale bytes: waves 0 and 1 would do; waves 2 and 3 repeat their transfers (same bytes to the same place) so
     // that every wave issues the same five instructions and the tap loop stays branch-free
     dma4(rsw, dst + QB_TILE + (wave & 1) * 256, lane * 4, base + QB_TILE + (wave & 1) * 256);
@@ -186,9 +199,9 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   // 136 = 17 * 8, so (P & 6) depends only on (Pc & 7) and the lane: eight per-lane bases (one per value of Pc & 7) are
   // computed once, and every fragment read is base[Pc & 7] + an immediate - no address arithmetic inside the K loop
   // (the first version recomputed ~100 VALU instructions per tap next to 32 MFMAs).
-  const int lanepix = 4 * wm * QWP + r16;
+  const int lanepix = RPW * wm * QWP + r16;
   const int apix = lanepix * 128;                                   // byte offset of the lane's pixel row (before Pc)
-  const int r7 = r16 & 7;
+  const int r7 = lanepix & 7;                                       // P & 6 = ((Pc & 7) + (lanepix & 7)) & 6  (NW = 4: 136 wm vanishes)
   // the eight swizzled per-lane bases (one per value of Pc & 7) and their (address ^ 64) partners: 16 registers, and NO address
   // arithmetic in the K loop (round 2 recomputed them per fragment - 4-5 VALU instructions x 8 fragments per step - because the
   // kernel had no registers to spare; the tied MFMAs freed 54)
@@ -208,6 +221,8 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   auto compute = [&](int tap, int slot) {
     const char* Bt = sB0 + slot * QB_BYTES;
     const int dy = tap / 3, dx = tap - dy * 3;
+    int r7t = r7;                                  // NW = 8: refreshed per step, so that no fragment address survives a step in a register
+    if constexpr (NW == 8) asm volatile("" : "+v"(r7t));
     v8i b0, b1, b2, b3;
 #ifdef SRGD_MXFP8_DIAG_NOB                  // timing-only diagnostic (wrong results): weight fragments made up in registers
     const int sbw = r7;
@@ -234,8 +249,11 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     {                                                                                \
       const int Pc = ((I >> 1) + dy) * QWP + (I & 1) * 16 + dx;                      \
       const int k7 = Pc & 7;                                                         \
-      const int o = k7 == 0 ? ab0 : k7 == 1 ? ab1 : k7 == 2 ? ab2 : k7 == 3 ? ab3 : k7 == 4 ? ab4 : k7 == 5 ? ab5 : k7 == 6 ? ab6 : ab7; \
-      const int o2 = k7 == 0 ? ac0 : k7 == 1 ? ac1 : k7 == 2 ? ac2 : k7 == 3 ? ac3 : k7 == 4 ? ac4 : k7 == 5 ? ac5 : k7 == 6 ? ac6 : ac7; \
+      /* NW = 4: one of the 16 precomputed bases; NW = 8 (128-register budget): 3 + 1 VALU from the opaque copy of r7 */ \
+      const int o = NW == 8 ? apix + ((g ^ ((k7 + r7t) & 6)) << 4)                                                      \
+                  : k7 == 0 ? ab0 : k7 == 1 ? ab1 : k7 == 2 ? ab2 : k7 == 3 ? ab3 : k7 == 4 ? ab4 : k7 == 5 ? ab5 : k7 == 6 ? ab6 : ab7; \
+      const int o2 = NW == 8 ? (o ^ 64)                                                                                 \
+                   : k7 == 0 ? ac0 : k7 == 1 ? ac1 : k7 == 2 ? ac2 : k7 == 3 ? ac3 : k7 == 4 ? ac4 : k7 == 5 ? ac5 : k7 == 6 ? ac6 : ac7; \
       const v4i lo = *reinterpret_cast<const v4i*>(sA + o + Pc * 128);               \
       const v4i hi = *reinterpret_cast<const v4i*>(sA + o2 + Pc * 128);              \
       a##I = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};            \
@@ -254,15 +272,42 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
 #define SRGD_QMM_OPSEL_1 "op_sel:[0,1,0] op_sel_hi:[0,0,0]"
 #define SRGD_QMM_OPSEL_2 "op_sel_hi:[0,1,0]"
 #define SRGD_QMM_OPSEL_3 "op_sel:[0,1,0] op_sel_hi:[0,1,0]"
+    // NW = 8: the accumulators live in AGPRs ("+a"; gfx950's register file is unified, 128 per wave at four waves per SIMD):
+    // 64 AGPRs + <= 64 VGPRs are two allocation problems the register allocator can solve; as one class of 128 with 4- and
+    // 8-register tuples it spilled 120-160 registers (accumulators included) into the K loop.
 #define SRGD_QMM(C_, A_, SA_, B_, J_)                                                                      \
-    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " SRGD_QMM_OPSEL_##J_            \
-                 : "+v"(C_) : "v"(A_), "v"(B_), "v"(SA_), "v"(sbw))
+    if constexpr (NW == 8)                                                                                 \
+      asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " SRGD_QMM_OPSEL_##J_          \
+                   : "+a"(C_) : "v"(A_), "v"(B_), "v"(SA_), "v"(sbw));                                     \
+    else                                                                                                   \
+      asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " SRGD_QMM_OPSEL_##J_          \
+                   : "+v"(C_) : "v"(A_), "v"(B_), "v"(SA_), "v"(sbw))
 #define SRGD_QROW(I)                                                                 \
     SRGD_QMM(c##I##0, a##I, sa##I, b0, 0); SRGD_QMM(c##I##1, a##I, sa##I, b1, 1);    \
     SRGD_QMM(c##I##2, a##I, sa##I, b2, 2); SRGD_QMM(c##I##3, a##I, sa##I, b3, 3);
     // software pipeline over the pixel fragments, fenced for the scheduler (left alone it hoists all eight fragment loads to
     // the top of the step and spills ~130 registers into the loop): the loads of fragment i+1 are issued ahead of the 4 MFMAs
     // (128 cycles of matrix pipe) of fragment i; two fragments live at a time
+    if constexpr (NW == 8) {
+      // 64 VGPRs next to the 64 accumulator AGPRs: the four weight fragments (32) stay, the pixel fragments stream through ONE
+      // at a time (9 registers) - with four waves per SIMD another wave's MFMAs cover the fragment's LDS latency
+      SRGD_QLOAD_A(0)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QROW(0)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QLOAD_A(1)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QROW(1)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QLOAD_A(2)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QROW(2)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QLOAD_A(3)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QROW(3)
+      return;
+    }
     SRGD_QLOAD_A(0)
     __builtin_amdgcn_sched_barrier(0);
     SRGD_QLOAD_A(1)
@@ -277,23 +322,27 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     SRGD_QROW(2)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(4)
-    __builtin_amdgcn_sched_barrier(0);
-    SRGD_QROW(3)
-    __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(5)
-    __builtin_amdgcn_sched_barrier(0);
-    SRGD_QROW(4)
-    __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(6)
-    __builtin_amdgcn_sched_barrier(0);
-    SRGD_QROW(5)
-    __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(7)
-    __builtin_amdgcn_sched_barrier(0);
-    SRGD_QROW(6)
-    __builtin_amdgcn_sched_barrier(0);
-    SRGD_QROW(7)
+    if constexpr (NM == 8) {
+      SRGD_QLOAD_A(4)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QROW(3)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QLOAD_A(5)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QROW(4)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QLOAD_A(6)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QROW(5)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QLOAD_A(7)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QROW(6)
+      __builtin_amdgcn_sched_barrier(0);
+      SRGD_QROW(7)
+    } else {
+      SRGD_QROW(3)
+    }
 #undef SRGD_QROW
 #undef SRGD_QMM
 #undef SRGD_QMM_OPSEL_0
@@ -333,7 +382,11 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
       QBARRIER();
 #endif
     }
+#ifdef SRGD_MXFP8_DIAG_NOAPATCH              // timing-only diagnostic (wrong results): the halo patch is staged once per tile
+    if (false) {
+#else
     if (cc + 1 < CC) {
+#endif
       issue_a(cc + 1);                             // every wave passed the barrier above: the old patch is dead
       QWAIT_VM(0);
       QBARRIER();
@@ -343,10 +396,17 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   // The MFMAs are inline asm (compute()): the compiler does not know that the accumulators were written by the matrix pipe and
   // inserts none of the wait states a VALU read of an XDL result needs (<= 18 for a 16-pass MFMA).  The accumulators are
   // threaded through these statements, so every epilogue read comes after >= 32 wait states behind the last MFMA.
-  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
-  asm volatile("" : "+v"(c20), "+v"(c21), "+v"(c22), "+v"(c23), "+v"(c30), "+v"(c31), "+v"(c32), "+v"(c33));
-  asm volatile("" : "+v"(c40), "+v"(c41), "+v"(c42), "+v"(c43), "+v"(c50), "+v"(c51), "+v"(c52), "+v"(c53));
-  asm volatile("" : "+v"(c60), "+v"(c61), "+v"(c62), "+v"(c63), "+v"(c70), "+v"(c71), "+v"(c72), "+v"(c73));
+  if constexpr (NW == 8) {
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(c00), "+a"(c01), "+a"(c02), "+a"(c03), "+a"(c10), "+a"(c11), "+a"(c12), "+a"(c13));
+    asm volatile("" : "+a"(c20), "+a"(c21), "+a"(c22), "+a"(c23), "+a"(c30), "+a"(c31), "+a"(c32), "+a"(c33));
+  } else {
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
+    asm volatile("" : "+v"(c20), "+v"(c21), "+v"(c22), "+v"(c23), "+v"(c30), "+v"(c31), "+v"(c32), "+v"(c33));
+  }
+  if constexpr (NM == 8) {
+    asm volatile("" : "+v"(c40), "+v"(c41), "+v"(c42), "+v"(c43), "+v"(c50), "+v"(c51), "+v"(c52), "+v"(c53));
+    asm volatile("" : "+v"(c60), "+v"(c61), "+v"(c62), "+v"(c63), "+v"(c70), "+v"(c71), "+v"(c72), "+v"(c73));
+  }
 
   // ------------------------------- epilogue -------------------------------------------
   // tile transposed through LDS ([256 pixels][128 ch] bf16, rows padded to 272 B), stored as whole 256-byte channel rows
@@ -365,11 +425,11 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     const int cl = wn * 64 + ni * 16 + r16E;               // column inside the tile
     const float bias = p.bias ? p.bias[nt * QBN + cl] : 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
+    for (int mi = 0; mi < NM; ++mi) {
       const f32x4 av = mi == 0 ? SRGD_QACC(0, ni) : mi == 1 ? SRGD_QACC(1, ni) : mi == 2 ? SRGD_QACC(2, ni) : mi == 3 ? SRGD_QACC(3, ni)
                      : mi == 4 ? SRGD_QACC(4, ni) : mi == 5 ? SRGD_QACC(5, ni) : mi == 6 ? SRGD_QACC(6, ni) : SRGD_QACC(7, ni);
-      // D map: column = laneE & 15, row = (laneE >> 4) * 4 + reg -> pixel (patch row 4 wm + (mi >> 1), x = 16 (mi & 1) + 4 gE + reg)
-      char* trow = smem + ((4 * wm + (mi >> 1)) * QPW + (mi & 1) * 16 + gE * 4) * EROW + cl * 2;
+      // D map: column = laneE & 15, row = (laneE >> 4) * 4 + reg -> pixel (patch row RPW wm + (mi >> 1), x = 16 (mi & 1) + 4 gE + reg)
+      char* trow = smem + ((RPW * wm + (mi >> 1)) * QPW + (mi & 1) * 16 + gE * 4) * EROW + cl * 2;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const float v = av[reg] + bias;
@@ -384,7 +444,7 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
 #undef SRGD_QACC
   // column sums behind the staged tile: one barrier publishes both, and nothing below waits for the output stores
   // (conv3x3_bf16.hip: reducing after the stores cost ~6,000 cycles per tile behind a vmcnt(0))
-  float* const cs = reinterpret_cast<float*>(smem + QPH * QPW * EROW);      // [2 (wm)][128][2] floats at byte 69,632 (< QLDS)
+  float* const cs = reinterpret_cast<float*>(smem + QPH * QPW * EROW);      // [NWM (wm)][128][2] floats at byte 69,632 (2 or 4 KiB: < QLDS)
   if (STATS) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -404,8 +464,8 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   {
     bf16* obase = p.out + ((size_t)(b * p.H + y0) * p.W + x0) * p.Cout + nt * QBN;
 #pragma unroll
-    for (int i = 0; i < (QPH * QPW * 16) / QNT; ++i) {
-      const int q = tidE + QNT * i;                        // 16-byte chunk: pixel q/16, channels (q%16)*8..+7
+    for (int i = 0; i < (QPH * QPW * 16) / NT; ++i) {
+      const int q = tidE + NT * i;                        // 16-byte chunk: pixel q/16, channels (q%16)*8..+7
       const int pix = q >> 4, c16 = q & 15;
       const int py = pix / QPW, px = pix - py * QPW;
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + pix * EROW + c16 * 16);
@@ -420,7 +480,7 @@ __global__ __launch_bounds__(QNT, 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
     float a1 = 0.f, a2 = 0.f;
     if (tidE < QBN) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < NWM; ++k) {
         a1 += cs[(k * QBN + tidE) * 2 + 0];
         a2 += cs[(k * QBN + tidE) * 2 + 1];
       }
@@ -543,13 +603,21 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   const int grid = a.B * (a.Hin / QPH) * (a.Win / QPW) * (a.Cout / QBN);
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<true>),
+#define SRGD_SETQ(S_, N_)                                                                                 \
+    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<S_, N_>),              \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
-    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+    SRGD_SETQ(true, 4) SRGD_SETQ(false, 4) SRGD_SETQ(true, 8) SRGD_SETQ(false, 8)
+#undef SRGD_SETQ
   }
-  if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true>), dim3(grid), dim3(QNT), QLDS, st, p);
-  else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false>), dim3(grid), dim3(QNT), QLDS, st, p);
+  static int nw = 0;                                       // SRGD_MXFP8_WAVES=8: the 8-wave shape (A/B switch)
+  if (!nw) { const char* v = getenv("SRGD_MXFP8_WAVES"); nw = v ? (atoi(v) == 8 ? 8 : 4) : QNW_DEFAULT; }
+  if (nw == 8) {
+    if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true, 8>), dim3(grid), dim3(512), QLDS, st, p);
+    else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false, 8>), dim3(grid), dim3(512), QLDS, st, p);
+  } else {
+    if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true, 4>), dim3(grid), dim3(256), QLDS, st, p);
+    else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false, 4>), dim3(grid), dim3(256), QLDS, st, p);
+  }
   SRGD_HIP(hipGetLastError());
   return 0;
 }
