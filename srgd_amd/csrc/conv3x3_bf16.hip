@@ -382,10 +382,13 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
   constexpr int NI = M16 ? 4 : 2;                         // column blocks per wave (16 or 32 wide)
   float s1[NI], s2[NI];
+  f32x2 s1p[NI], s2p[NI];                                 // 16x16 path: the column sums as register pairs (even | odd rows)
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     s1[ni] = 0.f;
     s2[ni] = 0.f;
+    s1p[ni] = f32x2{0.f, 0.f};
+    s2p[ni] = f32x2{0.f, 0.f};
     const int cl = M16 ? wn * 64 + ni * 16 + r16E : wn * 64 + ni * 32 + rE;       // column inside the tile
     const float bias = p.bias ? p.bias[nt * BN3 + cl] : 0.f;
     if constexpr (M16) {
@@ -397,15 +400,26 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
                                  : (ni == 0 ? c30 : ni == 1 ? c31 : ni == 2 ? c32 : c33);
         // C layout of 16x16: column = laneE & 15, row = (laneE >> 4) * 4 + reg  ->  pixel (mi & 1) * 16 + row of patch row
         char* trow = smem + ((2 * wm + (mi >> 1)) * PW + (mi & 1) * 16 + q16E * 4) * EROW + cl * 2;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const float v = av[reg] + bias;
-          if (STATS) {
-            s1[ni] += v;
-            s2[ni] += v * v;
-          }
-          *reinterpret_cast<bf16*>(trow + reg * EROW) = (bf16)v;
+        // round 3: the epilogue is ~40 % of the instruction stream of a 36-step tile, so it is written for instruction count:
+        // packed fp32 adds / fmas on register pairs (v_pk_add_f32, v_pk_fma_f32), ONE v_cvt_pk_bf16_f32 per two values whose
+        // halves go out as ds_write_b16 / ds_write_b16_d16_hi
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const f32x2 b2 = {bias, bias};
+        const f32x2 v01 = f32x2{av[0], av[1]} + b2, v23 = f32x2{av[2], av[3]} + b2;
+        if (STATS) {
+          s1p[ni] += v01 + v23;
+          s2p[ni] = __builtin_elementwise_fma(v01, v01, s2p[ni]);
+          s2p[ni] = __builtin_elementwise_fma(v23, v23, s2p[ni]);
         }
+        const bf16x2_t t01 = __builtin_convertvector(v01, bf16x2_t), t23 = __builtin_convertvector(v23, bf16x2_t);
+        *reinterpret_cast<bf16*>(trow) = t01[0];
+        *reinterpret_cast<bf16*>(trow + EROW) = t01[1];
+        *reinterpret_cast<bf16*>(trow + 2 * EROW) = t23[0];
+        *reinterpret_cast<bf16*>(trow + 3 * EROW) = t23[1];
+      }
+      if (STATS) {
+        s1[ni] = s1p[ni][0] + s1p[ni][1];
+        s2[ni] = s2p[ni][0] + s2p[ni][1];
       }
     } else {
 #pragma unroll
@@ -449,14 +463,17 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   __syncthreads();                                        // (no global store is outstanding yet: this does not wait for HBM)
   if (p.stamps) t3 = __builtin_amdgcn_s_memtime();
   {
-    bf16* obase = p.out + ((size_t)(b * p.H + y0) * p.W + x0) * p.Cout + nt * BN3;
+    // 16-byte chunk q = tidE + 512 i: pixel q / 16 = patch row i (512 threads = one 32-pixel row x 16 chunks), column tidE / 16,
+    // channels (tidE % 16) * 8 .. +7: ONE per-lane address and a uniform row stride instead of eight 64-bit address computations
+    static_assert(NT3 == PW * 16 && (PH * PW * 16) / NT3 == PH, "store loop: one patch row per iteration");
+    const int pxE = tidE >> 4, c16 = tidE & 15;
+    bf16* o = p.out + ((size_t)(b * p.H + y0) * p.W + x0 + pxE) * p.Cout + nt * BN3 + c16 * 8;
+    const char* src = smem + pxE * EROW + c16 * 16;
+    const size_t row_stride = (size_t)p.W * p.Cout;
 #pragma unroll
-    for (int i = 0; i < (PH * PW * 16) / NT3; ++i) {
-      const int q = tidE + NT3 * i;                       // 16-byte chunk: pixel q/16, channels (q%16)*8..+7
-      const int pix = q >> 4, c16 = q & 15;
-      const int py = pix / PW, px = pix - py * PW;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + pix * EROW + c16 * 16);
-      *reinterpret_cast<bf16x8*>(obase + ((size_t)py * p.W + px) * p.Cout + c16 * 8) = v;
+    for (int i = 0; i < PH; ++i) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + i * PW * EROW);
+      *reinterpret_cast<bf16x8*>(o + i * row_stride) = v;
     }
   }
   if (p.stamps) t4 = __builtin_amdgcn_s_memtime();

@@ -424,21 +424,32 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
     s2[ni] = 0.f;
     const int cl = wn * 64 + ni * 16 + r16E;               // column inside the tile
     const float bias = p.bias ? p.bias[nt * QBN + cl] : 0.f;
+    f32x2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};              // the column's sums as a register pair (even | odd rows)
 #pragma unroll
     for (int mi = 0; mi < NM; ++mi) {
       const f32x4 av = mi == 0 ? SRGD_QACC(0, ni) : mi == 1 ? SRGD_QACC(1, ni) : mi == 2 ? SRGD_QACC(2, ni) : mi == 3 ? SRGD_QACC(3, ni)
                      : mi == 4 ? SRGD_QACC(4, ni) : mi == 5 ? SRGD_QACC(5, ni) : mi == 6 ? SRGD_QACC(6, ni) : SRGD_QACC(7, ni);
       // D map: column = laneE & 15, row = (laneE >> 4) * 4 + reg -> pixel (patch row RPW wm + (mi >> 1), x = 16 (mi & 1) + 4 gE + reg)
       char* trow = smem + ((RPW * wm + (mi >> 1)) * QPW + (mi & 1) * 16 + gE * 4) * EROW + cl * 2;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const float v = av[reg] + bias;
-        if (STATS) {
-          s1[ni] += v;
-          s2[ni] += v * v;
-        }
-        *reinterpret_cast<bf16*>(trow + reg * EROW) = (bf16)v;
+      // written for instruction count (conv3x3_bf16.hip: the epilogue is 35-40 % of a 9-step tile's instruction stream here):
+      // packed fp32 adds / fmas on register pairs, one v_cvt_pk_bf16_f32 per two values, ds_write_b16 + ds_write_b16_d16_hi
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      const f32x2 b2 = {bias, bias};
+      const f32x2 v01 = f32x2{av[0], av[1]} + b2, v23 = f32x2{av[2], av[3]} + b2;
+      if (STATS) {
+        s1p += v01 + v23;
+        s2p = __builtin_elementwise_fma(v01, v01, s2p);
+        s2p = __builtin_elementwise_fma(v23, v23, s2p);
       }
+      const bf16x2_t t01 = __builtin_convertvector(v01, bf16x2_t), t23 = __builtin_convertvector(v23, bf16x2_t);
+      *reinterpret_cast<bf16*>(trow) = t01[0];
+      *reinterpret_cast<bf16*>(trow + EROW) = t01[1];
+      *reinterpret_cast<bf16*>(trow + 2 * EROW) = t23[0];
+      *reinterpret_cast<bf16*>(trow + 3 * EROW) = t23[1];
+    }
+    if (STATS) {
+      s1[ni] = s1p[0] + s1p[1];
+      s2[ni] = s2p[0] + s2p[1];
     }
   }
 #undef SRGD_QACC
@@ -462,16 +473,20 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
   }
   __syncthreads();
   {
-    bf16* obase = p.out + ((size_t)(b * p.H + y0) * p.W + x0) * p.Cout + nt * QBN;
+    // 16-byte chunk q = tidE + NT i: NT / 16 pixels per iteration = whole patch rows (NT = 256: half a row), so pixel
+    // (row, column) advances by a constant: ONE per-lane address + a uniform stride instead of a 64-bit computation per store
+    constexpr int PXI = NT / 16;                           // pixels per iteration: 16 (half a patch row) or 32 (one row)
+    const int pix0 = tidE >> 4, c16 = tidE & 15;
+    const int py0 = pix0 / QPW, px0 = pix0 - py0 * QPW;    // (py0 = 0: pix0 < 32)
+    const size_t o0 = ((size_t)(b * p.H + y0 + py0) * p.W + x0 + px0) * p.Cout + nt * QBN + c16 * 8;
+    const char* src = smem + pix0 * EROW + c16 * 16;
 #pragma unroll
     for (int i = 0; i < (QPH * QPW * 16) / NT; ++i) {
-      const int q = tidE + NT * i;                        // 16-byte chunk: pixel q/16, channels (q%16)*8..+7
-      const int pix = q >> 4, c16 = q & 15;
-      const int py = pix / QPW, px = pix - py * QPW;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + pix * EROW + c16 * 16);
-      const size_t oo = ((size_t)py * p.W + px) * p.Cout + c16 * 8;
-      *reinterpret_cast<bf16x8*>(obase + oo) = v;
-      if (p.oq) mx_store_twin(v, p.oq, p.os, (size_t)(obase - p.out) + oo, tidE & 3);
+      // NT = 512: row i, same column; NT = 256: row i / 2, column + 16 (i & 1)
+      const size_t oo = o0 + (PXI == 32 ? (size_t)i * p.W * p.Cout : (size_t)(i >> 1) * p.W * p.Cout + (size_t)(i & 1) * 16 * p.Cout);
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + i * PXI * EROW);
+      *reinterpret_cast<bf16x8*>(p.out + oo) = v;
+      if (p.oq) mx_store_twin(v, p.oq, p.os, oo, tidE & 3);
     }
   }
   if (STATS) {
