@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
   }
 
   // ---- epilogue (conv1x1_epilogue.hpp): transpose through LDS, then 16-byte channel-contiguous traffic only
-  conv1x1_epilogue<EPI>(p, smem, tid, nt, m0, b, p0, c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33);
+  conv1x1_epilogue<EPI, BM1>(p, smem, tid, nt, m0, b, p0, c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33);
 }
 
 }  // namespace

@@ -16,14 +16,17 @@ constexpr int EPI_LDS_BYTES = EPI_BM * EPI_ROW;    // 69,632 B of staging (every
 
 // `Args` supplies: Hout, Wout, Cout, bias, out, aux, gn_a, gn_b, oq, os, eps4, fin_w, fin_b (Conv1Args / Conv1QArgs).
 // m0: first output pixel of the tile (global), b: its image, p0: pixel offset inside the image, nt: 128-channel tile index.
-// Must be entered by all 512 threads AFTER a barrier that retired every read of the operand buffers in `smem`.
-template <int EPI, class Args>
+// Must be entered by all 2 * BM threads AFTER a barrier that retired every read of the operand buffers in `smem`.
+// BM: pixels per tile - 256 (8 waves, 512 threads) or 128 (4 waves, 256 threads; conv1x1_mxfp8's two-workgroups-per-CU shape);
+// two threads per pixel either way, so the store loop has the same eight iterations.
+template <int EPI, int BM, class Args>
 __device__ __forceinline__ void conv1x1_epilogue(const Args& p, char* smem, const int tid, const int nt, const long m0, const int b,
                                                  const int p0, const f32x4& c00, const f32x4& c01, const f32x4& c02, const f32x4& c03,
                                                  const f32x4& c10, const f32x4& c11, const f32x4& c12, const f32x4& c13,
                                                  const f32x4& c20, const f32x4& c21, const f32x4& c22, const f32x4& c23,
                                                  const f32x4& c30, const f32x4& c31, const f32x4& c32, const f32x4& c33) {
-  constexpr int BM1 = EPI_BM, BN1 = EPI_BN, NT1 = EPI_NT, EROW1 = EPI_ROW;
+  constexpr int BM1 = BM, BN1 = EPI_BN, NT1 = BM * 2, EROW1 = EPI_ROW;
+  static_assert(BM == 256 || BM == 128, "conv1x1_epilogue: tile of 256 or 128 pixels");
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -71,8 +74,29 @@ __device__ __forceinline__ void conv1x1_epilogue(const Args& p, char* smem, cons
       fw2[e] = p.fin_w[2 * BN1 + (tid & 15) * 8 + e];
     }
   }
+  // Round 3: the tail operand (`aux`: the tensor the GroupNorm tail is applied to / the residual) of ALL of the thread's chunks is
+  // loaded up front.  `aux` and `out` are both bf16 and may alias (the engine runs the tail in place), so written inside the
+  // loop the compiler must keep load i+1 behind store i: eight exposed HBM round trips per thread.  Each thread reads exactly the
+  // elements it later overwrites, so the hoist is safe in the in-place case; the 64 accumulator registers are dead by now.
+  // The GroupNorm coefficients depend on (image, channel chunk) only: once per thread.
+  constexpr int NCH = (BM1 * 16) / NT1;               // 16-byte chunks per thread: 8
+  bf16x8 auxv[NCH];
+  f32x4 a_lo = {0.f, 0.f, 0.f, 0.f}, a_hi = a_lo, b_lo = a_lo, b_hi = a_lo;
+  if (EPI == EPI_RESIDUAL || EPI == EPI_GNTAIL || EPI == EPI_GNTAIL_FINAL) {
 #pragma unroll
-  for (int i = 0; i < (BM1 * 16) / NT1; ++i) {
+    for (int i = 0; i < NCH; ++i) {
+      const int q = tid + NT1 * i;
+      auxv[i] = *reinterpret_cast<const bf16x8*>(p.aux + obase + (size_t)(q >> 4) * p.Cout + (q & 15) * 8);
+    }
+    if (EPI != EPI_RESIDUAL) {
+      const float* ga = p.gn_a + (size_t)b * p.Cout + col0 + (tid & 15) * 8;
+      const float* gb = p.gn_b + (size_t)b * p.Cout + col0 + (tid & 15) * 8;
+      a_lo = *reinterpret_cast<const f32x4*>(ga); a_hi = *reinterpret_cast<const f32x4*>(ga + 4);
+      b_lo = *reinterpret_cast<const f32x4*>(gb); b_hi = *reinterpret_cast<const f32x4*>(gb + 4);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
     const int q = tid + NT1 * i;
     const int pix = q >> 4, c16 = q & 15;
     bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + pix * EROW1 + c16 * 16);
@@ -86,15 +110,11 @@ __device__ __forceinline__ void conv1x1_epilogue(const Args& p, char* smem, cons
     } else {
       const size_t o = obase + (size_t)pix * p.Cout + c16 * 8;
       if (EPI == EPI_RESIDUAL) {
-        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(p.aux + o);
+        const bf16x8 rr = auxv[i];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rr[e]);
       } else if (EPI == EPI_GNTAIL || EPI == EPI_GNTAIL_FINAL) {
-        const bf16x8 hh = *reinterpret_cast<const bf16x8*>(p.aux + o);
-        const float* ga = p.gn_a + (size_t)b * p.Cout + col0 + c16 * 8;
-        const float* gb = p.gn_b + (size_t)b * p.Cout + col0 + c16 * 8;
-        const f32x4 a_lo = *reinterpret_cast<const f32x4*>(ga), a_hi = *reinterpret_cast<const f32x4*>(ga + 4);
-        const f32x4 b_lo = *reinterpret_cast<const f32x4*>(gb), b_hi = *reinterpret_cast<const f32x4*>(gb + 4);
+        const bf16x8 hh = auxv[i];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float ca = e < 4 ? a_lo[e & 3] : a_hi[e & 3], cb = e < 4 ? b_lo[e & 3] : b_hi[e & 3];

@@ -20,21 +20,32 @@
 //   * 128-byte LDS rows XOR-swizzled (chunk ^= row & 6) as in conv3x3_mxfp8.hip: conflict-free ds_read_b128 fragments;
 //   * MFMAs as inline asm with the accumulator tied (conv3x3_mxfp8.hip explains why).
 #include <cmath>
+#include <cstdlib>
 
 #include "conv1x1_epilogue.hpp"
 
 namespace srgd {
 namespace {
 
-constexpr int BMQ = 256, BNQ = 128, KQ = 128, NTQ = 512;
-constexpr int AQ_BYTES = BMQ * KQ;                 // 32 KiB of e4m3
-constexpr int ASQ_BYTES = BMQ * 4;                 // 1 KiB: 4 scale bytes per pixel
+constexpr int BNQ = 128, KQ = 128;
 constexpr int BQ_TILE = BNQ * KQ;                  // 16 KiB of e4m3 weights per K-step
 constexpr int BQ_BYTES = BQ_TILE + 512;            // + 512 scale bytes laid out [wn][r16][g][J] (one dword per lane)
-constexpr int STAGEQ = AQ_BYTES + ASQ_BYTES + BQ_BYTES;      // 50,688
-constexpr int RINGQ = 3;
-constexpr int LDSQ_BYTES = RINGQ * STAGEQ;         // 152,064 <= 163,840: one workgroup per CU
-static_assert(LDSQ_BYTES >= EPI_LDS_BYTES && BMQ == EPI_BM && BNQ == EPI_BN && NTQ == EPI_NT, "conv1x1_epilogue.hpp tile shape");
+// Tile shapes (template parameter BM = pixels per tile; 2 threads per pixel, wave tile 64 x 64 either way):
+//   BM = 256: 8 waves, 49.5 KiB stages, 3-deep ring = 148.5 KiB -> ONE workgroup per CU, two stages always in flight
+//   BM = 128: 4 waves, 33 KiB stages, 2-deep ring = 66 KiB -> TWO workgroups per CU (a tile's epilogue overlaps the other
+//             workgroup's loads - what the streaming layers need), weights re-streamed per 128 pixels instead of 256
+template <int BM> struct QShape {
+  static constexpr int NT = BM * 2, NW = BM / 32;
+  static constexpr int A_BYTES = BM * KQ;                     // e4m3 pixel rows
+  static constexpr int AS_BYTES = BM * 4;                     // 4 scale bytes per pixel
+  static constexpr int STAGE = A_BYTES + AS_BYTES + BQ_BYTES; // 50,688 / 33,792
+  static constexpr int RING = BM == 256 ? 3 : 2;
+  static constexpr int LDS = RING * STAGE;                    // 152,064 / 67,584
+  static constexpr int A_PER_WAVE = (A_BYTES / 1024) / NW;    // 4 / 4 DMA pieces of 1 KiB per wave and stage
+  static constexpr int B_PER_WAVE = 16 / NW;                  // 2 / 4
+  static constexpr int DMA_PER_STAGE = A_PER_WAVE + 1 + B_PER_WAVE + 1;   // 8 / 10 (the counted vmcnt waits)
+  static_assert(LDS >= BM * EPI_ROW && LDS <= 160 * 1024, "conv1x1_mxfp8: LDS budget");
+};
 
 typedef __attribute__((address_space(3))) void* lds_ptrq;
 typedef int v8iq __attribute__((ext_vector_type(8)));
@@ -62,8 +73,10 @@ struct Conv1QArgs {
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 
-template <int EPI>
-__global__ __launch_bounds__(NTQ, 2) void conv1x1_mxfp8_kernel(Conv1QArgs p) {
+template <int EPI, int BM>
+__global__ __launch_bounds__(BM * 2, 2) void conv1x1_mxfp8_kernel(Conv1QArgs p) {
+  using Q = QShape<BM>;
+  constexpr int BMQ = BM, NW = Q::NW, AQ_BYTES = Q::A_BYTES, ASQ_BYTES = Q::AS_BYTES, STAGEQ = Q::STAGE, RINGQ = Q::RING;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -98,9 +111,11 @@ __global__ __launch_bounds__(NTQ, 2) void conv1x1_mxfp8_kernel(Conv1QArgs p) {
     const int oy = op / p.Wout, ox = op - oy * p.Wout;
     return oy * p.stride * p.Win + ox * p.stride;
   };
-  const int pix0 = in_pix(wave * 8 + (lane >> 3)), pix1 = in_pix((wave + 8) * 8 + (lane >> 3)),
-            pix2 = in_pix((wave + 16) * 8 + (lane >> 3)), pix3 = in_pix((wave + 24) * 8 + (lane >> 3));
-  const int s_pix = in_pix((wave & 3) * 64 + lane);
+  static_assert(Q::A_PER_WAVE == 4, "four 1 KiB pixel pieces per wave and stage");
+  const int pix0 = in_pix(wave * 8 + (lane >> 3)), pix1 = in_pix((wave + NW) * 8 + (lane >> 3)),
+            pix2 = in_pix((wave + 2 * NW) * 8 + (lane >> 3)), pix3 = in_pix((wave + 3 * NW) * 8 + (lane >> 3));
+  constexpr int SW = BM / 64;                        // waves that cover the tile's scale dwords (the others repeat them)
+  const int s_pix = in_pix((wave % SW) * 64 + lane);
   const int a00 = pix0 * p.C0 + a_sub * 16, a01 = pix1 * p.C0 + a_sub * 16, a02 = pix2 * p.C0 + a_sub * 16, a03 = pix3 * p.C0 + a_sub * 16;
   // source 1 as a per-lane DIFFERENCE to source 0: offset = a0x + (d1x & mask) with a wave-uniform mask - written as a select
   // between two sets of registers hipcc selects between their ADDRESSES and parks both sets in scratch
@@ -132,13 +147,13 @@ __global__ __launch_bounds__(NTQ, 2) void conv1x1_mxfp8_kernel(Conv1QArgs p) {
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? qb0 : qb1), 0, first ? qn0 : qn1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? sb0 : sb1), 0, (first ? qn0 : qn1) >> 5, 0x00020000);
     SRGD_DMAQ(rq, st + wave * 1024, v0, soff, 16);
-    SRGD_DMAQ(rq, st + (wave + 8) * 1024, v1, soff, 16);
-    SRGD_DMAQ(rq, st + (wave + 16) * 1024, v2, soff, 16);
-    SRGD_DMAQ(rq, st + (wave + 24) * 1024, v3, soff, 16);
-    SRGD_DMAQ(rs, st + AQ_BYTES + (wave & 3) * 256, vs, ssoff, 4);
+    SRGD_DMAQ(rq, st + (wave + NW) * 1024, v1, soff, 16);
+    SRGD_DMAQ(rq, st + (wave + 2 * NW) * 1024, v2, soff, 16);
+    SRGD_DMAQ(rq, st + (wave + 3 * NW) * 1024, v3, soff, 16);
+    SRGD_DMAQ(rs, st + AQ_BYTES + (wave % SW) * 256, vs, ssoff, 4);
     char* sb = st + AQ_BYTES + ASQ_BYTES;
-    SRGD_DMAQ(rsw, sb + wave * 1024, lane16, i_w + wave * 1024, 16);
-    SRGD_DMAQ(rsw, sb + (wave + 8) * 1024, lane16, i_w + (wave + 8) * 1024, 16);
+#pragma unroll
+    for (int j = 0; j < Q::B_PER_WAVE; ++j) SRGD_DMAQ(rsw, sb + (wave + NW * j) * 1024, lane16, i_w + (wave + NW * j) * 1024, 16);
     SRGD_DMAQ(rsw, sb + BQ_TILE + (wave & 1) * 256, lane4, i_w + BQ_TILE + (wave & 1) * 256, 4);
 #undef SRGD_DMAQ
     i_w += (int)w_step_stride;
@@ -197,23 +212,40 @@ __global__ __launch_bounds__(NTQ, 2) void conv1x1_mxfp8_kernel(Conv1QArgs p) {
 #undef SRGD_QMM1_OPSEL_3
   };
 
-  // ---- pipeline: stages s+1 and s+2 in flight while stage s is consumed (8 DMA instructions per wave and stage)
-  issue();
-  if (S > 1) issue();
-  if (S > 1) WAIT_VMQ(8); else WAIT_VMQ(0);
-  BARRIERQ();
-  for (int s = 0; s < S; ++s) {
-    if (s + 2 < S) issue();
-    compute();
-    if (s + 2 < S) WAIT_VMQ(8); else WAIT_VMQ(0);   // stage s+1 has landed (this wave's part; the barrier covers the rest)
+  if constexpr (RINGQ == 3) {
+    // ---- 3-deep ring: stages s+1 and s+2 in flight while stage s is consumed (8 DMA instructions per wave and stage)
+    static_assert(Q::DMA_PER_STAGE == 8 || RINGQ != 3, "counted wait below");
+    issue();
+    if (S > 1) issue();
+    if (S > 1) WAIT_VMQ(8); else WAIT_VMQ(0);
     BARRIERQ();
+    for (int s = 0; s < S; ++s) {
+      if (s + 2 < S) issue();
+      compute();
+      if (s + 2 < S) WAIT_VMQ(8); else WAIT_VMQ(0);   // stage s+1 has landed (this wave's part; the barrier covers the rest)
+      BARRIERQ();
+    }
+  } else {
+    // ---- 2-deep ring: both slots are requested up front (the streaming layers have S = 2: nothing else ever is), afterwards
+    // stage s+2 goes into slot s % 2 once every wave is done with stage s, i.e. it is in flight under the MFMAs of stage s+1
+    static_assert(Q::DMA_PER_STAGE == 10 || RINGQ != 2, "counted wait below");
+    issue();
+    if (S > 1) issue();
+    if (S > 1) WAIT_VMQ(10); else WAIT_VMQ(0);
+    BARRIERQ();
+    for (int s = 0; s < S; ++s) {
+      compute();
+      WAIT_VMQ(0);                                   // stage s+1 (the only one in flight) has landed
+      BARRIERQ();                                    // ... for every wave, and every wave is done reading stage s
+      if (s + 2 < S) issue();
+    }
   }
   // The MFMAs are inline asm: the compiler inserts none of the wait states a VALU read of a matrix-pipe result needs (<= 18 for
   // a 16-pass MFMA); the accumulators are threaded through this statement, so every epilogue read comes >= 32 states later.
   asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
   asm volatile("" : "+v"(c20), "+v"(c21), "+v"(c22), "+v"(c23), "+v"(c30), "+v"(c31), "+v"(c32), "+v"(c33));
 
-  conv1x1_epilogue<EPI>(p, smem, tid, nt, m0, b, p0, c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33);
+  conv1x1_epilogue<EPI, BM>(p, smem, tid, nt, m0, b, p0, c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33);
 }
 
 }  // namespace
@@ -225,7 +257,7 @@ bool conv1x1_mxfp8_eligible(const ConvArgs& a) {
   if (a.ps0 != a.C0 || (a.C1 && a.ps1 != a.C1)) return false;
   if (a.C1 && (a.KH != 1 || a.KW != 1)) return false;
   if (a.C0 % KQ || a.C1 % KQ || a.Cout % BNQ || a.Cout != a.CoutPad) return false;
-  if (((long)a.Hout * a.Wout) % BMQ) return false;
+  if (((long)a.Hout * a.Wout) % 128) return false;              // tiles of 128 (or, when it divides, 256) pixels of ONE image
   if (a.gn_partial) return false;
   if (a.mode == CONV_PIXEL_SHUFFLE_SILU && ((a.Cout / 4) % BNQ || a.residual || a.gn_res_src)) return false;
   if (a.mode != CONV_PLAIN && a.mode != CONV_PIXEL_SHUFFLE_SILU) return false;
@@ -279,18 +311,28 @@ int conv1x1_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   p.oq = (unsigned char*)a.out_q; p.os = (unsigned char*)a.out_s;
   p.eps4 = a.eps4; p.fin_w = a.fin_w; p.fin_b = a.fin_b;
   if ((p.oq != nullptr) != (p.os != nullptr)) SRGD_FAIL("conv1x1_mxfp8: MX-fp8 twin needs both the element and the scale buffer");
-  const long m_tiles = (long)a.B * a.Hout * a.Wout / BMQ;
+  // tile shape: 128 pixels (two workgroups per CU) unless SRGD_MX1X1_BM=256 asks for the one-workgroup-per-CU shape
+  static int bm_knob = 0;
+  if (!bm_knob) { const char* v = getenv("SRGD_MX1X1_BM"); bm_knob = (v && atoi(v) == 256) ? 256 : 128; }
+  const int BM = (bm_knob == 256 && ((long)a.Hout * a.Wout) % 256 == 0) ? 256 : 128;
+  const long m_tiles = (long)a.B * a.Hout * a.Wout / BM;
   const long grid = m_tiles * (a.Cout / BNQ);
   if (grid <= 0 || grid > 0x7fffffffL) SRGD_FAIL("conv1x1_mxfp8: bad grid");
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-#define SRGD_SETQ1(E_)                                                                                  \
-  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_mxfp8_kernel<E_>),                \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSQ_BYTES));
+#define SRGD_SETQ1(E_)                                                                                       \
+  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_mxfp8_kernel<E_, 256>),                \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, QShape<256>::LDS));               \
+  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_mxfp8_kernel<E_, 128>),                \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, QShape<128>::LDS));
     SRGD_SETQ1(EPI_PLAIN) SRGD_SETQ1(EPI_RESIDUAL) SRGD_SETQ1(EPI_GNTAIL) SRGD_SETQ1(EPI_PS_SILU) SRGD_SETQ1(EPI_GNTAIL_FINAL)
 #undef SRGD_SETQ1
   }
-#define SRGD_GOQ1(E_) hipLaunchKernelGGL((conv1x1_mxfp8_kernel<E_>), dim3((unsigned)grid), dim3(NTQ), LDSQ_BYTES, st, p)
+#define SRGD_GOQ1(E_)                                                                                                             \
+  do {                                                                                                                            \
+    if (BM == 256) hipLaunchKernelGGL((conv1x1_mxfp8_kernel<E_, 256>), dim3((unsigned)grid), dim3(512), QShape<256>::LDS, st, p); \
+    else hipLaunchKernelGGL((conv1x1_mxfp8_kernel<E_, 128>), dim3((unsigned)grid), dim3(256), QShape<128>::LDS, st, p);           \
+  } while (0)
   if (a.mode == CONV_PIXEL_SHUFFLE_SILU) SRGD_GOQ1(EPI_PS_SILU);
   else if (a.gn_res_src && a.eps4) SRGD_GOQ1(EPI_GNTAIL_FINAL);
   else if (a.gn_res_src) SRGD_GOQ1(EPI_GNTAIL);

@@ -256,12 +256,11 @@ struct srgd_engine {
   bool no_final_fusion = false;   // SRGD_FINAL_FUSION=0: the last ResnetBlock stores its output and final_step applies the 1x1 (A/B switch)
   bool no_la256 = false;      // SRGD_LA256=0: the C = 256 LinearAttention sites run the unfused chain (A/B switch)
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
-  // fp8 modes: pointwise layers on the MX matrix cores (conv1x1_mxfp8).  OFF by default: per-shape the kernel beats
-  // conv1x1_bf16 (K-heavy layers +20-40 %, 256 -> 128 @256^2 +24 %, profiles/r3/conv1x1_mxfp8_per_shape.txt), but its
-  // 49.5 KiB K-step stages allow ONE workgroup per CU, so a tile's epilogue (GroupNorm tail: 128 B/pixel read + written) no
-  // longer overlaps another workgroup's loads: configs[4] end to end 0.4124 vs 0.4164 HR tiles/s without it, 0.4161 when only
-  // the layers with >= 768 input channels use it (same box, profiles/r3/mx1x1_ab.txt).  SRGD_MX1X1=1 switches it on.
-  bool no_mx1x1 = true;
+  // fp8 modes: pointwise layers with twinned inputs on the MX matrix cores (conv1x1_mxfp8, 128-pixel tiles: two workgroups
+  // per CU).  Per shape +20-40 % over conv1x1_bf16; end to end it only paid once the shared epilogue loaded its tail operand up
+  // front: configs[4] 0.430 -> 0.444 HR tiles/s, same box (profiles/r3/mx1x1_ab.txt), for -0.5 dB (fp8) / -1.2 dB
+  // (fp8_mixed) against the reference.  SRGD_MX1X1=0 keeps them on conv1x1_bf16.
+  bool no_mx1x1 = false;
   int mx1x1_min_cin = 0;      // SRGD_MX1X1_MIN_CIN: pointwise layers with fewer input channels stay on conv1x1_bf16
   unsigned fp8_bf16_zones = 0;   // SRGD_FP8_BF16_ZONES (bit mask over Ctx::zone): zones whose 3x3 convs stay bf16 in fp8 mode (study knob)
   bool no_twin_fusion = false;   // SRGD_Q_FUSED=0: fp8 mode quantises every conv input in a separate pass (A/B + bit-equality test)

@@ -36,8 +36,8 @@ _MODELS = {}
 
 
 # MX-fp8 modes vs the REFERENCE's fixtures: gates 3 dB under the MI355X measurements (profiles/r3_parity_report.jsonl)
-FP8_CONFIG5_GATE_DB, FP8_MIXED_CONFIG5_GATE_DB = 34.0, 50.3          # measured 36.99 / 53.29 dB (configs[4], one tile, 100 steps, CFG 2.0)
-FP8_CONFIG2_GATE_DB, FP8_MIXED_CONFIG2_GATE_DB = 25.4, 37.3          # measured 28.43 / 40.31 dB (configs[1] geometry, 2 steps from noise; bf16: 43.5)
+FP8_CONFIG5_GATE_DB, FP8_MIXED_CONFIG5_GATE_DB = 33.5, 49.1          # measured 36.48 / 52.14 dB (configs[4], one tile, 100 steps, CFG 2.0; 36.99 / 53.29 with SRGD_MX1X1=0)
+FP8_CONFIG2_GATE_DB, FP8_MIXED_CONFIG2_GATE_DB = 25.0, 36.6          # measured 27.98 / 39.63 dB (configs[1] geometry, 2 steps from noise; bf16: 43.7; 28.43 / 40.31 with SRGD_MX1X1=0)
 
 
 def build_sampler(dim, steps=50, weight_seed=0, fresh=False):
@@ -890,7 +890,7 @@ def test_fp8_unet_forward_vs_reference_and_bf16():
             bf16_rel_rms_vs_reference=rel(outs["bf16"], want), max_abs_vs_reference=float((outs["fp8"] - want).abs().max()))
     assert torch.isfinite(outs["fp8"]).all()
     assert not torch.equal(outs["fp8"], outs["bf16"])          # the fp8 kernels really ran
-    assert rel(outs["fp8"], want) < 0.078                       # measured 0.052 (x1.5): e4m3 carries 3 mantissa bits, 40 convs deep
+    assert rel(outs["fp8"], want) < 0.085                       # measured 0.0566 (x1.5; 0.052 with the pointwise layers in bf16): e4m3 carries 3 mantissa bits, 40 + 13 layers deep
 
 
 def test_fp8_mode_uses_the_mxfp8_kernels():
@@ -910,7 +910,8 @@ def test_fp8_mode_uses_the_mxfp8_kernels():
     # every tensor a 3x3 convolution reads gets its MX-fp8 twin from its producer's epilogue (conv1x1 variants, GroupNorm2 +
     # residual, both fused LinearAttention kernels, the 3x3 resamplers): no stand-alone quantisation pass is left
     assert prof["launches"]["quantize_mxfp8"] == 0
-    assert prof["launches"]["conv1x1_mxfp8"] == 0          # the MX pointwise kernel is opt-in (SRGD_MX1X1=1, engine.hip: measured)
+    # the pointwise layers whose inputs have MX-fp8 twins run on conv1x1_mxfp8 (13 of the 32 pointwise launches per forward)
+    assert prof["launches"]["conv1x1_mxfp8"] == 2 * 13, prof["launches"]
     # fp8_mixed: the 11 convolutions at the tile's own resolution (first down stage 4, last up stage 4 + its 3x3 resampler, final
     # block 2) stay on the bf16 kernel, the other 29 run MX-fp8; twins are written only for tensors an MX convolution reads, and
     # still no stand-alone quantisation pass is needed
@@ -926,15 +927,16 @@ def test_fp8_mode_uses_the_mxfp8_kernels():
     assert torch.isfinite(out).all() and out.min() >= 0 and out.max() <= 1
     assert prof["launches"]["conv3x3_mxfp8"] == 2 * 29 and prof["launches"]["conv3x3_bf16"] == 2 * 11
     assert prof["launches"]["quantize_mxfp8"] == 0
+    assert prof["launches"]["conv1x1_mxfp8"] == 2 * 9, prof["launches"]      # the 256^2 zones' pointwise layers stay bf16 too
 
 
-def test_fp8_pointwise_layers_on_the_mx_kernel_opt_in():
-    # SRGD_MX1X1=1 ("fp8 ... attention weights"): pointwise layers whose input tensors have MX-fp8 twins run
+def test_fp8_pointwise_layers_on_the_mx_kernel_and_the_switch_back():
+    # ("fp8 ... attention weights"; SRGD_MX1X1=0 switches back): pointwise layers whose input tensors have MX-fp8 twins run
     # on conv1x1_mxfp8 - the 8 res_convs of the up stages + the final block's (with the fused output convolution), the 3
     # Downsample 1x1s, the PixelShuffle 1x1 behind the first up stage's softmax attention = 13 of the 32 pointwise launches per
     # forward; to_qkv / to_out of the unfused attention sites (inputs come out of RMSNorm / the attention core) and the input
     # convolution stay on conv1x1_bf16.  In fp8_mixed the 256^2 zones' pointwise layers stay bf16 as well: 9.  The image must
-    # stay close to the default fp8 path's (same 3x3 kernels, 13 more e4m3 layers).
+    # stay close to the bf16-pointwise path's (same 3x3 kernels, 13 more e4m3 layers).
     import os
     sampler = build_sampler(128)
     cond = C.synthetic_lr_condition(0, 64, 64).cuda()
@@ -987,10 +989,10 @@ def test_config5_full_geometry_fp8_vs_bf16_parity_report():
     _report(test="config5_full_1024_fp8_vs_bf16", psnr_db=psnr, max_abs=float(err.max()), mean_abs=float(err.mean()),
             mixed_psnr_db=psnr_mixed, mixed_max_abs=float(errm.max()))
     # fp8 below the top resolution only (the 256x256-resolution zones keep bf16 3x3 convolutions): measured 53.2 dB
-    assert torch.isfinite(outs["fp8_mixed"]).all() and psnr_mixed > 50.0, psnr_mixed
+    assert torch.isfinite(outs["fp8_mixed"]).all() and psnr_mixed > 49.1, psnr_mixed      # measured 52.1 dB (53.5 with SRGD_MX1X1=0)
     assert outs["fp8"].shape == (1, 3, 1024, 1024)
     assert torch.isfinite(outs["fp8"]).all() and outs["fp8"].min() >= 0 and outs["fp8"].max() <= 1
-    assert psnr > 33.5, psnr           # measured 36.6 dB on MI355X (random-init weights; 3 mantissa bits on weights AND activations;
+    assert psnr > 33.0, psnr           # measured 36.0 dB on MI355X (36.6 with the pointwise layers in bf16, SRGD_MX1X1=0) (random-init weights; 3 mantissa bits on weights AND activations;
                                        # 34.1 dB with the OCP recipe's clamping scale rule)
 
 
