@@ -10,13 +10,12 @@
 //   the 2x matrix rate with half the LDS bytes per FLOP (they are LDS-/MFMA-bound at 0.7-0.9 PFLOP/s in bf16), the streaming
 //   layers (256 -> 128 @256^2 ...) read 1.03 B instead of 2 B per input element.
 //
-// Structure = conv1x1_bf16.hip with 128-channel K-steps:
-//   * workgroup = 512 threads = 8 waves (4 along M x 2 along N), output tile 256 consecutive pixels x 128 channels, wave
-//     tile 64 x 64 = 4 x 4 MFMA blocks (64 accumulator registers) - the same D layout as the bf16 kernel, so the epilogue
-//     (conv1x1_epilogue.hpp) is shared;
-//   * every K-step is ONE 49.5 KiB stage - A: 256 pixel rows x 128 B of e4m3 + 4 scale bytes per pixel, B: one pre-swizzled
-//     16 KiB weight tile + 512 scale bytes - brought in by LDS-DMA (8 buffer_load...lds per wave) into a 3-deep ring
-//     (148.5 KiB: one workgroup per CU, two stages = 99 KiB always in flight), counted s_waitcnt + one raw barrier per step;
+// Structure = conv1x1_bf16.hip with 128-channel K-steps (tile shapes: QShape below):
+//   * 2 threads per output pixel, waves 2 along N x (2 or 4) along M, wave tile 64 x 64 = 4 x 4 MFMA blocks (64 accumulator
+//     registers) - the same D layout as the bf16 kernel, so the epilogue (conv1x1_epilogue.hpp) is shared;
+//   * every K-step is ONE stage - A: pixel rows x 128 B of e4m3 + 4 scale bytes per pixel, B: one pre-swizzled 16 KiB weight
+//     tile + 512 scale bytes - brought in by LDS-DMA into a ring, counted s_waitcnt + one raw barrier per step; what changes
+//     from step to step rides in SGPRs (incremental issue stream, conv1x1_bf16.hip);
 //   * 128-byte LDS rows XOR-swizzled (chunk ^= row & 6) as in conv3x3_mxfp8.hip: conflict-free ds_read_b128 fragments;
 //   * MFMAs as inline asm with the accumulator tied (conv3x3_mxfp8.hip explains why).
 #include <cmath>
