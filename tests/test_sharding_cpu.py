@@ -232,3 +232,32 @@ def test_64_images_over_8_ranks_come_back_in_item_order(tmp_path):
                 assert img.dtype == torch.uint8 and img.shape == (8, 8, 3) and int(img[0, 0, 0]) == j % 200, j
         else:
             assert got["ordered"] is None
+
+
+def test_thread_communicator_matches_the_gloo_path_at_world_8():
+    # tests/thread_comm.py (ranks as threads of one process) is what the GPU suite runs the 8-rank partitionings on (a one-GPU
+    # box admits at most six GPU processes).  Here, on CPU, the same stand-in engine goes through the same sharded steps on
+    # that communicator: every rank must end with the single-rank canvases - i.e. the stand-in transport is a faithful
+    # all-gather / gather / broadcast / all-reduce - and the helper collectives are checked directly.
+    from tests.thread_comm import ThreadWorld
+    want_img, want_xs = _run_fake(None)
+    want_eimg, want_exs = _run_fake(None, edm=True)
+
+    def rank_body(comm):
+        img, xs = _run_fake(comm)
+        eimg, exs = _run_fake(comm, edm=True)
+        mine = torch.full((2, 3), float(comm.rank))
+        bucket = comm.gather(mine, dst=0)
+        flat = torch.arange(5.) if comm.rank == 0 else torch.zeros(5)
+        comm.broadcast(flat, src=0)
+        t = torch.tensor([float(comm.rank)], dtype=torch.float64)
+        comm.all_reduce_max(t)
+        return img, xs, eimg, exs, bucket, flat, t.item()
+
+    res = ThreadWorld(8, timeout=120.0).run(rank_body)
+    for r, (img, xs, eimg, exs, bucket, flat, tmax) in enumerate(res):
+        assert torch.equal(img, want_img) and torch.equal(xs, want_xs), r
+        assert torch.equal(eimg, want_eimg) and torch.equal(exs, want_exs), r
+        assert torch.equal(flat, torch.arange(5.)) and tmax == 7.0
+        assert (bucket is None) == (r != 0)
+    assert [float(b[0, 0]) for b in res[0][4]] == [float(k) for k in range(8)]
