@@ -34,6 +34,9 @@ constexpr int A_BYTES = 24 * 1024;             // 24 wave-instructions x 1 KiB (
 constexpr int B_BYTES = BN3 * KC * 2;          // 8 KiB
 constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 73,728: two workgroups per CU
 constexpr int COEF_BYTES = 2 * 256;            // GNIN: 32 scales | 32 shifts (fp32) per channel chunk, double-buffered
+#ifndef SRGD_CONV3_PAIR_WRITES
+#define SRGD_CONV3_PAIR_WRITES 1      // epilogue: dword LDS writes after a lane-pair exchange (0: four 2-byte writes per block; A/B builds)
+#endif
 constexpr int CONV3_M16_DEFAULT = 1;     // 16x16x32 measured +1..2 % over 32x32x16 on the production shapes
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -383,6 +386,9 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   constexpr int NI = M16 ? 4 : 2;                         // column blocks per wave (16 or 32 wide)
   float s1[NI], s2[NI];
   f32x2 s1p[NI], s2p[NI];                                 // 16x16 path: the column sums as register pairs (even | odd rows)
+  constexpr bool pair_writes = M16 && SRGD_CONV3_PAIR_WRITES;
+  const bool odd_lane = (r16E & 1) != 0;
+  const int pair_off = odd_lane ? 2 * (BN3 * 2 + 16) - 2 : 0;      // (EROW is declared above; rows 2-3, the even channel's column)
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     s1[ni] = 0.f;
@@ -412,10 +418,23 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
           s2p[ni] = __builtin_elementwise_fma(v23, v23, s2p[ni]);
         }
         const bf16x2_t t01 = __builtin_convertvector(v01, bf16x2_t), t23 = __builtin_convertvector(v23, bf16x2_t);
-        *reinterpret_cast<bf16*>(trow) = t01[0];
-        *reinterpret_cast<bf16*>(trow + EROW) = t01[1];
-        *reinterpret_cast<bf16*>(trow + 2 * EROW) = t23[0];
-        *reinterpret_cast<bf16*>(trow + 3 * EROW) = t23[1];
+        if (pair_writes) {
+          // Two adjacent lanes hold two adjacent channels of the same four rows.  They swap halves (one DPP quad_perm move) so
+          // that the even lane owns rows 0-1 and the odd lane rows 2-3 of BOTH channels: two conflict-free ds_write_b32 per
+          // block instead of four ds_write_b16 whose lane pairs share a dword.  The transposition phase is LDS-write-bound (64
+          // two-byte wave-writes per wave beside the co-resident workgroup's operand reads): 10.0k of a 48k-tick tile.
+          const unsigned own01 = __builtin_bit_cast(unsigned, t01), own23 = __builtin_bit_cast(unsigned, t23);
+          const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_lane ? own01 : own23), 0xB1, 0xf, 0xf, true);
+          const unsigned lo_ch = odd_lane ? recv : own01, hi_ch = odd_lane ? own23 : recv;     // channel c (even) | c + 1
+          char* prow = trow + pair_off;                 // even lane: rows 0, 1 at its own column; odd lane: rows 2, 3, one column left
+          *reinterpret_cast<unsigned*>(prow) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x05040100u);
+          *reinterpret_cast<unsigned*>(prow + EROW) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x07060302u);
+        } else {
+          *reinterpret_cast<bf16*>(trow) = t01[0];
+          *reinterpret_cast<bf16*>(trow + EROW) = t01[1];
+          *reinterpret_cast<bf16*>(trow + 2 * EROW) = t23[0];
+          *reinterpret_cast<bf16*>(trow + 3 * EROW) = t23[1];
+        }
       }
       if (STATS) {
         s1[ni] = s1p[ni][0] + s1p[ni][1];

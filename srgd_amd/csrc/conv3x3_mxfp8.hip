@@ -417,6 +417,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
   // weight DMA of tap 0 (one exposed L2 round trip per chunk = per tile on the 128-channel layers).
   const int laneE = lane_id_opaque(), tidE = wave * 64 + laneE, r16E = laneE & 15, gE = laneE >> 4;
   float s1[4], s2[4];                                     // (the loop's last barrier retired every operand read)
+  const bool odd_lane = (r16E & 1) != 0;
+  const int pair_off = odd_lane ? 2 * EROW - 2 : 0;       // odd lane: rows 2-3, the even channel's column
 #define SRGD_QACC(MI, NI) (NI == 0 ? c##MI##0 : NI == 1 ? c##MI##1 : NI == 2 ? c##MI##2 : c##MI##3)
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
@@ -442,10 +444,14 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
         s2p = __builtin_elementwise_fma(v23, v23, s2p);
       }
       const bf16x2_t t01 = __builtin_convertvector(v01, bf16x2_t), t23 = __builtin_convertvector(v23, bf16x2_t);
-      *reinterpret_cast<bf16*>(trow) = t01[0];
-      *reinterpret_cast<bf16*>(trow + EROW) = t01[1];
-      *reinterpret_cast<bf16*>(trow + 2 * EROW) = t23[0];
-      *reinterpret_cast<bf16*>(trow + 3 * EROW) = t23[1];
+      // lane-pair exchange + two conflict-free ds_write_b32 instead of four ds_write_b16 (conv3x3_bf16.hip): the even lane takes
+      // rows 0-1, the odd lane rows 2-3 of both lanes' channels
+      const unsigned own01 = __builtin_bit_cast(unsigned, t01), own23 = __builtin_bit_cast(unsigned, t23);
+      const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_lane ? own01 : own23), 0xB1, 0xf, 0xf, true);
+      const unsigned lo_ch = odd_lane ? recv : own01, hi_ch = odd_lane ? own23 : recv;
+      char* prow = trow + pair_off;
+      *reinterpret_cast<unsigned*>(prow) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x05040100u);
+      *reinterpret_cast<unsigned*>(prow + EROW) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x07060302u);
     }
     if (STATS) {
       s1[ni] = s1p[0] + s1p[1];
