@@ -140,16 +140,18 @@ def cpu_worker(argv):
         O.unet_forward(usd, cfg, x[:2], ls[:2], lab, c[:2])          # warm-up (allocator, oneDNN primitive cache): discarded
         print("READY", flush=True)
         sys.stdin.readline()
-        t0 = time.perf_counter()
+        t0 = time.monotonic()                              # CLOCK_MONOTONIC: one clock for all worker processes of the host
         for _ in range(n_mb):
             O.unet_forward(usd, cfg, x, ls, lab, c)
-        dt = time.perf_counter() - t0
+        dt = time.monotonic() - t0
     print(json.dumps({"tile_forwards": 8 * n_mb, "seconds": dt, "t_start": t0, "t_end": t0 + dt}), flush=True)
 
 
 def cpu_baseline_parallel(dim, threads_per_worker, minibatches, timeout_s=240.0):
     """k = physical cores / threads_per_worker concurrent worker processes (each pinned to its own cores) running the oracle on
-    disjoint tile batches; the aggregate rate is the sum of the workers' rates over their common window."""
+    disjoint tile batches; the aggregate rate is all workers' tile-forwards over the window from the first worker's start to
+    the last worker's end (one host-wide monotonic clock), so stragglers count against the baseline exactly once."""
+    import select
     import subprocess
     try:
         cpus = sorted(os.sched_getaffinity(0))
@@ -171,25 +173,34 @@ def cpu_baseline_parallel(dim, threads_per_worker, minibatches, timeout_s=240.0)
                                        str(minibatches), mine], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, cwd=ROOT))
     res = []
     try:
-        deadline = time.perf_counter() + timeout_s
+        deadline = time.monotonic() + timeout_s
+
+        def read_line(pr, what):                           # a line from a worker, or an error once the deadline has passed
+            left = deadline - time.monotonic()
+            if left <= 0 or not select.select([pr.stdout], [], [], left)[0]:
+                raise RuntimeError(f"cpu worker timed out waiting for {what} (budget {timeout_s:.0f} s)")
+            return pr.stdout.readline()
+
         for pr in procs:                                   # all workers warmed up and waiting
-            line = pr.stdout.readline()
-            if "READY" not in line or time.perf_counter() > deadline:
+            line = read_line(pr, "READY")
+            if "READY" not in line:
                 raise RuntimeError(f"cpu worker did not come up: {line!r}")
         for pr in procs:
             pr.stdin.write("go\n")
             pr.stdin.flush()
+        deadline = time.monotonic() + timeout_s
         for pr in procs:
-            res.append(json.loads(pr.stdout.readline()))
+            res.append(json.loads(read_line(pr, "its result")))
             pr.wait(timeout=30)
     finally:
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()
     total = sum(r["tile_forwards"] for r in res)
-    window = max(r["seconds"] for r in res)
+    window = max(r["t_end"] for r in res) - min(r["t_start"] for r in res)
     return {"workers": k, "threads_per_worker": threads, "tile_forwards": total, "seconds": window,
-            "tile_forwards_per_s": sum(r["tile_forwards"] / r["seconds"] for r in res)}
+            "tile_forwards_per_s": total / window,
+            "sum_of_worker_rates": sum(r["tile_forwards"] / r["seconds"] for r in res)}
 
 
 def cpu_baseline(sd, dim, n_tile_forwards, budget_s):

@@ -37,6 +37,7 @@ def _digest() -> str:
                 h.update(name.encode())
                 h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(b"version-script:srgd_*")
     return h.hexdigest()
 
 
@@ -60,7 +61,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs],
+    # version script: the dynamic symbol table holds the C ABI (srgd_*) and nothing else - without it the weak template
+    # instantiations of libstdc++ types (default visibility by the standard library's own attribute) leak out as exports
+    vers = os.path.join(OBJ_DIR, "exports.map")
+    with open(vers, "w") as f:
+        f.write("{ global: srgd_*; local: *; };\n")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={vers}", "-o", LIB, *objs],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

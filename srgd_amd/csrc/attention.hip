@@ -516,6 +516,7 @@ int full_attention(const void* qkv, void* out, int B, int N, int heads, int dh, 
     if (DeviceSetup once(attr_set); once.need) {
       SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&full_attn_bf16_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 64 + DH * (1024 * 2 + 16)));
+      once.done();
     }
     hipLaunchKernelGGL(full_attn_bf16_kernel, dim3(N / FA_QB, heads, B), dim3(FA_NT), lds, st, (const bf16*)qkv, (bf16*)out, N,
                        heads, scale * 1.4426950408889634f);

@@ -5,6 +5,7 @@
 
 #include <mutex>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string>
 
@@ -142,6 +143,14 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Integer tuning knob from the environment (`dflt` when unset).  Call sites keep the result in a function-local
+// `static const int`, whose initialisation C++11 makes thread-safe: engines driven from several host threads
+//  read every knob exactly once, race-free.
+static inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 // Kernel classes for the per-class timing that bench.py reads (srgd_profile_*).
 enum KClass {
   KC_CONV = 0,     // generic implicit-GEMM convolutions (1x1, 2x2/s2, pixel-shuffle, fp32 mode, odd shapes)
@@ -163,8 +172,10 @@ enum KClass {
 
 // One-time per-device setup of a kernel family (hipFuncSetAttribute for > 64 KiB of dynamic LDS), safe when several host threads
 // drive engines of their own: `if (DeviceSetup once(flags); once.need) { ...setup... }` - the first caller on a device runs the
-// block under a process-wide mutex and the flag is published (release) only when the block is left, so no other thread can
-// launch the kernel before its attribute is set; afterwards the check is one acquire load.
+// block under a process-wide mutex and ends it with `once.done()`; only then is the flag published (release) when the block
+// is left - a block abandoned half-way (SRGD_HIP returning on a failed hipFuncSetAttribute) leaves the flag clear, so the next
+// call repeats the setup and reports the real error instead of failing at launch.  No other thread can launch the kernel
+// before its attribute is set; afterwards the check is one acquire load.
 struct DeviceSetup {
   bool need = false;
   explicit DeviceSetup(bool (&flags)[64]) {
@@ -176,8 +187,9 @@ struct DeviceSetup {
     locked_ = true;
     need = !__atomic_load_n(flag_, __ATOMIC_ACQUIRE);
   }
+  void done() { done_ = true; }
   ~DeviceSetup() {
-    if (need && flag_) __atomic_store_n(flag_, true, __ATOMIC_RELEASE);
+    if (need && done_ && flag_) __atomic_store_n(flag_, true, __ATOMIC_RELEASE);
     if (locked_) mutex().unlock();
   }
   DeviceSetup(const DeviceSetup&) = delete;
@@ -187,6 +199,7 @@ struct DeviceSetup {
   static std::mutex& mutex() { static std::mutex m; return m; }
   bool* flag_ = nullptr;
   bool locked_ = false;
+  bool done_ = false;
 };
 
 }  // namespace srgd

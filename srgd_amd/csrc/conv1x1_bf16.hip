@@ -249,6 +249,7 @@ int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));
     SRGD_SET1(EPI_PLAIN) SRGD_SET1(EPI_RESIDUAL) SRGD_SET1(EPI_GNTAIL) SRGD_SET1(EPI_PS_SILU) SRGD_SET1(EPI_GNTAIL_FINAL)
 #undef SRGD_SET1
+    once.done();
   }
 #define SRGD_GO1(E_) hipLaunchKernelGGL((conv1x1_bf16_kernel<E_>), dim3((unsigned)grid), dim3(NT1), LDS1_BYTES, st, p)
   if (a.mode == CONV_PIXEL_SHUFFLE_SILU) SRGD_GO1(EPI_PS_SILU);

@@ -311,8 +311,7 @@ int conv1x1_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   p.eps4 = a.eps4; p.fin_w = a.fin_w; p.fin_b = a.fin_b;
   if ((p.oq != nullptr) != (p.os != nullptr)) SRGD_FAIL("conv1x1_mxfp8: MX-fp8 twin needs both the element and the scale buffer");
   // tile shape: 128 pixels (two workgroups per CU) unless SRGD_MX1X1_BM=256 asks for the one-workgroup-per-CU shape
-  static int bm_knob = 0;
-  if (!bm_knob) { const char* v = getenv("SRGD_MX1X1_BM"); bm_knob = (v && atoi(v) == 256) ? 256 : 128; }
+  static const int bm_knob = env_int("SRGD_MX1X1_BM", 128) == 256 ? 256 : 128;
   const int BM = (bm_knob == 256 && ((long)a.Hout * a.Wout) % 256 == 0) ? 256 : 128;
   const long m_tiles = (long)a.B * a.Hout * a.Wout / BM;
   const long grid = m_tiles * (a.Cout / BNQ);
@@ -326,6 +325,7 @@ int conv1x1_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
                                hipFuncAttributeMaxDynamicSharedMemorySize, QShape<128>::LDS));
     SRGD_SETQ1(EPI_PLAIN) SRGD_SETQ1(EPI_RESIDUAL) SRGD_SETQ1(EPI_GNTAIL) SRGD_SETQ1(EPI_PS_SILU) SRGD_SETQ1(EPI_GNTAIL_FINAL)
 #undef SRGD_SETQ1
+    once.done();
   }
 #define SRGD_GOQ1(E_)                                                                                                             \
   do {                                                                                                                            \

@@ -566,11 +566,7 @@ int conv3x3_bf16_stats_slots(const ConvArgs& a) {
 
 // Host-side packing: OIHW fp32 -> [tap][cc][ntile][128 rows][64 B swizzled] bf16 (the LDS image of each K-step tile).
 bool conv3x3_bf16_m16() {
-  static int m16 = -1;
-  if (m16 < 0) {
-    const char* v = getenv("SRGD_CONV3_M16");               // tuning knob; the shipped default is CONV3_M16_DEFAULT
-    m16 = v ? (atoi(v) != 0) : CONV3_M16_DEFAULT;
-  }
+  static const int m16 = env_int("SRGD_CONV3_M16", CONV3_M16_DEFAULT) != 0;   // tuning knob; the shipped default is CONV3_M16_DEFAULT
   return m16 != 0;
 }
 
@@ -608,8 +604,7 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   p.gn_in_a = gn_in_a;
   p.gn_in_b_off = gnin ? (int)((const char*)gn_in_b - (const char*)gn_in_a) : 0;
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
-  static int want_stamps = -1;
-  if (want_stamps < 0) { const char* v = getenv("SRGD_CONV3_STAMPS"); want_stamps = (v && atoi(v)) ? 1 : 0; }
+  static const int want_stamps = env_int("SRGD_CONV3_STAMPS", 0) ? 1 : 0;
   p.stamps = nullptr;
   if (want_stamps) {
     SRGD_HIP(hipGetSymbolAddress((void**)&p.stamps, HIP_SYMBOL(g_conv3_stamps)));
@@ -619,16 +614,16 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   if (DeviceSetup once(attr_set); once.need) {
 #define SRGD_SET(S_, G_, M_)                                                                              \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_, M_>),           \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024 + (G_ ? COEF_BYTES : 0)));
     SRGD_SET(true, false, false) SRGD_SET(false, false, false) SRGD_SET(true, true, false) SRGD_SET(false, true, false)
     SRGD_SET(true, false, true) SRGD_SET(false, false, true) SRGD_SET(true, true, true) SRGD_SET(false, true, true)
 #undef SRGD_SET
+    once.done();
   }
   const bool stats = a.gn_partial != nullptr;
   // diagnostic: SRGD_CONV3_ONE_WG=1 pads the LDS request so that only ONE workgroup fits a CU (what a warp-specialised
   // variant with helper waves would have to live with: at 128 VGPRs the register file holds 16 waves per CU either way)
-  static int lds_req = 0;
-  if (!lds_req) { const char* v = getenv("SRGD_CONV3_ONE_WG"); lds_req = (v && atoi(v)) ? 96 * 1024 : LDS_BYTES; }
+  static const int lds_req = env_int("SRGD_CONV3_ONE_WG", 0) ? 96 * 1024 : LDS_BYTES;
 #define SRGD_GO(S_, G_, M_) \
   hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_, M_>), dim3(grid), dim3(NT3), lds_req + (G_ ? COEF_BYTES : 0), st, p)
   if (conv3x3_bf16_m16()) {

@@ -629,9 +629,9 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
                                  hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
     SRGD_SETQ(true, 4) SRGD_SETQ(false, 4) SRGD_SETQ(true, 8) SRGD_SETQ(false, 8)
 #undef SRGD_SETQ
+    once.done();
   }
-  static int nw = 0;                                       // SRGD_MXFP8_WAVES=8: the 8-wave shape (A/B switch)
-  if (!nw) { const char* v = getenv("SRGD_MXFP8_WAVES"); nw = v ? (atoi(v) == 8 ? 8 : 4) : QNW_DEFAULT; }
+  static const int nw = env_int("SRGD_MXFP8_WAVES", QNW_DEFAULT) == 8 ? 8 : 4;    // SRGD_MXFP8_WAVES=8: the 8-wave shape (A/B switch)
   if (nw == 8) {
     if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true, 8>), dim3(grid), dim3(512), QLDS, st, p);
     else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false, 8>), dim3(grid), dim3(512), QLDS, st, p);

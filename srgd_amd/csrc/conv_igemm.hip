@@ -328,6 +328,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
   if (DeviceSetup once(attr_set); once.need) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BKC, PRECISE>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once.done();
   }
   hipLaunchKernelGGL((conv_igemm_kernel<T, BKC, PRECISE>), dim3(grid), dim3(NT), lds, st, a);
   SRGD_HIP(hipGetLastError());
@@ -347,8 +348,7 @@ static int pick_bkc(bool is_bf16, int C0, int C1) {
   const int n = is_bf16 ? 3 : 2;
   // fp32: 16-channel chunks (64-byte rows, 41 KB of LDS: three workgroups per CU instead of two) measured +4.4 % end to end
   // over 32-channel ones in the parity mode; same k order, bit-identical results.  SRGD_FP32_BKC=32 restores the larger chunk.
-  static int f32_max = -1;
-  if (f32_max < 0) { const char* v = getenv("SRGD_FP32_BKC"); f32_max = v ? atoi(v) : 16; }
+  static const int f32_max = env_int("SRGD_FP32_BKC", 16);
   for (int i = (!is_bf16 && f32_max < 32) ? 1 : 0; i < n; ++i)
     if (C0 % c[i] == 0 && (C1 == 0 || C1 % c[i] == 0)) return c[i];
   return 0;

@@ -1077,6 +1077,9 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   if (const char* v = getenv("SRGD_GN_FUSION_NTILES")) e->gn_fusion_max_ntiles = atoi(v);
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
+  // fp8_mixed is the quality-oriented fp8 mode: its pointwise layers stay on conv1x1_bf16 unless asked for (the MX pointwise
+  // kernel buys ~3 % there and costs 1.2 dB against the reference; round-3 advisor finding).  fp8 keeps them on the MX cores.
+  e->no_mx1x1 = e->cfg.precision == SRGD_PRECISION_FP8_MIXED;
   if (const char* v = getenv("SRGD_MX1X1")) e->no_mx1x1 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_MX1X1_MIN_CIN")) e->mx1x1_min_cin = atoi(v);
   if (const char* v = getenv("SRGD_LA256")) e->no_la256 = atoi(v) == 0;

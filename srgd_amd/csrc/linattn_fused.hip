@@ -412,8 +412,7 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
 // C = 128 on the 32-pixel-tile kernels of linattn_fused256.hip (3 workgroups per CU) instead of the 64-pixel ones here: A/B switch,
 // read once (the weight images differ, so it must not change between packing and launching)
 static bool la128_tm32() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SRGD_LA128_TM32"); v = (e && atoi(e)) ? 1 : 0; }
+  static const int v = env_int("SRGD_LA128_TM32", 0) ? 1 : 0;
   return v == 1;
 }
 
@@ -472,6 +471,7 @@ int linattn_fused(const void* x, void* y, int B, int N, int C, const void* wkv_i
   if (DeviceSetup once(attr); once.need) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    once.done();
   }
   hipLaunchKernelGGL(la1_kernel, dim3(nstrips, B), dim3(NTH), lds1, st, (const bf16*)x, N, (const bf16*)wkv_img, strip, pm,
                      pl, pctx, rinv);

@@ -418,6 +418,7 @@ static int launch_la_t(const void* x, void* y, int B, int N, const void* wkv, co
   if (DeviceSetup once(attr); once.need) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la1_t_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1));
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la2_t_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    once.done();
   }
   if (strip % TM2 || N % TM2) SRGD_FAIL("linattn_fused256: N and the strip length must be multiples of 32");
   hipLaunchKernelGGL(la1_t_kernel<C>, dim3(nstrips, B), dim3(NTH2), lds1, st, (const bf16*)x, N, (const bf16*)wkv, strip, pm, pl,

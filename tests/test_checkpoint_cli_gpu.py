@@ -50,7 +50,8 @@ def test_dim128_checkpoint_file_through_the_cli_reproduces_the_reference_image(t
     assert "engine precision: fp32" in r.stdout and "check: <All keys matched successfully>" in r.stderr + r.stdout
     m = re.search(r"engine ready: 280 tensors packed and uploaded in ([0-9.]+) s", r.stdout)
     assert m, r.stdout[-2000:]
-    assert float(m.group(1)) < 5.0                                          # 0.35 s (fp32) / 0.68 s (bf16) measured
+    # (no wall-clock bound here: a functional test must not flake on a loaded box; DESIGN section 8 quotes 0.35 s fp32 / 0.68 s
+    # bf16 from tools/time_weight_load.py)
     got = np.asarray(Image.open(outdir / "tile_out.png").convert("RGB"))
     want = (torch.from_numpy(z["image"])[0] * 255).to(torch.uint8).permute(1, 2, 0).numpy()      # ToPILImage: truncation
     diff = np.abs(got.astype(int) - want.astype(int))

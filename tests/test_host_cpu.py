@@ -158,6 +158,13 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     assert b"gfx950" in lib.srgd_version()
+    # ... and nothing else: the dynamic symbol table (nm -D) holds exactly the headers' functions (-fvisibility=hidden), so
+    # the export count quoted in INTEGRATION.md / DESIGN.md cannot drift from the headers again
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TtWw"}
+    exported = {n for n in exported if not n.startswith(("_init", "_fini", "__"))}
+    assert exported == declared, exported ^ declared
 
 
 def test_product_path_fails_loudly_without_gpu():

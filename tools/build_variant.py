@@ -31,7 +31,11 @@ def main():
             return obj
         with ThreadPoolExecutor(max_workers=6) as ex:
             objs = list(ex.map(one, SOURCES))
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
+        vers = os.path.join(tmp, "exports.map")
+        with open(vers, "w") as f:
+            f.write("{ global: srgd_*; local: *; };\n")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={vers}", "-o", lib, *objs],
+                           capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(r.stderr)
     print(lib)
