@@ -35,7 +35,10 @@ int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int H
  * kernel (conv_igemm.hip), 2 = the 3x3 bf16 halo/LDS-DMA kernel (conv3x3_bf16.hip; error if not eligible),
  * 3 = the pointwise bf16 streaming GEMM (conv1x1_bf16.hip; error if not eligible), 4 = the pointwise layer on the block-scaled
  * MX-fp8 matrix cores (conv1x1_mxfp8.hip, fp8 mode: the bf16 sources are quantised inside with srgd_k_quant_mxfp8's rule, the
- * weights per (output channel, tap, 32 input channels); C0, C1, Cout % 128 == 0; error if not eligible).
+ * weights per (output channel, tap, 32 input channels); C0, C1, Cout % 128 == 0; error if not eligible),
+ * 5 = impl 2 with the PRODUCER's GroupNorm + SiLU applied while the input is staged (Block.forward model.py:250-259 between
+ * two convolutions): conv(silu(gn_tail_a[b][c] * in0 + gn_tail_b[b][c])), zero padding applied after the activation; one source,
+ * gn_tail_a / gn_tail_b = device fp32 [B][C0] in ONE allocation (shift behind scale), gn_tail_src must be NULL.
  * gn_tail_src (nullable, NHWC like out): out = silu(gn_tail_a[b][c] * gn_tail_src + gn_tail_b[b][c]) + conv(in) -
  * the second GroupNorm+SiLU of a ResnetBlock and its residual add folded into the 1x1 res_conv (model.py:250-259,:285);
  * gn_tail_a / gn_tail_b: device fp32 [B][Cout].  May alias out.

@@ -37,6 +37,12 @@ constexpr int COEF_BYTES = 2 * 256;            // GNIN: 32 scales | 32 shifts (f
 #ifndef SRGD_CONV3_PAIR_WRITES
 #define SRGD_CONV3_PAIR_WRITES 1      // epilogue: dword LDS writes after a lane-pair exchange (0: four 2-byte writes per block; A/B builds)
 #endif
+#ifndef SRGD_GNIN_SCALAR
+#define SRGD_GNIN_SCALAR 1            // GNIN transform: single-lane-op fp32 arithmetic (inline asm) instead of what -O3 SLP-packs into
+#endif                                // v_pk_fma_f32 / v_pk_mul_f32 - packed f32 VALU beside MFMAs is an anti-lever on gfx950 (A/B builds: 0)
+#ifndef SRGD_GNIN_LEAN
+#define SRGD_GNIN_LEAN 3              // GNIN instances: the plain instances' shared fragment addressing and 8-fragment tap (needs the tied MFMAs)
+#endif
 constexpr int CONV3_M16_DEFAULT = 1;     // 16x16x32 measured +1..2 % over 32x32x16 on the production shapes
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
 #undef SRGD_A_DECL
   const int a_sub = (lane & 3) ^ row_swz<M16>(lane >> 2);
   // GNIN: which of this lane's three pieces lie inside the image, packed (bit J)
-  const int a_in = GNIN ? (a_pix0 >= 0 ? 1 : 0) | (a_pix1 >= 0 ? 2 : 0) | (a_pix2 >= 0 ? 4 : 0) : 0;
+  [[maybe_unused]] const int a_in = GNIN ? (a_pix0 >= 0 ? 1 : 0) | (a_pix1 >= 0 ? 2 : 0) | (a_pix2 >= 0 ? 4 : 0) : 0;
   // GNIN (one source): byte offset of each piece at chunk 0, or the out-of-range sentinel (stays out of range for every chunk)
   const unsigned a_off0 = a_pix0 >= 0 ? (unsigned)(a_pix0 * p.C0 + a_sub * 8) * 2u : 0x7ffffff0u;
   const unsigned a_off1 = a_pix1 >= 0 ? (unsigned)(a_pix1 * p.C0 + a_sub * 8) * 2u : 0x7ffffff0u;
@@ -160,12 +166,81 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // 256-byte slot of their own (every wave issues it: identical bytes, and the counted vmcnt waits stay the same for all
   // waves).  No VGPR load: the compiler would guard its use with s_waitcnt vmcnt(0) - it cannot see the counted waits - and
   // drain every DMA in flight.
+  int tid16 = tid * 16;                         // the weight DMA's per-lane offset; GNIN: lane * 16, lane * 4 and (after the loop) tid are derived from it
   int opq = 0;                                  // opaque zero, refreshed once per channel chunk (see the operand addresses below)
   char* const sCoef = smem + LDS_BYTES;
+#if SRGD_GNIN_SCALAR
+  // the per-lane offset is rebuilt from tid16 at its one use per chunk (3 VALU) rather than carried through the K loop
+  auto coef_dma = [&](int cc) {
+    int t = tid16;
+    asm volatile("" : "+v"(t));
+    const int l4 = (t >> 2) & 0xfc;               // lane * 4
+    const int voff = l4 < 128 ? l4 : p.gn_in_b_off + l4 - 128;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc, (lds_ptr)(sCoef + (cc & 1) * 256), 4, voff, cc * KC * 4, 0, 0);
+  };
+#else
   const int coef_voff = lane < 32 ? lane * 4 : p.gn_in_b_off + (lane - 32) * 4;
   auto coef_dma = [&](int cc) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc, (lds_ptr)(sCoef + (cc & 1) * 256), 4, coef_voff, cc * KC * 4, 0, 0);
   };
+#endif
+#if SRGD_GNIN_SCALAR
+  // Round 4.  The transform shares the SIMD's vector-issue port with the MFMAs (an MFMA 16x16x32 holds it for 8 of its 16
+  // cycles), so it is written for issue cycles: (1) plain v_fma_f32 / v_mul_f32 through inline asm - the compiler packs the
+  // four lanes' affine step and final product into v_pk_fma_f32 / v_pk_mul_f32, which beside MFMAs cost far more than the
+  // two single ops they replace (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); (2) two address instructions per
+  // half instead of five: per-lane parts (lane * 16, a_sub * 32) live in registers, everything uniform rides in an opaque
+  // SGPR (opaque so that lane part + uniform part is not hoisted into one VGPR per (buffer, piece)), the half / shift
+  // offsets are ds immediates; (3) out-of-image chunks keep the zeros the DMA wrote because their lanes are switched off
+  // for the store (exec = the piece's in-image ballot, two SALU) instead of two v_cndmask.  Same arithmetic as
+  // silu<false> in gn_apply: bit-identical results.
+  const unsigned asub32 = (unsigned)a_sub * 32u;
+#define lane16 ((unsigned)tid16 & 1023u)
+  const unsigned long long in_m0 = __builtin_amdgcn_ballot_w64(a_pix0 >= 0), in_m1 = __builtin_amdgcn_ballot_w64(a_pix1 >= 0),
+                           in_m2 = __builtin_amdgcn_ballot_w64(a_pix2 >= 0);
+  const unsigned smem_lds = (unsigned)(size_t)(lds_ptr)smem;
+  auto transform_half = [&](int cc, int j, int hf) {
+    int sq = (int)smem_lds + (cc & 1) * A_BYTES + (wave + 8 * j) * 1024 + hf * 8;
+    int sc = (int)smem_lds + LDS_BYTES + (cc & 1) * 256 + hf * 16;
+    asm volatile("" : "+s"(sq), "+s"(sc));
+    const unsigned qa = lane16 + (unsigned)sq, ca_ = asub32 + (unsigned)sc;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const u32x2* lds_u2;
+    typedef __attribute__((address_space(3))) const f32x4* lds_f4;
+    const u32x2 raw = *(lds_u2)(size_t)qa;
+    const f32x4 ca = *(lds_f4)(size_t)ca_, cb = *(lds_f4)(size_t)(ca_ + 128u);
+    const unsigned w0 = raw[0], w1 = raw[1];
+    const float x0 = __uint_as_float(w0 << 16), x1 = __uint_as_float(w0 & 0xffff0000u), x2 = __uint_as_float(w1 << 16),
+                x3 = __uint_as_float(w1 & 0xffff0000u);
+    // Two elements per asm block, interleaved: on gfx950 a VALU instruction may not read a transcendental's result in the very
+    // next issue slot (one wait state; the compiler inserts it for its own instructions but does not look inside inline asm -
+    // a build that scheduled v_rcp directly ahead of a single-instruction asm v_mul computed garbage), so each v_exp / v_rcp
+    // is followed by its sibling's before its result is used.
+    float y[4];
+#define SRGD_SILU2(Y0_, Y1_, E0_, E1_)                                                                                           \
+    do {                                                                                                                         \
+      float t0_, t1_;                                                                                                            \
+      asm("v_fma_f32 %0, %4, %6, %8\n\tv_fma_f32 %1, %5, %7, %9\n\t"                                                           \
+          "v_mul_f32 %2, 0xbfb8aa3b, %0\n\tv_mul_f32 %3, 0xbfb8aa3b, %1\n\t"                                                   \
+          "v_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"                                                                           \
+          "v_add_f32 %2, 1.0, %2\n\tv_add_f32 %3, 1.0, %3\n\t"                                                                 \
+          "v_rcp_f32 %2, %2\n\tv_rcp_f32 %3, %3\n\t"                                                                           \
+          "v_mul_f32 %0, %0, %2\n\tv_mul_f32 %1, %1, %3"                                                                        \
+          : "=&v"(Y0_), "=&v"(Y1_), "=&v"(t0_), "=&v"(t1_)                                                                       \
+          : "v"(ca[E0_]), "v"(ca[E1_]), "v"(x##E0_), "v"(x##E1_), "v"(cb[E0_]), "v"(cb[E1_]));                                   \
+    } while (0)
+    SRGD_SILU2(y[0], y[1], 0, 1);
+    SRGD_SILU2(y[2], y[3], 2, 3);
+#undef SRGD_SILU2
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const unsigned o0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{y[0], y[1]}, bf16x2_t));
+    const unsigned o1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{y[2], y[3]}, bf16x2_t));
+    const unsigned long long bits64 = (unsigned long long)o0 | ((unsigned long long)o1 << 32);
+    const unsigned long long m = j == 0 ? in_m0 : (j == 1 ? in_m1 : in_m2);
+    asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(qa), "v"(bits64), "s"(m) : "memory");
+  };
+#undef lane16
+#else
   auto transform_half = [&](int cc, int j, int hf) {
     // all ones / zero: out-of-image chunks are ANDed back to zero (a select on `inside` is if-converted by the compiler into
     // an exec-masked branch around the arithmetic: a basic-block split inside the unrolled tap loop, see above)
@@ -190,6 +265,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     const long long bits64 = __builtin_bit_cast(long long, bits);
     asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(size_t)(lds_ptr)(q + hf * 8)), "v"(bits64) : "memory");
   };
+#endif
 #define transform_a_half(CCV, J, HF) transform_half(CCV, J, HF)
 #define transform_a_piece(CCV, J) do { transform_a_half(CCV, J, 0); transform_a_half(CCV, J, 1); } while (0)
 
@@ -215,7 +291,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   const int w_tap_stride = (int)(CC * w_tile_stride);
   auto issue_b = [&](int cc, int tap) {
     if (tap >= 9) { tap -= 9; cc += 1; }
-    dma16(rsw, sB0 + (tap % 3) * B_BYTES + wave * 1024, tid * 16, tap * w_tap_stride + cc * (int)w_tile_stride);
+    dma16(rsw, sB0 + (tap % 3) * B_BYTES + wave * 1024, tid16, tap * w_tap_stride + cc * (int)w_tile_stride);
   };
 
   // ---- accumulators: 64 fp32 per lane in both shapes
@@ -237,17 +313,20 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // the opaque zero, and-xor, add) instead of six - the K loop carried ~28 address instructions per 16 MFMAs on the port the
   // MFMAs issue through.
   const int lp = 2 * wm * WP + r16, lp8 = lp << 3, lp64 = lp * 64, q16s = q16 << 4;
+  int lp8o = lp8;                               // GNIN instances: refreshed (made opaque) at every tap
   auto a_addr = [&](int tap, int i) {        // 32x32: i = patch row of the wave (0/1); 16x16: i = 16-pixel block (0..3)
     const int dy = tap / 3, dx = tap - dy * 3;
-    if constexpr (M16 && !GNIN) {
+    if constexpr (M16 && (!GNIN || (SRGD_GNIN_LEAN & 1))) {
       const int Pc = ((i >> 1) + dy) * WP + (i & 1) * 16 + dx;
       return lp64 + (((lp8 + Pc * 8 + opq) & 0x30) ^ q16s) + Pc * 64;
     } else if constexpr (M16) {
       // the GNIN instances refresh `opq` every tap so that NO address part survives a tap in a register (they carry ~13 more
       // long-lived registers; with the split form above the eight swizzle terms of a chunk stay live and 33 registers spill into
       // the K loop): P * 8 once, then P * 64 and the swizzle term from it - four VALU instructions per address instead of six
+      // (round 4: an opaque COPY of lp8 per tap instead of an opaque zero added to it - the compiler reassociated
+      // (lp8 + Pc * 8) + opq, hoisted the loop-invariant first half for every (tap, block) and spilled what did not fit)
       const int Pc = ((i >> 1) + dy) * WP + (i & 1) * 16 + dx;
-      const int t = lp8 + Pc * 8 + opq;
+      const int t = lp8o + Pc * 8;
       return (t << 3) + ((t & 0x30) ^ q16s);
     } else {
       const int P = (2 * wm + i + dy) * WP + r + dx + opq;
@@ -257,7 +336,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   auto compute = [&](int cc, int tap, int s) {
     const char* A = sA0 + (cc & 1) * A_BYTES;
     const char* Bt = sB0 + (tap % 3) * B_BYTES;          // (cc * 9 + tap) % 3
-    if constexpr (M16 && GNIN) {
+    if constexpr (M16 && GNIN && !(SRGD_GNIN_LEAN & 2)) {
       // GNIN carries ~13 more long-lived registers (piece offsets, coefficient addressing): the pixel fragments come in two
       // pairs here - 24 operand registers at a time instead of 32 - so that nothing spills into the K loop (a scratch reload
       // in this loop is a VMEM load the compiler guards with s_waitcnt vmcnt(0): it drains the DMA pipeline)
@@ -267,7 +346,13 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(3));
       bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 0));
       bf16x8 a1 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 1));
-#define MM(C_, A_, B_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, C_, 0, 0, 0)
+      // Round 4: the MFMAs of the GNIN instances go out as inline asm with the accumulator TIED (D = C).  Through the builtin the
+      // compiler gives every MFMA a fresh destination, the 64 accumulators migrate through the register file, and at the
+      // 128-register cap that fragmentation (not the live count: 97 at the loop's fullest point) spilled 3-4 loop invariants
+      // into the K loop - scratch reloads behind s_waitcnt vmcnt(0), i.e. behind every DMA in flight.  (Hazards: operands come
+      // from ds_read, whose waits the compiler inserts for asm operands too; the accumulators are first read by VALU code
+      // after the loop, behind the s_nop block ahead of the epilogue.)
+#define MM(C_, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(A_), "v"(B_))
       MM(c00, a0, b0); MM(c01, a0, b1); MM(c02, a0, b2); MM(c03, a0, b3);
       __builtin_amdgcn_sched_barrier(0);
       a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 2));
@@ -286,7 +371,11 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(1));
       const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(2));
       const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(3));
-#define MM(C_, A_, B_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, C_, 0, 0, 0)
+#define MM(C_, A_, B_)                                                                                   \
+  do {                                                                                                   \
+    if constexpr (GNIN) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(A_), "v"(B_)); \
+    else C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, C_, 0, 0, 0);                             \
+  } while (0)
       MM(c00, a0, b0); MM(c01, a0, b1); MM(c02, a0, b2); MM(c03, a0, b3);
       MM(c10, a1, b0); MM(c11, a1, b1); MM(c12, a1, b2); MM(c13, a1, b3);
       MM(c20, a2, b0); MM(c21, a2, b1); MM(c22, a2, b2); MM(c23, a2, b3);
@@ -332,11 +421,11 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // ---- main loop.  Per K-step: [issue A piece of the next chunk (taps 0..2)] [issue B[s+2]] compute(s)
   //      wait until B[s+1] (and, in order, everything older) has landed, barrier.
   for (int cc = 0; cc < CC - 1; ++cc) {
-    asm volatile("" : "+v"(opq));
+    if (!GNIN || (SRGD_GNIN_LEAN & 1)) asm volatile("" : "+v"(opq));
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int s = cc * 9 + tap;
-      if (GNIN) asm volatile("" : "+v"(opq));   // GNIN: per-tap refresh - no operand-address part survives a tap in a register
+      if (GNIN && !(SRGD_GNIN_LEAN & 1)) { lp8o = lp8; asm volatile("" : "+v"(lp8o)); }   // GNIN: per-tap refresh - no operand-address part survives a tap in a register
       // GNIN: the next chunk's coefficients are the OLDEST request of tap 0 (so the tap's counted wait covers them), published
       // by tap 0's barrier, read from tap 2 on
       if (GNIN && tap == 0) coef_dma(cc + 1);
@@ -377,10 +466,17 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // 256-byte channel rows, 16 B per lane - 8 store instructions per thread instead of 64.
   constexpr int EROW = BN3 * 2 + 16;
   BARRIER();                                              // every wave is done reading the operand buffers
+  if constexpr (M16 && GNIN) {
+    // asm MFMAs: the compiler does not know the accumulators were written by the matrix pipe and inserts no wait states ahead of
+    // their first VALU read (up to 18 for a 16x16 result); the barrier above does not count as one
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
+    asm volatile("" : "+v"(c20), "+v"(c21), "+v"(c22), "+v"(c23), "+v"(c30), "+v"(c31), "+v"(c32), "+v"(c33));
+  }
   // the epilogue's per-lane addresses are formed from an opaque copy of the thread id: computed here, not ahead of the K
   // loop where they would be carried through it (in registers the GNIN instances do not have, i.e. through scratch)
-  int tidE = tid;
+  int tidE = tid16;                                       // (tid itself is not kept alive through the K loop)
   asm volatile("" : "+v"(tidE));
+  tidE >>= 4;
   const int laneE = tidE & 63, r16E = laneE & 15, q16E = laneE >> 4, rE = laneE & 31, hE = laneE >> 5;
   if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
   constexpr int NI = M16 ? 4 : 2;                         // column blocks per wave (16 or 32 wide)
@@ -532,7 +628,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       dst[1] = a2;
     }
   }
-  if (p.stamps && tid == 0) {
+  if (p.stamps && tidE == 0) {
     const unsigned long long t5 = __builtin_amdgcn_s_memtime();
     atomicAdd(&p.stamps[0], t1 - t0); atomicAdd(&p.stamps[1], t2 - t1); atomicAdd(&p.stamps[2], t3 - t2);
     atomicAdd(&p.stamps[3], t4 - t3); atomicAdd(&p.stamps[4], t5 - t4); atomicAdd(&p.stamps[5], t5 - t0);

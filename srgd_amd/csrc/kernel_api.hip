@@ -49,7 +49,15 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   a.gn_partial = gn_partial; a.groups = groups;
   a.gn_res_src = gn_tail_src; a.gn_res_a = gn_tail_src ? gn_tail_a : nullptr; a.gn_res_b = gn_tail_src ? gn_tail_b : nullptr;
   if (gn_tail_src && (!gn_tail_a || !gn_tail_b)) SRGD_FAIL("srgd_k_conv2d: gn_tail_src needs gn_tail_a and gn_tail_b");
-  const bool fast = (impl == 0 || impl == 2) && is_bf16 && kind == 0 && conv3x3_bf16_eligible(a);
+  // impl 5: conv3x3_bf16 with the producer's GroupNorm + SiLU applied while the input is staged (GNIN): gn_tail_a / gn_tail_b
+  // are then the [B][Cin] scale / shift arrays of the INPUT (one allocation, shift behind scale), not a tail operand
+  const bool gnin = impl == 5;
+  if (gnin) {
+    if (!gn_tail_a || !gn_tail_b || C1) SRGD_FAIL("srgd_k_conv2d: impl 5 (GroupNorm-in-staging) needs one source and gn_tail_a / gn_tail_b");
+    a.gn_res_src = nullptr; a.gn_res_a = nullptr; a.gn_res_b = nullptr;
+  }
+  const bool fast = (impl == 0 || impl == 2 || gnin) && is_bf16 && kind == 0 && conv3x3_bf16_eligible(a);
+  if (gnin && !fast) SRGD_FAIL("srgd_k_conv2d: the conv3x3_bf16 fast path does not cover this shape");
   if (impl == 2 && !fast) SRGD_FAIL("srgd_k_conv2d: the conv3x3_bf16 fast path does not cover this shape");
   const bool fast1 = !fast && (impl == 0 || impl == 3) && is_bf16 && conv1x1_bf16_eligible(a);
   if (impl == 3 && !fast1) SRGD_FAIL("srgd_k_conv2d: the conv1x1_bf16 fast path does not cover this shape");
@@ -90,7 +98,7 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   if (stats_slots) *stats_slots = fast ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
   auto run = [&]() -> int {
     if (fastq1) return conv1x1_mxfp8(a, q0.p, s0.p, q1.p, s1.p, dwq1.p, st);
-    return fast ? conv3x3_bf16(a, dw3.p, nullptr, nullptr, st) : fast1 ? conv1x1_bf16(a, dw1.p, st) : conv_igemm(a, is_bf16 != 0, st);
+    return fast ? conv3x3_bf16(a, dw3.p, gnin ? gn_tail_a : nullptr, gnin ? gn_tail_b : nullptr, st) : fast1 ? conv1x1_bf16(a, dw1.p, st) : conv_igemm(a, is_bf16 != 0, st);
   };
   SRGD_TRY(run());
   SRGD_HIP(hipStreamSynchronize(st));

@@ -17,7 +17,9 @@ from srgd_amd.build import CSRC, FLAGS, SOURCES, _hipcc  # noqa: E402
 
 
 def main():
+    global CSRC
     name, defs = sys.argv[1], sys.argv[2:]
+    CSRC = os.environ.get("SRGD_CSRC", CSRC)          # A/B against an older source tree (e.g. `git worktree add /tmp/base HEAD~1`)
     out_dir = os.path.join(ROOT, "srgd_amd", "variants")
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, f"libsrgd_hip_{name}.so")
