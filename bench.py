@@ -333,6 +333,10 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    shard = sampler.canvas_group if canvas_mode else None
+    if shard:                                   # time every pack -> all-gather -> unpack of the timed region (HIP events)
+        shard.exchange_ms()
+        shard.timing = True
     t0 = time.perf_counter()
     outs, gathered = run(args.warmup, total, gather=True)
     torch.cuda.synchronize()
@@ -340,6 +344,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    exchange_ms = 0.0
+    if shard:
+        shard.timing = False
+        exchange_ms = shard.exchange_ms()
+        if dist:
+            from srgd_amd.parallel import max_over_ranks
+            exchange_ms = max_over_ranks(exchange_ms, device)
     if dist:
         from srgd_amd.parallel import max_over_ranks
         dt = max_over_ranks(dt, device)
@@ -365,6 +376,11 @@ def main():
                                    f"even/odd step, tiles sharded over {world} rank(s), per-step tile all-gather",
                        "tile_forwards_per_step": tf, "parallelism": f"canvas-sharded x{world}"},
             "forced_dist": force_dist, "tile_allgathers": sampler.canvas_group.exchanges if sampler.canvas_group else 0,
+            # per DDPM step of the timed region, max over ranks: pack + all-gather + unpack of the canvas tiles (HIP events on
+            # the engine's stream); exchange_share = that / the wall time, i.e. what strong scaling loses to the collective
+            "exchange_ms": exchange_ms / max(1, args.steps * args.ddpm_steps),
+            "exchange_share": exchange_ms / (1e3 * dt),
+            "exchange_mb_per_step": (3 * 256 * 256 * 4 * ((ne + no) / 2.0) / 1e6) if sampler.canvas_group else 0.0,
             "hr_tile_equivalents_per_s": args.steps * tf / dt / TILE_FORWARDS_PER_HR_TILE,
             "tflops_effective": args.steps * tf / dt * 0.7938}), flush=True)
     elif rank == 0:

@@ -261,6 +261,8 @@ struct srgd_engine {
   // front: configs[4] 0.430 -> 0.444 HR tiles/s, same box (profiles/r3/mx1x1_ab.txt), for -0.5 dB (fp8) / -1.2 dB
   // (fp8_mixed) against the reference.  SRGD_MX1X1=0 keeps them on conv1x1_bf16.
   bool no_mx1x1 = false;
+  bool no_attn_w8 = false;    // SRGD_FP8_ATTN_W=0: fp8 modes keep the attention projections' weights in bf16 (A/B switch)
+  int attn_w8_tensors = 0;    // attention weight tensors carried as MX-fp8 (weight-only) after srgd_finalize_weights
   int mx1x1_min_cin = 0;      // SRGD_MX1X1_MIN_CIN: pointwise layers with fewer input channels stay on conv1x1_bf16
   unsigned fp8_bf16_zones = 0;   // SRGD_FP8_BF16_ZONES (bit mask over Ctx::zone): zones whose 3x3 convs stay bf16 in fp8 mode (study knob)
   bool no_twin_fusion = false;   // SRGD_Q_FUSED=0: fp8 mode quantises every conv input in a separate pass (A/B + bit-equality test)
@@ -1082,6 +1084,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   e->no_mx1x1 = e->cfg.precision == SRGD_PRECISION_FP8_MIXED;
   if (const char* v = getenv("SRGD_MX1X1")) e->no_mx1x1 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_MX1X1_MIN_CIN")) e->mx1x1_min_cin = atoi(v);
+  if (const char* v = getenv("SRGD_FP8_ATTN_W")) e->no_attn_w8 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_LA256")) e->no_la256 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_FINAL_FUSION")) e->no_final_fusion = atoi(v) == 0;
   if (const char* v = getenv("SRGD_Q_FUSED")) e->no_twin_fusion = atoi(v) == 0;
@@ -1163,6 +1166,39 @@ int srgd_finalize_weights(srgd_engine* e) {
         const float scale = amax / 448.0f;
         for (size_t i = 0; i < per; ++i) w[i] = round_through_e4m3(w[i] / scale) * scale;
       }
+    }
+  }
+  if (e->fp8 && !e->no_attn_w8) {
+    // fp8 modes (BASELINE configs[4]: "fp8 conv + attention weights"): the projections of all attention sites - to_qkv and
+    // to_out of LinearAttention / Attention (reference model.py:300-303, 341-342), incl. the ones the fused LinearAttention
+    // kernels fold into their register-resident operands - are carried as MX-fp8: e4m3 elements, one E8M0 scale per (output
+    // channel, 32 input channels), the engine's scale rule (mx_block_exponent), dequantised here at pack time; the kernels
+    // keep multiplying bf16 activations with the (now e4m3-valued) bf16 weights.  Exact: an e4m3 value times a power of two
+    // is a bf16 value.  SRGD_FP8_ATTN_W=0 keeps these weights in bf16 (A/B switch).
+    for (auto& t : e->wt) {
+      if (t.shape.size() != 4 || t.shape[2] != 1 || t.shape[3] != 1 || t.shape[0] <= 1 || t.shape[1] % 32) continue;
+      if (t.name.find("to_qkv.weight") == std::string::npos && t.name.find("to_out.weight") == std::string::npos &&
+          t.name.find("to_out.0.weight") == std::string::npos)
+        continue;
+      // zone of the site (Ctx::zone: down stage s -> s, middle -> n, up stage s -> n + 1 + s): the zones that keep bf16 3x3
+      // convolutions (fp8_mixed: everything at the tile's own resolution; SRGD_FP8_BF16_ZONES) keep bf16 attention weights too -
+      // measured on the configs[4] fixture: e4m3 weights at the two 256x256-resolution LinearAttention sites alone take
+      // fp8_mixed from 53.3 dB to 34.8 dB against the reference (the level of bf16_w8, 35.3 dB)
+      int zone = e->n_stages;
+      if (t.name.rfind("downs.", 0) == 0) zone = atoi(t.name.c_str() + 6);
+      else if (t.name.rfind("ups.", 0) == 0) zone = e->n_stages + 1 + atoi(t.name.c_str() + 4);
+      if (e->fp8_bf16_zones & (1u << zone)) continue;
+      const int64_t O = t.shape[0], I = t.shape[1];
+      for (int64_t o = 0; o < O; ++o)
+        for (int64_t k0 = 0; k0 < I; k0 += 32) {
+          float* w = t.data.data() + (size_t)o * I + k0;
+          float amax = 0.f;
+          for (int k = 0; k < 32; ++k) amax = std::max(amax, std::fabs(w[k]));
+          const int ex = mx_block_exponent(amax);
+          const float inv = std::ldexp(1.0f, -ex), sc = std::ldexp(1.0f, ex);
+          for (int k = 0; k < 32; ++k) w[k] = round_through_e4m3(w[k] * inv) * sc;
+        }
+      e->attn_w8_tensors += 1;
     }
   }
   // 7x7 input conv: OIHW [dim,6,7,7] -> 7 taps (dy) x 64 virtual channels (dx*8 + ci), see kernels.hpp

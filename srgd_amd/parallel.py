@@ -174,6 +174,21 @@ class CanvasShard:
         self.always_exchange = always_exchange
         self._bufs = {}
         self.exchanges = 0                      # tile all-gathers issued so far (tests / bench report it)
+        # bench.py's canvas workload: time every exchange (pack -> all-gather -> unpack) with a pair of events on the stream the
+        # engine runs on, so that the JSON line of an N-GPU run shows what the per-step collective really costs (DESIGN section 7
+        # predicts ~3 ms per step for 856 MB at 8448^2 over 8 GPUs); off by default - a timed pair is two event records per exchange
+        self.timing = False
+        self._events = []
+
+    def exchange_ms(self, reset: bool = True) -> float:
+        """Sum of the timed exchanges so far, in ms (synchronises the device)."""
+        if not self._events:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = float(sum(a.elapsed_time(b) for a, b in self._events))
+        if reset:
+            self._events = []
+        return ms
 
     def buffers(self, width: int, world: int, device, tile: int = 256):
         """(packed [width,3,T,T], everyone [world*width,3,T,T]) views of buffers sized for the widest grid seen so far."""
@@ -205,10 +220,17 @@ def _exchange(eng, shard: CanvasShard, step: int, n_tiles: int, mine: range, wid
         if canvas is None:
             continue
         packed, everyone = shard.buffers(width, world, canvas.device)
+        ev = None
+        if shard.timing:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         eng.sampler_exchange_tiles(step & 1, mine.start, len(mine), canvas, packed, to_canvas=False)
         shard.comm.all_gather_tiles(everyone, packed)
         shard.exchanges += 1
         eng.sampler_exchange_tiles(step & 1, 0, n_tiles, canvas, everyone, to_canvas=True)
+        if ev is not None:
+            ev[1].record()
+            shard._events.append(ev)
 
 
 def sharded_step(eng, shard: CanvasShard, step: int, n_tiles: int, img, cond_canvas, x_start, noise_tiles, noise_canvas,
