@@ -40,9 +40,22 @@ constexpr int COEF_BYTES = 2 * 256;            // GNIN: 32 scales | 32 shifts (f
 #ifndef SRGD_GNIN_SCALAR
 #define SRGD_GNIN_SCALAR 1            // GNIN transform: single-lane-op fp32 arithmetic (inline asm) instead of what -O3 SLP-packs into
 #endif                                // v_pk_fma_f32 / v_pk_mul_f32 - packed f32 VALU beside MFMAs is an anti-lever on gfx950 (A/B builds: 0)
+#ifndef SRGD_CONV3_DMA_POS
+#define SRGD_CONV3_DMA_POS 0          // where a tap issues its LDS-DMA requests: 0 top of the tap, 1 behind its fragment loads, 2 behind its MFMAs, 3 behind its first 8 MFMAs, 4 top of the tap with the explicit-address tap body (A/B)
+#endif
+#ifndef SRGD_CONV3_EPI_SCALAR
+#define SRGD_CONV3_EPI_SCALAR 0       // epilogue bias / GroupNorm sums with single-lane-op instructions instead of v_pk_* (A/B builds)
+#endif
+#ifndef SRGD_CONV3_EPI_PRIO
+#define SRGD_CONV3_EPI_PRIO 0         // s_setprio level of the epilogue (0 = leave it at the kernel's default)
+#endif
+#ifndef SRGD_CONV3_TIED
+#define SRGD_CONV3_TIED 0             // plain instances: tied inline-asm MFMAs as well (A/B builds)
+#endif
 #ifndef SRGD_GNIN_LEAN
 #define SRGD_GNIN_LEAN 3              // GNIN instances: the plain instances' shared fragment addressing and 8-fragment tap (needs the tied MFMAs)
 #endif
+constexpr int CONV3_XCD_PIN_KB_DEFAULT = 0;   // (A/B knob SRGD_CONV3_XCD_PIN_KB; see the kernel's tile map)
 constexpr int CONV3_M16_DEFAULT = 1;     // 16x16x32 measured +1..2 % over 32x32x16 on the production shapes
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -62,6 +75,7 @@ struct Conv3Args {
   float* gn_partial; int groups;
   const float* gn_in_a;   // GNIN: y = silu(a[b][c] * x + b[b][c]) applied to the input while it is staged ([B][Cin] fp32)
   int gn_in_b_off;        // byte offset of the shift array from the scale array (same allocation)
+  int xcd_pin_ntiles;     // blockIdx -> tile map: n-tiles pinned to XCDs (weights stay in the XCD's L2); else contiguous bands of tiles per XCD
   unsigned long long* stamps;   // diagnostics (SRGD_CONV3_STAMPS=1): per-phase s_memtime deltas summed over workgroups; null otherwise
 };
 
@@ -102,12 +116,24 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   const int m_tiles = p.B * tiles_y * tiles_x;
   const int nwg = m_tiles * n_tiles;
   int wg = blockIdx.x;
-  {
+  int nt, mt;
+  if (p.xcd_pin_ntiles) {
+    // Round 4: pin the n-tiles to XCDs.  Blocks b, b + 8, ... share an XCD (round-robin dispatch).  With n-tiles walking fastest
+    // inside an XCD's band (below), every XCD streams ALL weights of the layer (18.9 MB at 1024 -> 1024) through its 4 MiB L2
+    // once per m-tile: the weight tiles come over the fabric from the Infinity Cache every time (~9.4 GB per launch), and a
+    // timing build without the K loop's DMA traffic holds 2.34 GHz where production holds 1.73 GHz at 99 % MFMA issue - the
+    // kernel is clock- (power-) limited and the data movement is what the clock pays for.  Here XCD x owns n-tile x % n_tiles
+    // for all of its m-tiles: its weight working set is 1 / n_tiles of the layer (2.4 MB) and stays L2-resident; the halo
+    // patches are fetched once per XCD that needs them instead (n_tiles x activation bytes over the fabric, 8x less in total).
+    const int x = wg & 7, k = wg >> 3, per = 8 / n_tiles;        // host: n_tiles in {2, 4, 8} and m_tiles % per == 0
+    nt = x % n_tiles;
+    mt = k * per + x / n_tiles;
+  } else {
     const int q = nwg >> 3, rem = nwg & 7, x = wg & 7, k = wg >> 3;
     wg = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + k;
+    nt = wg % n_tiles;
+    mt = wg / n_tiles;
   }
-  const int nt = wg % n_tiles;
-  const int mt = wg / n_tiles;
   const int b = mt / (tiles_y * tiles_x);
   const int trem = mt - b * tiles_y * tiles_x;
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -333,6 +359,10 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       return P * 64 + ((h ^ row_swz<M16>(P)) << 4);
     }
   };
+  // after_loads / after_half: hooks run behind the tap's fragment loads / behind its first 8 MFMAs (16x16 shape): where the
+  // step's LDS-DMA requests are issued is a tuning knob (SRGD_CONV3_DMA_POS) - a timing-only build without any DMA in the K loop
+  // runs 30-38 % faster and one that issues but never waits runs the same as production, i.e. the ISSUE of the 1-2 DMA
+  // instructions per wave and tap sits on the tap's critical path, not their latency
   auto compute = [&](int cc, int tap, int s) {
     const char* A = sA0 + (cc & 1) * A_BYTES;
     const char* Bt = sB0 + (tap % 3) * B_BYTES;          // (cc * 9 + tap) % 3
@@ -373,7 +403,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(3));
 #define MM(C_, A_, B_)                                                                                   \
   do {                                                                                                   \
-    if constexpr (GNIN) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(A_), "v"(B_)); \
+    if constexpr (GNIN || SRGD_CONV3_TIED) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(A_), "v"(B_)); \
     else C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, C_, 0, 0, 0);                             \
   } while (0)
       MM(c00, a0, b0); MM(c01, a0, b1); MM(c02, a0, b2); MM(c03, a0, b3);
@@ -398,8 +428,48 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     }
   };
 
-  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-  if (p.stamps) t0 = __builtin_amdgcn_s_memtime();
+  // The 8-fragment tap of the 16x16 shape written out at loop level (no closure between the tap loop and issue_a / issue_b: a
+  // nested lambda around them made the compiler keep the kernel arguments and captured descriptors in scratch), with the tap's
+  // LDS-DMA requests (DMA_) placed behind the fragment loads (SRGD_CONV3_DMA_POS 1) or behind the first 8 MFMAs (3).
+  // Fragment addresses here are explicit: halo pixel P = lp + Pc, Pc = (block row + dy) * 34 + 16 (x half) + dx a compile-time
+  // constant per (tap, block); 34 = 2 mod 8, so the swizzle term ((P >> 1) & 3) depends on the lane and on Pc & 7 only: eight
+  // per-lane row bases (one per value of Pc & 7), the buffer of the chunk rides in an opaque SGPR (one v_add per fragment, and
+  // nothing for the compiler to reassociate and hoist: the lambda form's (lp8 + Pc * 8) sums turned into ~16 long-lived
+  // registers here and spilled 62), Pc * 64 is the ds_read's immediate offset.
+#define SRGD_AB(K) const int ab##K = lp64 + ((((lp8 + (K) * 8) & 0x30)) ^ q16s);
+  SRGD_AB(0) SRGD_AB(1) SRGD_AB(2) SRGD_AB(3) SRGD_AB(4) SRGD_AB(5) SRGD_AB(6) SRGD_AB(7)
+#undef SRGD_AB
+#define SRGD_AFRAG(TAPV, I, SA_)                                                                           \
+  ({                                                                                                       \
+    const int Pc_ = (((I) >> 1) + (TAPV) / 3) * WP + ((I) & 1) * 16 + (TAPV) % 3;                          \
+    const int k7_ = Pc_ & 7;                                                                               \
+    const int base_ = k7_ == 0 ? ab0 : k7_ == 1 ? ab1 : k7_ == 2 ? ab2 : k7_ == 3 ? ab3 : k7_ == 4 ? ab4 : k7_ == 5 ? ab5 : k7_ == 6 ? ab6 : ab7; \
+    *reinterpret_cast<const bf16x8*>(smem + (base_ + (SA_)) + Pc_ * 64);                                   \
+  })
+#define SRGD_TAP8(CCV, TAPV, DMA_)                                                                         \
+  do {                                                                                                     \
+    int sa_ = ((CCV) & 1) * A_BYTES;                                                                       \
+    asm volatile("" : "+s"(sa_));                                                                          \
+    const char* Bt_ = sB0 + ((TAPV) % 3) * B_BYTES;                                                        \
+    const bf16x8 a0 = SRGD_AFRAG(TAPV, 0, sa_);                                                            \
+    const bf16x8 a1 = SRGD_AFRAG(TAPV, 1, sa_);                                                            \
+    const bf16x8 a2 = SRGD_AFRAG(TAPV, 2, sa_);                                                            \
+    const bf16x8 a3 = SRGD_AFRAG(TAPV, 3, sa_);                                                            \
+    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bt_ + b_addr(0));                                   \
+    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bt_ + b_addr(1));                                   \
+    const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bt_ + b_addr(2));                                   \
+    const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bt_ + b_addr(3));                                   \
+    if (SRGD_CONV3_DMA_POS == 1) { __builtin_amdgcn_sched_barrier(0); DMA_; __builtin_amdgcn_sched_barrier(0); } \
+    SRGD_MMT(c00, a0, b0); SRGD_MMT(c01, a0, b1); SRGD_MMT(c02, a0, b2); SRGD_MMT(c03, a0, b3);            \
+    SRGD_MMT(c10, a1, b0); SRGD_MMT(c11, a1, b1); SRGD_MMT(c12, a1, b2); SRGD_MMT(c13, a1, b3);            \
+    if (SRGD_CONV3_DMA_POS == 3) { __builtin_amdgcn_sched_barrier(0); DMA_; __builtin_amdgcn_sched_barrier(0); } \
+    SRGD_MMT(c20, a2, b0); SRGD_MMT(c21, a2, b1); SRGD_MMT(c22, a2, b2); SRGD_MMT(c23, a2, b3);            \
+    SRGD_MMT(c30, a3, b0); SRGD_MMT(c31, a3, b1); SRGD_MMT(c32, a3, b2); SRGD_MMT(c33, a3, b3);            \
+  } while (0)
+#define SRGD_MMT(C_, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(A_), "v"(B_))
+
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, r0 = 0;
+  if (p.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   // ---- prologue: A(0) and B[0], B[1]
   if (GNIN) coef_dma(0);
   issue_a_piece(0, 0);
@@ -429,8 +499,20 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       // GNIN: the next chunk's coefficients are the OLDEST request of tap 0 (so the tap's counted wait covers them), published
       // by tap 0's barrier, read from tap 2 on
       if (GNIN && tap == 0) coef_dma(cc + 1);
-      if (tap < 3) issue_a_piece(cc + 1, tap);
-      issue_b(cc, tap + 2);                      // always < S here (cc < CC-1)
+#ifndef SRGD_CONV3_DIAG_NODMA               // timing-only diagnostics (wrong results): 1 = no DMA issue inside the K loop, 2 = no A pieces, 3 = no weight tiles
+#define SRGD_CONV3_DIAG_NODMA 0
+#endif
+#define SRGD_TAP_DMA()                                                                                                  \
+      do {                                                                                                             \
+        /* 5 = every request re-fetches chunk 0's bytes into the slot it would fill (same DMA traffic, static LDS contents) */ \
+        if (SRGD_CONV3_DIAG_NODMA == 5) { if (tap < 3) issue_a_piece((cc + 1) & 1 ? 1 : 0, tap); issue_b(0, (tap + 2) % 3 + 3); } \
+        if (SRGD_CONV3_DIAG_NODMA == 0 || SRGD_CONV3_DIAG_NODMA == 3 || SRGD_CONV3_DIAG_NODMA == 4) { if (tap < 3) issue_a_piece(cc + 1, tap); } \
+        if (SRGD_CONV3_DIAG_NODMA == 6 && (tap & 1) == 0) issue_b(cc, tap + 2);   /* 6 = weight tiles on even taps only: -38 % DMA bytes */ \
+        if (SRGD_CONV3_DIAG_NODMA == 6 && tap < 3) issue_a_piece(cc + 1, tap);                                                                  \
+        if (SRGD_CONV3_DIAG_NODMA == 0 || SRGD_CONV3_DIAG_NODMA == 2 || SRGD_CONV3_DIAG_NODMA == 4) issue_b(cc, tap + 2); /* always < S here (cc < CC-1) */ \
+      } while (0)
+      constexpr int DP = (M16 && (!GNIN || (SRGD_GNIN_LEAN & 2))) ? SRGD_CONV3_DMA_POS : 0;     // (the hooks exist in the 8-fragment tap only)
+      if (DP == 0 || DP == 4) SRGD_TAP_DMA();
       // a wave rewrites only the pieces it DMA'd itself: piece issued at tap t has landed after the wait of tap t+1;
       // six half-piece transforms spread over taps 2..7 (j = 0, 0, 1, 1, 2, 2)
       if (GNIN && tap >= 2 && tap < 8) {
@@ -439,8 +521,14 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
         transform_a_half(cc + 1, (tap - 2) >> 1, (tap - 2) & 1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      compute(cc, tap, s);
-      if (tap < 3) WAIT_VM(2); else WAIT_VM(1);
+      if constexpr (DP == 1 || DP == 3 || DP == 4) { SRGD_TAP8(cc, tap, SRGD_TAP_DMA()); }
+      else compute(cc, tap, s);
+      if (DP == 2) SRGD_TAP_DMA();
+#undef SRGD_TAP_DMA
+      if (SRGD_CONV3_DIAG_NODMA == 4 || SRGD_CONV3_DIAG_NODMA == 6) WAIT_VM(6);         // 4 = DMA issued as usual, but (almost) never waited for
+      else if (SRGD_CONV3_DIAG_NODMA == 2) WAIT_VM(1);
+      else if (SRGD_CONV3_DIAG_NODMA == 3) { if (tap >= 3) WAIT_VM(0); else WAIT_VM(1); }
+      else if (tap < 3) WAIT_VM(2); else WAIT_VM(1);
       BARRIER();
     }
   }
@@ -450,8 +538,13 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int s = cc * 9 + tap;
-      if (tap < 7) issue_b(cc, tap + 2);
-      compute(cc, tap, s);
+#define SRGD_TAP_DMA() do { if (SRGD_CONV3_DIAG_NODMA != 1 && SRGD_CONV3_DIAG_NODMA != 3 && tap < 7) issue_b(cc, tap + 2); } while (0)
+      constexpr int DP = (M16 && (!GNIN || (SRGD_GNIN_LEAN & 2))) ? SRGD_CONV3_DMA_POS : 0;
+      if (DP == 0 || DP == 4) SRGD_TAP_DMA();
+      if constexpr (DP == 1 || DP == 3 || DP == 4) { SRGD_TAP8(cc, tap, SRGD_TAP_DMA()); }
+      else compute(cc, tap, s);
+      if (DP == 2) SRGD_TAP_DMA();
+#undef SRGD_TAP_DMA
       if (tap < 7) WAIT_VM(1); else WAIT_VM(0);
       if (tap < 8) BARRIER();
     }
@@ -466,7 +559,13 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // 256-byte channel rows, 16 B per lane - 8 store instructions per thread instead of 64.
   constexpr int EROW = BN3 * 2 + 16;
   BARRIER();                                              // every wave is done reading the operand buffers
-  if constexpr (M16 && GNIN) {
+#if SRGD_CONV3_EPI_PRIO
+  // the epilogue's ~250 VALU / LDS instructions per lane share the SIMD's issue port with the co-resident workgroup's MFMA stream
+  // (an MFMA holds the port 8 of its 16 cycles): at equal priority the phase crawls (11-12k ticks for ~2k cycles of work) while
+  // this workgroup holds half the CU's LDS and registers; raised priority finishes it and gets the next tile started sooner
+  __builtin_amdgcn_s_setprio(SRGD_CONV3_EPI_PRIO);
+#endif
+  if constexpr (M16 && (GNIN || SRGD_CONV3_TIED || SRGD_CONV3_EPI_SCALAR || SRGD_CONV3_DMA_POS == 1 || SRGD_CONV3_DMA_POS == 3 || SRGD_CONV3_DMA_POS == 4)) {
     // asm MFMAs: the compiler does not know the accumulators were written by the matrix pipe and inserts no wait states ahead of
     // their first VALU read (up to 18 for a 16x16 result); the barrier above does not count as one
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
@@ -506,6 +605,29 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
         // packed fp32 adds / fmas on register pairs (v_pk_add_f32, v_pk_fma_f32), ONE v_cvt_pk_bf16_f32 per two values whose
         // halves go out as ds_write_b16 / ds_write_b16_d16_hi
         typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+#if SRGD_CONV3_EPI_SCALAR
+        // Round 4: the same arithmetic in the same order with single-lane-op instructions (inline asm, so that -O3 does not pack
+        // them again): a v_pk_add_f32 / v_pk_fma_f32 issued beside the co-resident workgroup's MFMA stream costs several times
+        // the two plain ops it replaces (MI355X_MICROARCH.md: packed f32 VALU is an anti-lever beside MFMAs) - round 3's packed
+        // form measured faster in instruction count and slower where it mattered.  Bit-identical sums.
+        f32x2 v01, v23;
+        {
+          float w0, w1, w2, w3, e0, e1, a1 = s1p[ni][0], b1 = s1p[ni][1], a2 = s2p[ni][0], b2s = s2p[ni][1];
+          asm("v_add_f32 %0, %4, %8\n\tv_add_f32 %1, %5, %8\n\tv_add_f32 %2, %6, %8\n\tv_add_f32 %3, %7, %8"
+              : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(bias));
+          if (STATS) {
+            asm("v_add_f32 %0, %6, %8\n\tv_add_f32 %1, %7, %9\n\t"
+                "v_add_f32 %2, %2, %0\n\tv_add_f32 %3, %3, %1\n\t"
+                "v_fma_f32 %4, %6, %6, %4\n\tv_fma_f32 %5, %7, %7, %5\n\t"
+                "v_fma_f32 %4, %8, %8, %4\n\tv_fma_f32 %5, %9, %9, %5"
+                : "=&v"(e0), "=&v"(e1), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2s) : "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+            s1p[ni] = f32x2{a1, b1};
+            s2p[ni] = f32x2{a2, b2s};
+          }
+          v01 = f32x2{w0, w1};
+          v23 = f32x2{w2, w3};
+        }
+#else
         const f32x2 b2 = {bias, bias};
         const f32x2 v01 = f32x2{av[0], av[1]} + b2, v23 = f32x2{av[2], av[3]} + b2;
         if (STATS) {
@@ -513,6 +635,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
           s2p[ni] = __builtin_elementwise_fma(v01, v01, s2p[ni]);
           s2p[ni] = __builtin_elementwise_fma(v23, v23, s2p[ni]);
         }
+#endif
         const bf16x2_t t01 = __builtin_convertvector(v01, bf16x2_t), t23 = __builtin_convertvector(v23, bf16x2_t);
         if (pair_writes) {
           // Two adjacent lanes hold two adjacent channels of the same four rows.  They swap halves (one DPP quad_perm move) so
@@ -633,6 +756,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     atomicAdd(&p.stamps[0], t1 - t0); atomicAdd(&p.stamps[1], t2 - t1); atomicAdd(&p.stamps[2], t3 - t2);
     atomicAdd(&p.stamps[3], t4 - t3); atomicAdd(&p.stamps[4], t5 - t4); atomicAdd(&p.stamps[5], t5 - t0);
     atomicAdd(&p.stamps[6], 1ull);
+    atomicAdd(&p.stamps[7], __builtin_amdgcn_s_memrealtime() - r0);      // 100 MHz ticks: in-kernel clock = total / this * 100 MHz
   }
 }
 
@@ -700,6 +824,13 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   p.gn_in_a = gn_in_a;
   p.gn_in_b_off = gnin ? (int)((const char*)gn_in_b - (const char*)gn_in_a) : 0;
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
+  {
+    // SRGD_CONV3_XCD_PIN: minimum packed-weight bytes of a layer for the n-tile-per-XCD map (0 = never)
+    static const long pin_min = (long)env_int("SRGD_CONV3_XCD_PIN_KB", CONV3_XCD_PIN_KB_DEFAULT) * 1024L;
+    const int n_tiles = a.Cout / BN3, m_tiles = grid / n_tiles;
+    const long wbytes = 9L * (a.C0 + a.C1) * a.Cout * 2;
+    p.xcd_pin_ntiles = pin_min > 0 && wbytes >= pin_min && (n_tiles == 2 || n_tiles == 4 || n_tiles == 8) && m_tiles % (8 / n_tiles) == 0;
+  }
   static const int want_stamps = env_int("SRGD_CONV3_STAMPS", 0) ? 1 : 0;
   p.stamps = nullptr;
   if (want_stamps) {
@@ -737,8 +868,9 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
     SRGD_HIP(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));
     const double n = h[6] ? (double)h[6] : 1.0;
     fprintf(stderr, "[conv3x3_bf16 stamps] C %d+%d -> %d @%dx%d grid %d: prologue %.0f  main %.0f  transpose %.0f  stores %.0f  "
-                    "stats %.0f  total %.0f  (s_memtime ticks per workgroup)\n",
-            a.C0, a.C1, a.Cout, a.Hin, a.Win, grid, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n);
+                    "stats %.0f  total %.0f  (s_memtime ticks per workgroup)  in-kernel clock %.3f GHz\n",
+            a.C0, a.C1, a.Cout, a.Hin, a.Win, grid, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n,
+            h[7] ? 0.1 * (double)h[5] / (double)h[7] : 0.0);
   }
   return 0;
 }

@@ -33,6 +33,9 @@
 namespace srgd {
 namespace {
 
+#ifndef SRGD_MXFP8_EPI_PRIO
+#define SRGD_MXFP8_EPI_PRIO 0
+#endif
 constexpr int QPH = 8, QPW = 32;                 // output patch
 constexpr int QHP = QPH + 2, QWP = QPW + 2;      // halo patch: 10 x 34 = 340 pixels
 constexpr int QKC = 128;                         // channels per chunk = K of one MFMA
@@ -68,7 +71,11 @@ struct ConvQArgs {
   bf16* out;
   float* gn_partial; int groups;
   unsigned char* oq; unsigned char* os;   // optional MX-fp8 twin of the output (ConvArgs::out_q / out_s)
+  unsigned long long* stamps;             // diagnostics (SRGD_MXFP8_STAMPS=1): per-phase s_memtime deltas summed over workgroups; null otherwise
 };
+
+// phase accumulators of the diagnostic mode: [prologue, main loop, epilogue, total, workgroups, s_memrealtime ticks]
+__device__ unsigned long long g_convq_stamps[8];
 
 // lane id from v_mbcnt, as volatile asm: never hoisted or CSE'd, so no VGPR carries it (or the thread id) across the K loop
 __device__ __forceinline__ int lane_id_opaque() {
@@ -352,12 +359,15 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
 #undef SRGD_QLOAD_A
   };
 
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0;
+  if (p.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   // ---- prologue: A(0), B[0]
   issue_a(0);
   issue_b(0, 0, 0);
   QWAIT_VM(0);
   QBARRIER();
 
+  if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
   // ---- main loop.  Per K-step: issue B[s+1] into the other ring slot; compute(s) (32 MFMAs per wave, ~2,000 cycles with the
   // SIMD's second wave: plenty for a 16.5 KiB L2 hit to land); wait for it; barrier.  Every step issues one weight unit (the
   // last step re-fetches the final one into the slot nobody reads any more) so that the unrolled tap loop is branch-free:
@@ -393,6 +403,10 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
     }
   }
   QWAIT_VM(0);                                     // (nothing is in flight here; kept next to the epilogue's reuse of the ring)
+  if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
+#if SRGD_MXFP8_EPI_PRIO
+  __builtin_amdgcn_s_setprio(SRGD_MXFP8_EPI_PRIO);   // see conv3x3_bf16.hip: the epilogue competes with the co-resident workgroup's MFMA stream for issue slots
+#endif
   // The MFMAs are inline asm (compute()): the compiler does not know that the accumulators were written by the matrix pipe and
   // inserts none of the wait states a VALU read of an XDL result needs (<= 18 for a 16-pass MFMA).  The accumulators are
   // threaded through these statements, so every epilogue read comes after >= 32 wait states behind the last MFMA.
@@ -528,6 +542,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
       dst[1] = a2;
     }
   }
+  if (p.stamps && tidE == 0) {
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    atomicAdd(&p.stamps[0], t1 - t0); atomicAdd(&p.stamps[1], t2 - t1); atomicAdd(&p.stamps[2], t3 - t2);
+    atomicAdd(&p.stamps[3], t3 - t0); atomicAdd(&p.stamps[4], 1ull);
+    atomicAdd(&p.stamps[5], __builtin_amdgcn_s_memrealtime() - r0);
+  }
 }
 
 }  // namespace
@@ -622,6 +642,12 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   p.out = (bf16*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
   p.oq = (unsigned char*)a.out_q; p.os = (unsigned char*)a.out_s;
   const int grid = a.B * (a.Hin / QPH) * (a.Win / QPW) * (a.Cout / QBN);
+  static const int want_stamps = env_int("SRGD_MXFP8_STAMPS", 0) ? 1 : 0;
+  p.stamps = nullptr;
+  if (want_stamps) {
+    SRGD_HIP(hipGetSymbolAddress((void**)&p.stamps, HIP_SYMBOL(g_convq_stamps)));
+    SRGD_HIP(hipMemsetAsync(p.stamps, 0, sizeof(unsigned long long) * 8, st));
+  }
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
 #define SRGD_SETQ(S_, N_)                                                                                 \
@@ -640,6 +666,17 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
     else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false, 4>), dim3(grid), dim3(256), QLDS, st, p);
   }
   SRGD_HIP(hipGetLastError());
+  if (want_stamps) {                                    // diagnostic mode: synchronous, prints the mean ticks per workgroup and phase
+    unsigned long long h[8];
+    SRGD_HIP(hipStreamSynchronize(st));
+    SRGD_HIP(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));
+    const double n = h[4] ? (double)h[4] : 1.0;
+    const int steps = 9 * ((a.C0 + a.C1) / QKC);
+    fprintf(stderr, "[conv3x3_mxfp8 stamps] C %d+%d -> %d @%dx%d grid %d: prologue %.0f  main %.0f (%.0f per K-step)  epilogue %.0f  total %.0f  "
+                    "(s_memtime ticks per workgroup)  in-kernel clock %.3f GHz\n",
+            a.C0, a.C1, a.Cout, a.Hin, a.Win, grid, h[0] / n, h[1] / n, h[1] / n / steps, h[2] / n, h[3] / n,
+            h[5] ? 0.1 * (double)h[3] / (double)h[5] : 0.0);
+  }
   return 0;
 }
 

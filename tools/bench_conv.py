@@ -97,11 +97,12 @@ def main():
         d = (outs[0][0] - outs[1][0]).abs().max().item()
         ref = outs[0][0].abs().max().item()
         ds = ((outs[0][1] - outs[1][1]).abs().max().item() / max(1.0, outs[0][1].abs().max().item())) if outs[0][1] is not None else 0.0
-        rows.append(dict(shape=name, generic_tflops=round(res[1], 1), engine_tflops=round(res[0], 1),
+        ia, ib = [int(v) for v in args.impls.split(',')][:2]        # first = the reference arm (default: generic), second = the arm under test
+        rows.append(dict(shape=name, impl_a=ia, impl_b=ib, generic_tflops=round(res[ia], 1), engine_tflops=round(res[ib], 1),
                          max_abs_diff=d, ref_max=ref, stats_rel_diff=ds))
         gb = 2.0 * B * hw * hw * (c0 + c1 + cout) / 1e9           # bf16 in + out, once
-        ms0 = 2.0 * B * hw * hw * cout * ks * ks * (c0 + c1) / (res[0] * 1e12) * 1e3
-        print(f"{name:28s} generic {res[1]:7.1f} TF   engine {res[0]:7.1f} TF ({ms0:.3f} ms, {gb / ms0:.2f} TB/s in+out)   |diff| {d:.3g} (max {ref:.3g})  stats {ds:.2g}", flush=True)
+        ms0 = 2.0 * B * hw * hw * cout * ks * ks * (c0 + c1) / (res[ib] * 1e12) * 1e3
+        print(f"{name:28s} impl {ia} {res[ia]:7.1f} TF   impl {ib} {res[ib]:7.1f} TF ({ms0:.3f} ms, {gb / ms0:.2f} TB/s in+out)   |diff| {d:.3g} (max {ref:.3g})  stats {ds:.2g}", flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/bench_conv.json", "w") as f:
         json.dump(rows, f, indent=1)
