@@ -27,6 +27,12 @@
 namespace srgd {
 namespace {
 
+#ifndef SRGD_LA_DOT2
+#define SRGD_LA_DOT2 0    // row norms with v_dot2c_f32_bf16 (A/B: 0 = unpack + fma)
+#endif
+#ifndef SRGD_LA_PACK
+#define SRGD_LA_PACK 1    // pack8 through four packed converts (A/B: 0 = element-wise)
+#endif
 constexpr int TM = 64;                  // pixels per tile
 constexpr int TILE_BYTES = TM * 256;    // [64 rows][128 bf16] = 16 KiB
 constexpr int NTH = 256;                // 4 waves: one per head (la1) / per 32-channel block (la2)
@@ -68,13 +74,30 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* bu
 // 1 / max(||x_row||, 1e-12) for the 64 rows of a staged tile (4 threads per row)
 __device__ __forceinline__ void row_rinv(const char* tile, float* rinv, int tid) {
   const int row = tid >> 2, part = tid & 3;
+  // round 4, measured and NOT shipped (SRGD_LA_DOT2 = 0): v_dot2c_f32_bf16 on the packed pairs - 16 instructions per thread
+  // instead of 32 unpacks + 32 fmas - made la1 8 % SLOWER (517 -> 565 us per launch); so did taking the column sums l from a
+  // p . ones MFMA (SRGD_LA_LSUM, +7 %) and tied inline-asm MFMAs (SRGD_LA_ASM, no scheduling freedom): 34 % fewer vector
+  // instructions in the tile loop bought nothing - the kernel's phases are latency-serialised, not issue-bound.  What did pay:
+  // pack8 through packed converts (-5 %).
+  // (written out per component: with the four dwords indexed in a loop this hipcc emitted the dot product of dword 0 four times)
   float ss = 0.f;
+#if !SRGD_LA_DOT2
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * 256 + (part * 4 + j) * 16);
 #pragma unroll
     for (int e = 0; e < 8; ++e) ss += (float)v[e] * (float)v[e];
   }
+#else
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+#define LA_DOT2(W_) ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, (W_)), __builtin_bit_cast(bf16x2_t, (W_)), ss, false)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint4 v = *reinterpret_cast<const uint4*>(tile + row * 256 + (part * 4 + j) * 16);
+    LA_DOT2(v.x); LA_DOT2(v.y); LA_DOT2(v.z); LA_DOT2(v.w);
+  }
+#undef LA_DOT2
+#endif
   ss += __shfl_xor(ss, 1, 64);
   ss += __shfl_xor(ss, 2, 64);
   if (part == 0) rinv[row] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
@@ -84,10 +107,22 @@ __device__ __forceinline__ void row_rinv(const char* tile, float* rinv, int tid)
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
+  // four v_cvt_pk_bf16_f32 whose results ARE the operand tuple's dwords (element-wise assembly of the bf16x8 left the packed
+  // pairs in scattered registers and copied them together: 40 v_mov per tile)
+#if !SRGD_LA_PACK
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (bf16)a[8 * s + j];
   return o;
+#endif
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w;
+  w[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a[8 * s + 0], a[8 * s + 1]}, bf16x2_t));
+  w[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a[8 * s + 2], a[8 * s + 3]}, bf16x2_t));
+  w[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a[8 * s + 4], a[8 * s + 5]}, bf16x2_t));
+  w[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a[8 * s + 6], a[8 * s + 7]}, bf16x2_t));
+  return __builtin_bit_cast(bf16x8, w);
 }
 
 // ------------------------------------------------------------------------------------------- phase 1
@@ -123,8 +158,32 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
   }
   stage_tile(rsx, sA, head, lane, px_begin);
   if (T > 1) stage_tile(rsx, sA + TILE_BYTES, head, lane, px_begin + TM);
-  float m = -INFINITY, l = 0.f;                     // running max (log2 domain) / sum of this lane's k column d = r
+  float m = -INFINITY;                              // running max (log2 domain) of this lane's k column d = r
   f32x16 ctx = 0;
+  // round 4: the column sums l[d] = sum_n p[n][d] ride on the matrix pipe - p . ones, one extra MFMA per context MFMA - instead
+  // of 32 v_add per tile; every column of `lsum` holds l in the context's row order (d = row of the accumulator register)
+  f32x16 lsum = 0;
+  [[maybe_unused]] float lvec = 0.f;               // (SRGD_LA_LSUM = 0: the sums on the vector ALU, as in round 3)
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+  // MFMAs as inline asm with the accumulator tied (D = C): through the builtin every MFMA gets a fresh destination and the
+  // accumulators migrate through the register file (40 v_mov per tile, the kernel at the 256-register ceiling with spills)
+#ifndef SRGD_LA_LSUM
+#define SRGD_LA_LSUM 0
+#endif
+#ifndef SRGD_LA_ASM
+#define SRGD_LA_ASM 0     // 1: tied inline-asm MFMAs (A/B build)
+#endif
+#if SRGD_LA_ASM
+#define LA_MM(C_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(A_), "v"(B_))
+#define LA_MM0(C_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(C_) : "v"(A_), "v"(B_))
+#define LA_NOP(STR_, ...) asm volatile(STR_ : __VA_ARGS__)
+#else
+#define LA_MM(C_, A_, B_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
+#define LA_MM0(C_, A_, B_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, f32x16(0), 0, 0, 0)
+#define LA_NOP(STR_, ...) do {} while (0)
+#endif
   // tile 0 has landed once at most the second tile's 4 pieces are outstanding (wherever the compiler put the fragment
   // loads relative to the DMAs, "all but the 4 youngest" covers tile 0)
   if (T > 1) LA_WAIT_VM(4); else LA_WAIT_VM(0);
@@ -140,17 +199,26 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
       *reinterpret_cast<f32x4*>(rinv_out + (size_t)b * N + px_begin + t * TM + lane * 4) = *reinterpret_cast<const f32x4*>(rinv + lane * 4);
 
     // [k | v] of this wave's head for the tile's 64 rows
-    f32x16 k0 = 0, k1 = 0, v0 = 0, v1 = 0;
+    f32x16 k0, k1, v0, v1;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int c = 2 * s + hh;
       const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + swz(r, c));
       const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + swz(32 + r, c));
-      k0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fk[s], k0, 0, 0, 0);
-      k1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fk[s], k1, 0, 0, 0);
-      v0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fv[s], v0, 0, 0, 0);
-      v1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fv[s], v1, 0, 0, 0);
+      if (s == 0) {                                 // C = 0 as the inline constant: no 64-register zero fill per tile
+        LA_MM0(k0, fa0, fk[s]);
+        LA_MM0(k1, fa1, fk[s]);
+        LA_MM0(v0, fa0, fv[s]);
+        LA_MM0(v1, fa1, fv[s]);
+      } else {
+        LA_MM(k0, fa0, fk[s]);
+        LA_MM(k1, fa1, fk[s]);
+        LA_MM(v0, fa0, fv[s]);
+        LA_MM(v1, fa1, fv[s]);
+      }
     }
+    // (asm MFMAs: the compiler inserts no wait states ahead of the first VALU read of a matrix-pipe result)
+    LA_NOP("s_nop 15\n\ts_nop 3", "+v"(k0), "+v"(k1), "+v"(v0), "+v"(v1));
     // rows of the accumulator = pixels: k -> k / ||x_n|| in the log2 domain (one multiply), v -> v / ||x_n||
     float bm = -INFINITY;
 #pragma unroll
@@ -171,41 +239,59 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
     const float mn = fmaxf(m, bm);
     const float f = ex2(m - mn);                  // first tile: exp2(-inf) = 0
     m = mn;
-    l *= f;
+#if !SRGD_LA_LSUM
+    lvec *= f;
+#endif
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       k0[i] = ex2(k0[i] - mn);
       k1[i] = ex2(k1[i] - mn);
-      l += k0[i] + k1[i];
+#if !SRGD_LA_LSUM
+      lvec += k0[i] + k1[i];
+#endif
     }
     if (!__all(f == 1.0f)) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int d = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-        ctx[reg] *= __shfl(f, d, 64);             // lane d (< 32) holds the factor of context row d
+        const float fd = __shfl(f, d, 64);        // lane d (< 32) holds the factor of context row d
+        ctx[reg] *= fd;
+        if (SRGD_LA_LSUM) lsum[reg] *= fd;
       }
     }
-    // ctx[d][e] += sum_n p[n][d] v[n][e]: both operands come from accumulator tiles (same row permutation)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(k0, s), pack8(v0, s), ctx, 0, 0, 0);
-      ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(k1, s), pack8(v1, s), ctx, 0, 0, 0);
+    // ctx[d][e] += sum_n p[n][d] v[n][e]: both operands come from accumulator tiles (same row permutation);
+    // lsum[d][*] += sum_n p[n][d] from the same (bf16-rounded) p - numerator and denominator of the softmax see the same values
+    {
+      bf16x8 p00 = pack8(k0, 0), p01 = pack8(k0, 1), p10 = pack8(k1, 0), p11 = pack8(k1, 1);
+      bf16x8 q00 = pack8(v0, 0), q01 = pack8(v0, 1), q10 = pack8(v1, 0), q11 = pack8(v1, 1);
+      // a VALU-written register needs two wait states before an MFMA reads it (operands from v_cvt_pk, accumulators from the
+      // rescale): the compiler inserts them for its own MFMAs, not for inline asm - every operand is threaded through this nop
+      LA_NOP("s_nop 1", "+v"(ctx), "+v"(lsum), "+v"(p00), "+v"(p01), "+v"(p10), "+v"(p11), "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11));
+      LA_MM(ctx, p00, q00); if (SRGD_LA_LSUM) LA_MM(lsum, p00, ones);
+      LA_MM(ctx, p10, q10); if (SRGD_LA_LSUM) LA_MM(lsum, p10, ones);
+      LA_MM(ctx, p01, q01); if (SRGD_LA_LSUM) LA_MM(lsum, p01, ones);
+      LA_MM(ctx, p11, q11); if (SRGD_LA_LSUM) LA_MM(lsum, p11, ones);
     }
     // tile t+1 must have landed before the next iteration reads it; the DMA of tile t+2 (4 pieces) stays in flight
     if (t + 2 < T) LA_WAIT_VM(4); else LA_WAIT_VM(0);
     LA_BARRIER();
   }
-  l += __shfl_xor(l, 32, 64);
+  LA_NOP("s_nop 15\n\ts_nop 3", "+v"(ctx), "+v"(lsum));
+#undef LA_MM
+#undef LA_MM0
+#undef LA_NOP      // matrix-pipe results ahead of their first VALU / store read
   const size_t pidx = (size_t)(b * 4 + head) * nstrips + sidx;
-  if (hh == 0) {
-    pm[pidx * 32 + r] = m * LN2;                    // la_combine works in the natural-log domain
-    pl[pidx * 32 + r] = l;
-  }
+  if (hh == 0) pm[pidx * 32 + r] = m * LN2;         // la_combine works in the natural-log domain
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int d = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
     pctx[(pidx * 32 + d) * 32 + r] = ctx[reg];
+    if (SRGD_LA_LSUM && r == 0) pl[pidx * 32 + d] = lsum[reg];      // every column of lsum holds the same sums: column 0 writes them
   }
+#if !SRGD_LA_LSUM
+  lvec += __shfl_xor(lvec, 32, 64);
+  if (hh == 0) pl[pidx * 32 + r] = lvec;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------- phase 2

@@ -87,10 +87,16 @@ template <int PIECES> __device__ __forceinline__ void wait_all_but() {
 __device__ __forceinline__ float ex2_(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ bf16x8 pack8_(const f32x16& a, int s) {
-  bf16x8 o;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16)a[8 * s + j];
-  return o;
+  // four v_cvt_pk_bf16_f32 whose results are the operand tuple's dwords (linattn_fused.hip: element-wise assembly cost ~40
+  // register copies per tile and 7 % of la1's time)
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w;
+  w[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a[8 * s + 0], a[8 * s + 1]}, bf16x2_t));
+  w[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a[8 * s + 2], a[8 * s + 3]}, bf16x2_t));
+  w[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a[8 * s + 4], a[8 * s + 5]}, bf16x2_t));
+  w[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a[8 * s + 6], a[8 * s + 7]}, bf16x2_t));
+  return __builtin_bit_cast(bf16x8, w);
 }
 
 // ------------------------------------------------------------------------------------------- phase 1
