@@ -1471,6 +1471,11 @@ int srgd_edm_step_tiles(srgd_engine* e, int step, int tile_first, int tile_count
   if (tile_first < 0 || tile_count < 0 || tile_first + tile_count > n) SRGD_FAIL("srgd_edm_step_tiles: tile range outside the grid");
   const bool ring = do_ring != 0;
   sub_batch = std::max(1, std::min(sub_batch, std::max(tile_count, 1)));
+  // balanced launches: the same number of U-Net launches, but of (almost) equal size - 1,089 tiles at a limit of 125 run as
+  // 9 x 121, not 8 x 125 + 89, and a rank's 137-tile slice of a sharded canvas as 69 + 68, not 125 + 12 (a 12-tile launch
+  // fills a fraction of the chip on the deep layers and costs about as much as a 16-tile one).  Tiles are independent within
+  // a step, so the result does not depend on how a step's tiles are grouped (tested bit-identical).
+  if (tile_count > sub_batch) sub_batch = cdiv(tile_count, cdiv(tile_count, sub_batch));
   const size_t canvas1 = (size_t)3 * g.Hp * g.Wp;
   e->pool.reset_busy();
   // every allocation happens here, before any capture
@@ -1509,6 +1514,7 @@ int srgd_edm_dpmpp_step(srgd_engine* e, int step, float* img, const float* cond_
   const int n = n_local * g.n_images;
   const int* tiles = parity ? e->d_tiles_odd : e->d_tiles_even;
   sub_batch = std::min(sub_batch, n);
+  if (n > sub_batch) sub_batch = cdiv(n, cdiv(n, sub_batch));          // balanced launches (srgd_sampler_step_tiles)
   const size_t canvas_elems = (size_t)3 * g.Hp * g.Wp * g.n_images;
   e->pool.reset_busy();
   SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
@@ -1660,6 +1666,11 @@ int srgd_sampler_step_tiles(srgd_engine* e, int step, int tile_first, int tile_c
   if (tile_first < 0 || tile_count < 0 || tile_first + tile_count > n) SRGD_FAIL("srgd_sampler_step_tiles: tile range outside the grid");
   const bool ring = do_ring != 0;
   sub_batch = std::max(1, std::min(sub_batch, std::max(tile_count, 1)));
+  // balanced launches: the same number of U-Net launches, but of (almost) equal size - 1,089 tiles at a limit of 125 run as
+  // 9 x 121, not 8 x 125 + 89, and a rank's 137-tile slice of a sharded canvas as 69 + 68, not 125 + 12 (a 12-tile launch
+  // fills a fraction of the chip on the deep layers and costs about as much as a 16-tile one).  Tiles are independent within
+  // a step, so the result does not depend on how a step's tiles are grouped (tested bit-identical).
+  if (tile_count > sub_batch) sub_batch = cdiv(tile_count, cdiv(tile_count, sub_batch));
   e->pool.reset_busy();
   // every allocation happens here, before any capture
   SRGD_TRY(ensure_scratch(e, sub_batch * passes, g.tile, g.tile));
