@@ -364,7 +364,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
   // ---- prologue: A(0), B[0]
   issue_a(0);
   issue_b(0, 0, 0);
+#ifdef SRGD_MXFP8_DIAG_NOPROLOGUE_WAIT      // timing-only diagnostic (wrong results): the tile does not wait for its first patch and
+  QWAIT_VM(18);                             // weight unit - the upper bound of what a persistent, prefetching workgroup could hide
+#else
   QWAIT_VM(0);
+#endif
   QBARRIER();
 
   if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
