@@ -38,7 +38,8 @@ int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int H
  * weights per (output channel, tap, 32 input channels); C0, C1, Cout % 128 == 0; error if not eligible),
  * 5 = impl 2 with the PRODUCER's GroupNorm + SiLU applied while the input is staged (Block.forward model.py:250-259 between
  * two convolutions): conv(silu(gn_tail_a[b][c] * in0 + gn_tail_b[b][c])), zero padding applied after the activation; one source,
- * gn_tail_a / gn_tail_b = device fp32 [B][C0] in ONE allocation (shift behind scale), gn_tail_src must be NULL.
+ * gn_tail_a / gn_tail_b = device fp32 [B][C0] in ONE allocation (shift behind scale), gn_tail_src must be NULL,
+ * 6 = impl 3 on its 256-pixel x 256-channel tile (one 16-wave workgroup per CU; Cout % 256 == 0; error if not eligible).
  * gn_tail_src (nullable, NHWC like out): out = silu(gn_tail_a[b][c] * gn_tail_src + gn_tail_b[b][c]) + conv(in) -
  * the second GroupNorm+SiLU of a ResnetBlock and its residual add folded into the 1x1 res_conv (model.py:250-259,:285);
  * gn_tail_a / gn_tail_b: device fp32 [B][Cout].  May alias out.

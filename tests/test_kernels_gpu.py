@@ -398,6 +398,41 @@ def test_conv1x1_fast_path_matches_torch_and_generic(variant):
     assert (fast - generic).abs().max() <= tol(True, want, k=2.0)
 
 
+@pytest.mark.parametrize("variant", ["plain", "residual", "gn_tail", "pixel_shuffle", "unshuffle"])
+def test_conv1x1_wide_tile_equals_the_128_wide_kernel_bitwise(variant):
+    # round 4: the 256-pixel x 256-channel instance for the K-heavy pointwise layers (one 16-wave workgroup
+    # per CU, two adjacent weight tiles per K-step, the shared epilogue run by the two halves side by side) walks K in the same
+    # order and rounds at the same points as the 256 x 128 kernel: every epilogue, the two-source K walk and the 2x2 / stride-2
+    # gather must agree to the last bit (impl 6 vs impl 3), over a grid with several m- and n-tiles per XCD.
+    g = torch.Generator().manual_seed(31)
+    B, H, W = 3, 16, 32
+    kw = dict(ks=1, stride=1, pad=0, kind=0, bf16=True)
+    if variant == "pixel_shuffle":
+        x0, x1 = rnd(torch.randn(B, 128, H, W, generator=g), True), None
+        w = rnd(torch.randn(1024, 128, 1, 1, generator=g) / 11, True)         # Cout / 4 = 256
+        b = torch.randn(1024, generator=g)
+        kw["kind"] = 2
+    elif variant == "unshuffle":
+        x0, x1 = rnd(torch.randn(B, 64, 2 * H, 2 * W, generator=g), True), None
+        w = rnd(torch.randn(512, 256, 1, 1, generator=g) / 16, True)
+        b = torch.randn(512, generator=g)
+        kw.update(ks=2, stride=2, kind=1)
+    else:
+        x0 = rnd(torch.randn(B, 160, H, W, generator=g), True)
+        x1 = rnd(torch.randn(B, 96, H, W, generator=g), True)
+        w = rnd(torch.randn(512, 256, 1, 1, generator=g) / 16, True)
+        b = torch.randn(512, generator=g)
+        if variant == "residual":
+            kw["residual"] = rnd(torch.randn(B, 512, H, W, generator=g), True)
+        if variant == "gn_tail":
+            h = rnd(torch.randn(B, 512, H, W, generator=g), True)
+            kw["gn_tail"] = (h, 1 + 0.3 * torch.randn(B, 512, generator=g), 0.5 * torch.randn(B, 512, generator=g))
+    wide, _ = run_conv(x0, x1, w, b, impl=6, **kw)
+    narrow, _ = run_conv(x0, x1, w, b, impl=3, **kw)
+    assert torch.isfinite(wide).all() and wide.abs().max() > 0.5
+    assert torch.equal(wide, narrow)
+
+
 def test_conv1x1_production_shape_agrees_with_generic():
     # res_conv of the last up stage: 128+128 -> 128 at 256^2 with the GroupNorm tail, in place (out aliases the tail source
     # in the engine; here separate buffers), batch 3
