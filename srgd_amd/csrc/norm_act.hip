@@ -2,6 +2,9 @@
 // Memory-bound element-wise kernels: 16-byte vector accesses along the NHWC channel axis.
 #include "kernels.hpp"
 
+#ifndef SRGD_GN_TRIP8
+#define SRGD_GN_TRIP8 0     // eight vectors per trip ahead of the four-vector loop (A/B build)
+#endif
 namespace srgd {
 namespace {
 
@@ -51,7 +54,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(GnFinalizeArgs a) {
 // One grid row (blockIdx.y) per sample: the vector index inside the sample is a 32-bit int, its channel offset a 32-bit
 // remainder (a mask when C / N is a power of two) and the coefficient rows are block-uniform.  (The first version ran one flat
 // 64-bit index over the batch and paid a 64-bit division + remainder per 16-byte vector: VALU-bound at 5.1 TB/s.)
-template <typename T, bool PRECISE>
+// HOIST (round 4): when the grid stride is a multiple of the vectors per pixel (C / N a power of two <= 256: every production
+// layer), a thread meets the SAME channels in every trip - its 2 x N coefficients are loaded once, not per vector: the loop used
+// to issue four 16-byte coefficient loads (L1 hits, but full vector-memory instructions) next to each 16-byte data load.
+template <typename T, bool PRECISE, bool HOIST>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                         const T* __restrict__ res,
                                                         const float* __restrict__ cA,
@@ -68,14 +74,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   const float* pb0 = cB + (size_t)b * C;
   const bool pow2 = (vec_per_pixel & (vec_per_pixel - 1)) == 0;
   // one 16-byte vector: coefficients of its channels, y = silu(a x + b) (+ residual), store (+ MX-fp8 twin)
-  auto finish = [&](unsigned i, const Vec16<T>& v, const Vec16<T>& r) __attribute__((always_inline)) {
-    const int c = (int)(pow2 ? (i & (unsigned)(vec_per_pixel - 1)) : (i % (unsigned)vec_per_pixel)) * N;
-    float ca[N], cb[N];
+  float hca[N], hcb[N];
+  if (HOIST) {
+    const int c = (int)((blockIdx.x * 256u + threadIdx.x) & (unsigned)(vec_per_pixel - 1)) * N;
 #pragma unroll
     for (int j = 0; j < N; j += 4) {
       const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa0 + c + j), b4 = *reinterpret_cast<const f32x4*>(pb0 + c + j);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { ca[j + k] = a4[k]; cb[j + k] = b4[k]; }
+      for (int k = 0; k < 4; ++k) { hca[j + k] = a4[k]; hcb[j + k] = b4[k]; }
+    }
+  }
+  auto finish = [&](unsigned i, const Vec16<T>& v, const Vec16<T>& r) __attribute__((always_inline)) {
+    float ca[N], cb[N];
+    if (HOIST) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) { ca[j] = hca[j]; cb[j] = hcb[j]; }
+    } else {
+      const int c = (int)(pow2 ? (i & (unsigned)(vec_per_pixel - 1)) : (i % (unsigned)vec_per_pixel)) * N;
+#pragma unroll
+      for (int j = 0; j < N; j += 4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa0 + c + j), b4 = *reinterpret_cast<const f32x4*>(pb0 + c + j);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ca[j + k] = a4[k]; cb[j + k] = b4[k]; }
+      }
     }
     Vec16<T> o;
 #pragma unroll
@@ -93,6 +114,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   // trip left ~32 KiB in flight per CU (32 waves x 1 KiB), about half of what HBM's latency-bandwidth product asks for.
   const unsigned stride = gridDim.x * 256u, n = (unsigned)vec_per_sample;
   unsigned i = blockIdx.x * 256u + threadIdx.x;
+#if SRGD_GN_TRIP8
+  for (; i + 7u * stride < n; i += 8u * stride) {
+    const Vec16<T> v0 = xs[i], v1 = xs[i + stride], v2 = xs[i + 2u * stride], v3 = xs[i + 3u * stride], v4 = xs[i + 4u * stride],
+                   v5 = xs[i + 5u * stride], v6 = xs[i + 6u * stride], v7 = xs[i + 7u * stride];
+    Vec16<T> r0, r1, r2, r3, r4, r5, r6, r7;
+    if (rs) { r0 = rs[i]; r1 = rs[i + stride]; r2 = rs[i + 2u * stride]; r3 = rs[i + 3u * stride]; r4 = rs[i + 4u * stride];
+              r5 = rs[i + 5u * stride]; r6 = rs[i + 6u * stride]; r7 = rs[i + 7u * stride]; }
+    finish(i, v0, r0); finish(i + stride, v1, r1); finish(i + 2u * stride, v2, r2); finish(i + 3u * stride, v3, r3);
+    finish(i + 4u * stride, v4, r4); finish(i + 5u * stride, v5, r5); finish(i + 6u * stride, v6, r6); finish(i + 7u * stride, v7, r7);
+  }
+#endif
   for (; i + 3u * stride < n; i += 4u * stride) {
     const Vec16<T> v0 = xs[i], v1 = xs[i + stride], v2 = xs[i + 2u * stride], v3 = xs[i + 3u * stride];
     Vec16<T> r0, r1, r2, r3;
@@ -162,12 +194,18 @@ int gn_apply_silu(const void* x, void* y, const void* residual, const float* coe
   if ((long)hw * C / N >= (1L << 31) || B > 65535) SRGD_FAIL("gn_apply: sample too large for the 32-bit vector index");
   // ~64 blocks per CU over the whole launch, at least one block per sample
   const int gx = (int)std::max<long>(1, std::min<long>((vps + 255) / 256, (256L * 64 + B - 1) / B));
-  if (is_bf16)
-    hipLaunchKernelGGL((gn_apply_kernel<bf16, false>), dim3(gx, B), dim3(256), 0, st, (const bf16*)x, (bf16*)y,
-                       (const bf16*)residual, coefA, coefB, vps, vpp, C, (unsigned char*)out_q, (unsigned char*)out_s);
-  else
-    hipLaunchKernelGGL((gn_apply_kernel<float, true>), dim3(gx, B), dim3(256), 0, st, (const float*)x, (float*)y,
-                       (const float*)residual, coefA, coefB, vps, vpp, C, nullptr, nullptr);
+  // the grid stride gx * 256 is a multiple of the vectors per pixel whenever those are a power of two <= 256
+  static const int hoist_knob = env_int("SRGD_GN_HOIST", 1);
+  const bool hoist = hoist_knob && (vpp & (vpp - 1)) == 0 && vpp <= 256;
+#define SRGD_GN_GO(T_, P_, H_, ...) hipLaunchKernelGGL((gn_apply_kernel<T_, P_, H_>), dim3(gx, B), dim3(256), 0, st, __VA_ARGS__)
+  if (is_bf16) {
+    if (hoist) SRGD_GN_GO(bf16, false, true, (const bf16*)x, (bf16*)y, (const bf16*)residual, coefA, coefB, vps, vpp, C, (unsigned char*)out_q, (unsigned char*)out_s);
+    else SRGD_GN_GO(bf16, false, false, (const bf16*)x, (bf16*)y, (const bf16*)residual, coefA, coefB, vps, vpp, C, (unsigned char*)out_q, (unsigned char*)out_s);
+  } else {
+    if (hoist) SRGD_GN_GO(float, true, true, (const float*)x, (float*)y, (const float*)residual, coefA, coefB, vps, vpp, C, nullptr, nullptr);
+    else SRGD_GN_GO(float, true, false, (const float*)x, (float*)y, (const float*)residual, coefA, coefB, vps, vpp, C, nullptr, nullptr);
+  }
+#undef SRGD_GN_GO
   SRGD_HIP(hipGetLastError());
   return 0;
 }

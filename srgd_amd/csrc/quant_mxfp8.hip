@@ -14,7 +14,9 @@ namespace {
 
 // One grid row (blockIdx.y) per sample for the GroupNorm variant: 32-bit index arithmetic and block-uniform coefficient rows
 // (a flat 64-bit index costs a 64-bit division + remainder per 16-byte vector and makes the pass VALU-bound).
-template <bool GN>
+// HOIST (round 4, as gn_apply_kernel): the grid stride is a multiple of the vectors per pixel, so a thread's channels - and its 16
+// coefficients - are the same in every trip: loaded once instead of four 16-byte loads per vector.
+template <bool GN, bool HOIST>
 __global__ __launch_bounds__(256) void quant_mxfp8_kernel(const bf16* __restrict__ x, unsigned char* __restrict__ q,
                                                            unsigned char* __restrict__ s, int vec_per_sample, int C,
                                                            const float* __restrict__ cA, const float* __restrict__ cB) {
@@ -27,12 +29,18 @@ __global__ __launch_bounds__(256) void quant_mxfp8_kernel(const bf16* __restrict
   const float* pa = GN ? cA + (size_t)b * C : nullptr;
   const float* pb = GN ? cB + (size_t)b * C : nullptr;
   const bool pow2 = (vec_per_pixel & (vec_per_pixel - 1)) == 0;
+  f32x4 ha0 = {0.f, 0.f, 0.f, 0.f}, ha1 = ha0, hb0 = ha0, hb1 = ha0;
+  if (GN && HOIST) {
+    const int c = (int)((blockIdx.x * 256u + threadIdx.x) & (unsigned)(vec_per_pixel - 1)) * 8;
+    ha0 = *reinterpret_cast<const f32x4*>(pa + c); ha1 = *reinterpret_cast<const f32x4*>(pa + c + 4);
+    hb0 = *reinterpret_cast<const f32x4*>(pb + c); hb1 = *reinterpret_cast<const f32x4*>(pb + c + 4);
+  }
   auto finish = [&](unsigned i, const bf16x8& v) __attribute__((always_inline)) {
     float y[8];
     if (GN) {
-      const int c = (int)(pow2 ? (i & (unsigned)(vec_per_pixel - 1)) : (i % (unsigned)vec_per_pixel)) * 8;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(pa + c), a1 = *reinterpret_cast<const f32x4*>(pa + c + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(pb + c), b1 = *reinterpret_cast<const f32x4*>(pb + c + 4);
+      const int c = HOIST ? 0 : (int)(pow2 ? (i & (unsigned)(vec_per_pixel - 1)) : (i % (unsigned)vec_per_pixel)) * 8;
+      const f32x4 a0 = HOIST ? ha0 : *reinterpret_cast<const f32x4*>(pa + c), a1 = HOIST ? ha1 : *reinterpret_cast<const f32x4*>(pa + c + 4);
+      const f32x4 b0 = HOIST ? hb0 : *reinterpret_cast<const f32x4*>(pb + c), b1 = HOIST ? hb1 : *reinterpret_cast<const f32x4*>(pb + c + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         y[j] = silu<false>(a0[j] * (float)v[j] + b0[j]);
@@ -69,11 +77,17 @@ static int launch_quant(const void* x, void* q, void* s, int B, long hw, int C, 
   const long vps = hw * (C / 8);
   if (vps >= (1L << 31) || B > 65535 || B < 1) SRGD_FAIL("quant_mxfp8: tensor too large for the 32-bit vector index");
   const int gx = (int)std::max<long>(1, std::min<long>((vps + 255) / 256, (256L * 64 + B - 1) / B));
-  if (cA)
-    hipLaunchKernelGGL((quant_mxfp8_kernel<true>), dim3(gx, B), dim3(256), 0, st, (const bf16*)x, (unsigned char*)q,
+  static const int hoist_knob = env_int("SRGD_GN_HOIST", 1);
+  const int vpp = C / 8;
+  const bool hoist = hoist_knob && (vpp & (vpp - 1)) == 0 && vpp <= 256;       // the grid stride gx * 256 is then a multiple of vpp
+  if (cA && hoist)
+    hipLaunchKernelGGL((quant_mxfp8_kernel<true, true>), dim3(gx, B), dim3(256), 0, st, (const bf16*)x, (unsigned char*)q,
+                       (unsigned char*)s, (int)vps, C, cA, cB);
+  else if (cA)
+    hipLaunchKernelGGL((quant_mxfp8_kernel<true, false>), dim3(gx, B), dim3(256), 0, st, (const bf16*)x, (unsigned char*)q,
                        (unsigned char*)s, (int)vps, C, cA, cB);
   else
-    hipLaunchKernelGGL((quant_mxfp8_kernel<false>), dim3(gx, B), dim3(256), 0, st, (const bf16*)x, (unsigned char*)q,
+    hipLaunchKernelGGL((quant_mxfp8_kernel<false, false>), dim3(gx, B), dim3(256), 0, st, (const bf16*)x, (unsigned char*)q,
                        (unsigned char*)s, (int)vps, C, nullptr, nullptr);
   SRGD_HIP(hipGetLastError());
   return 0;
