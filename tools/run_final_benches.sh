@@ -1,3 +1,4 @@
+# Final bench lines of a round (default bf16 incl. cpu_baseline, configs[4] in three precisions, fp32, forced-dist, configs[3] canvas) -> gpurun_out/r4_final
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r4_final; mkdir -p $O
 python bench.py > $O/bench_r4_default.json 2>$O/bench_r4_default.err || { tail $O/bench_r4_default.err; exit 1; }
 for P in bf16 fp8 fp8_mixed; do
