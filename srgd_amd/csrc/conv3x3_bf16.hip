@@ -81,6 +81,7 @@ struct Conv3Args {
 
 // phase accumulators of the diagnostic mode: [prologue, main loop, LDS transpose, stores, statistics, total, workgroups]
 __device__ unsigned long long g_conv3_stamps[8];
+__device__ unsigned long long g_conv3_stamps2[4];   // the transposition phase split (wave 0 of each workgroup): accumulator -> LDS, statistics, barrier wait
 
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 // Raw barrier (no vmcnt drain: LDS-DMA prefetches stay in flight) fenced for the instruction scheduler:
@@ -681,6 +682,8 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // the output stores (the first version reduced the statistics after the stores, behind a __syncthreads() whose vmcnt(0)
   // drained them: ~6,000 cycles per tile during which the workgroup held its LDS and registers and issued nothing)
   float* const cs = reinterpret_cast<float*>(smem + PH * PW * EROW);       // [4 (wm)][128][2] = 4,096 B; 69,632 + 4,096 = LDS_BYTES
+  unsigned long long t2a = 0, t2b = 0;
+  if (p.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t2a = __builtin_amdgcn_s_memtime(); }
   if (STATS) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -698,6 +701,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       }
     }
   }
+  if (p.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t2b = __builtin_amdgcn_s_memtime(); }
   __syncthreads();                                        // (no global store is outstanding yet: this does not wait for HBM)
   if (p.stamps) t3 = __builtin_amdgcn_s_memtime();
   {
@@ -756,6 +760,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     atomicAdd(&p.stamps[0], t1 - t0); atomicAdd(&p.stamps[1], t2 - t1); atomicAdd(&p.stamps[2], t3 - t2);
     atomicAdd(&p.stamps[3], t4 - t3); atomicAdd(&p.stamps[4], t5 - t4); atomicAdd(&p.stamps[5], t5 - t0);
     atomicAdd(&p.stamps[6], 1ull);
+    atomicAdd(&g_conv3_stamps2[0], t2a - t2); atomicAdd(&g_conv3_stamps2[1], t2b - t2a); atomicAdd(&g_conv3_stamps2[2], t3 - t2b);
     atomicAdd(&p.stamps[7], __builtin_amdgcn_s_memrealtime() - r0);      // 100 MHz ticks: in-kernel clock = total / this * 100 MHz
   }
 }
@@ -836,6 +841,9 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   if (want_stamps) {
     SRGD_HIP(hipGetSymbolAddress((void**)&p.stamps, HIP_SYMBOL(g_conv3_stamps)));
     SRGD_HIP(hipMemsetAsync(p.stamps, 0, sizeof(unsigned long long) * 8, st));
+    void* s2p = nullptr;
+    SRGD_HIP(hipGetSymbolAddress(&s2p, HIP_SYMBOL(g_conv3_stamps2)));
+    SRGD_HIP(hipMemsetAsync(s2p, 0, sizeof(unsigned long long) * 4, st));
   }
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
@@ -867,6 +875,12 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
     SRGD_HIP(hipStreamSynchronize(st));
     SRGD_HIP(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));
     const double n = h[6] ? (double)h[6] : 1.0;
+    unsigned long long h2[4];
+    void* s2p = nullptr;
+    SRGD_HIP(hipGetSymbolAddress(&s2p, HIP_SYMBOL(g_conv3_stamps2)));
+    SRGD_HIP(hipMemcpy(h2, s2p, sizeof(h2), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[conv3x3_bf16 stamps] transposition phase of the stamping wave: accumulators -> LDS %.0f  statistics %.0f  barrier wait %.0f\n",
+            h2[0] / n, h2[1] / n, h2[2] / n);
     fprintf(stderr, "[conv3x3_bf16 stamps] C %d+%d -> %d @%dx%d grid %d: prologue %.0f  main %.0f  transpose %.0f  stores %.0f  "
                     "stats %.0f  total %.0f  (s_memtime ticks per workgroup)  in-kernel clock %.3f GHz\n",
             a.C0, a.C1, a.Cout, a.Hin, a.Win, grid, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n,
