@@ -249,10 +249,14 @@ struct srgd_engine {
   // Round 3, on the spill-free K loop (profiles/r3/gnin_ab.txt, same box): on for the layers with ONE 128-channel output tile
   // (+1.7 % HR tiles/s: GroupNorm share 10.1 -> 5.9 %, conv3x3 1304 -> 1249 TFLOP/s), off above (the transform is repeated per
   // n-tile: two tiles +1.3 %, all layers -0.7 %).  SRGD_GN_FUSION=0 switches it off, SRGD_GN_FUSION_NTILES=n moves the limit.
+  // Round 4, on the cheaper transform (profiles/r4/gnin_ab.txt): one tile / two tiles / all layers / off = 1.3278 / 1.3268 / 1.3106 /
+  // 1.2931 HR tiles/s, and with gn_apply's hoisted coefficient loads 1.3657 / 1.3677 and 1.3660 / 1.3676 on a faster box: two
+  // tiles is ahead by 0.1 % and takes the GroupNorm share from 6.0 to 5.0 % (one HBM pass less over every 256-channel tensor),
+  // so the limit is two now.
   bool fp8 = false;           // SRGD_PRECISION_FP8: 3x3 convolutions on the block-scaled MX-fp8 matrix cores, the rest as bf16
   bool w8 = false;            // SRGD_PRECISION_BF16_W8: conv weights rounded through fp8 e4m3 (per-output-channel scale)
   bool no_gn_fusion = false;
-  int gn_fusion_max_ntiles = 1;         // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile)
+  int gn_fusion_max_ntiles = 2;         // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile); round 4: 2 (was 1)
   bool no_final_fusion = false;   // SRGD_FINAL_FUSION=0: the last ResnetBlock stores its output and final_step applies the 1x1 (A/B switch)
   bool no_la256 = false;      // SRGD_LA256=0: the C = 256 LinearAttention sites run the unfused chain (A/B switch)
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
