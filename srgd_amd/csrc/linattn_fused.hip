@@ -33,6 +33,15 @@ namespace {
 #ifndef SRGD_LA_PACK
 #define SRGD_LA_PACK 1    // pack8 through four packed converts (A/B: 0 = element-wise)
 #endif
+#ifndef SRGD_LA_LATE_SYNC
+#define SRGD_LA_LATE_SYNC 0
+#endif
+#ifndef SRGD_LA_LAZY_MAX
+#define SRGD_LA_LAZY_MAX 1
+#endif
+#ifndef SRGD_LA_STAMPS
+#define SRGD_LA_STAMPS 0  // diagnostic build: per-phase s_memtime ticks of la1's tile loop (wave 0 of every workgroup), printed per launch
+#endif
 constexpr int TM = 64;                  // pixels per tile
 constexpr int TILE_BYTES = TM * 256;    // [64 rows][128 bf16] = 16 KiB
 constexpr int NTH = 256;                // 4 waves: one per head (la1) / per 32-channel block (la2)
@@ -40,6 +49,9 @@ constexpr int RING = 3;                 // x tiles in flight per workgroup (LDS-
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#if SRGD_LA_STAMPS
+__device__ unsigned long long g_la1_stamps[8];   // [norms + sync, k/v GEMM, scale + max + exp, rescale + context MFMAs, DMA wait + barrier, tiles]
+#endif
 
 __device__ __forceinline__ int swz(int row, int chunk16) { return row * 256 + ((chunk16 ^ (row & 15)) << 4); }
 
@@ -189,14 +201,26 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
   if (T > 1) LA_WAIT_VM(4); else LA_WAIT_VM(0);
   LA_BARRIER();
 
+#if SRGD_LA_STAMPS
+  unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0, tq = __builtin_amdgcn_s_memtime(), tn;
+#define LA_STAMP(ACC_) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tn = __builtin_amdgcn_s_memtime(); ACC_ += tn - tq; tq = tn; } while (0)
+#else
+#define LA_STAMP(ACC_) do {} while (0)
+#endif
   for (int t = 0; t < T; ++t) {
     const char* A = sA + (t % RING) * TILE_BYTES;
     float* rinv = sR + (t & 1) * TM;
     if (t + 2 < T) stage_tile(rsx, sA + ((t + 2) % RING) * TILE_BYTES, head, lane, px_begin + (t + 2) * TM);
+    // Round 4 (phase stamps, profiles/r4/linattn_audit.txt: norms + sync 1,365 of 5,725 ticks per tile): the row norms are only
+    // needed AFTER the k/v GEMM (to scale its rows); SRGD_LA_LATE_SYNC moves the barrier that publishes them behind the GEMM's 32
+    // MFMAs - measured 4 % SLOWER (484 -> 505 us per launch: the waves then meet at a point where they have drifted apart), off
     row_rinv(A, rinv, tid);
+#if !SRGD_LA_LATE_SYNC
     LA_SYNC();
+    LA_STAMP(ph0);
     if (head == 0 && lane < 16)                     // la2 re-uses the row norms: 4 B per pixel instead of a second reduction
       *reinterpret_cast<f32x4*>(rinv_out + (size_t)b * N + px_begin + t * TM + lane * 4) = *reinterpret_cast<const f32x4*>(rinv + lane * 4);
+#endif
 
     // [k | v] of this wave's head for the tile's 64 rows
     f32x16 k0, k1, v0, v1;
@@ -219,6 +243,16 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
     }
     // (asm MFMAs: the compiler inserts no wait states ahead of the first VALU read of a matrix-pipe result)
     LA_NOP("s_nop 15\n\ts_nop 3", "+v"(k0), "+v"(k1), "+v"(v0), "+v"(v1));
+#if SRGD_LA_STAMPS
+    asm volatile("s_nop 0" : "+v"(k0), "+v"(k1), "+v"(v0), "+v"(v1));      // (the stamp below waits for the GEMM's results)
+#endif
+    LA_STAMP(ph1);
+#if SRGD_LA_LATE_SYNC
+    LA_SYNC();
+    LA_STAMP(ph0);
+    if (head == 0 && lane < 16)                     // la2 re-uses the row norms: 4 B per pixel instead of a second reduction
+      *reinterpret_cast<f32x4*>(rinv_out + (size_t)b * N + px_begin + t * TM + lane * 4) = *reinterpret_cast<const f32x4*>(rinv + lane * 4);
+#endif
     // rows of the accumulator = pixels: k -> k / ||x_n|| in the log2 domain (one multiply), v -> v / ||x_n||
     float bm = -INFINITY;
 #pragma unroll
@@ -236,7 +270,15 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
       }
     }
     bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+#if SRGD_LA_LAZY_MAX
+    // lazy running maximum: the reference point of a column only moves when the tile's maximum exceeds it by more than 2^8 (or at
+    // the first tile); until then p = exp2(k - m) may be as large as 256 - harmless in fp32 / bf16 - and the rescale of the
+    // context (16 cross-lane shuffles + 32 multiplies) almost never runs.  pm carries the reference point actually used, so the
+    // combine step is unchanged; results differ from the eager form by bf16 rounding of p only.
+    const float mn = (bm > m + 8.0f) ? bm : m;
+#else
     const float mn = fmaxf(m, bm);
+#endif
     const float f = ex2(m - mn);                  // first tile: exp2(-inf) = 0
     m = mn;
 #if !SRGD_LA_LSUM
@@ -250,6 +292,7 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
       lvec += k0[i] + k1[i];
 #endif
     }
+    LA_STAMP(ph2);
     if (!__all(f == 1.0f)) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
@@ -272,10 +315,22 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
       LA_MM(ctx, p01, q01); if (SRGD_LA_LSUM) LA_MM(lsum, p01, ones);
       LA_MM(ctx, p11, q11); if (SRGD_LA_LSUM) LA_MM(lsum, p11, ones);
     }
+#if SRGD_LA_STAMPS
+    asm volatile("s_nop 0" : "+v"(ctx));
+#endif
+    LA_STAMP(ph3);
     // tile t+1 must have landed before the next iteration reads it; the DMA of tile t+2 (4 pieces) stays in flight
     if (t + 2 < T) LA_WAIT_VM(4); else LA_WAIT_VM(0);
     LA_BARRIER();
+    LA_STAMP(ph4);
   }
+#if SRGD_LA_STAMPS
+  if (tid == 0) {
+    atomicAdd(&g_la1_stamps[0], ph0); atomicAdd(&g_la1_stamps[1], ph1); atomicAdd(&g_la1_stamps[2], ph2);
+    atomicAdd(&g_la1_stamps[3], ph3); atomicAdd(&g_la1_stamps[4], ph4); atomicAdd(&g_la1_stamps[5], (unsigned long long)T);
+  }
+#endif
+#undef LA_STAMP
   LA_NOP("s_nop 15\n\ts_nop 3", "+v"(ctx), "+v"(lsum));
 #undef LA_MM
 #undef LA_MM0
@@ -559,9 +614,24 @@ int linattn_fused(const void* x, void* y, int B, int N, int C, const void* wkv_i
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&la2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
     once.done();
   }
+#if SRGD_LA_STAMPS
+  void* stp = nullptr;
+  SRGD_HIP(hipGetSymbolAddress(&stp, HIP_SYMBOL(g_la1_stamps)));
+  SRGD_HIP(hipMemsetAsync(stp, 0, 64, st));
+#endif
   hipLaunchKernelGGL(la1_kernel, dim3(nstrips, B), dim3(NTH), lds1, st, (const bf16*)x, N, (const bf16*)wkv_img, strip, pm,
                      pl, pctx, rinv);
   SRGD_HIP(hipGetLastError());
+#if SRGD_LA_STAMPS
+  {
+    unsigned long long h[8];
+    SRGD_HIP(hipStreamSynchronize(st));
+    SRGD_HIP(hipMemcpy(h, stp, sizeof(h), hipMemcpyDeviceToHost));
+    const double n = h[5] ? (double)h[5] : 1.0;
+    fprintf(stderr, "[la1 stamps] B %d N %d: per 64-pixel tile: norms+sync %.0f  kv GEMM %.0f  scale/max/exp %.0f  rescale+context %.0f  "
+                    "DMA wait+barrier %.0f  (s_memtime ticks, wave 0)\n", B, N, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n);
+  }
+#endif
   SRGD_TRY(linear_attention_combine(pm, pl, pctx, (int)bh, nch, 1.0f / sqrtf(32.0f), ctxn, st));
   La2Args a;
   a.x = (const bf16*)x; a.y = (bf16*)y; a.N = N; a.wq = (const bf16*)wq; a.wout = (const bf16*)wout; a.bout = bout;

@@ -166,7 +166,9 @@ __global__ __launch_bounds__(NTH2, C == 128 ? 3 : 2) void la1_t_kernel(const bf1
       }
     }
     bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-    const float mn = fmaxf(m, bm);
+    // lazy running maximum (linattn_fused.hip, round 4): the reference point moves only when the tile's maximum exceeds it by
+    // more than 2^8, so the context rescale almost never runs; pm carries the point actually used
+    const float mn = (bm > m + 8.0f) ? bm : m;
     const float f = ex2_(m - mn);
     m = mn;
     l *= f;
