@@ -137,6 +137,16 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
   return __builtin_bit_cast(bf16x8, w);
 }
 
+// four floats -> four bf16 through two packed converts (element-wise assembly leaves the halves in scattered registers)
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 w;
+  w[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2_t));
+  w[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{c, d}, bf16x2_t));
+  return __builtin_bit_cast(bf16x4, w);
+}
+
 // ------------------------------------------------------------------------------------------- phase 1
 // Workgroup = 4 waves = the 4 heads; each wave owns the k-columns and the v-columns of its head for all 64 rows of a tile.
 // Its slice of Wkv' (64 rows x 128) lives in registers as MFMA B fragments for the lifetime of the workgroup, so LDS holds
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
       }
       s0 += __shfl_xor(s0, 32, 64);
       s1 += __shfl_xor(s1, 32, 64);
-      const float i0 = __frcp_rn(s0), i1 = __frcp_rn(s1);
+      const float i0 = __builtin_amdgcn_rcpf(s0), i1 = __builtin_amdgcn_rcpf(s1);     // (1 ulp; __frcp_rn expands to the IEEE division sequence)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         q0[i] *= i0;
@@ -472,12 +482,8 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
     // att -> LDS as [pixel][k = head*32 + e] (swizzled rows): 4 consecutive e = 8 bytes per register quad
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      bf16x4 w0, w1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        w0[i] = (bf16)a0[4 * g + i];
-        w1[i] = (bf16)a1[4 * g + i];
-      }
+      const bf16x4 w0 = pack4(a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]);
+      const bf16x4 w1 = pack4(a1[4 * g], a1[4 * g + 1], a1[4 * g + 2], a1[4 * g + 3]);
       const int k = hd * 32 + 8 * g + 4 * hh;              // first of the 4 channels
       *reinterpret_cast<bf16x4*>(sT + swz(r, k >> 3) + (k & 7) * 2) = w0;
       *reinterpret_cast<bf16x4*>(sT + swz(32 + r, k >> 3) + (k & 7) * 2) = w1;
@@ -515,12 +521,10 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
       const float r0 = 1.0f / fmaxf(sqrtf(n0), 1e-12f), r1 = 1.0f / fmaxf(sqrtf(n1), 1e-12f);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        bf16x4 w0, w1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          w0[i] = (bf16)(o0[4 * g + i] * r0 * g2v[4 * g + i]);
-          w1[i] = (bf16)(o1[4 * g + i] * r1 * g2v[4 * g + i]);
-        }
+        const bf16x4 w0 = pack4(o0[4 * g] * r0 * g2v[4 * g], o0[4 * g + 1] * r0 * g2v[4 * g + 1], o0[4 * g + 2] * r0 * g2v[4 * g + 2],
+                                o0[4 * g + 3] * r0 * g2v[4 * g + 3]);
+        const bf16x4 w1 = pack4(o1[4 * g] * r1 * g2v[4 * g], o1[4 * g + 1] * r1 * g2v[4 * g + 1], o1[4 * g + 2] * r1 * g2v[4 * g + 2],
+                                o1[4 * g + 3] * r1 * g2v[4 * g + 3]);
         const int c = hd * 32 + 8 * g + 4 * hh;
         *reinterpret_cast<bf16x4*>(sT + swz(r, c >> 3) + (c & 7) * 2) = w0;
         *reinterpret_cast<bf16x4*>(sT + swz(32 + r, c >> 3) + (c & 7) * 2) = w1;
