@@ -18,6 +18,13 @@
 //   * epilogue: + bias, optional per-(sample, group) partial sum / sum of squares for the GroupNorm that
 //     follows (fixed-order, deterministic), bf16 store.
 //   * blockIdx is remapped so each XCD (private L2) gets a contiguous band of tiles (halo reuse in L2).
+//   * GNIN instances (template parameter): the PRODUCER's GroupNorm-apply + SiLU is applied to a chunk's halo patch in LDS right
+//     after it lands (reference Block.forward model.py:250-259 between two convolutions), which removes a full HBM pass; these
+//     instances issue their MFMAs as inline asm with the accumulator tied (no register migration: 123 VGPRs, no spills).
+// What bounds it (round 4, in-kernel stamps): the K loop of the deep layers uses 99 % of the MFMA issue slots at a power-limited
+// 1.7 GHz; the 128-channel layers lose ~25 % of a tile's lifetime to prologue + epilogue that the co-resident workgroup only partly
+// covers.  The compile-time switches below are the A/B and timing-only builds those statements rest on (DESIGN.md section 4.1,
+// profiles/r4/conv3x3_bf16_clock_and_dma_diagnostics.txt); the shipped configuration is their defaults.
 #include <cstdlib>
 
 #include "kernels.hpp"
