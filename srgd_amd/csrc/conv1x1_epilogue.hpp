@@ -9,6 +9,9 @@
 namespace srgd {
 namespace {
 
+#ifndef SRGD_CONV1_PAIR_WRITES
+#define SRGD_CONV1_PAIR_WRITES 1     // accumulator -> LDS: dword writes after a lane-pair exchange (0: four 2-byte writes per block; A/B builds)
+#endif
 enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GNTAIL = 2, EPI_PS_SILU = 3, EPI_GNTAIL_FINAL = 4 };
 constexpr int EPI_BM = 256, EPI_BN = 128, EPI_NT = 512;
 constexpr int EPI_ROW = EPI_BN * 2 + 16;           // transposed output row (272 B: conflict-free 2-byte column writes)
@@ -43,14 +46,31 @@ __device__ __forceinline__ void conv1x1_epilogue(const Args& p, char* smem, cons
                      : mi == 2 ? (ni == 0 ? c20 : ni == 1 ? c21 : ni == 2 ? c22 : c23)
                                : (ni == 0 ? c30 : ni == 1 ? c31 : ni == 2 ? c32 : c33);
       char* trow = smem + (wm * 64 + mi * 16 + q16 * 4) * EROW1 + cl * 2;      // C layout: row = (lane >> 4) * 4 + reg
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        float v = av[reg] + bias;
-        if (EPI == EPI_PS_SILU) v = silu<false>(v);
-        // staged in bf16 (LDS budget): with a residual / GroupNorm-tail add the conv term is rounded once here and the
-        // sum once more at the store
-        *reinterpret_cast<bf16*>(trow + reg * EROW1) = (bf16)v;
-      }
+      // staged in bf16 (LDS budget): with a residual / GroupNorm-tail add the conv term is rounded once here and the
+      // sum once more at the store
+      float v0 = av[0] + bias, v1 = av[1] + bias, v2 = av[2] + bias, v3 = av[3] + bias;
+      if (EPI == EPI_PS_SILU) { v0 = silu<false>(v0); v1 = silu<false>(v1); v2 = silu<false>(v2); v3 = silu<false>(v3); }
+#if SRGD_CONV1_PAIR_WRITES
+      // Round 4: the short-K pointwise layers are bound by this phase (a 256 -> 512 @128^2 tile spends 8 K-steps in its loop and
+      // emits output at the same ~2 TB/s as every other shape: 64 two-byte LDS writes per lane).  As in conv3x3_bf16.hip: two
+      // adjacent lanes hold two adjacent channels of the same four rows; they swap halves (one DPP quad_perm move) so that the
+      // even lane owns rows 0-1 and the odd lane rows 2-3 of BOTH channels - two conflict-free ds_write_b32 per block instead of
+      // four ds_write_b16 whose lane pairs share a dword.  Same values, same rounding: bit-identical.
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      const unsigned own01 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0, v1}, bf16x2_t));
+      const unsigned own23 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v2, v3}, bf16x2_t));
+      const bool odd_lane = (r16 & 1) != 0;
+      const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_lane ? own01 : own23), 0xB1, 0xf, 0xf, true);
+      const unsigned lo_ch = odd_lane ? recv : own01, hi_ch = odd_lane ? own23 : recv;     // channel c (even) | c + 1
+      char* prow = trow + (odd_lane ? 2 * EROW1 - 2 : 0);   // even lane: rows 0, 1 at its own column; odd lane: rows 2, 3, one column left
+      *reinterpret_cast<unsigned*>(prow) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x05040100u);
+      *reinterpret_cast<unsigned*>(prow + EROW1) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x07060302u);
+#else
+      *reinterpret_cast<bf16*>(trow) = (bf16)v0;
+      *reinterpret_cast<bf16*>(trow + EROW1) = (bf16)v1;
+      *reinterpret_cast<bf16*>(trow + 2 * EROW1) = (bf16)v2;
+      *reinterpret_cast<bf16*>(trow + 3 * EROW1) = (bf16)v3;
+#endif
     }
   }
   __syncthreads();
