@@ -4,7 +4,8 @@
 //
 // Implicit GEMM, M = output pixels, N = Cout, K = 9 * Cin, laid out for CDNA4:
 //   * workgroup = 512 threads = 8 waves (4 along M x 2 along N), output tile = an 8 x 32 pixel patch
-//     (M = 256) x 128 output channels; each wave owns 2 patch rows x 64 channels = 2x2 MFMA 32x32 blocks.
+//     (M = 256) x 128 output channels; each wave owns 2 patch rows x 64 channels = 4 x 4 blocks of
+//     v_mfma_f32_16x16x32_bf16 (the 32x32x16 shape measured 1-2 % slower on every production shape: lower sustained clock).
 //   * K is walked channel-chunk-major: for every 32-channel chunk the (8+2) x (32+2) halo patch is
 //     staged ONCE in LDS and all 9 taps are served from it by shifting the read address - global->LDS
 //     traffic for A drops 9x/1.33 versus gathering a fresh A tile per tap.
@@ -12,22 +13,35 @@
 //     (out-of-image halo pixels are zero-filled by the buffer descriptor's range check), and per K-step one
 //     8 KB weight tile, pre-swizzled on the host into its LDS image so the copy is linear and coalesced.
 //     A is double-buffered, B runs in a 3-deep ring; loads stay in flight across barriers
-//     (counted s_waitcnt vmcnt(N) + raw s_barrier, one barrier per K-step).  A 4-deep ring measured the same.
-//   * 64-byte LDS rows are XOR-swizzled (chunk ^= (row >> 2) & 3): ds_read_b128 is conflict-free for the
-//     MFMA operand pattern (16 consecutive rows, same chunk) at every tap shift.
-//   * epilogue: + bias, optional per-(sample, group) partial sum / sum of squares for the GroupNorm that
-//     follows (fixed-order, deterministic), bf16 store.
+//     (counted s_waitcnt vmcnt(N) + raw s_barrier, one barrier per K-step).
+//   * 64-byte LDS rows are XOR-swizzled (chunk ^= (row >> 1) & 3): ds_read_b128 is conflict-free for the
+//     MFMA operand pattern (16 consecutive rows x 4 chunks) at every tap shift.
+//   * the MFMAs take the WEIGHT fragment as their A operand and the PIXEL fragment as B (both fragments have the same register
+//     image, so the K loop does not change): D then holds, per lane, four consecutive weight rows of ONE pixel.  The host
+//     packs the weight rows of a tile in the order that makes a lane's sixteen values of a 16-pixel block two runs of eight
+//     consecutive output channels - the epilogue is register-direct: + bias, bf16 pack, two 16-byte stores per block straight
+//     from the accumulators, GroupNorm partial sums (reference Block.norm, model.py:250-259) by in-lane adds + a DPP row
+//     reduction, one slot per wave.  No LDS traffic, no barrier: the phase no longer competes with the co-resident workgroup's
+//     K loop for the LDS pipe (round 4's LDS transposition was 23 % of a 128 -> 128 @256^2 tile for that reason).
 //   * blockIdx is remapped so each XCD (private L2) gets a contiguous band of tiles (halo reuse in L2).
 //   * GNIN instances (template parameter): the PRODUCER's GroupNorm-apply + SiLU is applied to a chunk's halo patch in LDS right
 //     after it lands (reference Block.forward model.py:250-259 between two convolutions), which removes a full HBM pass; these
-//     instances issue their MFMAs as inline asm with the accumulator tied (no register migration: 123 VGPRs, no spills).
-// What bounds it (round 4, in-kernel stamps): the K loop of the deep layers uses 99 % of the MFMA issue slots at a power-limited
-// 1.7 GHz; the 128-channel layers lose ~25 % of a tile's lifetime to prologue + epilogue that the co-resident workgroup only partly
-// covers.  The compile-time switches below are the A/B and timing-only builds those statements rest on (DESIGN.md section 4.1,
-// profiles/r4/conv3x3_bf16_clock_and_dma_diagnostics.txt); the shipped configuration is their defaults.
+//     instances issue their MFMAs as inline asm with the accumulator tied (no register migration, no spills).
+// What bounds it (in-kernel stamps): the K loop of the deep layers uses 99 % of the MFMA issue slots at a
+// power-limited 1.7 GHz.  Diagnostic builds (tools/build_variant.py only): -DSRGD_CONV3_STAMPS=1 adds per-phase s_memtime stamps.
 #include <cstdlib>
 
 #include "kernels.hpp"
+
+#ifndef SRGD_CONV3_STAMPS
+#define SRGD_CONV3_STAMPS 0
+#endif
+#ifndef SRGD_CONV3_DIAG_READS
+#define SRGD_CONV3_DIAG_READS 0
+#endif
+#ifndef SRGD_CONV3_OUT_NT
+#define SRGD_CONV3_OUT_NT 0           // output stores with the non-temporal policy (A/B builds, tools/build_variant.py)
+#endif
 
 namespace srgd {
 namespace {
@@ -41,31 +55,11 @@ constexpr int A_BYTES = 24 * 1024;             // 24 wave-instructions x 1 KiB (
 constexpr int B_BYTES = BN3 * KC * 2;          // 8 KiB
 constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 73,728: two workgroups per CU
 constexpr int COEF_BYTES = 2 * 256;            // GNIN: 32 scales | 32 shifts (fp32) per channel chunk, double-buffered
-#ifndef SRGD_CONV3_PAIR_WRITES
-#define SRGD_CONV3_PAIR_WRITES 1      // epilogue: dword LDS writes after a lane-pair exchange (0: four 2-byte writes per block; A/B builds)
-#endif
-#ifndef SRGD_GNIN_SCALAR
-#define SRGD_GNIN_SCALAR 1            // GNIN transform: single-lane-op fp32 arithmetic (inline asm) instead of what -O3 SLP-packs into
-#endif                                // v_pk_fma_f32 / v_pk_mul_f32 - packed f32 VALU beside MFMAs is an anti-lever on gfx950 (A/B builds: 0)
-#ifndef SRGD_CONV3_DMA_POS
-#define SRGD_CONV3_DMA_POS 0          // where a tap issues its LDS-DMA requests: 0 top of the tap, 1 behind its fragment loads, 2 behind its MFMAs, 3 behind its first 8 MFMAs, 4 top of the tap with the explicit-address tap body (A/B)
-#endif
-#ifndef SRGD_CONV3_EPI_SCALAR
-#define SRGD_CONV3_EPI_SCALAR 0       // epilogue bias / GroupNorm sums with single-lane-op instructions instead of v_pk_* (A/B builds)
-#endif
-#ifndef SRGD_CONV3_EPI_PRIO
-#define SRGD_CONV3_EPI_PRIO 0         // s_setprio level of the epilogue (0 = leave it at the kernel's default)
-#endif
-#ifndef SRGD_CONV3_TIED
-#define SRGD_CONV3_TIED 0             // plain instances: tied inline-asm MFMAs as well (A/B builds)
-#endif
-#ifndef SRGD_GNIN_LEAN
-#define SRGD_GNIN_LEAN 3              // GNIN instances: the plain instances' shared fragment addressing and 8-fragment tap (needs the tied MFMAs)
-#endif
-constexpr int CONV3_XCD_PIN_KB_DEFAULT = 0;   // (A/B knob SRGD_CONV3_XCD_PIN_KB; see the kernel's tile map)
-constexpr int CONV3_M16_DEFAULT = 1;     // 16x16x32 measured +1..2 % over 32x32x16 on the production shapes
+constexpr int CONV3_XCD_PIN_KB_DEFAULT = 0;    // (A/B knob SRGD_CONV3_XCD_PIN_KB; see the kernel's tile map)
+constexpr bool STAMPS = SRGD_CONV3_STAMPS != 0;
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset, int soffset = 0) {
   // LDS destination = wave-uniform base + lane * 16; voffset per lane (VGPR), soffset wave-uniform (SGPR)
@@ -75,7 +69,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 struct Conv3Args {
   const bf16* in0; const bf16* in1; int C0, C1;
   int B, H, W;
-  const bf16* w;          // packed [tap][cc][ntile][128 rows][4 swizzled chunks][8]
+  const bf16* w;          // packed [tap][cc][ntile][128 rows (permuted, see pack_conv3x3_bf16)][4 swizzled chunks][8]
   const float* bias;
   int Cout;
   bf16* out;
@@ -83,12 +77,11 @@ struct Conv3Args {
   const float* gn_in_a;   // GNIN: y = silu(a[b][c] * x + b[b][c]) applied to the input while it is staged ([B][Cin] fp32)
   int gn_in_b_off;        // byte offset of the shift array from the scale array (same allocation)
   int xcd_pin_ntiles;     // blockIdx -> tile map: n-tiles pinned to XCDs (weights stay in the XCD's L2); else contiguous bands of tiles per XCD
-  unsigned long long* stamps;   // diagnostics (SRGD_CONV3_STAMPS=1): per-phase s_memtime deltas summed over workgroups; null otherwise
+  unsigned long long* stamps;   // SRGD_CONV3_STAMPS builds: per-phase s_memtime deltas summed over waves 0 of the workgroups; null otherwise
 };
 
-// phase accumulators of the diagnostic mode: [prologue, main loop, LDS transpose, stores, statistics, total, workgroups]
+// phase accumulators of the stamp build: [prologue, main loop, epilogue issue, store drain, -, total, workgroups, real time]
 __device__ unsigned long long g_conv3_stamps[8];
-__device__ unsigned long long g_conv3_stamps2[4];   // the transposition phase split (wave 0 of each workgroup): accumulator -> LDS, statistics, barrier wait
 
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 // Raw barrier (no vmcnt drain: LDS-DMA prefetches stay in flight) fenced for the instruction scheduler:
@@ -100,23 +93,35 @@ __device__ unsigned long long g_conv3_stamps2[4];   // the transposition phase s
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 
-// M16 selects the MFMA shape: false = v_mfma_f32_32x32x16_bf16 (2x2 blocks per wave, two k16 steps per chunk),
-// true = v_mfma_f32_16x16x32_bf16 (4x4 blocks, one k32 step).  Same LDS bytes read per FLOP and the same
-// accumulator count; the 16x16 shape sustains a higher clock on MI355X (MI355X_MICROARCH.md, DVFS item 7).
-// Row swizzle: chunk ^= (row >> 2) & 3 for the 32x32 operand pattern (32 rows x 1 chunk per lane half),
-//              chunk ^= (row >> 1) & 3 for the 16x16 pattern (16 rows x 4 chunks) - each conflict-free for its
-//              ds_read_b128 lane groups at every tap shift (checked exhaustively on the bank model).
-template <bool M16> __device__ __forceinline__ int row_swz(int row) { return M16 ? (row >> 1) & 3 : (row >> 2) & 3; }
+// Row swizzle: chunk ^= (row >> 1) & 3 for the 16x16x32 operand pattern (16 rows x 4 chunks per ds_read_b128) - conflict-free
+// for its lane groups at every tap shift (checked exhaustively on the bank model).
+__device__ __forceinline__ int row_swz(int row) { return (row >> 1) & 3; }
 
-template <bool STATS, bool GNIN, bool M16>
+// v + (the same register of lane ^ 16) / lane ^ 32, in every lane: one half-exchange of two copies (v_permlane16_swap swaps the
+// odd rows of its first operand with the even rows of its second, v_permlane32_swap the upper half with the lower half) and one
+// add - VALU only (the ds_bpermute form goes through the LDS crossbar).  After the swap the first register holds the even row's
+// (lower half's) value and the second the odd row's (upper half's) in BOTH partner lanes, so the sum is formed in the same
+// order everywhere.  Inline asm: the builtin of this toolchain (ROCm 7.2 clang) returns its first result twice.  The s_nop
+// covers the VALU-write -> v_permlane-read hazard (2 wait states), which the compiler does not insert inside asm.
+__device__ __forceinline__ float xor16_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
+template <bool STATS, bool GNIN>
 __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;            // 32x32 shape: row / k half
-  const int r16 = lane & 15, q16 = lane >> 4;        // 16x16 shape: row / 8-channel chunk
+  const int r16 = lane & 15, q16 = lane >> 4;        // fragment row / 8-channel chunk
 
   // ---- tile coordinates (XCD-aware remap: blocks b, b+8, ... share an XCD -> give each XCD a contiguous band)
   const int n_tiles = p.Cout / BN3;
@@ -126,13 +131,10 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   int wg = blockIdx.x;
   int nt, mt;
   if (p.xcd_pin_ntiles) {
-    // Round 4: pin the n-tiles to XCDs.  Blocks b, b + 8, ... share an XCD (round-robin dispatch).  With n-tiles walking fastest
+    // Pin the n-tiles to XCDs.  Blocks b, b + 8, ... share an XCD (round-robin dispatch).  With n-tiles walking fastest
     // inside an XCD's band (below), every XCD streams ALL weights of the layer (18.9 MB at 1024 -> 1024) through its 4 MiB L2
-    // once per m-tile: the weight tiles come over the fabric from the Infinity Cache every time (~9.4 GB per launch), and a
-    // timing build without the K loop's DMA traffic holds 2.34 GHz where production holds 1.73 GHz at 99 % MFMA issue - the
-    // kernel is clock- (power-) limited and the data movement is what the clock pays for.  Here XCD x owns n-tile x % n_tiles
-    // for all of its m-tiles: its weight working set is 1 / n_tiles of the layer (2.4 MB) and stays L2-resident; the halo
-    // patches are fetched once per XCD that needs them instead (n_tiles x activation bytes over the fabric, 8x less in total).
+    // once per m-tile.  Here XCD x owns n-tile x % n_tiles for all of its m-tiles: its weight working set is 1 / n_tiles of
+    // the layer (2.4 MB); the halo patches are fetched once per XCD that needs them instead.
     const int x = wg & 7, k = wg >> 3, per = 8 / n_tiles;        // host: n_tiles in {2, 4, 8} and m_tiles % per == 0
     nt = x % n_tiles;
     mt = k * per + x / n_tiles;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // Per-lane pixel offset (y*W+x) or -1 and source chunk (0..3) of its three pieces, as NAMED scalars (indexed
   // arrays of staging state end up in scratch: see conv_igemm.hip).
   // The source chunk is the same for all three pieces: P = (wave + 8 J) * 16 + (lane >> 2), and (wave + 8 J) * 16 vanishes
-  // from row_swz(P) (a multiple of 8 under (P >> 1) & 3, of 4 under (P >> 2) & 3) - ONE register, not three.
+  // from row_swz(P) (a multiple of 8 under (P >> 1) & 3) - ONE register, not three.
 #define SRGD_A_DECL(J)                                                        \
   int a_pix##J;                                                               \
   {                                                                           \
@@ -166,9 +168,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   }
   SRGD_A_DECL(0) SRGD_A_DECL(1) SRGD_A_DECL(2)
 #undef SRGD_A_DECL
-  const int a_sub = (lane & 3) ^ row_swz<M16>(lane >> 2);
-  // GNIN: which of this lane's three pieces lie inside the image, packed (bit J)
-  [[maybe_unused]] const int a_in = GNIN ? (a_pix0 >= 0 ? 1 : 0) | (a_pix1 >= 0 ? 2 : 0) | (a_pix2 >= 0 ? 4 : 0) : 0;
+  const int a_sub = (lane & 3) ^ row_swz(lane >> 2);
   // GNIN (one source): byte offset of each piece at chunk 0, or the out-of-range sentinel (stays out of range for every chunk)
   const unsigned a_off0 = a_pix0 >= 0 ? (unsigned)(a_pix0 * p.C0 + a_sub * 8) * 2u : 0x7ffffff0u;
   const unsigned a_off1 = a_pix1 >= 0 ? (unsigned)(a_pix1 * p.C0 + a_sub * 8) * 2u : 0x7ffffff0u;
@@ -191,19 +191,16 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // GNIN: GroupNorm-apply + SiLU of the PRODUCER fused into this conv's staging (reference Block.forward
   // model.py:250-259 between two convs): once a wave's own DMA pieces of a chunk have landed it rewrites them in
   // place, y = silu(a*x + b); out-of-image halo chunks stay zero (the conv pads the activated tensor).
-  // Round 3: the tap loop of the GNIN instances is branch-free.  Round 2's version had a per-lane `if (a_pix < 0) return` here
-  // and a wave-uniform `if (piece == 22)` around the coefficient DMA; either one splits the unrolled tap loop into basic
-  // blocks, and the 16x16 instance then spilled 19-25 VGPRs into the K loop (the GroupNorm-in-staging A/B of round 2 was
-  // measured on that spilling kernel).  Now: out-of-image chunks are ANDed back to zero, the DMA offsets are precomputed
-  // (no multiply / select in the loop: the compiler if-converts those into exec-masked branches too), and the chunk's
-  // coefficients (lane l: scale[c + l] or shift[c + l - 32]) come in through ONE 4-byte-per-lane LDS-DMA per wave into a
-  // 256-byte slot of their own (every wave issues it: identical bytes, and the counted vmcnt waits stay the same for all
-  // waves).  No VGPR load: the compiler would guard its use with s_waitcnt vmcnt(0) - it cannot see the counted waits - and
-  // drain every DMA in flight.
+  // The tap loop of the GNIN instances is branch-free: a per-lane `if (a_pix < 0) return` or a wave-uniform branch around the
+  // coefficient DMA splits the unrolled tap loop into basic blocks and the instance then spills into the K loop.  The DMA
+  // offsets are precomputed (no multiply / select in the loop: the compiler if-converts those into exec-masked branches too),
+  // and the chunk's coefficients (lane l: scale[c + l] or shift[c + l - 32]) come in through ONE 4-byte-per-lane LDS-DMA per
+  // wave into a 256-byte slot of their own (every wave issues it: identical bytes, and the counted vmcnt waits stay the same
+  // for all waves).  No VGPR load: the compiler would guard its use with s_waitcnt vmcnt(0) - it cannot see the counted
+  // waits - and drain every DMA in flight.
   int tid16 = tid * 16;                         // the weight DMA's per-lane offset; GNIN: lane * 16, lane * 4 and (after the loop) tid are derived from it
   int opq = 0;                                  // opaque zero, refreshed once per channel chunk (see the operand addresses below)
   char* const sCoef = smem + LDS_BYTES;
-#if SRGD_GNIN_SCALAR
   // the per-lane offset is rebuilt from tid16 at its one use per chunk (3 VALU) rather than carried through the K loop
   auto coef_dma = [&](int cc) {
     int t = tid16;
@@ -212,14 +209,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     const int voff = l4 < 128 ? l4 : p.gn_in_b_off + l4 - 128;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc, (lds_ptr)(sCoef + (cc & 1) * 256), 4, voff, cc * KC * 4, 0, 0);
   };
-#else
-  const int coef_voff = lane < 32 ? lane * 4 : p.gn_in_b_off + (lane - 32) * 4;
-  auto coef_dma = [&](int cc) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc, (lds_ptr)(sCoef + (cc & 1) * 256), 4, coef_voff, cc * KC * 4, 0, 0);
-  };
-#endif
-#if SRGD_GNIN_SCALAR
-  // Round 4.  The transform shares the SIMD's vector-issue port with the MFMAs (an MFMA 16x16x32 holds it for 8 of its 16
+  // The transform shares the SIMD's vector-issue port with the MFMAs (an MFMA 16x16x32 holds it for 8 of its 16
   // cycles), so it is written for issue cycles: (1) plain v_fma_f32 / v_mul_f32 through inline asm - the compiler packs the
   // four lanes' affine step and final product into v_pk_fma_f32 / v_pk_mul_f32, which beside MFMAs cost far more than the
   // two single ops they replace (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); (2) two address instructions per
@@ -271,35 +261,13 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     const unsigned o1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{y[2], y[3]}, bf16x2_t));
     const unsigned long long bits64 = (unsigned long long)o0 | ((unsigned long long)o1 << 32);
     const unsigned long long m = j == 0 ? in_m0 : (j == 1 ? in_m1 : in_m2);
-    asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(qa), "v"(bits64), "s"(m) : "memory");
+    // Precondition: full 64-lane waves in uniform control flow (512-thread workgroups, called from the unrolled tap loop only) -
+    // the incoming exec mask is saved and restored around the masked store.
+    unsigned long long saved_exec;
+    asm volatile("s_and_saveexec_b64 %0, %3\n\tds_write_b64 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved_exec) : "v"(qa), "v"(bits64), "s"(m) : "memory", "scc");
   };
 #undef lane16
-#else
-  auto transform_half = [&](int cc, int j, int hf) {
-    // all ones / zero: out-of-image chunks are ANDed back to zero (a select on `inside` is if-converted by the compiler into
-    // an exec-masked branch around the arithmetic: a basic-block split inside the unrolled tap loop, see above)
-    const int keep = __builtin_amdgcn_sbfe(a_in, j, 1);
-    // + opq: recomputed at every use (~3 VALU ops) instead of hoisted out of the K loop into a dozen long-lived VGPRs
-    char* q = sA0 + (cc & 1) * A_BYTES + (wave + 8 * j) * 1024 + (lane + opq) * 16;
-    const float* sC = reinterpret_cast<const float*>(sCoef + (cc & 1) * 256) + (a_sub + opq) * 8;
-    // 8-byte halves: small live temporaries (the kernel sits at the 128-VGPR cap of 2 workgroups/CU) and a unit of
-    // VALU work (8 transcendentals per lane) short enough to hide under one tap's MFMAs of the other waves
-    bf16x4 v = *reinterpret_cast<const bf16x4*>(q + hf * 8);
-    const f32x4 ca = *reinterpret_cast<const f32x4*>(sC + hf * 4);
-    const f32x4 cb = *reinterpret_cast<const f32x4*>(sC + 32 + hf * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (bf16)silu<false>(ca[e] * (float)v[e] + cb[e]);
-    int2 bits = __builtin_bit_cast(int2, v);
-    bits.x &= keep;
-    bits.y &= keep;
-    // The store goes out as inline asm: a compiler-visible ds_write to LDS that LDS-DMA also writes is guarded with
-    // s_waitcnt vmcnt(0) (write-after-write on "LDS" as a whole), which drains the A piece and the weight tile issued a few
-    // instructions earlier - one full L2 round trip per tap, the hidden cost of round 2's GNIN build.  The piece rewritten
-    // here is this wave's own and landed under the previous tap's counted wait.
-    const long long bits64 = __builtin_bit_cast(long long, bits);
-    asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(size_t)(lds_ptr)(q + hf * 8)), "v"(bits64) : "memory");
-  };
-#endif
 #define transform_a_half(CCV, J, HF) transform_half(CCV, J, HF)
 #define transform_a_piece(CCV, J) do { transform_a_half(CCV, J, 0); transform_a_half(CCV, J, 1); } while (0)
 
@@ -321,163 +289,82 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
 #define issue_a_piece(CCV, J) issue_a(CCV, J, (J) == 0 ? a_pix0 : ((J) == 1 ? a_pix1 : a_pix2))
   // K-step (cc, tap) -> weight tile (tap, cc) into ring slot (cc * 9 + tap) % 3 = tap % 3.  Called with compile-time `tap`
   // (0..10: the unrolled tap loop asks for "two steps ahead"; 9 and 10 mean taps 0 and 1 of the next chunk), so the tile offset is
-  // one scalar multiply-add - round 2's issue_b(s) divided the runtime step index by 9 and by 3: ~20 SALU instructions per tap.
+  // one scalar multiply-add.
   const int w_tap_stride = (int)(CC * w_tile_stride);
   auto issue_b = [&](int cc, int tap) {
     if (tap >= 9) { tap -= 9; cc += 1; }
     dma16(rsw, sB0 + (tap % 3) * B_BYTES + wave * 1024, tid16, tap * w_tap_stride + cc * (int)w_tile_stride);
   };
 
-  // ---- accumulators: 64 fp32 per lane in both shapes
-  f32x16 acc00 = 0, acc01 = 0, acc10 = 0, acc11 = 0;                                     // 32x32: [mi][ni]
-  f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c10 = 0, c11 = 0, c12 = 0, c13 = 0,          // 16x16: [mi][ni]
+  // ---- accumulators: 64 fp32 per lane, [pixel block mi][weight-row block ni]
+  f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c10 = 0, c11 = 0, c12 = 0, c13 = 0,
         c20 = 0, c21 = 0, c22 = 0, c23 = 0, c30 = 0, c31 = 0, c32 = 0, c33 = 0;
 
   // ---- operand read addresses.  `opq` is an opaque zero refreshed once per channel chunk: it stops the compiler
-  // from hoisting the per-tap A addresses out of the K loop into ~18 long-lived VGPRs (the kernel lives at the
-  // 128-VGPR cap of 2 workgroups per CU); recomputing one costs ~5 VALU ops.
-  // 32x32: B row n = wn*64 + j*32 + r, logical chunk 2*s2 + h;  16x16: B row n = wn*64 + j*16 + r16, chunk q16
-  // (the swizzle of weight row n = wn*64 + j*16 + r16 (or j*32 + r) does not depend on j or wn: ONE per-lane base, the
-  // column block rides in the ds_read offset field)
-  const int b_base = (M16 ? wn * 64 + r16 : wn * 64 + r) * 64 + (((M16 ? q16 : h) ^ row_swz<M16>(M16 ? r16 : r)) << 4);
-  auto b_addr = [&](int j) { return b_base + j * (M16 ? 16 : 32) * 64; };
-  // 16x16 (round 3): halo pixel P = lp + Pc with lp = 2 wm WP + r16 (per lane) and Pc a compile-time constant per (tap, block):
+  // from hoisting the per-tap addresses out of the K loop into ~18 long-lived VGPRs (the kernel lives at the
+  // 128-VGPR cap of 2 workgroups per CU).
+  // Weight row n = wn*64 + j*16 + r16, chunk q16: the swizzle of row n does not depend on j or wn - ONE per-lane base, the
+  // row block rides in the ds_read offset field.
+  const int b_base = (wn * 64 + r16) * 64 + ((q16 ^ row_swz(r16)) << 4);
+  auto b_addr = [&](int j) { return b_base + j * 16 * 64; };
+  // Halo pixel P = lp + Pc with lp = 2 wm WP + r16 (per lane) and Pc a compile-time constant per (tap, block):
   // P * 64 splits into lp * 64 (one per-lane base) + Pc * 64 (the ds_read's immediate offset), and the swizzle term
   // ((P >> 1) & 3) << 4 = ((P << 3) & 0x30) comes from lp8 = lp << 3: THREE VALU instructions per fragment address (add3 with
-  // the opaque zero, and-xor, add) instead of six - the K loop carried ~28 address instructions per 16 MFMAs on the port the
-  // MFMAs issue through.
+  // the opaque zero, and-xor, add), which the compiler shares inside a chunk.
   const int lp = 2 * wm * WP + r16, lp8 = lp << 3, lp64 = lp * 64, q16s = q16 << 4;
-  int lp8o = lp8;                               // GNIN instances: refreshed (made opaque) at every tap
-  auto a_addr = [&](int tap, int i) {        // 32x32: i = patch row of the wave (0/1); 16x16: i = 16-pixel block (0..3)
+  auto a_addr = [&](int tap, int i) {        // i = 16-pixel block of the wave (0..3): patch row i >> 1, x half i & 1
     const int dy = tap / 3, dx = tap - dy * 3;
-    if constexpr (M16 && (!GNIN || (SRGD_GNIN_LEAN & 1))) {
-      const int Pc = ((i >> 1) + dy) * WP + (i & 1) * 16 + dx;
-      return lp64 + (((lp8 + Pc * 8 + opq) & 0x30) ^ q16s) + Pc * 64;
-    } else if constexpr (M16) {
-      // the GNIN instances refresh `opq` every tap so that NO address part survives a tap in a register (they carry ~13 more
-      // long-lived registers; with the split form above the eight swizzle terms of a chunk stay live and 33 registers spill into
-      // the K loop): P * 8 once, then P * 64 and the swizzle term from it - four VALU instructions per address instead of six
-      // (round 4: an opaque COPY of lp8 per tap instead of an opaque zero added to it - the compiler reassociated
-      // (lp8 + Pc * 8) + opq, hoisted the loop-invariant first half for every (tap, block) and spilled what did not fit)
-      const int Pc = ((i >> 1) + dy) * WP + (i & 1) * 16 + dx;
-      const int t = lp8o + Pc * 8;
-      return (t << 3) + ((t & 0x30) ^ q16s);
-    } else {
-      const int P = (2 * wm + i + dy) * WP + r + dx + opq;
-      return P * 64 + ((h ^ row_swz<M16>(P)) << 4);
-    }
+    const int Pc = ((i >> 1) + dy) * WP + (i & 1) * 16 + dx;
+    return lp64 + (((lp8 + Pc * 8 + opq) & 0x30) ^ q16s) + Pc * 64;
   };
-  // after_loads / after_half: hooks run behind the tap's fragment loads / behind its first 8 MFMAs (16x16 shape): where the
-  // step's LDS-DMA requests are issued is a tuning knob (SRGD_CONV3_DMA_POS) - a timing-only build without any DMA in the K loop
-  // runs 30-38 % faster and one that issues but never waits runs the same as production, i.e. the ISSUE of the 1-2 DMA
-  // instructions per wave and tap sits on the tap's critical path, not their latency
-  auto compute = [&](int cc, int tap, int s) {
+  // One tap: 4 pixel fragments x 4 weight fragments -> 16 MFMAs.  Operand order: srcA = weight fragment, srcB = pixel fragment
+  // (D[i][j]: i = weight row of the block, j = pixel of the block; lane l holds rows 4 (l >> 4) .. + 3 of pixel l & 15).
+  // GNIN instances: inline asm with the accumulator TIED (D = C).  Through the builtin the compiler gives every MFMA a fresh
+  // destination, the 64 accumulators migrate through the register file, and at the 128-register cap that fragmentation spilled
+  // loop invariants into the K loop - scratch reloads behind s_waitcnt vmcnt(0), i.e. behind every DMA in flight.  (Hazards:
+  // operands come from ds_read, whose waits the compiler inserts for asm operands too; the accumulators are first read by VALU
+  // code after the loop, behind the s_nop block ahead of the epilogue.)
+  auto compute = [&](int cc, int tap) {
     const char* A = sA0 + (cc & 1) * A_BYTES;
     const char* Bt = sB0 + (tap % 3) * B_BYTES;          // (cc * 9 + tap) % 3
-    if constexpr (M16 && GNIN && !(SRGD_GNIN_LEAN & 2)) {
-      // GNIN carries ~13 more long-lived registers (piece offsets, coefficient addressing): the pixel fragments come in two
-      // pairs here - 24 operand registers at a time instead of 32 - so that nothing spills into the K loop (a scratch reload
-      // in this loop is a VMEM load the compiler guards with s_waitcnt vmcnt(0): it drains the DMA pipeline)
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(0));
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(1));
-      const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(2));
-      const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(3));
-      bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 0));
-      bf16x8 a1 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 1));
-      // Round 4: the MFMAs of the GNIN instances go out as inline asm with the accumulator TIED (D = C).  Through the builtin the
-      // compiler gives every MFMA a fresh destination, the 64 accumulators migrate through the register file, and at the
-      // 128-register cap that fragmentation (not the live count: 97 at the loop's fullest point) spilled 3-4 loop invariants
-      // into the K loop - scratch reloads behind s_waitcnt vmcnt(0), i.e. behind every DMA in flight.  (Hazards: operands come
-      // from ds_read, whose waits the compiler inserts for asm operands too; the accumulators are first read by VALU code
-      // after the loop, behind the s_nop block ahead of the epilogue.)
-#define MM(C_, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(A_), "v"(B_))
-      MM(c00, a0, b0); MM(c01, a0, b1); MM(c02, a0, b2); MM(c03, a0, b3);
-      __builtin_amdgcn_sched_barrier(0);
-      a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 2));
-      MM(c10, a1, b0); MM(c11, a1, b1); MM(c12, a1, b2); MM(c13, a1, b3);
-      __builtin_amdgcn_sched_barrier(0);
-      a1 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 3));
-      MM(c20, a0, b0); MM(c21, a0, b1); MM(c22, a0, b2); MM(c23, a0, b3);
-      MM(c30, a1, b0); MM(c31, a1, b1); MM(c32, a1, b2); MM(c33, a1, b3);
-#undef MM
-    } else if constexpr (M16) {
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 0));
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 1));
-      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 2));
-      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 3));
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(0));
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(1));
-      const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(2));
-      const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(3));
-#define MM(C_, A_, B_)                                                                                   \
-  do {                                                                                                   \
-    if constexpr (GNIN || SRGD_CONV3_TIED) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(A_), "v"(B_)); \
-    else C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, C_, 0, 0, 0);                             \
+#if SRGD_CONV3_DIAG_READS == 0
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 0));
+    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 1));
+    const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 2));
+    const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 3));
+    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(0));
+    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(1));
+    const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(2));
+    const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(3));
+#elif SRGD_CONV3_DIAG_READS == 1     // timing only (wrong results): half the fragment reads, as a 128 x 128 wave tile would need per MFMA
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 0));
+    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 1));
+    bf16x8 a2 = a0, a3 = a1;
+    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(0));
+    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(1));
+    bf16x8 b2 = b0, b3 = b1;
+    asm volatile("" : "+v"(a2), "+v"(a3), "+v"(b2), "+v"(b3));
+#else                                // timing only: one pixel and one weight fragment read per tap
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 0));
+    bf16x8 a1 = a0, a2 = a0, a3 = a0;
+    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(0));
+    bf16x8 b1 = b0, b2 = b0, b3 = b0;
+    asm volatile("" : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b1), "+v"(b2), "+v"(b3));
+#endif
+#define MM(C_, PX_, WT_)                                                                                    \
+  do {                                                                                                      \
+    if constexpr (GNIN) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(WT_), "v"(PX_)); \
+    else C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WT_, PX_, C_, 0, 0, 0);                              \
   } while (0)
-      MM(c00, a0, b0); MM(c01, a0, b1); MM(c02, a0, b2); MM(c03, a0, b3);
-      MM(c10, a1, b0); MM(c11, a1, b1); MM(c12, a1, b2); MM(c13, a1, b3);
-      MM(c20, a2, b0); MM(c21, a2, b1); MM(c22, a2, b2); MM(c23, a2, b3);
-      MM(c30, a3, b0); MM(c31, a3, b1); MM(c32, a3, b2); MM(c33, a3, b3);
+    MM(c00, a0, b0); MM(c01, a0, b1); MM(c02, a0, b2); MM(c03, a0, b3);
+    MM(c10, a1, b0); MM(c11, a1, b1); MM(c12, a1, b2); MM(c13, a1, b3);
+    MM(c20, a2, b0); MM(c21, a2, b1); MM(c22, a2, b2); MM(c23, a2, b3);
+    MM(c30, a3, b0); MM(c31, a3, b1); MM(c32, a3, b2); MM(c33, a3, b3);
 #undef MM
-    } else {
-      const int a0 = a_addr(tap, 0), a1 = a_addr(tap, 1), b0 = b_addr(0), b1 = b_addr(1);
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int x = s2 << 5;                 // k16 step toggles bit 1 of the chunk index = byte bit 5
-        const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + (a0 ^ x));
-        const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + (a1 ^ x));
-        const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(Bt + (b0 ^ x));
-        const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(Bt + (b1 ^ x));
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc11, 0, 0, 0);
-      }
-    }
   };
 
-  // The 8-fragment tap of the 16x16 shape written out at loop level (no closure between the tap loop and issue_a / issue_b: a
-  // nested lambda around them made the compiler keep the kernel arguments and captured descriptors in scratch), with the tap's
-  // LDS-DMA requests (DMA_) placed behind the fragment loads (SRGD_CONV3_DMA_POS 1) or behind the first 8 MFMAs (3).
-  // Fragment addresses here are explicit: halo pixel P = lp + Pc, Pc = (block row + dy) * 34 + 16 (x half) + dx a compile-time
-  // constant per (tap, block); 34 = 2 mod 8, so the swizzle term ((P >> 1) & 3) depends on the lane and on Pc & 7 only: eight
-  // per-lane row bases (one per value of Pc & 7), the buffer of the chunk rides in an opaque SGPR (one v_add per fragment, and
-  // nothing for the compiler to reassociate and hoist: the lambda form's (lp8 + Pc * 8) sums turned into ~16 long-lived
-  // registers here and spilled 62), Pc * 64 is the ds_read's immediate offset.
-#define SRGD_AB(K) const int ab##K = lp64 + ((((lp8 + (K) * 8) & 0x30)) ^ q16s);
-  SRGD_AB(0) SRGD_AB(1) SRGD_AB(2) SRGD_AB(3) SRGD_AB(4) SRGD_AB(5) SRGD_AB(6) SRGD_AB(7)
-#undef SRGD_AB
-#define SRGD_AFRAG(TAPV, I, SA_)                                                                           \
-  ({                                                                                                       \
-    const int Pc_ = (((I) >> 1) + (TAPV) / 3) * WP + ((I) & 1) * 16 + (TAPV) % 3;                          \
-    const int k7_ = Pc_ & 7;                                                                               \
-    const int base_ = k7_ == 0 ? ab0 : k7_ == 1 ? ab1 : k7_ == 2 ? ab2 : k7_ == 3 ? ab3 : k7_ == 4 ? ab4 : k7_ == 5 ? ab5 : k7_ == 6 ? ab6 : ab7; \
-    *reinterpret_cast<const bf16x8*>(smem + (base_ + (SA_)) + Pc_ * 64);                                   \
-  })
-#define SRGD_TAP8(CCV, TAPV, DMA_)                                                                         \
-  do {                                                                                                     \
-    int sa_ = ((CCV) & 1) * A_BYTES;                                                                       \
-    asm volatile("" : "+s"(sa_));                                                                          \
-    const char* Bt_ = sB0 + ((TAPV) % 3) * B_BYTES;                                                        \
-    const bf16x8 a0 = SRGD_AFRAG(TAPV, 0, sa_);                                                            \
-    const bf16x8 a1 = SRGD_AFRAG(TAPV, 1, sa_);                                                            \
-    const bf16x8 a2 = SRGD_AFRAG(TAPV, 2, sa_);                                                            \
-    const bf16x8 a3 = SRGD_AFRAG(TAPV, 3, sa_);                                                            \
-    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bt_ + b_addr(0));                                   \
-    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bt_ + b_addr(1));                                   \
-    const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bt_ + b_addr(2));                                   \
-    const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bt_ + b_addr(3));                                   \
-    if (SRGD_CONV3_DMA_POS == 1) { __builtin_amdgcn_sched_barrier(0); DMA_; __builtin_amdgcn_sched_barrier(0); } \
-    SRGD_MMT(c00, a0, b0); SRGD_MMT(c01, a0, b1); SRGD_MMT(c02, a0, b2); SRGD_MMT(c03, a0, b3);            \
-    SRGD_MMT(c10, a1, b0); SRGD_MMT(c11, a1, b1); SRGD_MMT(c12, a1, b2); SRGD_MMT(c13, a1, b3);            \
-    if (SRGD_CONV3_DMA_POS == 3) { __builtin_amdgcn_sched_barrier(0); DMA_; __builtin_amdgcn_sched_barrier(0); } \
-    SRGD_MMT(c20, a2, b0); SRGD_MMT(c21, a2, b1); SRGD_MMT(c22, a2, b2); SRGD_MMT(c23, a2, b3);            \
-    SRGD_MMT(c30, a3, b0); SRGD_MMT(c31, a3, b1); SRGD_MMT(c32, a3, b2); SRGD_MMT(c33, a3, b3);            \
-  } while (0)
-#define SRGD_MMT(C_, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(A_), "v"(B_))
-
-  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, r0 = 0;
-  if (p.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, r0 = 0;
+  if constexpr (STAMPS) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   // ---- prologue: A(0) and B[0], B[1]
   if (GNIN) coef_dma(0);
   issue_a_piece(0, 0);
@@ -494,33 +381,19 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   BARRIER();
-  if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
+  if constexpr (STAMPS) t1 = __builtin_amdgcn_s_memtime();
 
   // ---- main loop.  Per K-step: [issue A piece of the next chunk (taps 0..2)] [issue B[s+2]] compute(s)
   //      wait until B[s+1] (and, in order, everything older) has landed, barrier.
   for (int cc = 0; cc < CC - 1; ++cc) {
-    if (!GNIN || (SRGD_GNIN_LEAN & 1)) asm volatile("" : "+v"(opq));
+    asm volatile("" : "+v"(opq));
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int s = cc * 9 + tap;
-      if (GNIN && !(SRGD_GNIN_LEAN & 1)) { lp8o = lp8; asm volatile("" : "+v"(lp8o)); }   // GNIN: per-tap refresh - no operand-address part survives a tap in a register
       // GNIN: the next chunk's coefficients are the OLDEST request of tap 0 (so the tap's counted wait covers them), published
       // by tap 0's barrier, read from tap 2 on
       if (GNIN && tap == 0) coef_dma(cc + 1);
-#ifndef SRGD_CONV3_DIAG_NODMA               // timing-only diagnostics (wrong results): 1 = no DMA issue inside the K loop, 2 = no A pieces, 3 = no weight tiles
-#define SRGD_CONV3_DIAG_NODMA 0
-#endif
-#define SRGD_TAP_DMA()                                                                                                  \
-      do {                                                                                                             \
-        /* 5 = every request re-fetches chunk 0's bytes into the slot it would fill (same DMA traffic, static LDS contents) */ \
-        if (SRGD_CONV3_DIAG_NODMA == 5) { if (tap < 3) issue_a_piece((cc + 1) & 1 ? 1 : 0, tap); issue_b(0, (tap + 2) % 3 + 3); } \
-        if (SRGD_CONV3_DIAG_NODMA == 0 || SRGD_CONV3_DIAG_NODMA == 3 || SRGD_CONV3_DIAG_NODMA == 4) { if (tap < 3) issue_a_piece(cc + 1, tap); } \
-        if (SRGD_CONV3_DIAG_NODMA == 6 && (tap & 1) == 0) issue_b(cc, tap + 2);   /* 6 = weight tiles on even taps only: -38 % DMA bytes */ \
-        if (SRGD_CONV3_DIAG_NODMA == 6 && tap < 3) issue_a_piece(cc + 1, tap);                                                                  \
-        if (SRGD_CONV3_DIAG_NODMA == 0 || SRGD_CONV3_DIAG_NODMA == 2 || SRGD_CONV3_DIAG_NODMA == 4) issue_b(cc, tap + 2); /* always < S here (cc < CC-1) */ \
-      } while (0)
-      constexpr int DP = (M16 && (!GNIN || (SRGD_GNIN_LEAN & 2))) ? SRGD_CONV3_DMA_POS : 0;     // (the hooks exist in the 8-fragment tap only)
-      if (DP == 0 || DP == 4) SRGD_TAP_DMA();
+      if (tap < 3) issue_a_piece(cc + 1, tap);
+      issue_b(cc, tap + 2);                      // always a valid step here (cc < CC - 1)
       // a wave rewrites only the pieces it DMA'd itself: piece issued at tap t has landed after the wait of tap t+1;
       // six half-piece transforms spread over taps 2..7 (j = 0, 0, 1, 1, 2, 2)
       if (GNIN && tap >= 2 && tap < 8) {
@@ -529,14 +402,8 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
         transform_a_half(cc + 1, (tap - 2) >> 1, (tap - 2) & 1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (DP == 1 || DP == 3 || DP == 4) { SRGD_TAP8(cc, tap, SRGD_TAP_DMA()); }
-      else compute(cc, tap, s);
-      if (DP == 2) SRGD_TAP_DMA();
-#undef SRGD_TAP_DMA
-      if (SRGD_CONV3_DIAG_NODMA == 4 || SRGD_CONV3_DIAG_NODMA == 6) WAIT_VM(6);         // 4 = DMA issued as usual, but (almost) never waited for
-      else if (SRGD_CONV3_DIAG_NODMA == 2) WAIT_VM(1);
-      else if (SRGD_CONV3_DIAG_NODMA == 3) { if (tap >= 3) WAIT_VM(0); else WAIT_VM(1); }
-      else if (tap < 3) WAIT_VM(2); else WAIT_VM(1);
+      compute(cc, tap);
+      if (tap < 3) WAIT_VM(2); else WAIT_VM(1);
       BARRIER();
     }
   }
@@ -545,14 +412,8 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     asm volatile("" : "+v"(opq));
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int s = cc * 9 + tap;
-#define SRGD_TAP_DMA() do { if (SRGD_CONV3_DIAG_NODMA != 1 && SRGD_CONV3_DIAG_NODMA != 3 && tap < 7) issue_b(cc, tap + 2); } while (0)
-      constexpr int DP = (M16 && (!GNIN || (SRGD_GNIN_LEAN & 2))) ? SRGD_CONV3_DMA_POS : 0;
-      if (DP == 0 || DP == 4) SRGD_TAP_DMA();
-      if constexpr (DP == 1 || DP == 3 || DP == 4) { SRGD_TAP8(cc, tap, SRGD_TAP_DMA()); }
-      else compute(cc, tap, s);
-      if (DP == 2) SRGD_TAP_DMA();
-#undef SRGD_TAP_DMA
+      if (tap < 7) issue_b(cc, tap + 2);
+      compute(cc, tap);
       if (tap < 7) WAIT_VM(1); else WAIT_VM(0);
       if (tap < 8) BARRIER();
     }
@@ -561,214 +422,125 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
 #undef transform_a_piece
 #undef transform_a_half
 
-  // ------------------------------- epilogue -------------------------------------------
-  // The accumulator layout (lane = output channel, register = pixel) would store 2 bytes per lane; instead the
-  // tile is transposed through LDS ([256 pixels][128 ch] bf16, rows padded to 272 B) and written out as whole
-  // 256-byte channel rows, 16 B per lane - 8 store instructions per thread instead of 64.
-  constexpr int EROW = BN3 * 2 + 16;
-  BARRIER();                                              // every wave is done reading the operand buffers
-#if SRGD_CONV3_EPI_PRIO
-  // the epilogue's ~250 VALU / LDS instructions per lane share the SIMD's issue port with the co-resident workgroup's MFMA stream
-  // (an MFMA holds the port 8 of its 16 cycles): at equal priority the phase crawls (11-12k ticks for ~2k cycles of work) while
-  // this workgroup holds half the CU's LDS and registers; raised priority finishes it and gets the next tile started sooner
-  __builtin_amdgcn_s_setprio(SRGD_CONV3_EPI_PRIO);
-#endif
-  if constexpr (M16 && (GNIN || SRGD_CONV3_TIED || SRGD_CONV3_EPI_SCALAR || SRGD_CONV3_DMA_POS == 1 || SRGD_CONV3_DMA_POS == 3 || SRGD_CONV3_DMA_POS == 4)) {
+  if constexpr (STAMPS) t2 = __builtin_amdgcn_s_memtime();
+  // ------------------------------- epilogue (register-direct) --------------------------
+  // Accumulator block (mi, ni), register e of lane (r16, q16) = pixel (patch row 2 wm + (mi >> 1), x = 16 (mi & 1) + r16),
+  // weight row 16 ni + 4 q16 + e of the wave's 64-row half of the tile = output channel 32 (ni >> 1) + 8 q16 + 4 (ni & 1) + e
+  // (the host's row order, pack_conv3x3_bf16): blocks ni = 0, 1 are eight consecutive channels (16 B of bf16), blocks 2, 3 the
+  // eight 32 further on; the four lanes of a pixel (q16 = 0..3) fill 64 contiguous bytes per store instruction.
+  // No LDS and no barrier: every wave leaves on its own.
+  if constexpr (GNIN) {
     // asm MFMAs: the compiler does not know the accumulators were written by the matrix pipe and inserts no wait states ahead of
-    // their first VALU read (up to 18 for a 16x16 result); the barrier above does not count as one
+    // their first VALU read (up to 18 for a 16x16 result)
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
     asm volatile("" : "+v"(c20), "+v"(c21), "+v"(c22), "+v"(c23), "+v"(c30), "+v"(c31), "+v"(c32), "+v"(c33));
   }
   // the epilogue's per-lane addresses are formed from an opaque copy of the thread id: computed here, not ahead of the K
-  // loop where they would be carried through it (in registers the GNIN instances do not have, i.e. through scratch)
-  int tidE = tid16;                                       // (tid itself is not kept alive through the K loop)
+  // loop where they would be carried through it
+  int tidE = tid16;
   asm volatile("" : "+v"(tidE));
-  tidE >>= 4;
-  const int laneE = tidE & 63, r16E = laneE & 15, q16E = laneE >> 4, rE = laneE & 31, hE = laneE >> 5;
-  if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
-  constexpr int NI = M16 ? 4 : 2;                         // column blocks per wave (16 or 32 wide)
-  float s1[NI], s2[NI];
-  f32x2 s1p[NI], s2p[NI];                                 // 16x16 path: the column sums as register pairs (even | odd rows)
-  constexpr bool pair_writes = M16 && SRGD_CONV3_PAIR_WRITES;
-  const bool odd_lane = (r16E & 1) != 0;
-  const int pair_off = odd_lane ? 2 * (BN3 * 2 + 16) - 2 : 0;      // (EROW is declared above; rows 2-3, the even channel's column)
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    s1[ni] = 0.f;
-    s2[ni] = 0.f;
-    s1p[ni] = f32x2{0.f, 0.f};
-    s2p[ni] = f32x2{0.f, 0.f};
-    const int cl = M16 ? wn * 64 + ni * 16 + r16E : wn * 64 + ni * 32 + rE;       // column inside the tile
-    const float bias = p.bias ? p.bias[nt * BN3 + cl] : 0.f;
-    if constexpr (M16) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const f32x4 av = mi == 0 ? (ni == 0 ? c00 : ni == 1 ? c01 : ni == 2 ? c02 : c03)
-                       : mi == 1 ? (ni == 0 ? c10 : ni == 1 ? c11 : ni == 2 ? c12 : c13)
-                       : mi == 2 ? (ni == 0 ? c20 : ni == 1 ? c21 : ni == 2 ? c22 : c23)
-                                 : (ni == 0 ? c30 : ni == 1 ? c31 : ni == 2 ? c32 : c33);
-        // C layout of 16x16: column = laneE & 15, row = (laneE >> 4) * 4 + reg  ->  pixel (mi & 1) * 16 + row of patch row
-        char* trow = smem + ((2 * wm + (mi >> 1)) * PW + (mi & 1) * 16 + q16E * 4) * EROW + cl * 2;
-        // round 3: the epilogue is ~40 % of the instruction stream of a 36-step tile, so it is written for instruction count:
-        // packed fp32 adds / fmas on register pairs (v_pk_add_f32, v_pk_fma_f32), ONE v_cvt_pk_bf16_f32 per two values whose
-        // halves go out as ds_write_b16 / ds_write_b16_d16_hi
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-#if SRGD_CONV3_EPI_SCALAR
-        // Round 4: the same arithmetic in the same order with single-lane-op instructions (inline asm, so that -O3 does not pack
-        // them again): a v_pk_add_f32 / v_pk_fma_f32 issued beside the co-resident workgroup's MFMA stream costs several times
-        // the two plain ops it replaces (MI355X_MICROARCH.md: packed f32 VALU is an anti-lever beside MFMAs) - round 3's packed
-        // form measured faster in instruction count and slower where it mattered.  Bit-identical sums.
-        f32x2 v01, v23;
-        {
-          float w0, w1, w2, w3, e0, e1, a1 = s1p[ni][0], b1 = s1p[ni][1], a2 = s2p[ni][0], b2s = s2p[ni][1];
-          asm("v_add_f32 %0, %4, %8\n\tv_add_f32 %1, %5, %8\n\tv_add_f32 %2, %6, %8\n\tv_add_f32 %3, %7, %8"
-              : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3) : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(bias));
-          if (STATS) {
-            asm("v_add_f32 %0, %6, %8\n\tv_add_f32 %1, %7, %9\n\t"
-                "v_add_f32 %2, %2, %0\n\tv_add_f32 %3, %3, %1\n\t"
-                "v_fma_f32 %4, %6, %6, %4\n\tv_fma_f32 %5, %7, %7, %5\n\t"
-                "v_fma_f32 %4, %8, %8, %4\n\tv_fma_f32 %5, %9, %9, %5"
-                : "=&v"(e0), "=&v"(e1), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2s) : "v"(w0), "v"(w1), "v"(w2), "v"(w3));
-            s1p[ni] = f32x2{a1, b1};
-            s2p[ni] = f32x2{a2, b2s};
-          }
-          v01 = f32x2{w0, w1};
-          v23 = f32x2{w2, w3};
-        }
-#else
-        const f32x2 b2 = {bias, bias};
-        const f32x2 v01 = f32x2{av[0], av[1]} + b2, v23 = f32x2{av[2], av[3]} + b2;
-        if (STATS) {
-          s1p[ni] += v01 + v23;
-          s2p[ni] = __builtin_elementwise_fma(v01, v01, s2p[ni]);
-          s2p[ni] = __builtin_elementwise_fma(v23, v23, s2p[ni]);
-        }
-#endif
-        const bf16x2_t t01 = __builtin_convertvector(v01, bf16x2_t), t23 = __builtin_convertvector(v23, bf16x2_t);
-        if (pair_writes) {
-          // Two adjacent lanes hold two adjacent channels of the same four rows.  They swap halves (one DPP quad_perm move) so
-          // that the even lane owns rows 0-1 and the odd lane rows 2-3 of BOTH channels: two conflict-free ds_write_b32 per
-          // block instead of four ds_write_b16 whose lane pairs share a dword.  The transposition phase is LDS-write-bound (64
-          // two-byte wave-writes per wave beside the co-resident workgroup's operand reads): 10.0k of a 48k-tick tile.
-          const unsigned own01 = __builtin_bit_cast(unsigned, t01), own23 = __builtin_bit_cast(unsigned, t23);
-          const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_lane ? own01 : own23), 0xB1, 0xf, 0xf, true);
-          const unsigned lo_ch = odd_lane ? recv : own01, hi_ch = odd_lane ? own23 : recv;     // channel c (even) | c + 1
-          char* prow = trow + pair_off;                 // even lane: rows 0, 1 at its own column; odd lane: rows 2, 3, one column left
-          *reinterpret_cast<unsigned*>(prow) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x05040100u);
-          *reinterpret_cast<unsigned*>(prow + EROW) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x07060302u);
-        } else {
-          *reinterpret_cast<bf16*>(trow) = t01[0];
-          *reinterpret_cast<bf16*>(trow + EROW) = t01[1];
-          *reinterpret_cast<bf16*>(trow + 2 * EROW) = t23[0];
-          *reinterpret_cast<bf16*>(trow + 3 * EROW) = t23[1];
-        }
-      }
-      if (STATS) {
-        s1[ni] = s1p[ni][0] + s1p[ni][1];
-        s2[ni] = s2p[ni][0] + s2p[ni][1];
-      }
-    } else {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const f32x16 accv = mi == 0 ? (ni == 0 ? acc00 : acc01) : (ni == 0 ? acc10 : acc11);
-        char* trow = smem + ((2 * wm + mi) * PW) * EROW + cl * 2;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int px = (reg & 3) + 8 * (reg >> 2) + 4 * hE;
-          const float v = accv[reg] + bias;
-          if (STATS) {
-            s1[ni] += v;
-            s2[ni] += v * v;
-          }
-          *reinterpret_cast<bf16*>(trow + px * EROW) = (bf16)v;
-        }
-      }
-    }
+  const int laneE = (tidE >> 4) & 63, r16E = laneE & 15, q16E = laneE >> 4;
+  const int chw = nt * BN3 + wn * 64;                     // first output channel of the wave (uniform)
+  const int chl = q16E * 8;                               // the lane's 8-channel run inside each 32-channel half
+  f32x4 bl0 = {0.f, 0.f, 0.f, 0.f}, bl1 = bl0, bh0 = bl0, bh1 = bl0;
+  if (p.bias) {
+    const float* bp = p.bias + chw + chl;                 // 32-byte aligned relative to the array (host: the array is 16-byte aligned)
+    bl0 = *reinterpret_cast<const f32x4*>(bp);
+    bl1 = *reinterpret_cast<const f32x4*>(bp + 4);
+    bh0 = *reinterpret_cast<const f32x4*>(bp + 32);
+    bh1 = *reinterpret_cast<const f32x4*>(bp + 36);
   }
-  // the waves' column sums go to the 4 KiB behind the staged tile, so ONE barrier publishes both; nothing below waits for
-  // the output stores (the first version reduced the statistics after the stores, behind a __syncthreads() whose vmcnt(0)
-  // drained them: ~6,000 cycles per tile during which the workgroup held its LDS and registers and issued nothing)
-  float* const cs = reinterpret_cast<float*>(smem + PH * PW * EROW);       // [4 (wm)][128][2] = 4,096 B; 69,632 + 4,096 = LDS_BYTES
-  unsigned long long t2a = 0, t2b = 0;
-  if (p.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t2a = __builtin_amdgcn_s_memtime(); }
+  // output descriptor (raw buffer: base of the wave's first pixel / channel, two patch rows in range), built by hand for the asm store
+  const unsigned long long obase =
+      (unsigned long long)(size_t)(p.out + ((size_t)(b * p.H + y0 + 2 * wm) * p.W + x0) * p.Cout + chw);
+  const u32x4 rso = {(unsigned)obase, (unsigned)(obase >> 32) & 0xffffu, (unsigned)(2 * p.W * p.Cout * 2), 0x00020000u};
+  const int o_voff = (r16E * p.Cout + chl) * 2;
+  f32x4 s1l = {0.f, 0.f, 0.f, 0.f}, s2l = s1l, s1h = s1l, s2h = s1l;     // GroupNorm sums, per register position
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  auto emit = [&](const f32x4& A0, const f32x4& A1, const f32x4& B0, const f32x4& B1, f32x4& s1, f32x4& s2, int soff) {
+    const f32x4 v0 = A0 + B0, v1 = A1 + B1;
+    if (STATS) {
+      s1 += v0 + v1;
+      s2 = __builtin_elementwise_fma(v0, v0, s2);
+      s2 = __builtin_elementwise_fma(v1, v1, s2);
+    }
+    u32x4 pk;
+    pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0[0], v0[1]}, bf16x2_t));
+    pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0[2], v0[3]}, bf16x2_t));
+    pk[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v1[0], v1[1]}, bf16x2_t));
+    pk[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v1[2], v1[3]}, bf16x2_t));
+    // The store goes out as inline asm with two wait states behind it.  Compiled from the builtin, the next packed VALU write
+    // to the data registers followed the store directly (LLVM's hazard rule exempts stores whose soffset is an SGPR) and on
+    // gfx950 lanes 12-15 of every row then stored the NEW contents of the second data register: found by the kernel test.
+    if (SRGD_CONV3_OUT_NT)
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(pk), "v"(o_voff), "s"(rso), "s"(soff) : "memory");
+    else
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(pk), "v"(o_voff), "s"(rso), "s"(soff) : "memory");
+  };
+#define SRGD_EMIT(MI, C0_, C1_, C2_, C3_)                                                          \
+  do {                                                                                             \
+    const int so_ = ((((MI) >> 1) * p.W + ((MI) & 1) * 16) * p.Cout) * 2;                          \
+    emit(C0_, C1_, bl0, bl1, s1l, s2l, so_);                                                       \
+    emit(C2_, C3_, bh0, bh1, s1h, s2h, so_ + 64);                                                  \
+  } while (0)
+  // all four bias vectors are waited for here: behind the first asm store the compiler (which cannot count it) would wait with
+  // vmcnt(0) for the remaining two - and so for that store's completion
+  asm volatile("" : "+v"(bl0), "+v"(bl1), "+v"(bh0), "+v"(bh1));
+  SRGD_EMIT(0, c00, c01, c02, c03);
+  SRGD_EMIT(1, c10, c11, c12, c13);
+  SRGD_EMIT(2, c20, c21, c22, c23);
+  SRGD_EMIT(3, c30, c31, c32, c33);
+#undef SRGD_EMIT
   if (STATS) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      float t1 = s1[ni], t2 = s2[ni];
-      t1 += __shfl_xor(t1, 32, 64);
-      t2 += __shfl_xor(t2, 32, 64);
-      if (M16) {
-        t1 += __shfl_xor(t1, 16, 64);
-        t2 += __shfl_xor(t2, 16, 64);
-      }
-      if (M16 ? laneE < 16 : hE == 0) {
-        const int cl = M16 ? wn * 64 + ni * 16 + r16E : wn * 64 + ni * 32 + rE;
-        cs[(wm * BN3 + cl) * 2 + 0] = t1;
-        cs[(wm * BN3 + cl) * 2 + 1] = t2;
-      }
+    // Per-(sample, group) sums of this wave's 64 pixels x 64 channels: in-lane over the register positions, over the 16 pixels
+    // of a row by DPP, then over the rows that share a group (fixed order: deterministic).  cpg = channels per group:
+    //   16: lanes q16 = 0, 1 | 2, 3 hold one group each per 32-channel half -> four groups, written by lanes 0 and 32
+    //   32: one group per half -> two groups, lane 0;   >= 64: both halves are one group -> lane 0
+    // Slot layout: [b][group][(m-tile, n-tile of the group) x contributing waves]: 4 waves (wm) of the group's column half, or
+    // all 8 when a group spans the whole 128-channel tile; gn_finalize sums the slots in index order (fp64).
+    const int cpg = p.Cout / p.groups;                    // 16, 32, 64 or a multiple of 128
+    float a1l = (s1l[0] + s1l[1]) + (s1l[2] + s1l[3]), a2l = (s2l[0] + s2l[1]) + (s2l[2] + s2l[3]);
+    float a1h = (s1h[0] + s1h[1]) + (s1h[2] + s1h[3]), a2h = (s2h[0] + s2h[1]) + (s2h[2] + s2h[3]);
+    if (cpg >= 64) { a1l += a1h; a2l += a2h; }
+    a1l = xor16_sum(row16_sum(a1l));
+    a2l = xor16_sum(row16_sum(a2l));
+    if (cpg < 64) {
+      a1h = xor16_sum(row16_sum(a1h));
+      a2h = xor16_sum(row16_sum(a2h));
     }
-  }
-  if (p.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t2b = __builtin_amdgcn_s_memtime(); }
-  __syncthreads();                                        // (no global store is outstanding yet: this does not wait for HBM)
-  if (p.stamps) t3 = __builtin_amdgcn_s_memtime();
-  {
-    // 16-byte chunk q = tidE + 512 i: pixel q / 16 = patch row i (512 threads = one 32-pixel row x 16 chunks), column tidE / 16,
-    // channels (tidE % 16) * 8 .. +7: ONE per-lane address and a uniform row stride instead of eight 64-bit address computations
-    static_assert(NT3 == PW * 16 && (PH * PW * 16) / NT3 == PH, "store loop: one patch row per iteration");
-    const int pxE = tidE >> 4, c16 = tidE & 15;
-    bf16* o = p.out + ((size_t)(b * p.H + y0) * p.W + x0 + pxE) * p.Cout + nt * BN3 + c16 * 8;
-    const char* src = smem + pxE * EROW + c16 * 16;
-    const size_t row_stride = (size_t)p.W * p.Cout;
-#pragma unroll
-    for (int i = 0; i < PH; ++i) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + i * PW * EROW);
-      *reinterpret_cast<bf16x8*>(o + i * row_stride) = v;
-    }
-  }
-  if (p.stamps) t4 = __builtin_amdgcn_s_memtime();
-  if (STATS) {
-    // per-(sample, group) sums of this tile: columns summed over the 4 row blocks by 128 threads, then a shuffle tree over the
-    // group's span of columns (the first version let one thread per group walk its columns serially)
-    const int cpg = p.Cout / p.groups;                    // multiple of 16, divides or is a multiple of 128
-    const int span = cpg >= BN3 ? BN3 : cpg;              // columns of this tile that belong to one group: 16, 32, 64 or 128
-    float a1 = 0.f, a2 = 0.f;
-    if (tidE < BN3) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        a1 += cs[(k * BN3 + tidE) * 2 + 0];
-        a2 += cs[(k * BN3 + tidE) * 2 + 1];
-      }
-      for (int o = 1; o < span && o < 64; o <<= 1) {
-        a1 += __shfl_xor(a1, o, 64);
-        a2 += __shfl_xor(a2, o, 64);
+    if (cpg >= 32) {
+      a1l = xor32_sum(a1l);
+      a2l = xor32_sum(a2l);
+      if (cpg < 64) {
+        a1h = xor32_sum(a1h);
+        a2h = xor32_sum(a2h);
       }
     }
-    if (span == BN3) {                                    // a group spans both waves: combine through LDS (uniform branch);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // raw barriers: the output stores stay in flight
-      BARRIER();
-      if (tidE < BN3 && laneE == 0) { cs[wave * 2 + 0] = a1; cs[wave * 2 + 1] = a2; }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      BARRIER();
-      if (tidE == 0) { a1 = cs[0] + cs[2]; a2 = cs[1] + cs[3]; }
-    }
-    if (tidE < BN3 && (tidE % span) == 0) {
-      // slot layout: [b][group][m-tile within image (x n-tiles per group when a group spans several)]
-      const int tiles_per_group = cpg >= BN3 ? cpg / BN3 : 1;
-      const int g = (nt * BN3) / cpg + (cpg >= BN3 ? 0 : tidE / span);
-      const int nslots = tiles_y * tiles_x * tiles_per_group;
-      const int slot = trem * tiles_per_group + (cpg >= BN3 ? nt % tiles_per_group : 0);
+    if (laneE == 0 || (cpg == 16 && laneE == 32)) {
+      const int tpg = cpg >= BN3 ? cpg / BN3 : 1;         // 128-channel tiles per group
+      const int wpt = cpg >= BN3 ? 8 : 4;                 // contributing waves per tile
+      const int nslots = tiles_y * tiles_x * tpg * wpt;
+      const int slot = (trem * tpg + (cpg >= BN3 ? nt % tpg : 0)) * wpt + (cpg >= BN3 ? wave : wm);
+      const int sh = __builtin_ctz(cpg);                  // cpg < 128: a power of two (eligibility)
+      const int g = cpg >= BN3 ? chw / cpg : (chw + chl) >> sh;
       float* dst = p.gn_partial + ((size_t)(b * p.groups + g) * nslots + slot) * 2;
-      dst[0] = a1;
-      dst[1] = a2;
+      *reinterpret_cast<f32x2*>(dst) = f32x2{a1l, a2l};
+      if (cpg < 64) {
+        const int gh = (chw + 32 + chl) >> sh;
+        float* dsth = p.gn_partial + ((size_t)(b * p.groups + gh) * nslots + slot) * 2;
+        *reinterpret_cast<f32x2*>(dsth) = f32x2{a1h, a2h};
+      }
     }
   }
-  if (p.stamps && tidE == 0) {
-    const unsigned long long t5 = __builtin_amdgcn_s_memtime();
-    atomicAdd(&p.stamps[0], t1 - t0); atomicAdd(&p.stamps[1], t2 - t1); atomicAdd(&p.stamps[2], t3 - t2);
-    atomicAdd(&p.stamps[3], t4 - t3); atomicAdd(&p.stamps[4], t5 - t4); atomicAdd(&p.stamps[5], t5 - t0);
-    atomicAdd(&p.stamps[6], 1ull);
-    atomicAdd(&g_conv3_stamps2[0], t2a - t2); atomicAdd(&g_conv3_stamps2[1], t2b - t2a); atomicAdd(&g_conv3_stamps2[2], t3 - t2b);
-    atomicAdd(&p.stamps[7], __builtin_amdgcn_s_memrealtime() - r0);      // 100 MHz ticks: in-kernel clock = total / this * 100 MHz
+  if constexpr (STAMPS) {
+    t3 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t4 = __builtin_amdgcn_s_memtime();
+    if (p.stamps && tidE == 0) {
+      atomicAdd(&p.stamps[0], t1 - t0); atomicAdd(&p.stamps[1], t2 - t1); atomicAdd(&p.stamps[2], t3 - t2);
+      atomicAdd(&p.stamps[3], t4 - t3); atomicAdd(&p.stamps[5], t4 - t0); atomicAdd(&p.stamps[6], 1ull);
+      atomicAdd(&p.stamps[7], __builtin_amdgcn_s_memrealtime() - r0);      // 100 MHz ticks: in-kernel clock = total / this * 100 MHz
+    }
   }
 }
 
@@ -781,30 +553,33 @@ bool conv3x3_bf16_eligible(const ConvArgs& a) {
   if (a.Hin % PH || a.Win % PW) return false;
   if (a.gn_partial) {
     const int cpg = a.Cout / a.groups;
-    if (a.Cout % a.groups || cpg % 16) return false;
-    if (!(BN3 % cpg == 0 || cpg % BN3 == 0)) return false;
+    if (a.Cout % a.groups) return false;
+    if (!(cpg == 16 || cpg == 32 || cpg == 64 || cpg % BN3 == 0)) return false;
   }
   // per-image byte offsets must fit the 32-bit buffer offset
   if ((size_t)a.Hin * a.Win * (size_t)std::max(a.C0, a.C1) * 2 >= (1ull << 31)) return false;
+  if ((size_t)a.Hin * a.Win * (size_t)a.Cout * 2 >= (1ull << 31)) return false;
   if ((size_t)9 * ((a.C0 + a.C1) / KC) * (a.Cout / BN3) * B_BYTES >= (1ull << 31)) return false;
   return true;
 }
 
+// GroupNorm partial slots per (sample, group): one per contributing wave (see the kernel's epilogue)
 int conv3x3_bf16_stats_slots(const ConvArgs& a) {
   if (a.groups <= 0) return 0;
   const int cpg = a.Cout / a.groups;
-  return (a.Hin / PH) * (a.Win / PW) * (cpg >= BN3 ? cpg / BN3 : 1);
+  return (a.Hin / PH) * (a.Win / PW) * (cpg >= BN3 ? (cpg / BN3) * 8 : 4);
 }
 
 // Host-side packing: OIHW fp32 -> [tap][cc][ntile][128 rows][64 B swizzled] bf16 (the LDS image of each K-step tile).
-bool conv3x3_bf16_m16() {
-  static const int m16 = env_int("SRGD_CONV3_M16", CONV3_M16_DEFAULT) != 0;   // tuning knob; the shipped default is CONV3_M16_DEFAULT
-  return m16 != 0;
+// Row order inside a tile: row n = 64 wn + 16 ni + 4 q + e holds output channel 64 wn + 32 (ni >> 1) + 8 q + 4 (ni & 1) + e, so
+// that the accumulator registers of a lane (q = lane >> 4; e = register; ni = row block) are runs of eight consecutive channels.
+static inline int conv3_row_channel(int n) {
+  const int wn = n >> 6, ni = (n >> 4) & 3, q = (n >> 2) & 3, e = n & 3;
+  return wn * 64 + (ni >> 1) * 32 + q * 8 + (ni & 1) * 4 + e;
 }
 
 void pack_conv3x3_bf16(const float* src_oihw, int Cin, int Cout, std::vector<unsigned short>& out,
                        unsigned short (*to_bf16)(float)) {
-  const bool m16 = conv3x3_bf16_m16();
   const int CC = Cin / KC, NTL = Cout / BN3;
   out.assign((size_t)9 * CC * NTL * BN3 * KC, 0);
   for (int tap = 0; tap < 9; ++tap)
@@ -813,9 +588,9 @@ void pack_conv3x3_bf16(const float* src_oihw, int Cin, int Cout, std::vector<uns
         unsigned short* tile = out.data() + ((size_t)(tap * CC + cc) * NTL + nt) * BN3 * KC;
         for (int n = 0; n < BN3; ++n)
           for (int c = 0; c < 4; ++c) {
-            const int cs = c ^ (m16 ? (n >> 1) & 3 : (n >> 2) & 3);  // stored chunk position (row_swz of the kernel)
+            const int cs = c ^ ((n >> 1) & 3);  // stored chunk position (row_swz of the kernel)
             for (int e = 0; e < 8; ++e) {
-              const int ci = cc * KC + c * 8 + e, o = nt * BN3 + n;
+              const int ci = cc * KC + c * 8 + e, o = nt * BN3 + conv3_row_channel(n);
               const float v = src_oihw[(((size_t)o * Cin + ci) * 3 + tap / 3) * 3 + tap % 3];
               tile[n * KC + cs * 8 + e] = to_bf16(v);
             }
@@ -829,6 +604,7 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   const bool gnin = gn_in_a != nullptr;
   if (gnin && (a.C1 != 0 || !gn_in_b || gn_in_b < gn_in_a || (size_t)((const char*)gn_in_b - (const char*)gn_in_a) > (1u << 30)))
     SRGD_FAIL("conv3x3_bf16: fused input GroupNorm needs one source and scale/shift arrays in one allocation");
+  if (a.bias && ((size_t)a.bias & 15)) SRGD_FAIL("conv3x3_bf16: the bias array must be 16-byte aligned");
   Conv3Args p;
   p.in0 = (const bf16*)a.in0; p.in1 = (const bf16*)a.in1; p.C0 = a.C0; p.C1 = a.C1;
   p.B = a.B; p.H = a.Hin; p.W = a.Win; p.w = (const bf16*)packed_w; p.bias = a.bias; p.Cout = a.Cout;
@@ -837,60 +613,41 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   p.gn_in_b_off = gnin ? (int)((const char*)gn_in_b - (const char*)gn_in_a) : 0;
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
   {
-    // SRGD_CONV3_XCD_PIN: minimum packed-weight bytes of a layer for the n-tile-per-XCD map (0 = never)
+    // SRGD_CONV3_XCD_PIN_KB: minimum packed-weight bytes of a layer for the n-tile-per-XCD map (0 = never)
     static const long pin_min = (long)env_int("SRGD_CONV3_XCD_PIN_KB", CONV3_XCD_PIN_KB_DEFAULT) * 1024L;
     const int n_tiles = a.Cout / BN3, m_tiles = grid / n_tiles;
     const long wbytes = 9L * (a.C0 + a.C1) * a.Cout * 2;
     p.xcd_pin_ntiles = pin_min > 0 && wbytes >= pin_min && (n_tiles == 2 || n_tiles == 4 || n_tiles == 8) && m_tiles % (8 / n_tiles) == 0;
   }
-  static const int want_stamps = env_int("SRGD_CONV3_STAMPS", 0) ? 1 : 0;
   p.stamps = nullptr;
-  if (want_stamps) {
+  if (STAMPS) {
     SRGD_HIP(hipGetSymbolAddress((void**)&p.stamps, HIP_SYMBOL(g_conv3_stamps)));
     SRGD_HIP(hipMemsetAsync(p.stamps, 0, sizeof(unsigned long long) * 8, st));
-    void* s2p = nullptr;
-    SRGD_HIP(hipGetSymbolAddress(&s2p, HIP_SYMBOL(g_conv3_stamps2)));
-    SRGD_HIP(hipMemsetAsync(s2p, 0, sizeof(unsigned long long) * 4, st));
   }
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-#define SRGD_SET(S_, G_, M_)                                                                              \
-  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_, M_>),           \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024 + (G_ ? COEF_BYTES : 0)));
-    SRGD_SET(true, false, false) SRGD_SET(false, false, false) SRGD_SET(true, true, false) SRGD_SET(false, true, false)
-    SRGD_SET(true, false, true) SRGD_SET(false, false, true) SRGD_SET(true, true, true) SRGD_SET(false, true, true)
+#define SRGD_SET(S_, G_)                                                                                  \
+  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_>),               \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (G_ ? COEF_BYTES : 0)));
+    SRGD_SET(true, false) SRGD_SET(false, false) SRGD_SET(true, true) SRGD_SET(false, true)
 #undef SRGD_SET
     once.done();
   }
   const bool stats = a.gn_partial != nullptr;
-  // diagnostic: SRGD_CONV3_ONE_WG=1 pads the LDS request so that only ONE workgroup fits a CU (what a warp-specialised
-  // variant with helper waves would have to live with: at 128 VGPRs the register file holds 16 waves per CU either way)
-  static const int lds_req = env_int("SRGD_CONV3_ONE_WG", 0) ? 96 * 1024 : LDS_BYTES;
-#define SRGD_GO(S_, G_, M_) \
-  hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_, M_>), dim3(grid), dim3(NT3), lds_req + (G_ ? COEF_BYTES : 0), st, p)
-  if (conv3x3_bf16_m16()) {
-    if (stats && gnin) SRGD_GO(true, true, true); else if (stats) SRGD_GO(true, false, true);
-    else if (gnin) SRGD_GO(false, true, true); else SRGD_GO(false, false, true);
-  } else {
-    if (stats && gnin) SRGD_GO(true, true, false); else if (stats) SRGD_GO(true, false, false);
-    else if (gnin) SRGD_GO(false, true, false); else SRGD_GO(false, false, false);
-  }
+#define SRGD_GO(S_, G_) \
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_>), dim3(grid), dim3(NT3), LDS_BYTES + (G_ ? COEF_BYTES : 0), st, p)
+  if (stats && gnin) SRGD_GO(true, true); else if (stats) SRGD_GO(true, false);
+  else if (gnin) SRGD_GO(false, true); else SRGD_GO(false, false);
 #undef SRGD_GO
   SRGD_HIP(hipGetLastError());
-  if (want_stamps) {                                    // diagnostic mode: synchronous, prints the mean cycles per workgroup and phase
+  if (STAMPS) {                                         // stamp build: synchronous, prints the mean ticks per workgroup and phase
     unsigned long long h[8];
     SRGD_HIP(hipStreamSynchronize(st));
     SRGD_HIP(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));
     const double n = h[6] ? (double)h[6] : 1.0;
-    unsigned long long h2[4];
-    void* s2p = nullptr;
-    SRGD_HIP(hipGetSymbolAddress(&s2p, HIP_SYMBOL(g_conv3_stamps2)));
-    SRGD_HIP(hipMemcpy(h2, s2p, sizeof(h2), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[conv3x3_bf16 stamps] transposition phase of the stamping wave: accumulators -> LDS %.0f  statistics %.0f  barrier wait %.0f\n",
-            h2[0] / n, h2[1] / n, h2[2] / n);
-    fprintf(stderr, "[conv3x3_bf16 stamps] C %d+%d -> %d @%dx%d grid %d: prologue %.0f  main %.0f  transpose %.0f  stores %.0f  "
-                    "stats %.0f  total %.0f  (s_memtime ticks per workgroup)  in-kernel clock %.3f GHz\n",
-            a.C0, a.C1, a.Cout, a.Hin, a.Win, grid, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[5] / n,
+    fprintf(stderr, "[conv3x3_bf16 stamps] C %d+%d -> %d @%dx%d grid %d: prologue %.0f  main %.0f  epilogue (wave 0: bias, pack, "
+                    "stores issued, statistics) %.0f  store drain %.0f  total %.0f  (s_memtime ticks per workgroup)  in-kernel clock %.3f GHz\n",
+            a.C0, a.C1, a.Cout, a.Hin, a.Win, grid, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[5] / n,
             h[7] ? 0.1 * (double)h[5] / (double)h[7] : 0.0);
   }
   return 0;

@@ -855,9 +855,9 @@ int attn_block(Ctx& x, const AttnW& a, const void* in, void** out, bool want_twi
 int ensure_scratch(srgd_engine* e, int nb, int H, int W) {
   const int hw = H * W;
   const int cmax = *std::max_element(e->dims.begin(), e->dims.end());
-  // GroupNorm partial slots per (sample, group): generic kernel one per 128-pixel tile, conv3x3_bf16 one per 256-pixel patch
-  // (x the 128-channel tiles a group spans)
-  const size_t slots = std::max((size_t)cdiv(hw, conv_tile_m()), (size_t)cdiv(hw, 256) * std::max(1, cmax / e->cfg.groups / 128));
+  // GroupNorm partial slots per (sample, group): generic kernel one per 128-pixel tile; the 3x3 fast paths one per contributing
+  // wave of a 256-pixel patch (conv3x3_bf16_stats_slots: 4, or 8 per 128-channel tile a group spans)
+  const size_t slots = std::max((size_t)cdiv(hw, conv_tile_m()), (size_t)cdiv(hw, 256) * std::max(4, cmax / e->cfg.groups / 16));
   SRGD_TRY(ensure(e, &e->gn_partial, &e->gn_partial_cap, (size_t)nb * e->cfg.groups * slots * 2));
   size_t need = (size_t)nb * cmax;
   if (e->coef_cap < need) {

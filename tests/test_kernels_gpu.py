@@ -77,7 +77,9 @@ def run_conv(x0, x1, w, b, *, ks, stride, pad, kind, bf16, residual=None, groups
     dres = None if residual is None else to_dev_nhwc(residual, bf16)
     part = None
     if groups:
-        part = torch.full((B, groups, ho * wo // 128, 2), float("nan"), device=DEV)
+        # capacity: the 3x3 fast paths write one slot per contributing wave (4 per 256-pixel patch, 8 per 128-channel tile of a
+        # group that spans whole tiles); the call reports the count it used
+        part = torch.full((B, groups, (ho * wo // 32) * max(1, cout // groups // 64), 2), float("nan"), device=DEV)
     wh = w.contiguous().float()
     bh = None if b is None else b.contiguous().float()
     slots = C.c_int()
@@ -263,19 +265,21 @@ def test_full_attention_core(bf16, hw):
 
 
 @pytest.mark.parametrize("cfg", [(2, 32, 0, 128, 8, 32), (1, 64, 32, 256, 16, 64), (3, 128, 0, 128, 32, 32),
-                                 (1, 256, 128, 1024, 8, 32), (1, 32, 0, 2048, 8, 32)],
-                         ids=lambda s: "B%d_C%d+%d_Cout%d_%dx%d" % s)
+                                 (1, 256, 128, 1024, 8, 32), (1, 32, 0, 2048, 8, 32), (2, 32, 0, 512, 16, 32), (1, 32, 0, 2048, 16, 32, 8)],
+                         ids=lambda s: "B%d_C%d+%d_Cout%d_%dx%d" % s[:6] + ("_g%d" % s[6] if len(s) > 6 else ""))
 def test_conv3x3_bf16_fast_path_borders_sources_stats(cfg):
     # conv3x3_bf16.hip (halo patch in LDS, LDS-DMA staging, zero fill by the buffer range check) against the
-    # oracle's conv2d on bf16-rounded operands, incl. tiles touching every image border and two sources.
-    B, c0, c1, cout, H, W = cfg
+    # oracle's conv2d on bf16-rounded operands, incl. tiles touching every image border and two sources.  GroupNorm partials
+    # for every channels-per-group class of the register-direct epilogue: 16 (two groups per 32-channel half), 32, 64 (one
+    # group per wave), 128 and 256 (a group spans one / two whole 128-channel tiles).
+    B, c0, c1, cout, H, W = cfg[:6]
     lib = L().lib()
     g = torch.Generator().manual_seed(11)
     x0 = rnd(torch.randn(B, c0, H, W, generator=g), True)
     x1 = rnd(torch.randn(B, c1, H, W, generator=g), True) if c1 else None
     w = rnd(torch.randn(cout, c0 + c1, 3, 3, generator=g) / (3 * (c0 + c1) ** 0.5), True)
     b = torch.randn(cout, generator=g)
-    groups = 8 if cout <= 1024 else 0
+    groups = cfg[6] if len(cfg) > 6 else (8 if cout <= 1024 else 0)
     got, part, nslots = run_conv(x0, x1, w, b, ks=3, stride=1, pad=1, kind=0, bf16=True, groups=groups, impl=2,
                                  want_slots=True)
     xin = x0 if x1 is None else torch.cat((x0, x1), 1)
@@ -604,7 +608,7 @@ def test_conv3x3_mxfp8_matches_the_quantised_reference(shape):
     d = to_dev_nhwc(x, True)
     out = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
     nslots = C.c_int(0)
-    part = torch.zeros(B * 8 * (H * W // 128) * 2 + 16, device=DEV)
+    part = torch.zeros(B * 8 * (H * W // 32) * 2 + 16, device=DEV)
     L().check(lib.srgd_k_conv3x3_mxfp8(ptr(d), ptr(None), Cin, 0, B, H, W, ptr(w), ptr(b), Cout, ptr(out), ptr(part), 8, 0, None,
                                        C.byref(nslots), stream()), "conv3x3_mxfp8")
     got = from_dev_nhwc(out)

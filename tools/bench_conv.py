@@ -73,7 +73,7 @@ def main():
         for impl in [int(v) for v in args.impls.split(',')]:
             out = torch.empty(B, hw, hw, cout, device="cuda", dtype=torch.bfloat16)
             groups = 8 if (args.stats and ks == 3) else 0
-            part = torch.zeros(B * 8 * (hw * hw // 128) * 2, device="cuda") if groups else None
+            part = torch.zeros(B * 8 * (hw * hw // 32) * 2, device="cuda") if groups else None
             ms = C.c_float()
             slots = C.c_int()
             coef = None

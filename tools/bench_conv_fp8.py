@@ -38,7 +38,7 @@ def main():
         w = (torch.randn(cout, c0 + c1, 3, 3) / (3 * (c0 + c1) ** 0.5)).float().contiguous()
         bias = torch.randn(cout).float()
         out = torch.empty(B, hw, hw, cout, device="cuda", dtype=torch.bfloat16)
-        part = torch.zeros(B * 8 * (hw * hw // 128) * 2 + 64, device="cuda")
+        part = torch.zeros(B * 8 * (hw * hw // 32) * 2 + 64, device="cuda")
         flops = 2.0 * B * hw * hw * cout * 9 * (c0 + c1)
         ms, slots = C.c_float(), C.c_int()
         _lib.check(lib.srgd_k_conv3x3_mxfp8(C.c_void_p(x0.data_ptr()), C.c_void_p(x1.data_ptr() if c1 else 0), c0, c1, B, hw, hw,

@@ -14,7 +14,7 @@ def run(lib, st, x, w, bias, impl, coef, stats=True):
     B, H, W_, c0 = x.shape
     cout = w.shape[0]
     out = torch.empty(B, H, W_, cout, device="cuda", dtype=torch.bfloat16)
-    part = torch.zeros(B * 8 * (H * W_ // 128) * 2, device="cuda") if stats else None
+    part = torch.zeros(B * 8 * (H * W_ // 32) * 2, device="cuda") if stats else None
     ms, slots = C.c_float(), C.c_int()
     rc = lib.srgd_k_conv2d_timed(C.c_void_p(x.data_ptr()), C.c_void_p(0), c0, 0, B, H, W_, 3, 1, 1, 0, C.c_void_p(w.data_ptr()),
                                  C.c_void_p(bias.data_ptr()), cout, C.c_void_p(out.data_ptr()), C.c_void_p(0),
