@@ -267,6 +267,13 @@ __global__ __launch_bounds__(256) void full_attn_mfma_kernel(const T* __restrict
   const T* base = qkv + (size_t)b * N * C3 + head * DH;
   constexpr int VN = Vec16<T>::N;
 
+  // element 2 t + hh of a row held in registers, as a bit select: written `hh ? row[2t+1] : row[2t]` the compiler turns the pair
+  // into ONE dynamically indexed read row[2t + hh] and moves the row into scratch memory (144 B per lane inside the key loop)
+  const unsigned hh_mask = 0u - (unsigned)hh;
+  auto sel_hh = [&](float even, float odd) {
+    const unsigned a = __float_as_uint(even), o = __float_as_uint(odd);
+    return __uint_as_float(a ^ ((a ^ o) & hh_mask));
+  };
   // this lane's share of its query row: Q[q0 + r][2t + hh] * scale, t = 0..15
   float qv[16];
   {
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(256) void full_attn_mfma_kernel(const T* __restrict
       for (int j = 0; j < VN; ++j) row[v * VN + j] = t.get(j);
     }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) qv[t] = (hh ? row[2 * t + 1] : row[2 * t]) * scale;
+    for (int t = 0; t < 16; ++t) qv[t] = sel_hh(row[2 * t], row[2 * t + 1]) * scale;
   }
   f32x16 o = 0;
   float m = -INFINITY, l = 0.f;
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(256) void full_attn_mfma_kernel(const T* __restrict
         for (int j = 0; j < VN; ++j) row[v * VN + j] = t.get(j);
       }
 #pragma unroll
-      for (int t = 0; t < 16; ++t) kk[t] = hh ? row[2 * t + 1] : row[2 * t];
+      for (int t = 0; t < 16; ++t) kk[t] = sel_hh(row[2 * t], row[2 * t + 1]);
     }
     // V[k0 + kappa_t + 4 hh][e = r] for the second product, issued early
     float vv[16];
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(FA_NT) void full_attn_bf16_kernel(const bf16* __res
     f32x4 sa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf0, z, 0, 0, 0);
     f32x4 sb0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf1, z, 0, 0, 0);
     f32x4 sb1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf1, z, 0, 0, 0);
-#define SRGD_FA_SOFTMAX(S0, S1, M, L, OA, OB, PB)                                              \
+#define K_FA_SOFTMAX(S0, S1, M, L, OA, OB, PB)                                              \
     {                                                                                          \
       S0 *= scale_log2e;                                                                       \
       S1 *= scale_log2e;                                                                       \
@@ -435,9 +442,9 @@ __global__ __launch_bounds__(FA_NT) void full_attn_bf16_kernel(const bf16* __res
       OB *= corr;                                                                              \
     }
     bf16x8 pa, pb;
-    SRGD_FA_SOFTMAX(sa0, sa1, m0, l0, o00, o01, pa)
-    SRGD_FA_SOFTMAX(sb0, sb1, m1, l1, o10, o11, pb)
-#undef SRGD_FA_SOFTMAX
+    K_FA_SOFTMAX(sa0, sa1, m0, l0, o00, o01, pa)
+    K_FA_SOFTMAX(sb0, sb1, m1, l1, o10, o11, pb)
+#undef K_FA_SOFTMAX
     o00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pa, o00, 0, 0, 0);
     o01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, pa, o01, 0, 0, 0);
     o10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, pb, o10, 0, 0, 0);

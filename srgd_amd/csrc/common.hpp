@@ -130,6 +130,77 @@ __device__ __forceinline__ void mx_store_twin(const bf16x8& v, unsigned char* q,
   if (lane_in_quad == 0) s[elem >> 5] = (unsigned char)sb;
 }
 
+// ---- register-direct MFMA epilogues (conv3x3_bf16, conv3x3_mxfp8, conv1x1_epilogue.hpp) --------------------------------------
+// The convolution kernels issue their 16x16 MFMAs with the WEIGHT fragment as the A operand and the PIXEL fragment as B, so that
+// D holds, for lane (r16 = lane & 15, g = lane >> 4), rows 4 g .. 4 g + 3 of the weight block for pixel r16.  With four weight
+// blocks J = 0..3 per wave (64 rows) the host stores the rows of a 128-row weight tile in the order
+//     tile row 64 wn + 16 J + 4 g + e   <-   output channel 64 wn + 16 g + 4 J + e
+// so that the sixteen accumulator registers (J, e) of a lane are the SIXTEEN CONSECUTIVE output channels 64 wn + 16 g + 4 J + e of
+// its pixel: 32 bytes of bf16 = two 16-byte stores straight from the registers, an MX-fp8 32-channel block = the lane pair
+// (g, g ^ 1) = lanes l and l ^ 16, a GroupNorm group of 16 channels = one lane.  No LDS transposition, no barrier.
+static inline int regepi_row_channel(int n) {            // host: output channel (inside the 128-channel tile) stored in tile row n
+  const int wn = n >> 6, J = (n >> 4) & 3, g = (n >> 2) & 3, e = n & 3;
+  return wn * 64 + g * 16 + J * 4 + e;
+}
+// v (+ | max) the same register of lane ^ 16 / lane ^ 32, in every lane: one half-exchange of two copies (v_permlane16_swap swaps
+// the odd rows of its first operand with the even rows of its second, v_permlane32_swap the upper half with the lower half) and
+// one VALU op - no ds_bpermute (that form goes through the LDS crossbar).  After the swap the first register holds the even
+// row's (lower half's) value and the second the odd row's (upper half's) in BOTH partner lanes: sums are formed in the same
+// order everywhere.  Inline asm: the builtins of this toolchain (ROCm 7.2 clang) return their first result twice.  The s_nop
+// covers the VALU-write -> v_permlane-read hazard (2 wait states), which the compiler does not insert inside asm.
+__device__ __forceinline__ void permlane16_swap2(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void permlane32_swap2(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float xor16_sum(float v) { float a = v, b = v; permlane16_swap2(a, b); return a + b; }
+__device__ __forceinline__ float xor32_sum(float v) { float a = v, b = v; permlane32_swap2(a, b); return a + b; }
+__device__ __forceinline__ float xor16_max(float v) { float a = v, b = v; permlane16_swap2(a, b); return fmaxf(a, b); }
+// A 16-byte store from registers through a raw buffer descriptor (SGPR quad {base lo, base hi & 0xffff, bytes in range, 0x00020000}),
+// per-lane byte offset + wave-uniform byte offset, followed by two wait states.  Why asm: compiled from the builtin, the next
+// packed VALU write to the data registers may follow the store directly (LLVM's store-data hazard rule exempts stores whose
+// soffset is an SGPR), and on gfx950 lanes 12-15 of every row then stored the NEW contents of the second data register
+// (found by the conv3x3_bf16 kernel test, round 5).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT = false>
+__device__ __forceinline__ void buffer_store16(const u32x4& data, const u32x4& rsrc, int voffset, int soffset) {
+  if (NT) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(data), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+  else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(data), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
+__device__ __forceinline__ u32x4 make_raw_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)(size_t)base;
+  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
+}
+// OCP MX-fp8 quantisation of the 16 consecutive channels a lane holds in the register-direct layout; the 32-channel block is
+// shared with lane ^ 16 (all lanes active).  Same scale rule and arithmetic as mx_quant8: bit-identical to quant_mxfp8.
+__device__ __forceinline__ u32x4 mx_quant16_pair(const float (&y)[16], int* scale_byte) {
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) amax = fmaxf(amax, fabsf(y[j]));
+  amax = xor16_max(amax);
+  const int bexp = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+  const int over = ((__float_as_uint(amax) & 0x7fffffu) > 0x600000u) ? 1 : 0;
+  const int sb = min(max(bexp - 8 + over, 0), 254);
+  const float inv = __uint_as_float((unsigned)(254 - sb) << 23);      // 2^(127 - sb)
+  float t[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float u = y[j] * inv;
+    t[j] = (u != u) ? u : fminf(fmaxf(u, -448.f), 448.f);
+  }
+  u32x4 w = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned d = 0;
+    d = __builtin_amdgcn_cvt_pk_fp8_f32(t[4 * k + 0], t[4 * k + 1], d, false);
+    d = __builtin_amdgcn_cvt_pk_fp8_f32(t[4 * k + 2], t[4 * k + 3], d, true);
+    w[k] = d;
+  }
+  *scale_byte = sb;
+  return w;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

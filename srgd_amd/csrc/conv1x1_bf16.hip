@@ -24,10 +24,6 @@ constexpr int B1_BYTES = BN1 * KC1 * 2;            // 8 KiB
 constexpr int STAGE1 = A1_BYTES + B1_BYTES;        // 24 KiB
 constexpr int RING1 = 3;
 constexpr int LDS1_BYTES = RING1 * STAGE1;         // 73,728 >= EPI_LDS_BYTES = 69,632 (epilogue staging)
-// Wide (256 x 256) tile: measured +3-14 % on the five K-heavy shapes in tools/bench_conv.py (impl 6 vs 3: 1024+512 -> 1024 @32^2
-// 793 -> 904 TF, 1024 -> 2048 @32^2 775 -> 839-878) and +-0.1 % on the whole benchmark (1.3374 / 1.3353 without, 1.3367 / 1.3371
-// with, one box): not shipped on; SRGD_CONV1X1_WIDE_MIN_K=768 switches it on for layers with K >= 768.
-constexpr int CONV1X1_WIDE_MIN_K_DEFAULT = 0;
 static_assert(LDS1_BYTES >= EPI_LDS_BYTES && BM1 == EPI_BM && BN1 == EPI_BN && NT1 == EPI_NT, "conv1x1_epilogue.hpp tile shape");
 
 typedef __attribute__((address_space(3))) void* lds_ptr1;
@@ -91,7 +87,7 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
   // changes from K-step to K-step (tap offset, channel chunk, ring slot, weight tile) is wave-uniform and rides in SGPRs - the
   // buffer instruction's scalar offset and M0.  Round 2 recomputed the per-lane offsets every step from a runtime s / CC and
   // tap / KW (66 SALU + 17 VALU instructions, two of them v_mul_lo, per 16 MFMAs).
-#define SRGD_A1_DECL(J)                                                      \
+#define K_A1_DECL(J)                                                      \
   int a_b0##J, a_b1##J;                                                      \
   {                                                                          \
     const int g = (wave + 8 * J) * 64 + lane;                                \
@@ -103,8 +99,8 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
     a_b0##J = (pix * p.ps0 + sub * 8) * 2;                                   \
     a_b1##J = (pix * p.ps1 + sub * 8) * 2;                                   \
   }
-  SRGD_A1_DECL(0) SRGD_A1_DECL(1)
-#undef SRGD_A1_DECL
+  K_A1_DECL(0) K_A1_DECL(1)
+#undef K_A1_DECL
   const size_t img0 = (size_t)p.Hin * p.Win * p.ps0, img1 = (size_t)p.Hin * p.Win * p.ps1;
   const __amdgpu_buffer_rsrc_t rs0 =
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (size_t)b * img0), 0, (int)(img0 * 2), 0x00020000);
@@ -189,147 +185,6 @@ __global__ __launch_bounds__(NT1, 4) void conv1x1_bf16_kernel(Conv1Args p) {
   conv1x1_epilogue<EPI, BM1>(p, smem, tid, nt, m0, b, p0, c00, c01, c02, c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33);
 }
 
-// ------------------------------------------------------------------------------------------- wide tile (round 4)
-// The K-heavy pointwise layers (1024 -> 2048 @32^2, 1024+512 -> 1024 @32^2, 512+256 -> 512 @64^2, 512 -> 1024 @64^2, ...) are
-// MFMA-shaped work: the 256 x 128 tile above moves 24 KB through LDS-DMA per K-step of 4.2 MFLOP (87 FLOP per byte) and runs
-// them at 740-900 TFLOP/s.  This instance gives them a 256-pixel x 256-channel tile: ONE workgroup of 1,024 threads per CU
-// (16 waves = 4 along M x 4 along N, the same 64 x 64 wave tile, 16x16x32 MFMAs and operand pattern), a K-step = one 32 KB stage
-// (A 256 x 64 B + TWO adjacent pre-swizzled 8 KB weight tiles: the packing is unchanged) = 128 FLOP per byte, two DMA
-// instructions per wave and step instead of three, 4-deep ring (128 KB: three stages in flight).  The epilogue is conv1x1_epilogue.hpp run by the two
-// halves of the workgroup side by side: waves with wn < 2 handle channel tile 2 nt2, the others 2 nt2 + 1, each half with a
-// staging area of its own (2 x 68 KB fit one workgroup's LDS).  Bit-identical to the 128-wide kernel (same K order, same
-// rounding points).  Selected by conv1x1_bf16() for layers with Cout % 256 == 0 and K >= SRGD_CONV1X1_WIDE_MIN_K.
-constexpr int BNW = 256, NTW = 1024;
-constexpr int BW_BYTES = BNW * KC1 * 2;             // 16 KiB: two adjacent weight tiles
-constexpr int STAGEW = A1_BYTES + BW_BYTES;         // 32 KiB
-constexpr int LDSW_BYTES = 2 * EPI_LDS_BYTES;       // 139,264 >= RING1 * STAGEW = 98,304
-#ifndef SRGD_CONV1X1_WIDE_RING
-#define SRGD_CONV1X1_WIDE_RING 4
-#endif
-constexpr int RINGW = SRGD_CONV1X1_WIDE_RING;      // 4 stages = 128 KiB: three K-steps (96 KiB) in flight per CU
-static_assert(LDSW_BYTES >= RINGW * STAGEW && LDSW_BYTES <= 160 * 1024, "wide tile LDS");
-
-template <int EPI>
-__global__ __launch_bounds__(NTW, 1) void conv1x1_bf16_wide_kernel(Conv1Args p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int r16 = lane & 15, q16 = lane >> 4;
-
-  const int n_tiles2 = p.Cout / BNW;
-  const int HWo = p.Hout * p.Wout;
-  int wg = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, x = wg & 7, k = wg >> 3;
-    wg = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + k;
-  }
-  const int nt2 = wg % n_tiles2;
-  const int mt = wg / n_tiles2;
-  const long m0 = (long)mt * BM1;
-  const int b = (int)(m0 / HWo);
-  const int p0 = (int)(m0 - (long)b * HWo);
-  const int Cin = p.C0 + p.C1;
-  const int CC = Cin / KC1;
-  const int S = p.KH * p.KW * CC;
-
-  // A staging: 16 pieces per stage, one per wave
-  int a_b0, a_b1;
-  {
-    const int g = wave * 64 + lane;
-    const int P = g >> 2;
-    const int op = p0 + P;
-    const int oy = op / p.Wout, ox = op - oy * p.Wout;
-    const int pix = oy * p.stride * p.Win + ox * p.stride;
-    const int sub = (g & 3) ^ row_swz1(P);
-    a_b0 = (pix * p.ps0 + sub * 8) * 2;
-    a_b1 = (pix * p.ps1 + sub * 8) * 2;
-  }
-  const size_t img0 = (size_t)p.Hin * p.Win * p.ps0, img1 = (size_t)p.Hin * p.Win * p.ps1;
-  const __amdgpu_buffer_rsrc_t rs0 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (size_t)b * img0), 0, (int)(img0 * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.in1 ? p.in1 + (size_t)b * img1 : p.in0), 0, p.in1 ? (int)(img1 * 2) : 0, 0x00020000);
-  const size_t w_tile_stride = (size_t)(p.Cout / BN1) * B1_BYTES;         // bytes between consecutive (tap, cc) rows of tiles
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const char*)p.w + (size_t)nt2 * BW_BYTES), 0, (int)((size_t)(S - 1) * w_tile_stride + BW_BYTES), 0x00020000);
-
-  int i_ty = 0, i_tx = 0, i_cc = 0, i_slot = 0, i_w = 0;
-  const int tid16 = tid * 16;
-  auto issue = [&]() __attribute__((always_inline)) {
-    const int c = i_cc * KC1;
-    const bool first = c < p.C0;
-    const int soff = first ? ((i_ty * p.Win + i_tx) * p.ps0 + c) * 2 : ((i_ty * p.Win + i_tx) * p.ps1 + c - p.C0) * 2;
-    char* st = smem + i_slot * STAGEW;
-    const int vo = first ? a_b0 : a_b1;              // (arithmetic select: see the 128-wide kernel)
-    if (first) dma16_1(rs0, st + wave * 1024, vo, soff);
-    else dma16_1(rs1, st + wave * 1024, vo, soff);
-    dma16_1(rsw, st + A1_BYTES + wave * 1024, tid16, i_w);
-    i_w += (int)w_tile_stride;
-    i_slot = i_slot == RINGW - 1 ? 0 : i_slot + 1;
-    if (++i_cc == CC) {
-      i_cc = 0;
-      if (++i_tx == p.KW) { i_tx = 0; ++i_ty; }
-    }
-  };
-
-  f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c10 = 0, c11 = 0, c12 = 0, c13 = 0,
-        c20 = 0, c21 = 0, c22 = 0, c23 = 0, c30 = 0, c31 = 0, c32 = 0, c33 = 0;
-  auto a_addr = [&](int i) {
-    const int P = wm * 64 + i * 16 + r16;
-    return P * 64 + ((q16 ^ row_swz1(P)) << 4);
-  };
-  auto b_addr = [&](int j) {
-    const int n = wn * 64 + j * 16 + r16;            // row of the 256-row weight stage (two 128-row tiles back to back)
-    return A1_BYTES + n * 64 + ((q16 ^ row_swz1(n)) << 4);
-  };
-  const int aa0 = a_addr(0), aa1 = a_addr(1), aa2 = a_addr(2), aa3 = a_addr(3);
-  const int ba0 = b_addr(0), ba1 = b_addr(1), ba2 = b_addr(2), ba3 = b_addr(3);
-  int c_slot = 0;
-  auto compute = [&]() __attribute__((always_inline)) {
-    const char* st = smem + c_slot * STAGEW;
-    c_slot = c_slot == RINGW - 1 ? 0 : c_slot + 1;
-    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + aa0);
-    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(st + aa1);
-    const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(st + aa2);
-    const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(st + aa3);
-    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + ba0);
-    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(st + ba1);
-    const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(st + ba2);
-    const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(st + ba3);
-#define MM(C_, A_, B_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, C_, 0, 0, 0)
-    MM(c00, a0, b0); MM(c01, a0, b1); MM(c02, a0, b2); MM(c03, a0, b3);
-    MM(c10, a1, b0); MM(c11, a1, b1); MM(c12, a1, b2); MM(c13, a1, b3);
-    MM(c20, a2, b0); MM(c21, a2, b1); MM(c22, a2, b2); MM(c23, a2, b3);
-    MM(c30, a3, b0); MM(c31, a3, b1); MM(c32, a3, b2); MM(c33, a3, b3);
-#undef MM
-  };
-
-  // stages s+1 .. s+RINGW-1 in flight while stage s is consumed (2 DMA instructions per wave and stage)
-  static_assert(RINGW == 3 || RINGW == 4, "wait counts below");
-#pragma unroll
-  for (int k = 0; k < RINGW - 1; ++k) if (k < S) issue();
-  // stage 0 has landed when at most the younger stages' requests are outstanding
-  if (S >= RINGW - 1) { if (RINGW == 4) WAIT_VM1(4); else WAIT_VM1(2); }
-  else if (RINGW == 4 && S == 2) WAIT_VM1(2);
-  else WAIT_VM1(0);
-  BARRIER1();
-  for (int s = 0; s < S; ++s) {
-    if (s + RINGW - 1 < S) issue();
-    compute();
-    // stage s+1 must have landed: everything but the stages behind it may stay in flight
-    const int behind = min(S - 1, s + RINGW - 1) - (s + 1);          // stages s+2 .. issued so far
-    if (behind >= 2) WAIT_VM1(4); else if (behind == 1) WAIT_VM1(2); else WAIT_VM1(0);
-    BARRIER1();
-  }
-
-  // the two halves of the workgroup run the shared epilogue side by side, each on its own staging area and channel tile
-  const int half = wn >> 1;
-  conv1x1_epilogue<EPI, BM1>(p, smem + half * EPI_LDS_BYTES, ((wm * 2 + (wn & 1)) << 6) | lane, nt2 * 2 + half, m0, b, p0, c00, c01, c02,
-                             c03, c10, c11, c12, c13, c20, c21, c22, c23, c30, c31, c32, c33);
-}
-
 }  // namespace
 
 // Which generic-conv calls this kernel takes over (bf16 activations only).
@@ -372,13 +227,7 @@ void pack_conv1x1_bf16(const float* src_tap_o_i, int taps, int Cin, int Cout, st
       }
 }
 
-// the 256 x 256 tile additionally needs a 256-channel output tiling and no fused output convolution (that epilogue is Cout = 128)
-bool conv1x1_bf16_wide_eligible(const ConvArgs& a) {
-  return conv1x1_bf16_eligible(a) && a.Cout % BNW == 0 && !a.eps4 &&
-         (a.mode != CONV_PIXEL_SHUFFLE_SILU || (a.Cout / 4) % BN1 == 0);
-}
-
-int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st, bool force_wide) {
+int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st) {
   if (!conv1x1_bf16_eligible(a)) SRGD_FAIL("conv1x1_bf16: shape not eligible");
   Conv1Args p;
   p.in0 = (const bf16*)a.in0; p.in1 = (const bf16*)a.in1; p.C0 = a.C0; p.C1 = a.C1;
@@ -395,37 +244,20 @@ int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st, bool f
   if (grid <= 0 || grid > 0x7fffffffL) SRGD_FAIL("conv1x1_bf16: bad grid");
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-#define SRGD_SET1(E_)                                                                                   \
+#define K_SET1(E_)                                                                                   \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bf16_kernel<E_>),                 \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));                \
-  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_bf16_wide_kernel<E_>),            \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDSW_BYTES));
-    SRGD_SET1(EPI_PLAIN) SRGD_SET1(EPI_RESIDUAL) SRGD_SET1(EPI_GNTAIL) SRGD_SET1(EPI_PS_SILU) SRGD_SET1(EPI_GNTAIL_FINAL)
-#undef SRGD_SET1
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS1_BYTES));
+    K_SET1(EPI_PLAIN) K_SET1(EPI_RESIDUAL) K_SET1(EPI_GNTAIL) K_SET1(EPI_PS_SILU) K_SET1(EPI_GNTAIL_FINAL)
+#undef K_SET1
     once.done();
   }
-  // wide tile for the K-heavy layers: SRGD_CONV1X1_WIDE_MIN_K = smallest K (taps x input channels) it takes (0 = never)
-  static const int wide_min_k = env_int("SRGD_CONV1X1_WIDE_MIN_K", CONV1X1_WIDE_MIN_K_DEFAULT);
-  const bool wide = force_wide || (wide_min_k > 0 && a.KH * a.KW * (a.C0 + a.C1) >= wide_min_k && conv1x1_bf16_wide_eligible(a));
-  if (force_wide && !conv1x1_bf16_wide_eligible(a)) SRGD_FAIL("conv1x1_bf16: the wide tile does not cover this shape");
-  if (wide) {
-    const long gridw = m_tiles * (a.Cout / BNW);
-#define SRGD_GOW(E_) hipLaunchKernelGGL((conv1x1_bf16_wide_kernel<E_>), dim3((unsigned)gridw), dim3(NTW), LDSW_BYTES, st, p)
-    if (a.mode == CONV_PIXEL_SHUFFLE_SILU) SRGD_GOW(EPI_PS_SILU);
-    else if (a.gn_res_src) SRGD_GOW(EPI_GNTAIL);
-    else if (a.residual) SRGD_GOW(EPI_RESIDUAL);
-    else SRGD_GOW(EPI_PLAIN);
-#undef SRGD_GOW
-    SRGD_HIP(hipGetLastError());
-    return 0;
-  }
-#define SRGD_GO1(E_) hipLaunchKernelGGL((conv1x1_bf16_kernel<E_>), dim3((unsigned)grid), dim3(NT1), LDS1_BYTES, st, p)
-  if (a.mode == CONV_PIXEL_SHUFFLE_SILU) SRGD_GO1(EPI_PS_SILU);
-  else if (a.gn_res_src && a.eps4) SRGD_GO1(EPI_GNTAIL_FINAL);
-  else if (a.gn_res_src) SRGD_GO1(EPI_GNTAIL);
-  else if (a.residual) SRGD_GO1(EPI_RESIDUAL);
-  else SRGD_GO1(EPI_PLAIN);
-#undef SRGD_GO1
+#define K_GO1(E_) hipLaunchKernelGGL((conv1x1_bf16_kernel<E_>), dim3((unsigned)grid), dim3(NT1), LDS1_BYTES, st, p)
+  if (a.mode == CONV_PIXEL_SHUFFLE_SILU) K_GO1(EPI_PS_SILU);
+  else if (a.gn_res_src && a.eps4) K_GO1(EPI_GNTAIL_FINAL);
+  else if (a.gn_res_src) K_GO1(EPI_GNTAIL);
+  else if (a.residual) K_GO1(EPI_RESIDUAL);
+  else K_GO1(EPI_PLAIN);
+#undef K_GO1
   SRGD_HIP(hipGetLastError());
   return 0;
 }

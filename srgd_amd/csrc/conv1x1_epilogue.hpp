@@ -9,9 +9,6 @@
 namespace srgd {
 namespace {
 
-#ifndef SRGD_CONV1_PAIR_WRITES
-#define SRGD_CONV1_PAIR_WRITES 1     // accumulator -> LDS: dword writes after a lane-pair exchange (0: four 2-byte writes per block; A/B builds)
-#endif
 enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GNTAIL = 2, EPI_PS_SILU = 3, EPI_GNTAIL_FINAL = 4 };
 constexpr int EPI_BM = 256, EPI_BN = 128, EPI_NT = 512;
 constexpr int EPI_ROW = EPI_BN * 2 + 16;           // transposed output row (272 B: conflict-free 2-byte column writes)
@@ -50,7 +47,6 @@ __device__ __forceinline__ void conv1x1_epilogue(const Args& p, char* smem, cons
       // sum once more at the store
       float v0 = av[0] + bias, v1 = av[1] + bias, v2 = av[2] + bias, v3 = av[3] + bias;
       if (EPI == EPI_PS_SILU) { v0 = silu<false>(v0); v1 = silu<false>(v1); v2 = silu<false>(v2); v3 = silu<false>(v3); }
-#if SRGD_CONV1_PAIR_WRITES
       // Round 4: the short-K pointwise layers are bound by this phase (a 256 -> 512 @128^2 tile spends 8 K-steps in its loop and
       // emits output at the same ~2 TB/s as every other shape: 64 two-byte LDS writes per lane).  As in conv3x3_bf16.hip: two
       // adjacent lanes hold two adjacent channels of the same four rows; they swap halves (one DPP quad_perm move) so that the
@@ -65,12 +61,6 @@ __device__ __forceinline__ void conv1x1_epilogue(const Args& p, char* smem, cons
       char* prow = trow + (odd_lane ? 2 * EROW1 - 2 : 0);   // even lane: rows 0, 1 at its own column; odd lane: rows 2, 3, one column left
       *reinterpret_cast<unsigned*>(prow) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x05040100u);
       *reinterpret_cast<unsigned*>(prow + EROW1) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x07060302u);
-#else
-      *reinterpret_cast<bf16*>(trow) = (bf16)v0;
-      *reinterpret_cast<bf16*>(trow + EROW1) = (bf16)v1;
-      *reinterpret_cast<bf16*>(trow + 2 * EROW1) = (bf16)v2;
-      *reinterpret_cast<bf16*>(trow + 3 * EROW1) = (bf16)v3;
-#endif
     }
   }
   __syncthreads();

@@ -142,19 +142,19 @@ __global__ __launch_bounds__(BM * 2, 2) void conv1x1_mxfp8_kernel(Conv1QArgs p) 
     char* st = smem + i_slot * STAGEQ;
     const int m1 = first ? 0 : -1;
     const int v0 = a00 + (d10 & m1), v1 = a01 + (d11 & m1), v2 = a02 + (d12 & m1), v3 = a03 + (d13 & m1), vs = as0 + (ds1 & m1);
-#define SRGD_DMAQ(RS_, DST_, VO_, SO_, SZ_) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_, (lds_ptrq)(DST_), SZ_, VO_, SO_, 0, 0)
+#define K_DMAQ(RS_, DST_, VO_, SO_, SZ_) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_, (lds_ptrq)(DST_), SZ_, VO_, SO_, 0, 0)
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? qb0 : qb1), 0, first ? qn0 : qn1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(first ? sb0 : sb1), 0, (first ? qn0 : qn1) >> 5, 0x00020000);
-    SRGD_DMAQ(rq, st + wave * 1024, v0, soff, 16);
-    SRGD_DMAQ(rq, st + (wave + NW) * 1024, v1, soff, 16);
-    SRGD_DMAQ(rq, st + (wave + 2 * NW) * 1024, v2, soff, 16);
-    SRGD_DMAQ(rq, st + (wave + 3 * NW) * 1024, v3, soff, 16);
-    SRGD_DMAQ(rs, st + AQ_BYTES + (wave % SW) * 256, vs, ssoff, 4);
+    K_DMAQ(rq, st + wave * 1024, v0, soff, 16);
+    K_DMAQ(rq, st + (wave + NW) * 1024, v1, soff, 16);
+    K_DMAQ(rq, st + (wave + 2 * NW) * 1024, v2, soff, 16);
+    K_DMAQ(rq, st + (wave + 3 * NW) * 1024, v3, soff, 16);
+    K_DMAQ(rs, st + AQ_BYTES + (wave % SW) * 256, vs, ssoff, 4);
     char* sb = st + AQ_BYTES + ASQ_BYTES;
 #pragma unroll
-    for (int j = 0; j < Q::B_PER_WAVE; ++j) SRGD_DMAQ(rsw, sb + (wave + NW * j) * 1024, lane16, i_w + (wave + NW * j) * 1024, 16);
-    SRGD_DMAQ(rsw, sb + BQ_TILE + (wave & 1) * 256, lane4, i_w + BQ_TILE + (wave & 1) * 256, 4);
-#undef SRGD_DMAQ
+    for (int j = 0; j < Q::B_PER_WAVE; ++j) K_DMAQ(rsw, sb + (wave + NW * j) * 1024, lane16, i_w + (wave + NW * j) * 1024, 16);
+    K_DMAQ(rsw, sb + BQ_TILE + (wave & 1) * 256, lane4, i_w + BQ_TILE + (wave & 1) * 256, 4);
+#undef K_DMAQ
     i_w += (int)w_step_stride;
     i_slot = i_slot == RINGQ - 1 ? 0 : i_slot + 1;
     if (++i_cc == CC) {
@@ -178,37 +178,37 @@ __global__ __launch_bounds__(BM * 2, 2) void conv1x1_mxfp8_kernel(Conv1QArgs p) 
     c_slot = c_slot == RINGQ - 1 ? 0 : c_slot + 1;
     v8iq a0, a1, a2, a3, b0, b1, b2, b3;
     int sa0, sa1, sa2, sa3;
-#define SRGD_LOADQ(DST_, BASE_, I_)                                                     \
+#define K_LOADQ(DST_, BASE_, I_)                                                     \
     {                                                                                   \
       const v4iq lo = *reinterpret_cast<const v4iq*>(st + BASE_ + I_ * 2048);           \
       const v4iq hi = *reinterpret_cast<const v4iq*>(st + (BASE_ ^ 64) + I_ * 2048);    \
       DST_ = v8iq{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};              \
     }
-    SRGD_LOADQ(b0, bb, 0) SRGD_LOADQ(b1, bb, 1) SRGD_LOADQ(b2, bb, 2) SRGD_LOADQ(b3, bb, 3)
+    K_LOADQ(b0, bb, 0) K_LOADQ(b1, bb, 1) K_LOADQ(b2, bb, 2) K_LOADQ(b3, bb, 3)
     const int sbw = *reinterpret_cast<const int*>(st + bsb);
-    SRGD_LOADQ(a0, aa, 0) SRGD_LOADQ(a1, aa, 1) SRGD_LOADQ(a2, aa, 2) SRGD_LOADQ(a3, aa, 3)
-#undef SRGD_LOADQ
+    K_LOADQ(a0, aa, 0) K_LOADQ(a1, aa, 1) K_LOADQ(a2, aa, 2) K_LOADQ(a3, aa, 3)
+#undef K_LOADQ
     sa0 = *reinterpret_cast<const unsigned char*>(st + asb);
     sa1 = *reinterpret_cast<const unsigned char*>(st + asb + 64);
     sa2 = *reinterpret_cast<const unsigned char*>(st + asb + 128);
     sa3 = *reinterpret_cast<const unsigned char*>(st + asb + 192);
     // opsel of the weight scale (byte J of sbw): bit 0 -> op_sel[1], bit 1 -> op_sel_hi[1]
-#define SRGD_QMM1_OPSEL_0 "op_sel_hi:[0,0,0]"
-#define SRGD_QMM1_OPSEL_1 "op_sel:[0,1,0] op_sel_hi:[0,0,0]"
-#define SRGD_QMM1_OPSEL_2 "op_sel_hi:[0,1,0]"
-#define SRGD_QMM1_OPSEL_3 "op_sel:[0,1,0] op_sel_hi:[0,1,0]"
-#define SRGD_QMM1(C_, A_, SA_, B_, J_)                                                                     \
-    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " SRGD_QMM1_OPSEL_##J_           \
+#define K_QMM1_OPSEL_0 "op_sel_hi:[0,0,0]"
+#define K_QMM1_OPSEL_1 "op_sel:[0,1,0] op_sel_hi:[0,0,0]"
+#define K_QMM1_OPSEL_2 "op_sel_hi:[0,1,0]"
+#define K_QMM1_OPSEL_3 "op_sel:[0,1,0] op_sel_hi:[0,1,0]"
+#define K_QMM1(C_, A_, SA_, B_, J_)                                                                     \
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " K_QMM1_OPSEL_##J_           \
                  : "+v"(C_) : "v"(A_), "v"(B_), "v"(SA_), "v"(sbw))
-    SRGD_QMM1(c00, a0, sa0, b0, 0); SRGD_QMM1(c01, a0, sa0, b1, 1); SRGD_QMM1(c02, a0, sa0, b2, 2); SRGD_QMM1(c03, a0, sa0, b3, 3);
-    SRGD_QMM1(c10, a1, sa1, b0, 0); SRGD_QMM1(c11, a1, sa1, b1, 1); SRGD_QMM1(c12, a1, sa1, b2, 2); SRGD_QMM1(c13, a1, sa1, b3, 3);
-    SRGD_QMM1(c20, a2, sa2, b0, 0); SRGD_QMM1(c21, a2, sa2, b1, 1); SRGD_QMM1(c22, a2, sa2, b2, 2); SRGD_QMM1(c23, a2, sa2, b3, 3);
-    SRGD_QMM1(c30, a3, sa3, b0, 0); SRGD_QMM1(c31, a3, sa3, b1, 1); SRGD_QMM1(c32, a3, sa3, b2, 2); SRGD_QMM1(c33, a3, sa3, b3, 3);
-#undef SRGD_QMM1
-#undef SRGD_QMM1_OPSEL_0
-#undef SRGD_QMM1_OPSEL_1
-#undef SRGD_QMM1_OPSEL_2
-#undef SRGD_QMM1_OPSEL_3
+    K_QMM1(c00, a0, sa0, b0, 0); K_QMM1(c01, a0, sa0, b1, 1); K_QMM1(c02, a0, sa0, b2, 2); K_QMM1(c03, a0, sa0, b3, 3);
+    K_QMM1(c10, a1, sa1, b0, 0); K_QMM1(c11, a1, sa1, b1, 1); K_QMM1(c12, a1, sa1, b2, 2); K_QMM1(c13, a1, sa1, b3, 3);
+    K_QMM1(c20, a2, sa2, b0, 0); K_QMM1(c21, a2, sa2, b1, 1); K_QMM1(c22, a2, sa2, b2, 2); K_QMM1(c23, a2, sa2, b3, 3);
+    K_QMM1(c30, a3, sa3, b0, 0); K_QMM1(c31, a3, sa3, b1, 1); K_QMM1(c32, a3, sa3, b2, 2); K_QMM1(c33, a3, sa3, b3, 3);
+#undef K_QMM1
+#undef K_QMM1_OPSEL_0
+#undef K_QMM1_OPSEL_1
+#undef K_QMM1_OPSEL_2
+#undef K_QMM1_OPSEL_3
   };
 
   if constexpr (RINGQ == 3) {
@@ -310,34 +310,28 @@ int conv1x1_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   p.oq = (unsigned char*)a.out_q; p.os = (unsigned char*)a.out_s;
   p.eps4 = a.eps4; p.fin_w = a.fin_w; p.fin_b = a.fin_b;
   if ((p.oq != nullptr) != (p.os != nullptr)) SRGD_FAIL("conv1x1_mxfp8: MX-fp8 twin needs both the element and the scale buffer");
-  // tile shape: 128 pixels (two workgroups per CU) unless SRGD_MX1X1_BM=256 asks for the one-workgroup-per-CU shape
-  static const int bm_knob = env_int("SRGD_MX1X1_BM", 128) == 256 ? 256 : 128;
-  const int BM = (bm_knob == 256 && ((long)a.Hout * a.Wout) % 256 == 0) ? 256 : 128;
+  // tile shape: 128 pixels, two workgroups per CU (a 256-pixel one-workgroup-per-CU shape measured slower and was removed)
+  constexpr int BM = 128;
   const long m_tiles = (long)a.B * a.Hout * a.Wout / BM;
   const long grid = m_tiles * (a.Cout / BNQ);
   if (grid <= 0 || grid > 0x7fffffffL) SRGD_FAIL("conv1x1_mxfp8: bad grid");
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-#define SRGD_SETQ1(E_)                                                                                       \
-  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_mxfp8_kernel<E_, 256>),                \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, QShape<256>::LDS));               \
+#define K_SETQ1(E_)                                                                                       \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_mxfp8_kernel<E_, 128>),                \
                                hipFuncAttributeMaxDynamicSharedMemorySize, QShape<128>::LDS));
-    SRGD_SETQ1(EPI_PLAIN) SRGD_SETQ1(EPI_RESIDUAL) SRGD_SETQ1(EPI_GNTAIL) SRGD_SETQ1(EPI_PS_SILU) SRGD_SETQ1(EPI_GNTAIL_FINAL)
-#undef SRGD_SETQ1
+    K_SETQ1(EPI_PLAIN) K_SETQ1(EPI_RESIDUAL) K_SETQ1(EPI_GNTAIL) K_SETQ1(EPI_PS_SILU) K_SETQ1(EPI_GNTAIL_FINAL)
+#undef K_SETQ1
     once.done();
   }
-#define SRGD_GOQ1(E_)                                                                                                             \
-  do {                                                                                                                            \
-    if (BM == 256) hipLaunchKernelGGL((conv1x1_mxfp8_kernel<E_, 256>), dim3((unsigned)grid), dim3(512), QShape<256>::LDS, st, p); \
-    else hipLaunchKernelGGL((conv1x1_mxfp8_kernel<E_, 128>), dim3((unsigned)grid), dim3(256), QShape<128>::LDS, st, p);           \
-  } while (0)
-  if (a.mode == CONV_PIXEL_SHUFFLE_SILU) SRGD_GOQ1(EPI_PS_SILU);
-  else if (a.gn_res_src && a.eps4) SRGD_GOQ1(EPI_GNTAIL_FINAL);
-  else if (a.gn_res_src) SRGD_GOQ1(EPI_GNTAIL);
-  else if (a.residual) SRGD_GOQ1(EPI_RESIDUAL);
-  else SRGD_GOQ1(EPI_PLAIN);
-#undef SRGD_GOQ1
+#define K_GOQ1(E_)                                                                                                             \
+  hipLaunchKernelGGL((conv1x1_mxfp8_kernel<E_, 128>), dim3((unsigned)grid), dim3(256), QShape<128>::LDS, st, p)
+  if (a.mode == CONV_PIXEL_SHUFFLE_SILU) K_GOQ1(EPI_PS_SILU);
+  else if (a.gn_res_src && a.eps4) K_GOQ1(EPI_GNTAIL_FINAL);
+  else if (a.gn_res_src) K_GOQ1(EPI_GNTAIL);
+  else if (a.residual) K_GOQ1(EPI_RESIDUAL);
+  else K_GOQ1(EPI_PLAIN);
+#undef K_GOQ1
   SRGD_HIP(hipGetLastError());
   return 0;
 }

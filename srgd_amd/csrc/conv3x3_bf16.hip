@@ -18,10 +18,10 @@
 //     MFMA operand pattern (16 consecutive rows x 4 chunks) at every tap shift.
 //   * the MFMAs take the WEIGHT fragment as their A operand and the PIXEL fragment as B (both fragments have the same register
 //     image, so the K loop does not change): D then holds, per lane, four consecutive weight rows of ONE pixel.  The host
-//     packs the weight rows of a tile in the order that makes a lane's sixteen values of a 16-pixel block two runs of eight
-//     consecutive output channels - the epilogue is register-direct: + bias, bf16 pack, two 16-byte stores per block straight
-//     from the accumulators, GroupNorm partial sums (reference Block.norm, model.py:250-259) by in-lane adds + a DPP row
-//     reduction, one slot per wave.  No LDS traffic, no barrier: the phase no longer competes with the co-resident workgroup's
+//     packs the weight rows of a tile in the order that makes a lane's sixteen values of a 16-pixel block sixteen consecutive
+//     output channels (common.hpp, regepi_row_channel) - the epilogue is register-direct: + bias, bf16 pack, two 16-byte stores
+//     per block straight from the accumulators, GroupNorm partial sums (reference Block.norm, model.py:250-259) by in-lane adds
+//     + a DPP row reduction (+ permlane swaps across rows), one slot per wave.  No LDS traffic, no barrier: the phase no longer competes with the co-resident workgroup's
 //     K loop for the LDS pipe (round 4's LDS transposition was 23 % of a 128 -> 128 @256^2 tile for that reason).
 //   * blockIdx is remapped so each XCD (private L2) gets a contiguous band of tiles (halo reuse in L2).
 //   * GNIN instances (template parameter): the PRODUCER's GroupNorm-apply + SiLU is applied to a chunk's halo patch in LDS right
@@ -35,9 +35,6 @@
 
 #ifndef SRGD_CONV3_STAMPS
 #define SRGD_CONV3_STAMPS 0
-#endif
-#ifndef SRGD_CONV3_DIAG_READS
-#define SRGD_CONV3_DIAG_READS 0
 #endif
 #ifndef SRGD_CONV3_OUT_NT
 #define SRGD_CONV3_OUT_NT 0           // output stores with the non-temporal policy (A/B builds, tools/build_variant.py)
@@ -59,7 +56,6 @@ constexpr int CONV3_XCD_PIN_KB_DEFAULT = 0;    // (A/B knob SRGD_CONV3_XCD_PIN_K
 constexpr bool STAMPS = SRGD_CONV3_STAMPS != 0;
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset, int soffset = 0) {
   // LDS destination = wave-uniform base + lane * 16; voffset per lane (VGPR), soffset wave-uniform (SGPR)
@@ -96,23 +92,6 @@ __device__ unsigned long long g_conv3_stamps[8];
 // Row swizzle: chunk ^= (row >> 1) & 3 for the 16x16x32 operand pattern (16 rows x 4 chunks per ds_read_b128) - conflict-free
 // for its lane groups at every tap shift (checked exhaustively on the bank model).
 __device__ __forceinline__ int row_swz(int row) { return (row >> 1) & 3; }
-
-// v + (the same register of lane ^ 16) / lane ^ 32, in every lane: one half-exchange of two copies (v_permlane16_swap swaps the
-// odd rows of its first operand with the even rows of its second, v_permlane32_swap the upper half with the lower half) and one
-// add - VALU only (the ds_bpermute form goes through the LDS crossbar).  After the swap the first register holds the even row's
-// (lower half's) value and the second the odd row's (upper half's) in BOTH partner lanes, so the sum is formed in the same
-// order everywhere.  Inline asm: the builtin of this toolchain (ROCm 7.2 clang) returns its first result twice.  The s_nop
-// covers the VALU-write -> v_permlane-read hazard (2 wait states), which the compiler does not insert inside asm.
-__device__ __forceinline__ float xor16_sum(float v) {
-  float a = v, b = v;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  return a + b;
-}
-__device__ __forceinline__ float xor32_sum(float v) {
-  float a = v, b = v;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  return a + b;
-}
 
 template <bool STATS, bool GNIN>
 __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
@@ -156,7 +135,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // arrays of staging state end up in scratch: see conv_igemm.hip).
   // The source chunk is the same for all three pieces: P = (wave + 8 J) * 16 + (lane >> 2), and (wave + 8 J) * 16 vanishes
   // from row_swz(P) (a multiple of 8 under (P >> 1) & 3) - ONE register, not three.
-#define SRGD_A_DECL(J)                                                        \
+#define K_A_DECL(J)                                                        \
   int a_pix##J;                                                               \
   {                                                                           \
     const int g = (wave + 8 * J) * 64 + lane; /* 16-byte chunk in the image */ \
@@ -166,8 +145,8 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     const bool ok = P < HP * WP && y >= 0 && y < p.H && x >= 0 && x < p.W;    \
     a_pix##J = ok ? y * p.W + x : -1;                                         \
   }
-  SRGD_A_DECL(0) SRGD_A_DECL(1) SRGD_A_DECL(2)
-#undef SRGD_A_DECL
+  K_A_DECL(0) K_A_DECL(1) K_A_DECL(2)
+#undef K_A_DECL
   const int a_sub = (lane & 3) ^ row_swz(lane >> 2);
   // GNIN (one source): byte offset of each piece at chunk 0, or the out-of-range sentinel (stays out of range for every chunk)
   const unsigned a_off0 = a_pix0 >= 0 ? (unsigned)(a_pix0 * p.C0 + a_sub * 8) * 2u : 0x7ffffff0u;
@@ -241,7 +220,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     // a build that scheduled v_rcp directly ahead of a single-instruction asm v_mul computed garbage), so each v_exp / v_rcp
     // is followed by its sibling's before its result is used.
     float y[4];
-#define SRGD_SILU2(Y0_, Y1_, E0_, E1_)                                                                                           \
+#define K_SILU2(Y0_, Y1_, E0_, E1_)                                                                                           \
     do {                                                                                                                         \
       float t0_, t1_;                                                                                                            \
       asm("v_fma_f32 %0, %4, %6, %8\n\tv_fma_f32 %1, %5, %7, %9\n\t"                                                           \
@@ -253,9 +232,9 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
           : "=&v"(Y0_), "=&v"(Y1_), "=&v"(t0_), "=&v"(t1_)                                                                       \
           : "v"(ca[E0_]), "v"(ca[E1_]), "v"(x##E0_), "v"(x##E1_), "v"(cb[E0_]), "v"(cb[E1_]));                                   \
     } while (0)
-    SRGD_SILU2(y[0], y[1], 0, 1);
-    SRGD_SILU2(y[2], y[3], 2, 3);
-#undef SRGD_SILU2
+    K_SILU2(y[0], y[1], 0, 1);
+    K_SILU2(y[2], y[3], 2, 3);
+#undef K_SILU2
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     const unsigned o0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{y[0], y[1]}, bf16x2_t));
     const unsigned o1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{y[2], y[3]}, bf16x2_t));
@@ -327,7 +306,6 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   auto compute = [&](int cc, int tap) {
     const char* A = sA0 + (cc & 1) * A_BYTES;
     const char* Bt = sB0 + (tap % 3) * B_BYTES;          // (cc * 9 + tap) % 3
-#if SRGD_CONV3_DIAG_READS == 0
     const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 0));
     const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 1));
     const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 2));
@@ -336,21 +314,6 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(1));
     const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(2));
     const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(3));
-#elif SRGD_CONV3_DIAG_READS == 1     // timing only (wrong results): half the fragment reads, as a 128 x 128 wave tile would need per MFMA
-    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 0));
-    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 1));
-    bf16x8 a2 = a0, a3 = a1;
-    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(0));
-    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(1));
-    bf16x8 b2 = b0, b3 = b1;
-    asm volatile("" : "+v"(a2), "+v"(a3), "+v"(b2), "+v"(b3));
-#else                                // timing only: one pixel and one weight fragment read per tap
-    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(A + a_addr(tap, 0));
-    bf16x8 a1 = a0, a2 = a0, a3 = a0;
-    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bt + b_addr(0));
-    bf16x8 b1 = b0, b2 = b0, b3 = b0;
-    asm volatile("" : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b1), "+v"(b2), "+v"(b3));
-#endif
 #define MM(C_, PX_, WT_)                                                                                    \
   do {                                                                                                      \
     if constexpr (GNIN) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(WT_), "v"(PX_)); \
@@ -424,11 +387,10 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
 
   if constexpr (STAMPS) t2 = __builtin_amdgcn_s_memtime();
   // ------------------------------- epilogue (register-direct) --------------------------
-  // Accumulator block (mi, ni), register e of lane (r16, q16) = pixel (patch row 2 wm + (mi >> 1), x = 16 (mi & 1) + r16),
-  // weight row 16 ni + 4 q16 + e of the wave's 64-row half of the tile = output channel 32 (ni >> 1) + 8 q16 + 4 (ni & 1) + e
-  // (the host's row order, pack_conv3x3_bf16): blocks ni = 0, 1 are eight consecutive channels (16 B of bf16), blocks 2, 3 the
-  // eight 32 further on; the four lanes of a pixel (q16 = 0..3) fill 64 contiguous bytes per store instruction.
-  // No LDS and no barrier: every wave leaves on its own.
+  // Accumulator block (mi, J), register e of lane (r16, g) = pixel (patch row 2 wm + (mi >> 1), x = 16 (mi & 1) + r16), tile row
+  // 64 wn + 16 J + 4 g + e = output channel 64 wn + 16 g + 4 J + e (the host's row order, common.hpp: regepi_row_channel): the
+  // sixteen registers of a pixel block are 16 consecutive channels - two 16-byte stores, the four lanes of a pixel fill 128
+  // contiguous bytes.  No LDS and no barrier: every wave leaves on its own.
   if constexpr (GNIN) {
     // asm MFMAs: the compiler does not know the accumulators were written by the matrix pipe and inserts no wait states ahead of
     // their first VALU read (up to 18 for a 16x16 result)
@@ -441,95 +403,62 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   asm volatile("" : "+v"(tidE));
   const int laneE = (tidE >> 4) & 63, r16E = laneE & 15, q16E = laneE >> 4;
   const int chw = nt * BN3 + wn * 64;                     // first output channel of the wave (uniform)
-  const int chl = q16E * 8;                               // the lane's 8-channel run inside each 32-channel half
-  f32x4 bl0 = {0.f, 0.f, 0.f, 0.f}, bl1 = bl0, bh0 = bl0, bh1 = bl0;
+  const int chl = q16E * 16;                              // the lane's 16-channel run
+  f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0, bs2 = bs0, bs3 = bs0;
   if (p.bias) {
-    const float* bp = p.bias + chw + chl;                 // 32-byte aligned relative to the array (host: the array is 16-byte aligned)
-    bl0 = *reinterpret_cast<const f32x4*>(bp);
-    bl1 = *reinterpret_cast<const f32x4*>(bp + 4);
-    bh0 = *reinterpret_cast<const f32x4*>(bp + 32);
-    bh1 = *reinterpret_cast<const f32x4*>(bp + 36);
+    const float* bp = p.bias + chw + chl;                 // 64-byte aligned (host: the array is 16-byte aligned)
+    bs0 = *reinterpret_cast<const f32x4*>(bp);
+    bs1 = *reinterpret_cast<const f32x4*>(bp + 4);
+    bs2 = *reinterpret_cast<const f32x4*>(bp + 8);
+    bs3 = *reinterpret_cast<const f32x4*>(bp + 12);
   }
-  // output descriptor (raw buffer: base of the wave's first pixel / channel, two patch rows in range), built by hand for the asm store
-  const unsigned long long obase =
-      (unsigned long long)(size_t)(p.out + ((size_t)(b * p.H + y0 + 2 * wm) * p.W + x0) * p.Cout + chw);
-  const u32x4 rso = {(unsigned)obase, (unsigned)(obase >> 32) & 0xffffu, (unsigned)(2 * p.W * p.Cout * 2), 0x00020000u};
+  // output descriptor: base of the wave's first pixel / channel, two patch rows in range
+  const u32x4 rso = make_raw_rsrc(p.out + ((size_t)(b * p.H + y0 + 2 * wm) * p.W + x0) * p.Cout + chw, (unsigned)(2 * p.W * p.Cout * 2));
   const int o_voff = (r16E * p.Cout + chl) * 2;
-  f32x4 s1l = {0.f, 0.f, 0.f, 0.f}, s2l = s1l, s1h = s1l, s2h = s1l;     // GroupNorm sums, per register position
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  auto emit = [&](const f32x4& A0, const f32x4& A1, const f32x4& B0, const f32x4& B1, f32x4& s1, f32x4& s2, int soff) {
-    const f32x4 v0 = A0 + B0, v1 = A1 + B1;
-    if (STATS) {
-      s1 += v0 + v1;
-      s2 = __builtin_elementwise_fma(v0, v0, s2);
-      s2 = __builtin_elementwise_fma(v1, v1, s2);
-    }
-    u32x4 pk;
-    pk[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0[0], v0[1]}, bf16x2_t));
-    pk[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0[2], v0[3]}, bf16x2_t));
-    pk[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v1[0], v1[1]}, bf16x2_t));
-    pk[3] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v1[2], v1[3]}, bf16x2_t));
-    // The store goes out as inline asm with two wait states behind it.  Compiled from the builtin, the next packed VALU write
-    // to the data registers followed the store directly (LLVM's hazard rule exempts stores whose soffset is an SGPR) and on
-    // gfx950 lanes 12-15 of every row then stored the NEW contents of the second data register: found by the kernel test.
-    if (SRGD_CONV3_OUT_NT)
-      asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(pk), "v"(o_voff), "s"(rso), "s"(soff) : "memory");
-    else
-      asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(pk), "v"(o_voff), "s"(rso), "s"(soff) : "memory");
-  };
-#define SRGD_EMIT(MI, C0_, C1_, C2_, C3_)                                                          \
+  f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = s1v;            // GroupNorm sums, per register position
+  // all four bias vectors are waited for here: behind the first asm store the compiler (which cannot count it) would wait with
+  // vmcnt(0) for the remaining ones - and so for that store's completion
+  asm volatile("" : "+v"(bs0), "+v"(bs1), "+v"(bs2), "+v"(bs3));
+#define K_EMIT(MI, C0_, C1_, C2_, C3_)                                                          \
   do {                                                                                             \
     const int so_ = ((((MI) >> 1) * p.W + ((MI) & 1) * 16) * p.Cout) * 2;                          \
-    emit(C0_, C1_, bl0, bl1, s1l, s2l, so_);                                                       \
-    emit(C2_, C3_, bh0, bh1, s1h, s2h, so_ + 64);                                                  \
+    const f32x4 v0 = C0_ + bs0, v1 = C1_ + bs1, v2 = C2_ + bs2, v3 = C3_ + bs3;                    \
+    if (STATS) {                                                                                   \
+      s1v += (v0 + v1) + (v2 + v3);                                                                \
+      s2v = __builtin_elementwise_fma(v0, v0, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v1, v1, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v2, v2, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v3, v3, s2v);                                                \
+    }                                                                                              \
+    buffer_store16<SRGD_CONV3_OUT_NT != 0>(u32x4{pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])}, rso, o_voff, so_); \
+    buffer_store16<SRGD_CONV3_OUT_NT != 0>(u32x4{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]), pack_bf16x2(v3[0], v3[1]), pack_bf16x2(v3[2], v3[3])}, rso, o_voff, so_ + 16); \
   } while (0)
-  // all four bias vectors are waited for here: behind the first asm store the compiler (which cannot count it) would wait with
-  // vmcnt(0) for the remaining two - and so for that store's completion
-  asm volatile("" : "+v"(bl0), "+v"(bl1), "+v"(bh0), "+v"(bh1));
-  SRGD_EMIT(0, c00, c01, c02, c03);
-  SRGD_EMIT(1, c10, c11, c12, c13);
-  SRGD_EMIT(2, c20, c21, c22, c23);
-  SRGD_EMIT(3, c30, c31, c32, c33);
-#undef SRGD_EMIT
+  K_EMIT(0, c00, c01, c02, c03);
+  K_EMIT(1, c10, c11, c12, c13);
+  K_EMIT(2, c20, c21, c22, c23);
+  K_EMIT(3, c30, c31, c32, c33);
+#undef K_EMIT
   if (STATS) {
     // Per-(sample, group) sums of this wave's 64 pixels x 64 channels: in-lane over the register positions, over the 16 pixels
     // of a row by DPP, then over the rows that share a group (fixed order: deterministic).  cpg = channels per group:
-    //   16: lanes q16 = 0, 1 | 2, 3 hold one group each per 32-channel half -> four groups, written by lanes 0 and 32
-    //   32: one group per half -> two groups, lane 0;   >= 64: both halves are one group -> lane 0
+    //   16: one group per lane row (g) -> four groups, written by lanes 0, 16, 32, 48;   32: row pairs -> lanes 0 and 32;
+    //   >= 64: the whole wave -> lane 0.
     // Slot layout: [b][group][(m-tile, n-tile of the group) x contributing waves]: 4 waves (wm) of the group's column half, or
     // all 8 when a group spans the whole 128-channel tile; gn_finalize sums the slots in index order (fp64).
     const int cpg = p.Cout / p.groups;                    // 16, 32, 64 or a multiple of 128
-    float a1l = (s1l[0] + s1l[1]) + (s1l[2] + s1l[3]), a2l = (s2l[0] + s2l[1]) + (s2l[2] + s2l[3]);
-    float a1h = (s1h[0] + s1h[1]) + (s1h[2] + s1h[3]), a2h = (s2h[0] + s2h[1]) + (s2h[2] + s2h[3]);
-    if (cpg >= 64) { a1l += a1h; a2l += a2h; }
-    a1l = xor16_sum(row16_sum(a1l));
-    a2l = xor16_sum(row16_sum(a2l));
-    if (cpg < 64) {
-      a1h = xor16_sum(row16_sum(a1h));
-      a2h = xor16_sum(row16_sum(a2h));
-    }
-    if (cpg >= 32) {
-      a1l = xor32_sum(a1l);
-      a2l = xor32_sum(a2l);
-      if (cpg < 64) {
-        a1h = xor32_sum(a1h);
-        a2h = xor32_sum(a2h);
-      }
-    }
-    if (laneE == 0 || (cpg == 16 && laneE == 32)) {
+    float a1 = row16_sum((s1v[0] + s1v[1]) + (s1v[2] + s1v[3]));
+    float a2 = row16_sum((s2v[0] + s2v[1]) + (s2v[2] + s2v[3]));
+    if (cpg >= 32) { a1 = xor16_sum(a1); a2 = xor16_sum(a2); }
+    if (cpg >= 64) { a1 = xor32_sum(a1); a2 = xor32_sum(a2); }
+    const int rows_per_group = cpg >= 64 ? 4 : cpg >> 4;  // lane rows (16 channels each) that share a group: 1, 2 or 4
+    if (r16E == 0 && (q16E & (rows_per_group - 1)) == 0) {
       const int tpg = cpg >= BN3 ? cpg / BN3 : 1;         // 128-channel tiles per group
       const int wpt = cpg >= BN3 ? 8 : 4;                 // contributing waves per tile
       const int nslots = tiles_y * tiles_x * tpg * wpt;
       const int slot = (trem * tpg + (cpg >= BN3 ? nt % tpg : 0)) * wpt + (cpg >= BN3 ? wave : wm);
-      const int sh = __builtin_ctz(cpg);                  // cpg < 128: a power of two (eligibility)
-      const int g = cpg >= BN3 ? chw / cpg : (chw + chl) >> sh;
+      const int g = cpg >= BN3 ? chw / cpg : (chw + chl) >> __builtin_ctz(cpg);      // cpg < 128: a power of two (eligibility)
       float* dst = p.gn_partial + ((size_t)(b * p.groups + g) * nslots + slot) * 2;
-      *reinterpret_cast<f32x2*>(dst) = f32x2{a1l, a2l};
-      if (cpg < 64) {
-        const int gh = (chw + 32 + chl) >> sh;
-        float* dsth = p.gn_partial + ((size_t)(b * p.groups + gh) * nslots + slot) * 2;
-        *reinterpret_cast<f32x2*>(dsth) = f32x2{a1h, a2h};
-      }
+      *reinterpret_cast<f32x2*>(dst) = f32x2{a1, a2};
     }
   }
   if constexpr (STAMPS) {
@@ -571,12 +500,7 @@ int conv3x3_bf16_stats_slots(const ConvArgs& a) {
 }
 
 // Host-side packing: OIHW fp32 -> [tap][cc][ntile][128 rows][64 B swizzled] bf16 (the LDS image of each K-step tile).
-// Row order inside a tile: row n = 64 wn + 16 ni + 4 q + e holds output channel 64 wn + 32 (ni >> 1) + 8 q + 4 (ni & 1) + e, so
-// that the accumulator registers of a lane (q = lane >> 4; e = register; ni = row block) are runs of eight consecutive channels.
-static inline int conv3_row_channel(int n) {
-  const int wn = n >> 6, ni = (n >> 4) & 3, q = (n >> 2) & 3, e = n & 3;
-  return wn * 64 + (ni >> 1) * 32 + q * 8 + (ni & 1) * 4 + e;
-}
+// Row order inside a tile: regepi_row_channel (common.hpp) - the accumulator registers of a lane are 16 consecutive channels.
 
 void pack_conv3x3_bf16(const float* src_oihw, int Cin, int Cout, std::vector<unsigned short>& out,
                        unsigned short (*to_bf16)(float)) {
@@ -590,7 +514,7 @@ void pack_conv3x3_bf16(const float* src_oihw, int Cin, int Cout, std::vector<uns
           for (int c = 0; c < 4; ++c) {
             const int cs = c ^ ((n >> 1) & 3);  // stored chunk position (row_swz of the kernel)
             for (int e = 0; e < 8; ++e) {
-              const int ci = cc * KC + c * 8 + e, o = nt * BN3 + conv3_row_channel(n);
+              const int ci = cc * KC + c * 8 + e, o = nt * BN3 + regepi_row_channel(n);
               const float v = src_oihw[(((size_t)o * Cin + ci) * 3 + tap / 3) * 3 + tap % 3];
               tile[n * KC + cs * 8 + e] = to_bf16(v);
             }
@@ -626,19 +550,19 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   }
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-#define SRGD_SET(S_, G_)                                                                                  \
+#define K_SET(S_, G_)                                                                                  \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_>),               \
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (G_ ? COEF_BYTES : 0)));
-    SRGD_SET(true, false) SRGD_SET(false, false) SRGD_SET(true, true) SRGD_SET(false, true)
-#undef SRGD_SET
+    K_SET(true, false) K_SET(false, false) K_SET(true, true) K_SET(false, true)
+#undef K_SET
     once.done();
   }
   const bool stats = a.gn_partial != nullptr;
-#define SRGD_GO(S_, G_) \
+#define K_GO(S_, G_) \
   hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_>), dim3(grid), dim3(NT3), LDS_BYTES + (G_ ? COEF_BYTES : 0), st, p)
-  if (stats && gnin) SRGD_GO(true, true); else if (stats) SRGD_GO(true, false);
-  else if (gnin) SRGD_GO(false, true); else SRGD_GO(false, false);
-#undef SRGD_GO
+  if (stats && gnin) K_GO(true, true); else if (stats) K_GO(true, false);
+  else if (gnin) K_GO(false, true); else K_GO(false, false);
+#undef K_GO
   SRGD_HIP(hipGetLastError());
   if (STAMPS) {                                         // stamp build: synchronous, prints the mean ticks per workgroup and phase
     unsigned long long h[8];

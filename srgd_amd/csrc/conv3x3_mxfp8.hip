@@ -23,7 +23,12 @@
 //   * per chunk: the (8+2) x (32+2) halo patch x 128 B (42.5 KiB) + its scale bytes (4 B / pixel); per K-step (tap, chunk) one
 //     16 KiB weight tile + 512 B of weight scales, double-buffered; rows XOR-swizzled (chunk ^= row & 6): every ds_read_b128 of
 //     the operand pattern is conflict-free at every tap shift (exhaustive search over the lane groups of ds_read_b128)
-//   * epilogue as in the bf16 kernel: + bias, GroupNorm partial sums, LDS transpose, 16-byte stores.
+//   * the MFMAs take the WEIGHT fragment (and its scales) as the A operand and the PIXEL fragment as B (symmetric maps), so a lane
+//     holds four consecutive weight rows of ONE pixel per block; with the tile rows stored in regepi_row_channel order
+//     (common.hpp) that is 16 consecutive output channels per pixel block - the epilogue is register-direct as in
+//     conv3x3_bf16.hip: + bias, GroupNorm partial sums (DPP + permlane swaps, one slot per wave), two 16-byte bf16 stores and,
+//     for the MX-fp8 twin, one 16-byte e4m3 store + one scale byte per lane pair.  No LDS, no barrier.
+// Diagnostic build (tools/build_variant.py only): -DSRGD_MXFP8_STAMPS=1 adds per-phase s_memtime stamps.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -33,14 +38,15 @@
 namespace srgd {
 namespace {
 
-#ifndef SRGD_MXFP8_EPI_PRIO
-#define SRGD_MXFP8_EPI_PRIO 0
+#ifndef SRGD_MXFP8_STAMPS
+#define SRGD_MXFP8_STAMPS 0
 #endif
+constexpr bool QSTAMPS = SRGD_MXFP8_STAMPS != 0;
 constexpr int QPH = 8, QPW = 32;                 // output patch
 constexpr int QHP = QPH + 2, QWP = QPW + 2;      // halo patch: 10 x 34 = 340 pixels
 constexpr int QKC = 128;                         // channels per chunk = K of one MFMA
 constexpr int QBN = 128;
-constexpr int QNW_DEFAULT = 4;                   // waves per workgroup of the shipped instance (kernel template parameter NW; 8 measured 3-7 % slower)
+constexpr int NW = 4;                            // waves per workgroup (an 8-wave instance with 64 x 64 wave tiles measured 3-7 % slower: DESIGN 4.3)
 constexpr int QA_PIECES = 11;                    // 1 KiB LDS-DMA pieces per wave and chunk
 constexpr int QA_BYTES = 4 * QA_PIECES * 1024;   // 44 KiB (340 px * 128 B = 43,520 used)
 constexpr int QAS_BYTES = 2048;                  // activation scales: 4 B per halo pixel (1,360 used), 2 dword pieces per wave
@@ -71,7 +77,7 @@ struct ConvQArgs {
   bf16* out;
   float* gn_partial; int groups;
   unsigned char* oq; unsigned char* os;   // optional MX-fp8 twin of the output (ConvArgs::out_q / out_s)
-  unsigned long long* stamps;             // diagnostics (SRGD_MXFP8_STAMPS=1): per-phase s_memtime deltas summed over workgroups; null otherwise
+  unsigned long long* stamps;             // SRGD_MXFP8_STAMPS builds: per-phase s_memtime deltas summed over workgroups; null otherwise
 };
 
 // phase accumulators of the diagnostic mode: [prologue, main loop, epilogue, total, workgroups, s_memrealtime ticks]
@@ -91,20 +97,15 @@ __device__ __forceinline__ int lane_id_opaque() {
     __builtin_amdgcn_sched_barrier(0);   \
   } while (0)
 
-// NW = waves per workgroup.  4 (round 2): 2 x 2 waves, wave tile 128 x 64 (128 accumulators, <= 256 VGPRs), two waves per SIMD.
-// 8 (round 3): 4 x 2 waves, wave tile 64 x 64 (64 accumulators, <= 128 VGPRs), FOUR waves per SIMD at the same two workgroups per
-// CU - the bf16 kernel's shape.  Round 3's diagnostics showed the 4-wave kernel is bound by neither LDS, DMA nor
-// barriers; the hypothesis behind this shape - a wave's MFMA stream has gaps and with two waves per SIMD nothing fills them while
-// the co-resident workgroup is in its prologue, epilogue or a chunk-boundary patch reload - did not hold: correct (same tests),
-// and 3-7 % SLOWER on all twelve shapes (profiles/r3/conv3x3_mxfp8_w8_ab.txt; 33 % more ds_read bytes per FLOP, pixel fragments
-// single-buffered to fit 64 VGPRs next to 64 accumulator AGPRs).  Kept as an A/B switch (SRGD_MXFP8_WAVES=8); 4 ships.
-template <bool STATS, int NW>
+// 2 x 2 waves, wave tile 128 pixels x 64 channels (128 accumulators, <= 256 VGPRs), two waves per SIMD, two workgroups per CU.
+template <bool STATS>
 __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArgs p) {
   constexpr int NT = NW * 64;               // threads
   constexpr int NWM = NW / 2;               // wave rows (along pixels); 2 wave columns (along channels)
-  constexpr int RPW = QPH / NWM;            // patch rows per wave: 4 or 2
-  constexpr int NM = RPW * 2;               // 16-pixel fragments per wave: 8 or 4
-  constexpr int A_PIECES = (4 * QA_PIECES + NW - 1) / NW;      // 1 KiB halo-patch pieces per wave and chunk: 11 or 6
+  constexpr int RPW = QPH / NWM;            // patch rows per wave: 4
+  constexpr int NM = RPW * 2;               // 16-pixel fragments per wave: 8
+  constexpr int A_PIECES = (4 * QA_PIECES + NW - 1) / NW;      // 1 KiB halo-patch pieces per wave and chunk: 11
+  static_assert(NM == 8 && NT == 256, "conv3x3_mxfp8: 4-wave shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sA = smem;
   char* const sAs = smem + QA_BYTES;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.w + (size_t)nt * QB_BYTES), 0, (int)((size_t)(9 * CC - 1) * w_step_stride + QB_BYTES), 0x00020000);
 
-  auto issue_a = [&](int cc) {                    // 11 + 2 (NW = 4) or <= 6 + 1 (NW = 8) DMA instructions per wave
+  auto issue_a = [&](int cc) {                    // 11 + 2 DMA instructions per wave
     const bool first = cc < CC0;
     const int Cs = first ? p.C0 : p.C1;
     const int ccl = first ? cc : cc - CC0;
@@ -165,7 +166,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
     const int opq_a = lane_id_opaque();
 #pragma unroll
     for (int j = 0; j < A_PIECES; ++j) {
-      if (NW * j + wave >= 4 * QA_PIECES) break;  // (NW = 8: 44 pieces over 8 waves - the last round only has waves 0..3; uniform)
       const int idx = (wave + NW * j) * 64 + opq_a;
       const int P = idx >> 3;
       const int pix = halo_pix(P);
@@ -212,9 +212,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
   // the eight swizzled per-lane bases (one per value of Pc & 7) and their (address ^ 64) partners: 16 registers, and NO address
   // arithmetic in the K loop (round 2 recomputed them per fragment - 4-5 VALU instructions x 8 fragments per step - because the
   // kernel had no registers to spare; the tied MFMAs freed 54)
-#define SRGD_QABASE(K) const int ab##K = apix + ((g ^ (((K) + r7) & 6)) << 4), ac##K = ab##K ^ 64;
-  SRGD_QABASE(0) SRGD_QABASE(1) SRGD_QABASE(2) SRGD_QABASE(3) SRGD_QABASE(4) SRGD_QABASE(5) SRGD_QABASE(6) SRGD_QABASE(7)
-#undef SRGD_QABASE
+#define K_QABASE(K) const int ab##K = apix + ((g ^ (((K) + r7) & 6)) << 4), ac##K = ab##K ^ 64;
+  K_QABASE(0) K_QABASE(1) K_QABASE(2) K_QABASE(3) K_QABASE(4) K_QABASE(5) K_QABASE(6) K_QABASE(7)
+#undef K_QABASE
   const int asb = lanepix * 4 + g;                                  // scale byte of (pixel, channel block g)
   // B: n = 64 wn + 16 J + r16 -> n & 6 = r16 & 6
   const int bb = (wn * 64 + r16) * 128 + ((g ^ (r16 & 6)) << 4);
@@ -228,39 +228,23 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
   auto compute = [&](int tap, int slot) {
     const char* Bt = sB0 + slot * QB_BYTES;
     const int dy = tap / 3, dx = tap - dy * 3;
-    int r7t = r7;                                  // NW = 8: refreshed per step, so that no fragment address survives a step in a register
-    if constexpr (NW == 8) asm volatile("" : "+v"(r7t));
     v8i b0, b1, b2, b3;
-#ifdef SRGD_MXFP8_DIAG_NOB                  // timing-only diagnostic (wrong results): weight fragments made up in registers
-    const int sbw = r7;
-#define SRGD_QLOAD_B(J) b##J = v8i{r7, lane, r7 + J, lane, r7, lane + J, r7, lane};
-#else
     const int sbw = *reinterpret_cast<const int*>(Bt + bsb);
-#define SRGD_QLOAD_B(J)                                                              \
+#define K_QLOAD_B(J)                                                              \
     {                                                                                \
       const v4i lo = *reinterpret_cast<const v4i*>(Bt + bb + J * 2048);              \
       const v4i hi = *reinterpret_cast<const v4i*>(Bt + (bb ^ 64) + J * 2048);       \
       b##J = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};            \
     }
-#endif
-    SRGD_QLOAD_B(0) SRGD_QLOAD_B(1) SRGD_QLOAD_B(2) SRGD_QLOAD_B(3)
-#undef SRGD_QLOAD_B
-    // SRGD_MXFP8_DIAG_NOLDS (timing-only diagnostic build, wrong results): fragments 1..7 are register copies of fragment 0 -
-    // 2/3 of the step's ds_read traffic gone - to price the kernel's LDS-bandwidth limit (tools/build_variant.py)
-#ifndef SRGD_MXFP8_DIAG_NOLDS
-#define SRGD_MXFP8_DIAG_NOLDS 0
-#endif
-#define SRGD_QLOAD_A(I)                                                              \
+    K_QLOAD_B(0) K_QLOAD_B(1) K_QLOAD_B(2) K_QLOAD_B(3)
+#undef K_QLOAD_B
+#define K_QLOAD_A(I)                                                              \
     v8i a##I; int sa##I;                                                             \
-    if (SRGD_MXFP8_DIAG_NOLDS && (I) > 0) { a##I = a0; sa##I = sa0; } else           \
     {                                                                                \
       const int Pc = ((I >> 1) + dy) * QWP + (I & 1) * 16 + dx;                      \
       const int k7 = Pc & 7;                                                         \
-      /* NW = 4: one of the 16 precomputed bases; NW = 8 (128-register budget): 3 + 1 VALU from the opaque copy of r7 */ \
-      const int o = NW == 8 ? apix + ((g ^ ((k7 + r7t) & 6)) << 4)                                                      \
-                  : k7 == 0 ? ab0 : k7 == 1 ? ab1 : k7 == 2 ? ab2 : k7 == 3 ? ab3 : k7 == 4 ? ab4 : k7 == 5 ? ab5 : k7 == 6 ? ab6 : ab7; \
-      const int o2 = NW == 8 ? (o ^ 64)                                                                                 \
-                   : k7 == 0 ? ac0 : k7 == 1 ? ac1 : k7 == 2 ? ac2 : k7 == 3 ? ac3 : k7 == 4 ? ac4 : k7 == 5 ? ac5 : k7 == 6 ? ac6 : ac7; \
+      const int o = k7 == 0 ? ab0 : k7 == 1 ? ab1 : k7 == 2 ? ab2 : k7 == 3 ? ab3 : k7 == 4 ? ab4 : k7 == 5 ? ab5 : k7 == 6 ? ab6 : ab7; \
+      const int o2 = k7 == 0 ? ac0 : k7 == 1 ? ac1 : k7 == 2 ? ac2 : k7 == 3 ? ac3 : k7 == 4 ? ac4 : k7 == 5 ? ac5 : k7 == 6 ? ac6 : ac7; \
       const v4i lo = *reinterpret_cast<const v4i*>(sA + o + Pc * 128);               \
       const v4i hi = *reinterpret_cast<const v4i*>(sA + o2 + Pc * 128);              \
       a##I = v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};            \
@@ -273,105 +257,71 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
     // in their tap: left to itself hipcc SINKS the register-only chains of all nine taps below the chunk's last barrier.
     // Hazards the compiler no longer sees: the operand fragments are overwritten by ds_reads no sooner than four MFMAs
     // (>= 128 cycles) later, the accumulators are next touched by MFMAs with the same D (interlocked) or by the epilogue behind
-    // a barrier, and the inputs come from LDS reads whose lgkmcnt waits the compiler still inserts.
-    // opsel of the weight scale (byte J of sbw): bit 0 -> op_sel[1], bit 1 -> op_sel_hi[1]
-#define SRGD_QMM_OPSEL_0 "op_sel_hi:[0,0,0]"
-#define SRGD_QMM_OPSEL_1 "op_sel:[0,1,0] op_sel_hi:[0,0,0]"
-#define SRGD_QMM_OPSEL_2 "op_sel_hi:[0,1,0]"
-#define SRGD_QMM_OPSEL_3 "op_sel:[0,1,0] op_sel_hi:[0,1,0]"
-    // NW = 8: the accumulators live in AGPRs ("+a"; gfx950's register file is unified, 128 per wave at four waves per SIMD):
-    // 64 AGPRs + <= 64 VGPRs are two allocation problems the register allocator can solve; as one class of 128 with 4- and
-    // 8-register tuples it spilled 120-160 registers (accumulators included) into the K loop.
-#define SRGD_QMM(C_, A_, SA_, B_, J_)                                                                      \
-    if constexpr (NW == 8)                                                                                 \
-      asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " SRGD_QMM_OPSEL_##J_          \
-                   : "+a"(C_) : "v"(A_), "v"(B_), "v"(SA_), "v"(sbw));                                     \
-    else                                                                                                   \
-      asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " SRGD_QMM_OPSEL_##J_          \
-                   : "+v"(C_) : "v"(A_), "v"(B_), "v"(SA_), "v"(sbw))
-#define SRGD_QROW(I)                                                                 \
-    SRGD_QMM(c##I##0, a##I, sa##I, b0, 0); SRGD_QMM(c##I##1, a##I, sa##I, b1, 1);    \
-    SRGD_QMM(c##I##2, a##I, sa##I, b2, 2); SRGD_QMM(c##I##3, a##I, sa##I, b3, 3);
+    // its s_nop block, and the inputs come from LDS reads whose lgkmcnt waits the compiler still inserts.
+    // Operand order: srcA = weight fragment B_ (scale dword sbw, byte J picked by op_sel / op_sel_hi index 0: bit 0 -> op_sel[0],
+    // bit 1 -> op_sel_hi[0]), srcB = pixel fragment A_ (scale byte 0 of SA_): D[i][j], i = weight row, j = pixel.
+#define K_QMM_OPSEL_0 "op_sel_hi:[0,0,0]"
+#define K_QMM_OPSEL_1 "op_sel:[1,0,0] op_sel_hi:[0,0,0]"
+#define K_QMM_OPSEL_2 "op_sel_hi:[1,0,0]"
+#define K_QMM_OPSEL_3 "op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+#define K_QMM(C_, A_, SA_, B_, J_)                                                                      \
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " K_QMM_OPSEL_##J_            \
+                 : "+v"(C_) : "v"(B_), "v"(A_), "v"(sbw), "v"(SA_))
+#define K_QROW(I)                                                                 \
+    K_QMM(c##I##0, a##I, sa##I, b0, 0); K_QMM(c##I##1, a##I, sa##I, b1, 1);    \
+    K_QMM(c##I##2, a##I, sa##I, b2, 2); K_QMM(c##I##3, a##I, sa##I, b3, 3);
     // software pipeline over the pixel fragments, fenced for the scheduler (left alone it hoists all eight fragment loads to
     // the top of the step and spills ~130 registers into the loop): the loads of fragment i+1 are issued ahead of the 4 MFMAs
     // (128 cycles of matrix pipe) of fragment i; two fragments live at a time
-    if constexpr (NW == 8) {
-      // 64 VGPRs next to the 64 accumulator AGPRs: the four weight fragments (32) stay, the pixel fragments stream through ONE
-      // at a time (9 registers) - with four waves per SIMD another wave's MFMAs cover the fragment's LDS latency
-      SRGD_QLOAD_A(0)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QROW(0)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QLOAD_A(1)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QROW(1)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QLOAD_A(2)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QROW(2)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QLOAD_A(3)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QROW(3)
-      return;
-    }
-    SRGD_QLOAD_A(0)
+    K_QLOAD_A(0)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(1)
+    K_QLOAD_A(1)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QROW(0)
+    K_QROW(0)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(2)
+    K_QLOAD_A(2)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QROW(1)
+    K_QROW(1)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QLOAD_A(3)
+    K_QLOAD_A(3)
     __builtin_amdgcn_sched_barrier(0);
-    SRGD_QROW(2)
+    K_QROW(2)
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NM == 8) {
-      SRGD_QLOAD_A(4)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QROW(3)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QLOAD_A(5)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QROW(4)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QLOAD_A(6)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QROW(5)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QLOAD_A(7)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QROW(6)
-      __builtin_amdgcn_sched_barrier(0);
-      SRGD_QROW(7)
-    } else {
-      SRGD_QROW(3)
-    }
-#undef SRGD_QROW
-#undef SRGD_QMM
-#undef SRGD_QMM_OPSEL_0
-#undef SRGD_QMM_OPSEL_1
-#undef SRGD_QMM_OPSEL_2
-#undef SRGD_QMM_OPSEL_3
-#undef SRGD_QLOAD_A
+    K_QLOAD_A(4)
+    __builtin_amdgcn_sched_barrier(0);
+    K_QROW(3)
+    __builtin_amdgcn_sched_barrier(0);
+    K_QLOAD_A(5)
+    __builtin_amdgcn_sched_barrier(0);
+    K_QROW(4)
+    __builtin_amdgcn_sched_barrier(0);
+    K_QLOAD_A(6)
+    __builtin_amdgcn_sched_barrier(0);
+    K_QROW(5)
+    __builtin_amdgcn_sched_barrier(0);
+    K_QLOAD_A(7)
+    __builtin_amdgcn_sched_barrier(0);
+    K_QROW(6)
+    __builtin_amdgcn_sched_barrier(0);
+    K_QROW(7)
+#undef K_QROW
+#undef K_QMM
+#undef K_QMM_OPSEL_0
+#undef K_QMM_OPSEL_1
+#undef K_QMM_OPSEL_2
+#undef K_QMM_OPSEL_3
+#undef K_QLOAD_A
   };
 
-  unsigned long long t0 = 0, t1 = 0, t2 = 0, r0 = 0;
-  if (p.stamps) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, r0 = 0;
+  if constexpr (QSTAMPS) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   // ---- prologue: A(0), B[0]
   issue_a(0);
   issue_b(0, 0, 0);
-#ifdef SRGD_MXFP8_DIAG_NOPROLOGUE_WAIT      // timing-only diagnostic (wrong results): the tile does not wait for its first patch and
-  QWAIT_VM(18);                             // weight unit - the upper bound of what a persistent, prefetching workgroup could hide
-#else
   QWAIT_VM(0);
-#endif
   QBARRIER();
 
-  if (p.stamps) t1 = __builtin_amdgcn_s_memtime();
+  if constexpr (QSTAMPS) t1 = __builtin_amdgcn_s_memtime();
   // ---- main loop.  Per K-step: issue B[s+1] into the other ring slot; compute(s) (32 MFMAs per wave, ~2,000 cycles with the
   // SIMD's second wave: plenty for a 16.5 KiB L2 hit to land); wait for it; barrier.  Every step issues one weight unit (the
   // last step re-fetches the final one into the slot nobody reads any more) so that the unrolled tap loop is branch-free:
@@ -382,175 +332,105 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int slot = (cc + tap) & 1;               // step s = cc * 9 + tap lives in ring slot s % 2
-#ifndef SRGD_MXFP8_DIAG_NODMA              // timing-only diagnostic (wrong results): no weight DMA inside the K loop
       if (tap < 8) issue_b(cc, tap + 1, slot ^ 1);
       else issue_b(min(cc + 1, CC - 1), cc + 1 < CC ? 0 : 8, slot ^ 1);   // (the last step re-fetches its own unit into the idle slot)
-#endif
       compute(tap, slot);
-#ifdef SRGD_MXFP8_DIAG_LATE_WAIT           // timing-only diagnostic (wrong results): the step does not wait for its weight DMA -
-      QWAIT_VM(10);                        // two more steps' worth may stay in flight - to price the DMA latency on the critical path
-#else
       QWAIT_VM(0);
-#endif
-#ifndef SRGD_MXFP8_DIAG_NO_BARRIER         // timing-only diagnostic (wrong results): no per-step workgroup barrier
       QBARRIER();
-#endif
     }
-#ifdef SRGD_MXFP8_DIAG_NOAPATCH              // timing-only diagnostic (wrong results): the halo patch is staged once per tile
-    if (false) {
-#else
     if (cc + 1 < CC) {
-#endif
       issue_a(cc + 1);                             // every wave passed the barrier above: the old patch is dead
       QWAIT_VM(0);
       QBARRIER();
     }
   }
-  QWAIT_VM(0);                                     // (nothing is in flight here; kept next to the epilogue's reuse of the ring)
-  if (p.stamps) t2 = __builtin_amdgcn_s_memtime();
-#if SRGD_MXFP8_EPI_PRIO
-  __builtin_amdgcn_s_setprio(SRGD_MXFP8_EPI_PRIO);   // see conv3x3_bf16.hip: the epilogue competes with the co-resident workgroup's MFMA stream for issue slots
-#endif
+  if constexpr (QSTAMPS) t2 = __builtin_amdgcn_s_memtime();
   // The MFMAs are inline asm (compute()): the compiler does not know that the accumulators were written by the matrix pipe and
   // inserts none of the wait states a VALU read of an XDL result needs (<= 18 for a 16-pass MFMA).  The accumulators are
   // threaded through these statements, so every epilogue read comes after >= 32 wait states behind the last MFMA.
-  if constexpr (NW == 8) {
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(c00), "+a"(c01), "+a"(c02), "+a"(c03), "+a"(c10), "+a"(c11), "+a"(c12), "+a"(c13));
-    asm volatile("" : "+a"(c20), "+a"(c21), "+a"(c22), "+a"(c23), "+a"(c30), "+a"(c31), "+a"(c32), "+a"(c33));
-  } else {
-    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
-    asm volatile("" : "+v"(c20), "+v"(c21), "+v"(c22), "+v"(c23), "+v"(c30), "+v"(c31), "+v"(c32), "+v"(c33));
-  }
-  if constexpr (NM == 8) {
-    asm volatile("" : "+v"(c40), "+v"(c41), "+v"(c42), "+v"(c43), "+v"(c50), "+v"(c51), "+v"(c52), "+v"(c53));
-    asm volatile("" : "+v"(c60), "+v"(c61), "+v"(c62), "+v"(c63), "+v"(c70), "+v"(c71), "+v"(c72), "+v"(c73));
-  }
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
+  asm volatile("" : "+v"(c20), "+v"(c21), "+v"(c22), "+v"(c23), "+v"(c30), "+v"(c31), "+v"(c32), "+v"(c33));
+  asm volatile("" : "+v"(c40), "+v"(c41), "+v"(c42), "+v"(c43), "+v"(c50), "+v"(c51), "+v"(c52), "+v"(c53));
+  asm volatile("" : "+v"(c60), "+v"(c61), "+v"(c62), "+v"(c63), "+v"(c70), "+v"(c71), "+v"(c72), "+v"(c73));
 
-  // ------------------------------- epilogue -------------------------------------------
-  // tile transposed through LDS ([256 pixels][128 ch] bf16, rows padded to 272 B), stored as whole 256-byte channel rows
-  constexpr int EROW = QBN * 2 + 16;
-  // Per-lane epilogue addresses come from a lane id re-derived HERE (v_mbcnt, opaque to the optimiser): derived from `tid` they are
-  // computed ahead of the K loop and carried through it - in registers this kernel does not have (256-VGPR budget): the <STATS>
-  // instance spilled 6 of them, and the reload of one at the top of every chunk put an s_waitcnt vmcnt(0) right behind the
-  // weight DMA of tap 0 (one exposed L2 round trip per chunk = per tile on the 128-channel layers).
-  const int laneE = lane_id_opaque(), tidE = wave * 64 + laneE, r16E = laneE & 15, gE = laneE >> 4;
-  float s1[4], s2[4];                                     // (the loop's last barrier retired every operand read)
-  const bool odd_lane = (r16E & 1) != 0;
-  const int pair_off = odd_lane ? 2 * EROW - 2 : 0;       // odd lane: rows 2-3, the even channel's column
-#define SRGD_QACC(MI, NI) (NI == 0 ? c##MI##0 : NI == 1 ? c##MI##1 : NI == 2 ? c##MI##2 : c##MI##3)
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    s1[ni] = 0.f;
-    s2[ni] = 0.f;
-    const int cl = wn * 64 + ni * 16 + r16E;               // column inside the tile
-    const float bias = p.bias ? p.bias[nt * QBN + cl] : 0.f;
-    f32x2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};              // the column's sums as a register pair (even | odd rows)
-#pragma unroll
-    for (int mi = 0; mi < NM; ++mi) {
-      const f32x4 av = mi == 0 ? SRGD_QACC(0, ni) : mi == 1 ? SRGD_QACC(1, ni) : mi == 2 ? SRGD_QACC(2, ni) : mi == 3 ? SRGD_QACC(3, ni)
-                     : mi == 4 ? SRGD_QACC(4, ni) : mi == 5 ? SRGD_QACC(5, ni) : mi == 6 ? SRGD_QACC(6, ni) : SRGD_QACC(7, ni);
-      // D map: column = laneE & 15, row = (laneE >> 4) * 4 + reg -> pixel (patch row RPW wm + (mi >> 1), x = 16 (mi & 1) + 4 gE + reg)
-      char* trow = smem + ((RPW * wm + (mi >> 1)) * QPW + (mi & 1) * 16 + gE * 4) * EROW + cl * 2;
-      // written for instruction count (conv3x3_bf16.hip: the epilogue is 35-40 % of a 9-step tile's instruction stream here):
-      // packed fp32 adds / fmas on register pairs, one v_cvt_pk_bf16_f32 per two values, ds_write_b16 + ds_write_b16_d16_hi
-      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-      const f32x2 b2 = {bias, bias};
-      const f32x2 v01 = f32x2{av[0], av[1]} + b2, v23 = f32x2{av[2], av[3]} + b2;
-      if (STATS) {
-        s1p += v01 + v23;
-        s2p = __builtin_elementwise_fma(v01, v01, s2p);
-        s2p = __builtin_elementwise_fma(v23, v23, s2p);
-      }
-      const bf16x2_t t01 = __builtin_convertvector(v01, bf16x2_t), t23 = __builtin_convertvector(v23, bf16x2_t);
-      // lane-pair exchange + two conflict-free ds_write_b32 instead of four ds_write_b16 (conv3x3_bf16.hip): the even lane takes
-      // rows 0-1, the odd lane rows 2-3 of both lanes' channels
-      const unsigned own01 = __builtin_bit_cast(unsigned, t01), own23 = __builtin_bit_cast(unsigned, t23);
-      const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_lane ? own01 : own23), 0xB1, 0xf, 0xf, true);
-      const unsigned lo_ch = odd_lane ? recv : own01, hi_ch = odd_lane ? own23 : recv;
-      char* prow = trow + pair_off;
-      *reinterpret_cast<unsigned*>(prow) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x05040100u);
-      *reinterpret_cast<unsigned*>(prow + EROW) = __builtin_amdgcn_perm(hi_ch, lo_ch, 0x07060302u);
-    }
-    if (STATS) {
-      s1[ni] = s1p[0] + s1p[1];
-      s2[ni] = s2p[0] + s2p[1];
-    }
+  // ------------------------------- epilogue (register-direct) --------------------------
+  // Accumulator block (mi, J), register e of lane (r16, g) = pixel (patch row 4 wm + (mi >> 1), x = 16 (mi & 1) + r16), tile row
+  // 64 wn + 16 J + 4 g + e = output channel 64 wn + 16 g + 4 J + e (pack_conv3x3_mxfp8: regepi_row_channel): 16 consecutive channels
+  // per pixel block.  Per-lane addresses come from a lane id re-derived HERE (v_mbcnt, opaque to the optimiser): derived from
+  // `tid` they are computed ahead of the K loop and carried through it - in registers this kernel does not have.
+  const int laneE = lane_id_opaque(), r16E = laneE & 15, gE = laneE >> 4;
+  const int chw = nt * QBN + wn * 64;                     // first output channel of the wave (uniform)
+  const int chl = gE * 16;                                // the lane's 16-channel run
+  f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0, bs2 = bs0, bs3 = bs0;
+  if (p.bias) {
+    const float* bp = p.bias + chw + chl;
+    bs0 = *reinterpret_cast<const f32x4*>(bp);
+    bs1 = *reinterpret_cast<const f32x4*>(bp + 4);
+    bs2 = *reinterpret_cast<const f32x4*>(bp + 8);
+    bs3 = *reinterpret_cast<const f32x4*>(bp + 12);
   }
-#undef SRGD_QACC
-  // column sums behind the staged tile: one barrier publishes both, and nothing below waits for the output stores
-  // (conv3x3_bf16.hip: reducing after the stores cost ~6,000 cycles per tile behind a vmcnt(0))
-  float* const cs = reinterpret_cast<float*>(smem + QPH * QPW * EROW);      // [NWM (wm)][128][2] floats at byte 69,632 (2 or 4 KiB: < QLDS)
+  const size_t pix_base = (size_t)(b * p.H + y0 + RPW * wm) * p.W + x0;      // the wave's first pixel
+  const u32x4 rso = make_raw_rsrc(p.out + pix_base * p.Cout + chw, (unsigned)(RPW * p.W * p.Cout * 2));
+  const u32x4 rsq = make_raw_rsrc(p.oq ? p.oq + pix_base * p.Cout + chw : (unsigned char*)p.out, p.oq ? (unsigned)(RPW * p.W * p.Cout) : 0u);
+  const int lane_elem = r16E * p.Cout + chl;              // element offset of the lane's run from the wave's base
+  f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = s1v;            // GroupNorm sums, per register position
+  asm volatile("" : "+v"(bs0), "+v"(bs1), "+v"(bs2), "+v"(bs3));      // (all bias loads are waited for ahead of the first asm store)
+#define K_QEMIT(MI)                                                                             \
+  do {                                                                                             \
+    const int eo_ = (((MI) >> 1) * p.W + ((MI) & 1) * 16) * p.Cout;       /* elements from the wave's base */ \
+    const f32x4 v0 = c##MI##0 + bs0, v1 = c##MI##1 + bs1, v2 = c##MI##2 + bs2, v3 = c##MI##3 + bs3; \
+    if (STATS) {                                                                                   \
+      s1v += (v0 + v1) + (v2 + v3);                                                                \
+      s2v = __builtin_elementwise_fma(v0, v0, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v1, v1, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v2, v2, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v3, v3, s2v);                                                \
+    }                                                                                              \
+    const u32x4 lo_ = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])}; \
+    const u32x4 hi_ = {pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]), pack_bf16x2(v3[0], v3[1]), pack_bf16x2(v3[2], v3[3])}; \
+    buffer_store16(lo_, rso, lane_elem * 2, eo_ * 2);                                              \
+    buffer_store16(hi_, rso, lane_elem * 2, eo_ * 2 + 16);                                         \
+    if (p.oq) {                                                                                    \
+      /* MX-fp8 twin of the STORED bf16 values (identical to quant_mxfp8 of the output): the 32-channel block = lanes l, l ^ 16 */ \
+      float y_[16];                                                                                \
+      _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                           \
+        y_[2 * k_] = __uint_as_float(lo_[k_] << 16);          y_[2 * k_ + 1] = __uint_as_float(lo_[k_] & 0xffff0000u);     \
+        y_[8 + 2 * k_] = __uint_as_float(hi_[k_] << 16);      y_[8 + 2 * k_ + 1] = __uint_as_float(hi_[k_] & 0xffff0000u); \
+      }                                                                                            \
+      int sb_;                                                                                     \
+      const u32x4 w_ = mx_quant16_pair(y_, &sb_);                                                  \
+      buffer_store16(w_, rsq, lane_elem, eo_);                                                     \
+      if ((gE & 1) == 0) p.os[((pix_base * p.Cout + chw) >> 5) + ((size_t)(eo_ + lane_elem) >> 5)] = (unsigned char)sb_; \
+    }                                                                                              \
+  } while (0)
+  K_QEMIT(0); K_QEMIT(1); K_QEMIT(2); K_QEMIT(3); K_QEMIT(4); K_QEMIT(5); K_QEMIT(6); K_QEMIT(7);
+#undef K_QEMIT
   if (STATS) {
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      float t1 = s1[ni], t2 = s2[ni];
-      t1 += __shfl_xor(t1, 32, 64);
-      t2 += __shfl_xor(t2, 32, 64);
-      t1 += __shfl_xor(t1, 16, 64);
-      t2 += __shfl_xor(t2, 16, 64);
-      if (laneE < 16) {
-        const int cl = wn * 64 + ni * 16 + r16E;
-        cs[(wm * QBN + cl) * 2 + 0] = t1;
-        cs[(wm * QBN + cl) * 2 + 1] = t2;
-      }
-    }
-  }
-  __syncthreads();
-  {
-    // 16-byte chunk q = tidE + NT i: NT / 16 pixels per iteration = whole patch rows (NT = 256: half a row), so pixel
-    // (row, column) advances by a constant: ONE per-lane address + a uniform stride instead of a 64-bit computation per store
-    constexpr int PXI = NT / 16;                           // pixels per iteration: 16 (half a patch row) or 32 (one row)
-    const int pix0 = tidE >> 4, c16 = tidE & 15;
-    const int py0 = pix0 / QPW, px0 = pix0 - py0 * QPW;    // (py0 = 0: pix0 < 32)
-    const size_t o0 = ((size_t)(b * p.H + y0 + py0) * p.W + x0 + px0) * p.Cout + nt * QBN + c16 * 8;
-    const char* src = smem + pix0 * EROW + c16 * 16;
-#pragma unroll
-    for (int i = 0; i < (QPH * QPW * 16) / NT; ++i) {
-      // NT = 512: row i, same column; NT = 256: row i / 2, column + 16 (i & 1)
-      const size_t oo = o0 + (PXI == 32 ? (size_t)i * p.W * p.Cout : (size_t)(i >> 1) * p.W * p.Cout + (size_t)(i & 1) * 16 * p.Cout);
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + i * PXI * EROW);
-      *reinterpret_cast<bf16x8*>(p.out + oo) = v;
-      if (p.oq) mx_store_twin(v, p.oq, p.os, oo, tidE & 3);
-    }
-  }
-  if (STATS) {
-    const int cpg = p.Cout / p.groups;                    // multiple of 16, divides or is a multiple of 128
-    const int span = cpg >= QBN ? QBN : cpg;              // columns of this tile that belong to one group: 16, 32, 64 or 128
-    float a1 = 0.f, a2 = 0.f;
-    if (tidE < QBN) {
-#pragma unroll
-      for (int k = 0; k < NWM; ++k) {
-        a1 += cs[(k * QBN + tidE) * 2 + 0];
-        a2 += cs[(k * QBN + tidE) * 2 + 1];
-      }
-      for (int o = 1; o < span && o < 64; o <<= 1) {
-        a1 += __shfl_xor(a1, o, 64);
-        a2 += __shfl_xor(a2, o, 64);
-      }
-    }
-    if (span == QBN) {                                    // a group spans both waves: combine through LDS, raw barriers
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      QBARRIER();
-      if (tidE < QBN && laneE == 0) { cs[wave * 2 + 0] = a1; cs[wave * 2 + 1] = a2; }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      QBARRIER();
-      if (tidE == 0) { a1 = cs[0] + cs[2]; a2 = cs[1] + cs[3]; }
-    }
-    if (tidE < QBN && (tidE % span) == 0) {
-      const int tiles_per_group = cpg >= QBN ? cpg / QBN : 1;
-      const int grp = (nt * QBN) / cpg + (cpg >= QBN ? 0 : tidE / span);
-      const int nslots = tiles_y * tiles_x * tiles_per_group;
-      const int slot = trem * tiles_per_group + (cpg >= QBN ? nt % tiles_per_group : 0);
+    // per-(sample, group) sums of this wave's 128 pixels x 64 channels (conv3x3_bf16.hip): cpg 16 -> one group per lane row,
+    // 32 -> row pairs, >= 64 -> the wave; one slot per contributing wave: the 2 waves (wm) of the group's column half, or all 4
+    const int cpg = p.Cout / p.groups;                    // 16, 32, 64 or a multiple of 128
+    float a1 = row16_sum((s1v[0] + s1v[1]) + (s1v[2] + s1v[3]));
+    float a2 = row16_sum((s2v[0] + s2v[1]) + (s2v[2] + s2v[3]));
+    if (cpg >= 32) { a1 = xor16_sum(a1); a2 = xor16_sum(a2); }
+    if (cpg >= 64) { a1 = xor32_sum(a1); a2 = xor32_sum(a2); }
+    const int rows_per_group = cpg >= 64 ? 4 : cpg >> 4;
+    if (r16E == 0 && (gE & (rows_per_group - 1)) == 0) {
+      const int tpg = cpg >= QBN ? cpg / QBN : 1;
+      const int wpt = cpg >= QBN ? NW : NWM;
+      const int nslots = tiles_y * tiles_x * tpg * wpt;
+      const int slot = (trem * tpg + (cpg >= QBN ? nt % tpg : 0)) * wpt + (cpg >= QBN ? wave : wm);
+      const int grp = cpg >= QBN ? chw / cpg : (chw + chl) >> __builtin_ctz(cpg);
       float* dst = p.gn_partial + ((size_t)(b * p.groups + grp) * nslots + slot) * 2;
-      dst[0] = a1;
-      dst[1] = a2;
+      *reinterpret_cast<f32x2*>(dst) = f32x2{a1, a2};
     }
   }
-  if (p.stamps && tidE == 0) {
-    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-    atomicAdd(&p.stamps[0], t1 - t0); atomicAdd(&p.stamps[1], t2 - t1); atomicAdd(&p.stamps[2], t3 - t2);
-    atomicAdd(&p.stamps[3], t3 - t0); atomicAdd(&p.stamps[4], 1ull);
-    atomicAdd(&p.stamps[5], __builtin_amdgcn_s_memrealtime() - r0);
+  if constexpr (QSTAMPS) {
+    t3 = __builtin_amdgcn_s_memtime();
+    if (p.stamps && wave == 0 && laneE == 0) {
+      atomicAdd(&p.stamps[0], t1 - t0); atomicAdd(&p.stamps[1], t2 - t1); atomicAdd(&p.stamps[2], t3 - t2);
+      atomicAdd(&p.stamps[3], t3 - t0); atomicAdd(&p.stamps[4], 1ull);
+      atomicAdd(&p.stamps[5], __builtin_amdgcn_s_memrealtime() - r0);
+    }
   }
 }
 
@@ -588,10 +468,11 @@ bool conv3x3_mxfp8_eligible(const ConvArgs& a) {
   if (a.Hin % QPH || a.Win % QPW) return false;
   if (a.gn_partial) {
     const int cpg = a.Cout / a.groups;
-    if (a.Cout % a.groups || cpg % 16) return false;
-    if (!(QBN % cpg == 0 || cpg % QBN == 0)) return false;
+    if (a.Cout % a.groups) return false;
+    if (!(cpg == 16 || cpg == 32 || cpg == 64 || cpg % QBN == 0)) return false;
   }
   if ((size_t)a.Hin * a.Win * (size_t)std::max(a.C0, a.C1) >= (1ull << 31)) return false;
+  if ((size_t)a.Hin * a.Win * (size_t)a.Cout * 2 >= (1ull << 31)) return false;
   if ((size_t)9 * ((a.C0 + a.C1) / QKC) * (a.Cout / QBN) * QB_BYTES >= (1ull << 31)) return false;
   return true;
 }
@@ -599,10 +480,11 @@ bool conv3x3_mxfp8_eligible(const ConvArgs& a) {
 int conv3x3_mxfp8_stats_slots(const ConvArgs& a) {
   if (a.groups <= 0) return 0;
   const int cpg = a.Cout / a.groups;
-  return (a.Hin / QPH) * (a.Win / QPW) * (cpg >= QBN ? cpg / QBN : 1);
+  return (a.Hin / QPH) * (a.Win / QPW) * (cpg >= QBN ? (cpg / QBN) * NW : NW / 2);      // one slot per contributing wave
 }
 
 // OIHW fp32 -> [tap][cc][ntile][16.5 KiB]: 128 rows x 128 B of e4m3 (swizzled LDS image) + 512 E8M0 bytes [wn][r16][blk][J].
+// Tile row n holds output channel regepi_row_channel(n) (common.hpp: the register-direct epilogue's row order).
 // One scale per (output channel, tap, 32 input channels): w = q * 2^(byte - 127).
 void pack_conv3x3_mxfp8(const float* src_oihw, int Cin, int Cout, std::vector<unsigned char>& out) {
   const int CC = Cin / QKC, NTL = Cout / QBN;
@@ -612,7 +494,7 @@ void pack_conv3x3_mxfp8(const float* src_oihw, int Cin, int Cout, std::vector<un
       for (int nt = 0; nt < NTL; ++nt) {
         unsigned char* unit = out.data() + ((size_t)(tap * CC + cc) * NTL + nt) * QB_BYTES;
         for (int n = 0; n < QBN; ++n) {
-          const int o = nt * QBN + n;
+          const int o = nt * QBN + regepi_row_channel(n);
           for (int blk = 0; blk < 4; ++blk) {
             float amax = 0.f;
             for (int e = 0; e < 32; ++e) {
@@ -646,31 +528,22 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   p.out = (bf16*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
   p.oq = (unsigned char*)a.out_q; p.os = (unsigned char*)a.out_s;
   const int grid = a.B * (a.Hin / QPH) * (a.Win / QPW) * (a.Cout / QBN);
-  static const int want_stamps = env_int("SRGD_MXFP8_STAMPS", 0) ? 1 : 0;
+  if (a.bias && ((size_t)a.bias & 15)) SRGD_FAIL("conv3x3_mxfp8: the bias array must be 16-byte aligned");
   p.stamps = nullptr;
-  if (want_stamps) {
+  if (QSTAMPS) {
     SRGD_HIP(hipGetSymbolAddress((void**)&p.stamps, HIP_SYMBOL(g_convq_stamps)));
     SRGD_HIP(hipMemsetAsync(p.stamps, 0, sizeof(unsigned long long) * 8, st));
   }
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-#define SRGD_SETQ(S_, N_)                                                                                 \
-    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<S_, N_>),              \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
-    SRGD_SETQ(true, 4) SRGD_SETQ(false, 4) SRGD_SETQ(true, 8) SRGD_SETQ(false, 8)
-#undef SRGD_SETQ
+    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
     once.done();
   }
-  static const int nw = env_int("SRGD_MXFP8_WAVES", QNW_DEFAULT) == 8 ? 8 : 4;    // SRGD_MXFP8_WAVES=8: the 8-wave shape (A/B switch)
-  if (nw == 8) {
-    if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true, 8>), dim3(grid), dim3(512), QLDS, st, p);
-    else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false, 8>), dim3(grid), dim3(512), QLDS, st, p);
-  } else {
-    if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true, 4>), dim3(grid), dim3(256), QLDS, st, p);
-    else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false, 4>), dim3(grid), dim3(256), QLDS, st, p);
-  }
+  if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true>), dim3(grid), dim3(NW * 64), QLDS, st, p);
+  else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false>), dim3(grid), dim3(NW * 64), QLDS, st, p);
   SRGD_HIP(hipGetLastError());
-  if (want_stamps) {                                    // diagnostic mode: synchronous, prints the mean ticks per workgroup and phase
+  if (QSTAMPS) {                                        // stamp build: synchronous, prints the mean ticks per workgroup and phase
     unsigned long long h[8];
     SRGD_HIP(hipStreamSynchronize(st));
     SRGD_HIP(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 && BKC == 16) ? 4 : 1) void con
   // Per-thread staging state: PER (<= 4) 16-byte chunks of A and of B per K-step.  Everything is a NAMED
   // scalar/vector (token-pasted), never an indexed array: hipcc keeps indexed fragment arrays in scratch,
   // which puts a vmcnt(0) behind every global load and serialises the pipeline.
-#define SRGD_DECL(I)                                                        \
+#define K_DECL(I)                                                        \
   int iy0_##I = 0, ix0_##I = 0, ib_##I = 0, arow_##I = 0, aq_##I = 0;       \
   bool mval_##I = false, ok_##I = false;                                    \
   Frag<T> ra_##I, rb_##I;                                                   \
@@ -101,11 +101,11 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 && BKC == 16) ? 4 : 1) void con
     ix0_##I = ox * p.stride - p.pad;                                        \
     ib_##I = b * p.Hin * p.Win;                                             \
   }
-  SRGD_DECL(0) SRGD_DECL(1) SRGD_DECL(2) SRGD_DECL(3)
-#undef SRGD_DECL
+  K_DECL(0) K_DECL(1) K_DECL(2) K_DECL(3)
+#undef K_DECL
 
   // branch-free zero fill: out-of-image taps read a valid dummy address and are zeroed when staged to LDS
-#define SRGD_LOAD1(I)                                                                                              \
+#define K_LOAD1(I)                                                                                              \
   if (I < PER) {                                                                                                   \
     const int iy_ = iy0_##I + dy_, ix_ = ix0_##I + dx_;                                                            \
     ok_##I = mval_##I && iy_ >= 0 && iy_ < p.Hin && ix_ >= 0 && ix_ < p.Win;                                       \
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 && BKC == 16) ? 4 : 1) void con
     const size_t woff_ = ((size_t)(tap_ * p.CoutPad + n0 + arow_##I) * Cin + c_ + aq_##I * EPC) * sizeof(T);       \
     rb_##I = *reinterpret_cast<const Frag<T>*>((const char*)p.w + woff_);                                          \
   }
-#define SRGD_LOAD_STEP(S)                                                    \
+#define K_LOAD_STEP(S)                                                    \
   {                                                                          \
     const int tap_ = (S) / CC, cc_ = (S)-tap_ * CC;                          \
     const int dy_ = tap_ / p.KW, dx_ = tap_ - dy_ * p.KW;                    \
@@ -124,24 +124,24 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 && BKC == 16) ? 4 : 1) void con
     const char* src_ = first_ ? (const char*)p.in0 : (const char*)p.in1;     \
     const int Cs_ = first_ ? p.ps0 : p.ps1;                                  \
     const int coff_ = first_ ? c_ : c_ - p.C0;                               \
-    SRGD_LOAD1(0) SRGD_LOAD1(1) SRGD_LOAD1(2) SRGD_LOAD1(3)                  \
+    K_LOAD1(0) K_LOAD1(1) K_LOAD1(2) K_LOAD1(3)                  \
   }
-#define SRGD_STORE1(I, BUF)                                                                   \
+#define K_STORE1(I, BUF)                                                                   \
   if (I < PER) {                                                                              \
     if (!ok_##I) ra_##I.v = 0; /* masked here, not at the load: keeps the loads in flight */  \
     *reinterpret_cast<Frag<T>*>(sA(BUF) + arow_##I * STRIDE + aq_##I * 16) = ra_##I;          \
     *reinterpret_cast<Frag<T>*>(sB(BUF) + arow_##I * STRIDE + aq_##I * 16) = rb_##I;          \
   }
-#define SRGD_STORE_STEP(BUF) { SRGD_STORE1(0, BUF) SRGD_STORE1(1, BUF) SRGD_STORE1(2, BUF) SRGD_STORE1(3, BUF) }
+#define K_STORE_STEP(BUF) { K_STORE1(0, BUF) K_STORE1(1, BUF) K_STORE1(2, BUF) K_STORE1(3, BUF) }
 
   f32x16 acc00 = 0, acc01 = 0, acc10 = 0, acc11 = 0;
 
-  SRGD_LOAD_STEP(0);
-  SRGD_STORE_STEP(0);
+  K_LOAD_STEP(0);
+  K_STORE_STEP(0);
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < steps) SRGD_LOAD_STEP(s + 1);
+    if (s + 1 < steps) K_LOAD_STEP(s + 1);
     const char* a_base = sA(buf) + (wm * 64 + r) * STRIDE + h * 16;
     const char* b_base = sB(buf) + (wn * 64 + r) * STRIDE + h * 16;
 #pragma unroll
@@ -155,13 +155,13 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 && BKC == 16) ? 4 : 1) void con
       mma(acc10, fa1, fb0);
       mma(acc11, fa1, fb1);
     }
-    if (s + 1 < steps) SRGD_STORE_STEP(buf ^ 1);
+    if (s + 1 < steps) K_STORE_STEP(buf ^ 1);
     __syncthreads();
   }
-#undef SRGD_LOAD1
-#undef SRGD_LOAD_STEP
-#undef SRGD_STORE1
-#undef SRGD_STORE_STEP
+#undef K_LOAD1
+#undef K_LOAD_STEP
+#undef K_STORE1
+#undef K_STORE_STEP
 
   // ------------------------------- epilogue -------------------------------------------
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
@@ -347,9 +347,8 @@ static int pick_bkc(bool is_bf16, int C0, int C1) {
   const int* c = is_bf16 ? cands_bf16 : cands_f32;
   const int n = is_bf16 ? 3 : 2;
   // fp32: 16-channel chunks (64-byte rows, 41 KB of LDS: three workgroups per CU instead of two) measured +4.4 % end to end
-  // over 32-channel ones in the parity mode; same k order, bit-identical results.  SRGD_FP32_BKC=32 restores the larger chunk.
-  static const int f32_max = env_int("SRGD_FP32_BKC", 16);
-  for (int i = (!is_bf16 && f32_max < 32) ? 1 : 0; i < n; ++i)
+  // over 32-channel ones in the parity mode; same k order, bit-identical results.
+  for (int i = is_bf16 ? 0 : 1; i < n; ++i)
     if (C0 % c[i] == 0 && (C1 == 0 || C1 % c[i] == 0)) return c[i];
   return 0;
 }

@@ -59,11 +59,8 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   const bool fast = (impl == 0 || impl == 2 || gnin) && is_bf16 && kind == 0 && conv3x3_bf16_eligible(a);
   if (gnin && !fast) SRGD_FAIL("srgd_k_conv2d: the conv3x3_bf16 fast path does not cover this shape");
   if (impl == 2 && !fast) SRGD_FAIL("srgd_k_conv2d: the conv3x3_bf16 fast path does not cover this shape");
-  // impl 6: the 256 x 256 tile of conv1x1_bf16 (16-wave workgroups; K-heavy pointwise layers), forced
-  const bool wide1 = impl == 6;
-  const bool fast1 = !fast && (impl == 0 || impl == 3 || wide1) && is_bf16 && conv1x1_bf16_eligible(a);
-  if ((impl == 3 || wide1) && !fast1) SRGD_FAIL("srgd_k_conv2d: the conv1x1_bf16 fast path does not cover this shape");
-  if (wide1 && !conv1x1_bf16_wide_eligible(a)) SRGD_FAIL("srgd_k_conv2d: the wide conv1x1_bf16 tile does not cover this shape");
+  const bool fast1 = !fast && (impl == 0 || impl == 3) && is_bf16 && conv1x1_bf16_eligible(a);
+  if (impl == 3 && !fast1) SRGD_FAIL("srgd_k_conv2d: the conv1x1_bf16 fast path does not cover this shape");
   if (fast1) {
     std::vector<unsigned char> f32p;
     std::vector<float> unused;
@@ -101,7 +98,7 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   if (stats_slots) *stats_slots = fast ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
   auto run = [&]() -> int {
     if (fastq1) return conv1x1_mxfp8(a, q0.p, s0.p, q1.p, s1.p, dwq1.p, st);
-    return fast ? conv3x3_bf16(a, dw3.p, gnin ? gn_tail_a : nullptr, gnin ? gn_tail_b : nullptr, st) : fast1 ? conv1x1_bf16(a, dw1.p, st, wide1) : conv_igemm(a, is_bf16 != 0, st);
+    return fast ? conv3x3_bf16(a, dw3.p, gnin ? gn_tail_a : nullptr, gnin ? gn_tail_b : nullptr, st) : fast1 ? conv1x1_bf16(a, dw1.p, st) : conv_igemm(a, is_bf16 != 0, st);
   };
   SRGD_TRY(run());
   SRGD_HIP(hipStreamSynchronize(st));

@@ -60,8 +60,7 @@ const char* last_error();
 bool conv1x1_bf16_eligible(const ConvArgs& a);
 void pack_conv1x1_bf16(const float* src_tap_o_i, int taps, int Cin, int Cout, std::vector<unsigned short>& out,
                        unsigned short (*to_bf16)(float));
-int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st, bool force_wide = false);
-bool conv1x1_bf16_wide_eligible(const ConvArgs& a);      // the 256-pixel x 256-channel instance (K-heavy layers)
+int conv1x1_bf16(const ConvArgs& a, const void* packed_w, hipStream_t st);
 
 // ---------------------------------------------------------------- conv3x3_bf16.hip
 // Fast path for the 3x3/s1/p1 bf16 convolutions (halo patch in LDS, LDS-DMA staging).  Takes the same

@@ -27,18 +27,6 @@
 namespace srgd {
 namespace {
 
-#ifndef SRGD_LA_DOT2
-#define SRGD_LA_DOT2 0    // row norms with v_dot2c_f32_bf16 (A/B: 0 = unpack + fma)
-#endif
-#ifndef SRGD_LA_PACK
-#define SRGD_LA_PACK 1    // pack8 through four packed converts (A/B: 0 = element-wise)
-#endif
-#ifndef SRGD_LA_LATE_SYNC
-#define SRGD_LA_LATE_SYNC 0
-#endif
-#ifndef SRGD_LA_LAZY_MAX
-#define SRGD_LA_LAZY_MAX 1
-#endif
 #ifndef SRGD_LA_STAMPS
 #define SRGD_LA_STAMPS 0  // diagnostic build: per-phase s_memtime ticks of la1's tile loop (wave 0 of every workgroup), printed per launch
 #endif
@@ -83,33 +71,21 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* bu
   }
 }
 
-// 1 / max(||x_row||, 1e-12) for the 64 rows of a staged tile (4 threads per row)
+// 1 / max(||x_row||, 1e-12) for the 64 rows of a staged tile (4 threads per row).
+// Measured alternatives, none shipped: v_dot2c_f32_bf16 on the packed pairs (round 4: la1 +8 %); the column sums l from a
+// p . ones MFMA (+7 %); tied inline-asm MFMAs; the barrier moved behind the GEMM (+4 %); and round 5: the sums of squares taken
+// from the GEMM's own operand fragments by v_dot2 beside the MFMAs, which removes this pass, its LDS re-read and its barrier -
+// the GEMM phase then takes 3,369 instead of 1,653 ticks per tile (more than the 1,331 it replaces: la1 +4.5 %,
+// profiles/r5/la1_norms_from_gemm_fragments_stamps.txt) and the fdot2 sums cost 8 dB of bf16-mode PSNR against the reference.
 __device__ __forceinline__ void row_rinv(const char* tile, float* rinv, int tid) {
   const int row = tid >> 2, part = tid & 3;
-  // round 4, measured and NOT shipped (SRGD_LA_DOT2 = 0): v_dot2c_f32_bf16 on the packed pairs - 16 instructions per thread
-  // instead of 32 unpacks + 32 fmas - made la1 8 % SLOWER (517 -> 565 us per launch); so did taking the column sums l from a
-  // p . ones MFMA (SRGD_LA_LSUM, +7 %) and tied inline-asm MFMAs (SRGD_LA_ASM, no scheduling freedom): 34 % fewer vector
-  // instructions in the tile loop bought nothing - the kernel's phases are latency-serialised, not issue-bound.  What did pay:
-  // pack8 through packed converts (-5 %).
-  // (written out per component: with the four dwords indexed in a loop this hipcc emitted the dot product of dword 0 four times)
   float ss = 0.f;
-#if !SRGD_LA_DOT2
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * 256 + (part * 4 + j) * 16);
 #pragma unroll
     for (int e = 0; e < 8; ++e) ss += (float)v[e] * (float)v[e];
   }
-#else
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-#define LA_DOT2(W_) ss = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, (W_)), __builtin_bit_cast(bf16x2_t, (W_)), ss, false)
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint4 v = *reinterpret_cast<const uint4*>(tile + row * 256 + (part * 4 + j) * 16);
-    LA_DOT2(v.x); LA_DOT2(v.y); LA_DOT2(v.z); LA_DOT2(v.w);
-  }
-#undef LA_DOT2
-#endif
   ss += __shfl_xor(ss, 1, 64);
   ss += __shfl_xor(ss, 2, 64);
   if (part == 0) rinv[row] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
@@ -121,12 +97,6 @@ __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x)
 __device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s) {
   // four v_cvt_pk_bf16_f32 whose results ARE the operand tuple's dwords (element-wise assembly of the bf16x8 left the packed
   // pairs in scattered registers and copied them together: 40 v_mov per tile)
-#if !SRGD_LA_PACK
-  bf16x8 o;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16)a[8 * s + j];
-  return o;
-#endif
   typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   u32x4 w;
@@ -182,30 +152,9 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
   if (T > 1) stage_tile(rsx, sA + TILE_BYTES, head, lane, px_begin + TM);
   float m = -INFINITY;                              // running max (log2 domain) of this lane's k column d = r
   f32x16 ctx = 0;
-  // round 4: the column sums l[d] = sum_n p[n][d] ride on the matrix pipe - p . ones, one extra MFMA per context MFMA - instead
-  // of 32 v_add per tile; every column of `lsum` holds l in the context's row order (d = row of the accumulator register)
-  f32x16 lsum = 0;
-  [[maybe_unused]] float lvec = 0.f;               // (SRGD_LA_LSUM = 0: the sums on the vector ALU, as in round 3)
-  bf16x8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
-  // MFMAs as inline asm with the accumulator tied (D = C): through the builtin every MFMA gets a fresh destination and the
-  // accumulators migrate through the register file (40 v_mov per tile, the kernel at the 256-register ceiling with spills)
-#ifndef SRGD_LA_LSUM
-#define SRGD_LA_LSUM 0
-#endif
-#ifndef SRGD_LA_ASM
-#define SRGD_LA_ASM 0     // 1: tied inline-asm MFMAs (A/B build)
-#endif
-#if SRGD_LA_ASM
-#define LA_MM(C_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(C_) : "v"(A_), "v"(B_))
-#define LA_MM0(C_, A_, B_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(C_) : "v"(A_), "v"(B_))
-#define LA_NOP(STR_, ...) asm volatile(STR_ : __VA_ARGS__)
-#else
+  float lvec = 0.f;                                 // running column sum l[d = r] (this lane's half of the rows)
 #define LA_MM(C_, A_, B_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, C_, 0, 0, 0)
 #define LA_MM0(C_, A_, B_) C_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, f32x16(0), 0, 0, 0)
-#define LA_NOP(STR_, ...) do {} while (0)
-#endif
   // tile 0 has landed once at most the second tile's 4 pieces are outstanding (wherever the compiler put the fragment
   // loads relative to the DMAs, "all but the 4 youngest" covers tile 0)
   if (T > 1) LA_WAIT_VM(4); else LA_WAIT_VM(0);
@@ -221,24 +170,23 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
     const char* A = sA + (t % RING) * TILE_BYTES;
     float* rinv = sR + (t & 1) * TM;
     if (t + 2 < T) stage_tile(rsx, sA + ((t + 2) % RING) * TILE_BYTES, head, lane, px_begin + (t + 2) * TM);
-    // Round 4 (phase stamps, profiles/r4/linattn_audit.txt: norms + sync 1,365 of 5,725 ticks per tile): the row norms are only
-    // needed AFTER the k/v GEMM (to scale its rows); SRGD_LA_LATE_SYNC moves the barrier that publishes them behind the GEMM's 32
-    // MFMAs - measured 4 % SLOWER (484 -> 505 us per launch: the waves then meet at a point where they have drifted apart), off
     row_rinv(A, rinv, tid);
-#if !SRGD_LA_LATE_SYNC
     LA_SYNC();
     LA_STAMP(ph0);
     if (head == 0 && lane < 16)                     // la2 re-uses the row norms: 4 B per pixel instead of a second reduction
       *reinterpret_cast<f32x4*>(rinv_out + (size_t)b * N + px_begin + t * TM + lane * 4) = *reinterpret_cast<const f32x4*>(rinv + lane * 4);
-#endif
 
-    // [k | v] of this wave's head for the tile's 64 rows
+    // [k | v] of this wave's head for the tile's 64 rows.  Fragment addresses: swz(row, 2 s + hh) = swz(row, hh) ^ (s << 5) (2 s and
+    // hh ^ (row & 15) occupy different bits of the chunk index), and rows r and 32 + r swizzle alike: ONE base register, made
+    // opaque per tile so that the sixteen addresses are recomputed (one v_xor each) instead of hoisted out of the tile loop into
+    // sixteen long-lived registers - the kernel sat at the 256-register ceiling with two spilled (round-4 review).
+    int fa_base = swz(r, hh);
+    asm volatile("" : "+v"(fa_base));
     f32x16 k0, k1, v0, v1;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const int c = 2 * s + hh;
-      const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + swz(r, c));
-      const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + swz(32 + r, c));
+      const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(A + (fa_base ^ (s << 5)));
+      const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(A + (fa_base ^ (s << 5)) + 32 * 256);
       if (s == 0) {                                 // C = 0 as the inline constant: no 64-register zero fill per tile
         LA_MM0(k0, fa0, fk[s]);
         LA_MM0(k1, fa1, fk[s]);
@@ -251,18 +199,7 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
         LA_MM(v1, fa1, fv[s]);
       }
     }
-    // (asm MFMAs: the compiler inserts no wait states ahead of the first VALU read of a matrix-pipe result)
-    LA_NOP("s_nop 15\n\ts_nop 3", "+v"(k0), "+v"(k1), "+v"(v0), "+v"(v1));
-#if SRGD_LA_STAMPS
-    asm volatile("s_nop 0" : "+v"(k0), "+v"(k1), "+v"(v0), "+v"(v1));      // (the stamp below waits for the GEMM's results)
-#endif
     LA_STAMP(ph1);
-#if SRGD_LA_LATE_SYNC
-    LA_SYNC();
-    LA_STAMP(ph0);
-    if (head == 0 && lane < 16)                     // la2 re-uses the row norms: 4 B per pixel instead of a second reduction
-      *reinterpret_cast<f32x4*>(rinv_out + (size_t)b * N + px_begin + t * TM + lane * 4) = *reinterpret_cast<const f32x4*>(rinv + lane * 4);
-#endif
     // rows of the accumulator = pixels: k -> k / ||x_n|| in the log2 domain (one multiply), v -> v / ||x_n||
     float bm = -INFINITY;
 #pragma unroll
@@ -280,27 +217,19 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
       }
     }
     bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-#if SRGD_LA_LAZY_MAX
     // lazy running maximum: the reference point of a column only moves when the tile's maximum exceeds it by more than 2^8 (or at
     // the first tile); until then p = exp2(k - m) may be as large as 256 - harmless in fp32 / bf16 - and the rescale of the
     // context (16 cross-lane shuffles + 32 multiplies) almost never runs.  pm carries the reference point actually used, so the
     // combine step is unchanged; results differ from the eager form by bf16 rounding of p only.
     const float mn = (bm > m + 8.0f) ? bm : m;
-#else
-    const float mn = fmaxf(m, bm);
-#endif
     const float f = ex2(m - mn);                  // first tile: exp2(-inf) = 0
     m = mn;
-#if !SRGD_LA_LSUM
     lvec *= f;
-#endif
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       k0[i] = ex2(k0[i] - mn);
       k1[i] = ex2(k1[i] - mn);
-#if !SRGD_LA_LSUM
       lvec += k0[i] + k1[i];
-#endif
     }
     LA_STAMP(ph2);
     if (!__all(f == 1.0f)) {
@@ -309,21 +238,16 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
         const int d = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
         const float fd = __shfl(f, d, 64);        // lane d (< 32) holds the factor of context row d
         ctx[reg] *= fd;
-        if (SRGD_LA_LSUM) lsum[reg] *= fd;
       }
     }
-    // ctx[d][e] += sum_n p[n][d] v[n][e]: both operands come from accumulator tiles (same row permutation);
-    // lsum[d][*] += sum_n p[n][d] from the same (bf16-rounded) p - numerator and denominator of the softmax see the same values
+    // ctx[d][e] += sum_n p[n][d] v[n][e]: both operands come from accumulator tiles (same row permutation)
     {
-      bf16x8 p00 = pack8(k0, 0), p01 = pack8(k0, 1), p10 = pack8(k1, 0), p11 = pack8(k1, 1);
-      bf16x8 q00 = pack8(v0, 0), q01 = pack8(v0, 1), q10 = pack8(v1, 0), q11 = pack8(v1, 1);
-      // a VALU-written register needs two wait states before an MFMA reads it (operands from v_cvt_pk, accumulators from the
-      // rescale): the compiler inserts them for its own MFMAs, not for inline asm - every operand is threaded through this nop
-      LA_NOP("s_nop 1", "+v"(ctx), "+v"(lsum), "+v"(p00), "+v"(p01), "+v"(p10), "+v"(p11), "+v"(q00), "+v"(q01), "+v"(q10), "+v"(q11));
-      LA_MM(ctx, p00, q00); if (SRGD_LA_LSUM) LA_MM(lsum, p00, ones);
-      LA_MM(ctx, p10, q10); if (SRGD_LA_LSUM) LA_MM(lsum, p10, ones);
-      LA_MM(ctx, p01, q01); if (SRGD_LA_LSUM) LA_MM(lsum, p01, ones);
-      LA_MM(ctx, p11, q11); if (SRGD_LA_LSUM) LA_MM(lsum, p11, ones);
+      const bf16x8 p00 = pack8(k0, 0), p01 = pack8(k0, 1), p10 = pack8(k1, 0), p11 = pack8(k1, 1);
+      const bf16x8 q00 = pack8(v0, 0), q01 = pack8(v0, 1), q10 = pack8(v1, 0), q11 = pack8(v1, 1);
+      LA_MM(ctx, p00, q00);
+      LA_MM(ctx, p10, q10);
+      LA_MM(ctx, p01, q01);
+      LA_MM(ctx, p11, q11);
     }
 #if SRGD_LA_STAMPS
     asm volatile("s_nop 0" : "+v"(ctx));
@@ -341,22 +265,17 @@ __global__ __launch_bounds__(NTH, 2) void la1_kernel(const bf16* __restrict__ x,
   }
 #endif
 #undef LA_STAMP
-  LA_NOP("s_nop 15\n\ts_nop 3", "+v"(ctx), "+v"(lsum));
 #undef LA_MM
 #undef LA_MM0
-#undef LA_NOP      // matrix-pipe results ahead of their first VALU / store read
   const size_t pidx = (size_t)(b * 4 + head) * nstrips + sidx;
   if (hh == 0) pm[pidx * 32 + r] = m * LN2;         // la_combine works in the natural-log domain
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int d = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
     pctx[(pidx * 32 + d) * 32 + r] = ctx[reg];
-    if (SRGD_LA_LSUM && r == 0) pl[pidx * 32 + d] = lsum[reg];      // every column of lsum holds the same sums: column 0 writes them
   }
-#if !SRGD_LA_LSUM
   lvec += __shfl_xor(lvec, 32, 64);
   if (hh == 0) pl[pidx * 32 + r] = lvec;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------- phase 2
@@ -554,15 +473,8 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
 
 }  // namespace
 
-// C = 128 on the 32-pixel-tile kernels of linattn_fused256.hip (3 workgroups per CU) instead of the 64-pixel ones here: A/B switch,
-// read once (the weight images differ, so it must not change between packing and launching)
-static bool la128_tm32() {
-  static const int v = env_int("SRGD_LA128_TM32", 0) ? 1 : 0;
-  return v == 1;
-}
-
 bool linattn_fused_eligible(int C, int heads, int dh, int N, bool is_bf16) {
-  if (C == 256 || (C == 128 && la128_tm32())) return linattn_fused256_eligible(C, heads, dh, N, is_bf16);
+  if (C == 256) return linattn_fused256_eligible(C, heads, dh, N, is_bf16);
   return is_bf16 && C == 128 && heads == 4 && dh == 32 && N % TM == 0 && (size_t)N * 256 < (1ull << 31);
 }
 
@@ -579,7 +491,7 @@ size_t linattn_fused_workspace(int B, int N) {
 void linattn_fused_pack(const float* to_qkv /*[384][C]*/, const float* norm_g /*[C]*/, const float* to_out /*[C][128]*/,
                         int C, std::vector<unsigned short>& wkv_img, std::vector<unsigned short>& wq,
                         std::vector<unsigned short>& wout) {
-  if (C == 256 || (C == 128 && la128_tm32())) return linattn_fused256_pack(to_qkv, norm_g, to_out, C, wkv_img, wq, wout);
+  if (C == 256) return linattn_fused256_pack(to_qkv, norm_g, to_out, C, wkv_img, wq, wout);
   const float sq = sqrtf((float)C);
   wkv_img.assign(256 * 128, 0);
   wq.assign(128 * 128, 0);
@@ -607,7 +519,7 @@ int linattn_fused(const void* x, void* y, int B, int N, int C, const void* wkv_i
   float* pctx = pl + bh * nch * 32;
   float* ctxn = pctx + bh * nch * 1024;
   float* rinv = ctxn + bh * 1024;
-  if (C == 256 || (C == 128 && la128_tm32()))
+  if (C == 256)
     return linattn_fused256(x, y, B, N, C, wkv_img, wq, wout, bout, g2_scaled, pm, pl, pctx, ctxn, rinv, strip, st, y_q, y_s);
   if (C != 128) SRGD_FAIL("linattn_fused: C must be 128 or 256");
   static bool attr[64] = {};

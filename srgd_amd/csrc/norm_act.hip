@@ -2,9 +2,6 @@
 // Memory-bound element-wise kernels: 16-byte vector accesses along the NHWC channel axis.
 #include "kernels.hpp"
 
-#ifndef SRGD_GN_TRIP8
-#define SRGD_GN_TRIP8 0     // eight vectors per trip ahead of the four-vector loop (A/B build)
-#endif
 namespace srgd {
 namespace {
 
@@ -114,17 +111,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   // trip left ~32 KiB in flight per CU (32 waves x 1 KiB), about half of what HBM's latency-bandwidth product asks for.
   const unsigned stride = gridDim.x * 256u, n = (unsigned)vec_per_sample;
   unsigned i = blockIdx.x * 256u + threadIdx.x;
-#if SRGD_GN_TRIP8
-  for (; i + 7u * stride < n; i += 8u * stride) {
-    const Vec16<T> v0 = xs[i], v1 = xs[i + stride], v2 = xs[i + 2u * stride], v3 = xs[i + 3u * stride], v4 = xs[i + 4u * stride],
-                   v5 = xs[i + 5u * stride], v6 = xs[i + 6u * stride], v7 = xs[i + 7u * stride];
-    Vec16<T> r0, r1, r2, r3, r4, r5, r6, r7;
-    if (rs) { r0 = rs[i]; r1 = rs[i + stride]; r2 = rs[i + 2u * stride]; r3 = rs[i + 3u * stride]; r4 = rs[i + 4u * stride];
-              r5 = rs[i + 5u * stride]; r6 = rs[i + 6u * stride]; r7 = rs[i + 7u * stride]; }
-    finish(i, v0, r0); finish(i + stride, v1, r1); finish(i + 2u * stride, v2, r2); finish(i + 3u * stride, v3, r3);
-    finish(i + 4u * stride, v4, r4); finish(i + 5u * stride, v5, r5); finish(i + 6u * stride, v6, r6); finish(i + 7u * stride, v7, r7);
-  }
-#endif
   for (; i + 3u * stride < n; i += 4u * stride) {
     const Vec16<T> v0 = xs[i], v1 = xs[i + stride], v2 = xs[i + 2u * stride], v3 = xs[i + 3u * stride];
     Vec16<T> r0, r1, r2, r3;
@@ -195,17 +181,16 @@ int gn_apply_silu(const void* x, void* y, const void* residual, const float* coe
   // ~64 blocks per CU over the whole launch, at least one block per sample
   const int gx = (int)std::max<long>(1, std::min<long>((vps + 255) / 256, (256L * 64 + B - 1) / B));
   // the grid stride gx * 256 is a multiple of the vectors per pixel whenever those are a power of two <= 256
-  static const int hoist_knob = env_int("SRGD_GN_HOIST", 1);
-  const bool hoist = hoist_knob && (vpp & (vpp - 1)) == 0 && vpp <= 256;
-#define SRGD_GN_GO(T_, P_, H_, ...) hipLaunchKernelGGL((gn_apply_kernel<T_, P_, H_>), dim3(gx, B), dim3(256), 0, st, __VA_ARGS__)
+  const bool hoist = (vpp & (vpp - 1)) == 0 && vpp <= 256;
+#define K_GN_GO(T_, P_, H_, ...) hipLaunchKernelGGL((gn_apply_kernel<T_, P_, H_>), dim3(gx, B), dim3(256), 0, st, __VA_ARGS__)
   if (is_bf16) {
-    if (hoist) SRGD_GN_GO(bf16, false, true, (const bf16*)x, (bf16*)y, (const bf16*)residual, coefA, coefB, vps, vpp, C, (unsigned char*)out_q, (unsigned char*)out_s);
-    else SRGD_GN_GO(bf16, false, false, (const bf16*)x, (bf16*)y, (const bf16*)residual, coefA, coefB, vps, vpp, C, (unsigned char*)out_q, (unsigned char*)out_s);
+    if (hoist) K_GN_GO(bf16, false, true, (const bf16*)x, (bf16*)y, (const bf16*)residual, coefA, coefB, vps, vpp, C, (unsigned char*)out_q, (unsigned char*)out_s);
+    else K_GN_GO(bf16, false, false, (const bf16*)x, (bf16*)y, (const bf16*)residual, coefA, coefB, vps, vpp, C, (unsigned char*)out_q, (unsigned char*)out_s);
   } else {
-    if (hoist) SRGD_GN_GO(float, true, true, (const float*)x, (float*)y, (const float*)residual, coefA, coefB, vps, vpp, C, nullptr, nullptr);
-    else SRGD_GN_GO(float, true, false, (const float*)x, (float*)y, (const float*)residual, coefA, coefB, vps, vpp, C, nullptr, nullptr);
+    if (hoist) K_GN_GO(float, true, true, (const float*)x, (float*)y, (const float*)residual, coefA, coefB, vps, vpp, C, nullptr, nullptr);
+    else K_GN_GO(float, true, false, (const float*)x, (float*)y, (const float*)residual, coefA, coefB, vps, vpp, C, nullptr, nullptr);
   }
-#undef SRGD_GN_GO
+#undef K_GN_GO
   SRGD_HIP(hipGetLastError());
   return 0;
 }

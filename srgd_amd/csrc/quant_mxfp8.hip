@@ -77,9 +77,8 @@ static int launch_quant(const void* x, void* q, void* s, int B, long hw, int C, 
   const long vps = hw * (C / 8);
   if (vps >= (1L << 31) || B > 65535 || B < 1) SRGD_FAIL("quant_mxfp8: tensor too large for the 32-bit vector index");
   const int gx = (int)std::max<long>(1, std::min<long>((vps + 255) / 256, (256L * 64 + B - 1) / B));
-  static const int hoist_knob = env_int("SRGD_GN_HOIST", 1);
   const int vpp = C / 8;
-  const bool hoist = hoist_knob && (vpp & (vpp - 1)) == 0 && vpp <= 256;       // the grid stride gx * 256 is then a multiple of vpp
+  const bool hoist = (vpp & (vpp - 1)) == 0 && vpp <= 256;       // the grid stride gx * 256 is then a multiple of vpp
   if (cA && hoist)
     hipLaunchKernelGGL((quant_mxfp8_kernel<true, true>), dim3(gx, B), dim3(256), 0, st, (const bf16*)x, (unsigned char*)q,
                        (unsigned char*)s, (int)vps, C, cA, cB);
