@@ -398,7 +398,9 @@ def main():
                                    f"{args.precision}, device Philox noise; {min(args.images, args.steps)} steps "
                                    f"(HR tiles) advance in lock-step so their U-Net tiles share launches",
                        "images_in_lockstep": min(args.images, args.steps),
-                       "tiles_per_unet_launch": args.sub_batch or n_even * min(args.images, args.steps),
+                       # the engine's balanced-launch rule (engine.hip: cdiv(n, cdiv(n, limit))) for the even-step tile count
+                       "tiles_per_unet_launch": (lambda n, lim: -(-n // -(-n // lim)))(n_even * min(args.images, args.steps),
+                                                                                        args.sub_batch or n_even * min(args.images, args.steps)),
                        "tile_forwards_per_step": TILE_FORWARDS_PER_HR_TILE,
                        "parallelism": f"image-sharded x{world}"},
             "tflops_effective": value * TFLOP_PER_HR_TILE,

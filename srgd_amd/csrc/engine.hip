@@ -266,7 +266,11 @@ struct srgd_engine {
   // (fp8_mixed) against the reference.  SRGD_MX1X1=0 keeps them on conv1x1_bf16.
   bool no_mx1x1 = false;
   bool no_attn_w8 = false;    // SRGD_FP8_ATTN_W=0: fp8 modes keep the attention projections' weights in bf16 (A/B switch)
+  unsigned attn_bf16_zones = 1;   // zones whose attention weights stay bf16 on top of fp8_bf16_zones: the first down stage's 256x256 LinearAttention
+                                  // site (round 5, tools/fp8_attn_site_study.py); SRGD_FP8_ATTN_BF16_ZONES=<mask> overrides
+  bool attn_w8_rowscale = false;  // SRGD_FP8_ATTN_ROWSCALE=1: one power-of-two scale per output channel instead of per 32 input channels (study only)
   int attn_w8_tensors = 0;    // attention weight tensors carried as MX-fp8 (weight-only) after srgd_finalize_weights
+  int attn_w8_skipped = 0;    // ... and attention weight tensors left in bf16 because Cin % 32 != 0 (dim-16 test models)
   int mx1x1_min_cin = 0;      // SRGD_MX1X1_MIN_CIN: pointwise layers with fewer input channels stay on conv1x1_bf16
   unsigned fp8_bf16_zones = 0;   // SRGD_FP8_BF16_ZONES (bit mask over Ctx::zone): zones whose 3x3 convs stay bf16 in fp8 mode (study knob)
   bool no_twin_fusion = false;   // SRGD_Q_FUSED=0: fp8 mode quantises every conv input in a separate pass (A/B + bit-equality test)
@@ -1089,6 +1093,8 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   if (const char* v = getenv("SRGD_MX1X1")) e->no_mx1x1 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_MX1X1_MIN_CIN")) e->mx1x1_min_cin = atoi(v);
   if (const char* v = getenv("SRGD_FP8_ATTN_W")) e->no_attn_w8 = atoi(v) == 0;
+  if (const char* v = getenv("SRGD_FP8_ATTN_BF16_ZONES")) e->attn_bf16_zones = (unsigned)strtoul(v, nullptr, 0);
+  if (const char* v = getenv("SRGD_FP8_ATTN_ROWSCALE")) e->attn_w8_rowscale = atoi(v) != 0;
   if (const char* v = getenv("SRGD_LA256")) e->no_la256 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_FINAL_FUSION")) e->no_final_fusion = atoi(v) == 0;
   if (const char* v = getenv("SRGD_Q_FUSED")) e->no_twin_fusion = atoi(v) == 0;
@@ -1177,13 +1183,20 @@ int srgd_finalize_weights(srgd_engine* e) {
     // to_out of LinearAttention / Attention (reference model.py:300-303, 341-342), incl. the ones the fused LinearAttention
     // kernels fold into their register-resident operands - are carried as MX-fp8: e4m3 elements, one E8M0 scale per (output
     // channel, 32 input channels), the engine's scale rule (mx_block_exponent), dequantised here at pack time; the kernels
-    // keep multiplying bf16 activations with the (now e4m3-valued) bf16 weights.  Exact: an e4m3 value times a power of two
-    // is a bf16 value.  SRGD_FP8_ATTN_W=0 keeps these weights in bf16 (A/B switch).
+    // keep multiplying bf16 activations with the (now e4m3-valued) bf16 weights - a weight-FORMAT emulation: numerics of e4m3
+    // storage, no speed or memory gain yet.  Exact: an e4m3 value times a power of two is a bf16 value.
+    // Placement (round 5, tools/fp8_attn_site_study.py, profiles/r5/fp8_attn_site_study.json; PSNR against the reference on the
+    // configs[4] one-tile fixture / at configs[1]'s geometry): bf16 weights at all nine sites 36.5 / 28.0 dB; any ONE site in e4m3
+    // 36.3-36.9; all nine 35.1 / 26.8 under either scale rule (E8M0 per 32 input channels or per output channel: 35.09 vs 35.06);
+    // all but the first down stage's 256x256 LinearAttention site (zone 0) 36.9 / 27.8.  Shipped: e4m3 at eight of the nine sites
+    // in "fp8" (zone 0 keeps bf16 weights; "fp8_mixed" additionally keeps the last up stage's, as its 3x3 convolutions do).
+    // SRGD_FP8_ATTN_W=0 keeps all of them in bf16, SRGD_FP8_ATTN_BF16_ZONES=<mask> chooses the zones (A/B switches).
     for (auto& t : e->wt) {
-      if (t.shape.size() != 4 || t.shape[2] != 1 || t.shape[3] != 1 || t.shape[0] <= 1 || t.shape[1] % 32) continue;
+      if (t.shape.size() != 4 || t.shape[2] != 1 || t.shape[3] != 1 || t.shape[0] <= 1) continue;
       if (t.name.find("to_qkv.weight") == std::string::npos && t.name.find("to_out.weight") == std::string::npos &&
           t.name.find("to_out.0.weight") == std::string::npos)
         continue;
+      if (t.shape[1] % 32) { e->attn_w8_skipped += 1; continue; }      // no whole 32-channel block: the tensor stays bf16 (counted)
       // zone of the site (Ctx::zone: down stage s -> s, middle -> n, up stage s -> n + 1 + s): the zones that keep bf16 3x3
       // convolutions (fp8_mixed: everything at the tile's own resolution; SRGD_FP8_BF16_ZONES) keep bf16 attention weights too -
       // measured on the configs[4] fixture: e4m3 weights at the two 256x256-resolution LinearAttention sites alone take
@@ -1191,19 +1204,25 @@ int srgd_finalize_weights(srgd_engine* e) {
       int zone = e->n_stages;
       if (t.name.rfind("downs.", 0) == 0) zone = atoi(t.name.c_str() + 6);
       else if (t.name.rfind("ups.", 0) == 0) zone = e->n_stages + 1 + atoi(t.name.c_str() + 4);
-      if (e->fp8_bf16_zones & (1u << zone)) continue;
+      if ((e->fp8_bf16_zones | e->attn_bf16_zones) & (1u << zone)) continue;
       const int64_t O = t.shape[0], I = t.shape[1];
-      for (int64_t o = 0; o < O; ++o)
+      for (int64_t o = 0; o < O; ++o) {
+        float row_amax = 0.f;
+        for (int64_t k = 0; k < I; ++k) row_amax = std::max(row_amax, std::fabs(t.data[(size_t)o * I + k]));
         for (int64_t k0 = 0; k0 < I; k0 += 32) {
           float* w = t.data.data() + (size_t)o * I + k0;
           float amax = 0.f;
           for (int k = 0; k < 32; ++k) amax = std::max(amax, std::fabs(w[k]));
-          const int ex = mx_block_exponent(amax);
+          const int ex = mx_block_exponent(e->attn_w8_rowscale ? row_amax : amax);
           const float inv = std::ldexp(1.0f, -ex), sc = std::ldexp(1.0f, ex);
           for (int k = 0; k < 32; ++k) w[k] = round_through_e4m3(w[k] * inv) * sc;
         }
+      }
       e->attn_w8_tensors += 1;
     }
+    if (e->attn_w8_skipped)          // (dim-16 test models: to_qkv has 16 input channels) - said once per engine, not silently
+      fprintf(stderr, "[srgd] fp8 mode: %d attention weight tensor(s) carried as MX-e4m3, %d left in bf16 (input channels not a multiple of 32)\n",
+              e->attn_w8_tensors, e->attn_w8_skipped);
   }
   // 7x7 input conv: OIHW [dim,6,7,7] -> 7 taps (dy) x 64 virtual channels (dx*8 + ci), see kernels.hpp
   {

@@ -174,11 +174,13 @@ class CanvasShard:
         self.always_exchange = always_exchange
         self._bufs = {}
         self.exchanges = 0                      # tile all-gathers issued so far (tests / bench report it)
-        # bench.py's canvas workload: time every exchange (pack -> all-gather -> unpack) with a pair of events on the stream the
-        # engine runs on, so that the JSON line of an N-GPU run shows what the per-step collective really costs (DESIGN section 7
-        # predicts ~3 ms per step for 856 MB at 8448^2 over 8 GPUs); off by default - a timed pair is two event records per exchange
+        # bench.py's canvas workload: time what every exchange leaves on the compute stream (second half's pack -> all-gather, the
+        # wait for the side stream, the unpacking) with a pair of events, so that the JSON line of an N-GPU run shows what the
+        # per-step collective really costs; off by default - a timed pair is two event records per exchange
         self.timing = False
         self._events = []
+        self.overlap = True                     # first half of my slice all-gathered on a side stream under the second half's compute
+        self._side = {}
 
     def exchange_ms(self, reset: bool = True) -> float:
         """Sum of the timed exchanges so far, in ms (synchronises the device)."""
@@ -190,9 +192,29 @@ class CanvasShard:
             self._events = []
         return ms
 
-    def buffers(self, width: int, world: int, device, tile: int = 256):
-        """(packed [width,3,T,T], everyone [world*width,3,T,T]) views of buffers sized for the widest grid seen so far."""
-        key = (str(device), tile)
+    def side_stream(self, device):
+        """The stream the first half's exchange runs on while the second half computes (one per device, created once)."""
+        key = str(device)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=device)
+        return self._side[key]
+
+    def _timed_begin(self):
+        if not self.timing:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        return ev
+
+    def _timed_end(self, ev) -> None:
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
+
+    def buffers(self, width: int, world: int, device, tile: int = 256, slot=(0, 0)):
+        """(packed [width,3,T,T], everyone [world*width,3,T,T]) views of buffers sized for the widest grid seen so far; one
+        pair per ``slot`` = (half of the slice, canvas): two halves and two canvases can be in flight at once."""
+        key = (str(device), tile, slot)
         need = world * width
         have = self._bufs.get(key)
         if have is None or have[1].shape[0] < need or have[0].shape[0] < width:
@@ -212,36 +234,89 @@ def shard_canvas(sampler, group=None, always_exchange: bool = False, comm=None):
     return sampler
 
 
-def _exchange(eng, shard: CanvasShard, step: int, n_tiles: int, mine: range, width: int, canvases) -> None:
+def _gather_part(eng, shard: CanvasShard, step: int, first: int, count: int, part: int, pw: int, canvases) -> list:
+    """Pack my tiles [first, first + count) of every canvas and all-gather them, on the CURRENT stream.  Returns the gathered
+    buffers (one per canvas, [world * pw, 3, T, T]; rank r's tiles in rows [r * pw, r * pw + its count))."""
     world = shard.comm.world
-    if world == 1 and not shard.always_exchange:
-        return
-    for canvas in canvases:
+    out = []
+    for ci, canvas in enumerate(canvases):
         if canvas is None:
+            out.append(None)
             continue
-        packed, everyone = shard.buffers(width, world, canvas.device)
-        ev = None
-        if shard.timing:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        eng.sampler_exchange_tiles(step & 1, mine.start, len(mine), canvas, packed, to_canvas=False)
+        packed, everyone = shard.buffers(pw, world, canvas.device, slot=(part, ci))
+        eng.sampler_exchange_tiles(step & 1, first, count, canvas, packed, to_canvas=False)
         shard.comm.all_gather_tiles(everyone, packed)
         shard.exchanges += 1
-        eng.sampler_exchange_tiles(step & 1, 0, n_tiles, canvas, everyone, to_canvas=True)
-        if ev is not None:
-            ev[1].record()
-            shard._events.append(ev)
+        out.append(everyone)
+    return out
+
+
+def _scatter_part(eng, shard: CanvasShard, step: int, n_tiles: int, w: int, off: int, pw: int, canvases, gathered) -> None:
+    """Write a gathered part back: rank r's rows are tiles [r * w + off, r * w + off + pw) of the grid (clipped to n_tiles)."""
+    world = shard.comm.world
+    for canvas, everyone in zip(canvases, gathered):
+        if canvas is None:
+            continue
+        if off == 0 and pw == w:                         # whole slices: the gathered buffer IS the grid in order - one launch
+            eng.sampler_exchange_tiles(step & 1, 0, n_tiles, canvas, everyone, to_canvas=True)
+            continue
+        for r in range(world):
+            t0 = min(n_tiles, r * w + off)
+            cnt = min(n_tiles, r * w + off + pw) - t0
+            if cnt > 0:
+                eng.sampler_exchange_tiles(step & 1, t0, cnt, canvas, everyone[r * pw:r * pw + cnt], to_canvas=True)
+
+
+def _step_and_exchange(eng, shard: CanvasShard, step: int, n_tiles: int, canvases, run_tiles) -> None:
+    """My slice of the step's tiles through ``run_tiles(first, count, do_ring)``, then the exchange.  Round 5: the slice runs
+    as two halves (the engine already splits it into balanced launches), and the FIRST half's tiles are packed and all-gathered
+    on a side stream while the second half computes; only the second half's gather and the unpacking are left on the compute
+    stream.  Tiles of a step are disjoint canvas regions and the odd-step ring lies outside all of them, so the side stream reads
+    finished tiles only.  Every rank splits at the same offset h = ceil(w / 2) of its slice, so the two gathers have the same
+    shape everywhere (short and empty slices send zeros, as before)."""
+    rank, world = shard.comm.rank, shard.comm.world
+    sl = tile_slices(n_tiles, world)
+    mine, w = sl[rank], len(sl[0])
+    if world == 1 and not shard.always_exchange:
+        run_tiles(mine.start, len(mine), True)
+        return
+    cuda = any(c is not None and c.is_cuda for c in canvases)
+    h = (w + 1) // 2 if (shard.overlap and cuda and w >= 2) else w
+    a0, a1 = mine.start, min(mine.stop, mine.start + h)
+    if h == w:                                           # one part: compute, then pack -> all-gather -> unpack per canvas, in sequence
+        run_tiles(a0, a1 - a0, True)                     # (through ONE buffer pair: a canvas is unpacked before the next one is packed)
+        ev = shard._timed_begin()
+        for canvas in canvases:
+            g = _gather_part(eng, shard, step, a0, a1 - a0, 0, w, (canvas,))
+            _scatter_part(eng, shard, step, n_tiles, w, 0, w, (canvas,), g)
+        shard._timed_end(ev)
+        return
+    main = torch.cuda.current_stream()
+    side = shard.side_stream(main.device)
+    run_tiles(a0, a1 - a0, False)
+    first_done = torch.cuda.Event()
+    first_done.record(main)
+    with torch.cuda.stream(side):
+        side.wait_event(first_done)
+        g0 = _gather_part(eng, shard, step, a0, a1 - a0, 0, h, canvases)
+        gathered = torch.cuda.Event()
+        gathered.record(side)
+    run_tiles(a1, mine.stop - a1, True)                  # overlaps the first half's exchange
+    ev = shard._timed_begin()                            # what is left on the compute stream is the EXPOSED exchange time
+    g1 = _gather_part(eng, shard, step, a1, mine.stop - a1, 1, w - h, canvases)
+    main.wait_event(gathered)
+    _scatter_part(eng, shard, step, n_tiles, w, 0, h, canvases, g0)
+    _scatter_part(eng, shard, step, n_tiles, w, h, w - h, canvases, g1)
+    shard._timed_end(ev)
 
 
 def sharded_step(eng, shard: CanvasShard, step: int, n_tiles: int, img, cond_canvas, x_start, noise_tiles, noise_canvas,
                  passes: int, kind: int, scale: float, sub_batch: int, seed: int) -> None:
     """One DDPM step of a canvas shared by the ranks of ``shard.comm``: my slice of the tiles, then exchange."""
-    rank, world = shard.comm.rank, shard.comm.world
-    sl = tile_slices(n_tiles, world)
-    mine, width = sl[rank], len(sl[0])
-    eng.sampler_step_tiles(step, mine.start, len(mine), True, img, cond_canvas, x_start, noise_tiles, noise_canvas,
-                           passes, kind, scale, sub_batch, seed)
-    _exchange(eng, shard, step, n_tiles, mine, width, (img, x_start))
+    _step_and_exchange(eng, shard, step, n_tiles, (img, x_start),
+                       lambda first, count, ring: eng.sampler_step_tiles(step, first, count, ring, img, cond_canvas, x_start,
+                                                                         noise_tiles, noise_canvas, passes, kind, scale,
+                                                                         sub_batch, seed))
 
 
 def sharded_edm_step(eng, shard: CanvasShard, step: int, n_tiles: int, img, cond_canvas, x_start, work, noise_canvas,
@@ -249,9 +324,7 @@ def sharded_edm_step(eng, shard: CanvasShard, step: int, n_tiles: int, img, cond
     """One EDM (Heun) step of a canvas shared by the ranks of ``shard.comm`` (reference model.py:2379-2463): my slice of the
     tiles (both network evaluations; the scratch canvases stay rank-local), the odd-step ring on every rank's own canvas, then
     the same tile exchange as the DDPM loop."""
-    rank, world = shard.comm.rank, shard.comm.world
-    sl = tile_slices(n_tiles, world)
-    mine, width = sl[rank], len(sl[0])
-    eng.edm_step_tiles(step, mine.start, len(mine), True, img, cond_canvas, x_start, work, noise_canvas, ring_noise_canvas,
-                       passes, kind, scale, sub_batch, seed)
-    _exchange(eng, shard, step, n_tiles, mine, width, (img, x_start))
+    _step_and_exchange(eng, shard, step, n_tiles, (img, x_start),
+                       lambda first, count, ring: eng.edm_step_tiles(step, first, count, ring, img, cond_canvas, x_start, work,
+                                                                     noise_canvas, ring_noise_canvas, passes, kind, scale,
+                                                                     sub_batch, seed))

@@ -68,7 +68,7 @@ def test_bare_gpus4_canvas_workload_unequal_slices_and_exchange_timing():
     # all_gather_into_tensor with unequal fill through TorchComm itself, not the thread stand-in
     d = _run_bare(["--workload", "canvas", "--lr_size", "256"], gpus=4)
     assert d["n_gpus"] == 4 and d["rccl_ranks"] == 4 and d["scaling"] == "strong" and d["value"] > 0
-    assert d["tile_allgathers"] == 3 * 4                                   # one per step of the 3 runs (warm-up + 2 timed)
+    assert d["tile_allgathers"] == 3 * 4 * 2                               # two (half slices) per step of the 3 runs (warm-up + 2 timed)
     assert d["exchange_ms"] > 0 and 0 < d["exchange_share"] < 1            # timed with HIP events over the timed region
     assert abs(d["exchange_mb_per_step"] - 3 * 256 * 256 * 4 * 20.5 / 1e6) < 1e-6
 
@@ -104,5 +104,5 @@ def test_forced_dist_world1_runs_the_canvas_all_gather_on_rccl():
     d = _run_forced(["--workload", "canvas", "--lr_size", "128", "--steps", "2", "--warmup", "1", "--ddpm_steps", "4",
                      "--dim", "16"])
     assert d["dist_backend"] == "nccl" and d["rccl_ranks"] == 1 and d["forced_dist"] is True and d["scaling"] == "strong"
-    assert d["tile_allgathers"] == 3 * 4 and d["value"] > 0        # all_gather_into_tensor once per step of 3 runs
+    assert d["tile_allgathers"] == 3 * 4 * 2 and d["value"] > 0    # all_gather_into_tensor twice (half slices) per step of 3 runs
     assert d["exchange_ms"] > 0 and 0 < d["exchange_share"] < 1

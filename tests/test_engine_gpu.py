@@ -40,7 +40,8 @@ _MODELS = {}
 # resolution in fp8_mixed) and fp8_mixed's pointwise layers back on conv1x1_bf16: fp8 35.06 / 26.83 dB (round 3, bf16 attention
 # weights: 36.48 / 27.98), fp8_mixed 52.62 / 39.96 dB (round 3 with the MX pointwise kernel: 52.14 / 39.63) - fp8_mixed's
 # gates moved UP to 3 dB under those.
-FP8_CONFIG5_GATE_DB, FP8_MIXED_CONFIG5_GATE_DB = 33.5, 49.6          # configs[4], one tile, 100 steps, CFG 2.0
+FP8_CONFIG5_GATE_DB, FP8_MIXED_CONFIG5_GATE_DB = 33.8, 49.6          # configs[4], one tile, 100 steps, CFG 2.0 (round 5: fp8 36.9 dB with e4m3 attention weights at eight sites)
+FP8_CONFIG5_FULL_GATE_DB, FP8_MIXED_CONFIG5_FULL_GATE_DB = 33.2, 49.2   # configs[4] at its full geometry, against the bf16 ENGINE on the same noise
 FP8_CONFIG2_GATE_DB, FP8_MIXED_CONFIG2_GATE_DB = 25.0, 36.9          # configs[1] geometry, 2 steps from noise (bf16: 43.7)
 
 
@@ -976,9 +977,10 @@ def test_fp8_pointwise_layers_on_the_mx_kernel_and_the_switch_back():
 def test_fp8_modes_carry_mx_e4m3_attention_weights():
     # BASELINE configs[4] "fp8 conv + attention weights" (VERDICT r3 item 3): in the fp8 modes to_qkv / to_out of the attention
     # sites (model.py:300-303, 341-342) - incl. the operands the fused LinearAttention kernels keep in registers - are MX-fp8
-    # values (e4m3 elements, E8M0 scale per 32 input channels, the engine's scale rule), dequantised at pack time: all nine
-    # sites in "fp8", the seven below the tile's own resolution in "fp8_mixed" (its 256x256 zones keep bf16 weights like their
-    # 3x3 convolutions do).  Pinned against the format emulation: a checkpoint whose attention weights were rounded by
+    # values (e4m3 elements, E8M0 scale per 32 input channels, the engine's scale rule), dequantised at pack time: eight of the
+    # nine sites in "fp8" (round 5, tools/fp8_attn_site_study.py: all nine cost 1.4 dB against the reference, all but the first
+    # down stage's 256x256 LinearAttention site cost nothing measurable), the seven below the tile's own resolution in "fp8_mixed"
+    # (its 256x256 zones keep bf16 weights like their 3x3 convolutions do).  Pinned against the format emulation: a checkpoint whose attention weights were rounded by
     # oracle/mxfp8.py, run with the engine's own rounding switched off (SRGD_FP8_ATTN_W=0), must give the same eps bit for bit;
     # and the rounding must actually move the result against the bf16-weight run.
     import os
@@ -987,13 +989,13 @@ def test_fp8_modes_carry_mx_e4m3_attention_weights():
     sd = synth_state_dict(_schema(128), seed=case["weight_seed"])
     attn_keys = [k for k in sd if k.endswith(("to_qkv.weight", "to_out.weight", "to_out.0.weight"))]
     assert len(attn_keys) == 18                                   # 9 sites x (to_qkv, to_out)
-    top_res = ("model.downs.0.", "model.ups.3.")                  # the LinearAttention sites at 256x256 (zones 0 and 2n)
+    kept_bf16 = {"fp8": ("model.downs.0.",), "fp8_mixed": ("model.downs.0.", "model.ups.3.")}     # the LinearAttention sites at 256x256 (zones 0 and 2n)
     x, cnd, ls = C.unet_inputs(case)
     label, c = C.unet_mode_args("label_cond", case, cnd)
     rel = lambda a, b: float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
     try:
-        for prec, n_sites in (("fp8", 9), ("fp8_mixed", 7)):
-            rounded = [k for k in attn_keys if prec == "fp8" or not k.startswith(top_res)]
+        for prec, n_sites in (("fp8", 8), ("fp8_mixed", 7)):
+            rounded = [k for k in attn_keys if not k.startswith(kept_bf16[prec])]
             assert len(rounded) == 2 * n_sites
             sd_q = {k: (mxfp8.quantize_conv_weight(v) if k in rounded else v.clone()) for k, v in sd.items()}
             assert all(not torch.equal(sd_q[k], sd[k]) for k in rounded)
@@ -1037,10 +1039,10 @@ def test_config5_full_geometry_fp8_vs_bf16_parity_report():
     _report(test="config5_full_1024_fp8_vs_bf16", psnr_db=psnr, max_abs=float(err.max()), mean_abs=float(err.mean()),
             mixed_psnr_db=psnr_mixed, mixed_max_abs=float(errm.max()))
     # fp8 below the top resolution only (the 256x256-resolution zones keep bf16 3x3 convolutions): measured 53.2 dB
-    assert torch.isfinite(outs["fp8_mixed"]).all() and psnr_mixed > 49.1, psnr_mixed      # round 4: 52.2 dB (7 attention sites in e4m3, pointwise layers bf16); round 3: 52.1 dB
+    assert torch.isfinite(outs["fp8_mixed"]).all() and psnr_mixed > FP8_MIXED_CONFIG5_FULL_GATE_DB, psnr_mixed      # round 4: 52.2 dB (7 attention sites in e4m3, pointwise layers bf16); round 3: 52.1 dB
     assert outs["fp8"].shape == (1, 3, 1024, 1024)
     assert torch.isfinite(outs["fp8"]).all() and outs["fp8"].min() >= 0 and outs["fp8"].max() <= 1
-    assert psnr > 33.0, psnr           # round 4: 34.5 dB with MX-e4m3 attention weights at all nine sites (round 3: 36.0 dB; 36.6 with the pointwise layers in bf16) (random-init weights; 3 mantissa bits on weights AND activations;
+    assert psnr > FP8_CONFIG5_FULL_GATE_DB, psnr           # round 4: 34.5 dB with MX-e4m3 attention weights at all nine sites (round 3: 36.0 dB; 36.6 with the pointwise layers in bf16) (random-init weights; 3 mantissa bits on weights AND activations;
                                        # 34.1 dB with the OCP recipe's clamping scale rule)
 
 

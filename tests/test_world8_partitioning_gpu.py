@@ -119,6 +119,9 @@ def test_configs3_shape_canvas_over_8_ranks_equals_the_single_process_run(name, 
         got = res[r]
         for k in want:
             assert torch.equal(got[k], want[k]), (r, k)
-        # two runs x 3 steps x (img + x_start) exchanges, through ONE preallocated buffer pair sized for the even grid
-        assert got["exchanges"] == 2 * 3 * 2
-        assert list(got["buffers"].values()) == [((width, 3, 256, 256), (WORLD * width, 3, 256, 256))]
+        # two runs x 3 steps x (img + x_start) x two halves of every slice (round 5: the first half's all-gather runs on a side
+        # stream under the second half's compute), through four preallocated buffer pairs (half, canvas) sized for the even grid
+        h = (width + 1) // 2
+        assert got["exchanges"] == 2 * 3 * 2 * 2
+        assert sorted(got["buffers"].values()) == sorted([((h, 3, 256, 256), (WORLD * h, 3, 256, 256))] * 2 +
+                                                         [((width - h, 3, 256, 256), (WORLD * (width - h), 3, 256, 256))] * 2)
