@@ -36,10 +36,6 @@
 #ifndef SRGD_CONV3_STAMPS
 #define SRGD_CONV3_STAMPS 0
 #endif
-#ifndef SRGD_CONV3_OUT_NT
-#define SRGD_CONV3_OUT_NT 0           // output stores with the non-temporal policy (A/B builds, tools/build_variant.py)
-#endif
-
 namespace srgd {
 namespace {
 
@@ -52,7 +48,6 @@ constexpr int A_BYTES = 24 * 1024;             // 24 wave-instructions x 1 KiB (
 constexpr int B_BYTES = BN3 * KC * 2;          // 8 KiB
 constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 73,728: two workgroups per CU
 constexpr int COEF_BYTES = 2 * 256;            // GNIN: 32 scales | 32 shifts (fp32) per channel chunk, double-buffered
-constexpr int CONV3_XCD_PIN_KB_DEFAULT = 0;    // (A/B knob SRGD_CONV3_XCD_PIN_KB; see the kernel's tile map)
 constexpr bool STAMPS = SRGD_CONV3_STAMPS != 0;
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -72,7 +67,6 @@ struct Conv3Args {
   float* gn_partial; int groups;
   const float* gn_in_a;   // GNIN: y = silu(a[b][c] * x + b[b][c]) applied to the input while it is staged ([B][Cin] fp32)
   int gn_in_b_off;        // byte offset of the shift array from the scale array (same allocation)
-  int xcd_pin_ntiles;     // blockIdx -> tile map: n-tiles pinned to XCDs (weights stay in the XCD's L2); else contiguous bands of tiles per XCD
   unsigned long long* stamps;   // SRGD_CONV3_STAMPS builds: per-phase s_memtime deltas summed over waves 0 of the workgroups; null otherwise
 };
 
@@ -108,21 +102,16 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   const int m_tiles = p.B * tiles_y * tiles_x;
   const int nwg = m_tiles * n_tiles;
   int wg = blockIdx.x;
-  int nt, mt;
-  if (p.xcd_pin_ntiles) {
-    // Pin the n-tiles to XCDs.  Blocks b, b + 8, ... share an XCD (round-robin dispatch).  With n-tiles walking fastest
-    // inside an XCD's band (below), every XCD streams ALL weights of the layer (18.9 MB at 1024 -> 1024) through its 4 MiB L2
-    // once per m-tile.  Here XCD x owns n-tile x % n_tiles for all of its m-tiles: its weight working set is 1 / n_tiles of
-    // the layer (2.4 MB); the halo patches are fetched once per XCD that needs them instead.
-    const int x = wg & 7, k = wg >> 3, per = 8 / n_tiles;        // host: n_tiles in {2, 4, 8} and m_tiles % per == 0
-    nt = x % n_tiles;
-    mt = k * per + x / n_tiles;
-  } else {
-    const int q = nwg >> 3, rem = nwg & 7, x = wg & 7, k = wg >> 3;
-    wg = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + k;
-    nt = wg % n_tiles;
-    mt = wg / n_tiles;
-  }
+  // Tile map, measured with the L2's own counters (round 5, profiles/r5/conv3x3_bf16_tcc_*.txt; 1024 -> 1024 @32^2, 125 tiles):
+  // this map - n-tiles fastest inside an XCD's band, so the 64 workgroups an XCD runs at a time are 8 m-tiles x 8 n-tiles - reads
+  // 112.7 M 128-byte lines per launch with an 81 % L2 hit rate (23.4 M misses = 3.0 GB from the Infinity Cache).  Pinning one
+  // n-tile per XCD makes the weight stream L2-resident and every XCD read every halo patch: 21.4 M misses, the same clock and
+  // throughput.  Blocks of 32 m-tiles x 2 n-tiles cut the misses to 17.1 M (-27 %): clock 1.653 vs 1.648 GHz, +0.4 % (noise).
+  // Non-temporal halo DMAs and output stores: 29-36 M misses, 1.55-1.59 GHz, -4 ... -12 %.  The kernel's clock does not follow
+  // its traffic beyond L2 within what a tile map can change, so the simplest map stays.
+  const int q = nwg >> 3, rem = nwg & 7, x = wg & 7, k = wg >> 3;
+  wg = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + k;
+  const int nt = wg % n_tiles, mt = wg / n_tiles;
   const int b = mt / (tiles_y * tiles_x);
   const int trem = mt - b * tiles_y * tiles_x;
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -430,8 +419,8 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       s2v = __builtin_elementwise_fma(v2, v2, s2v);                                                \
       s2v = __builtin_elementwise_fma(v3, v3, s2v);                                                \
     }                                                                                              \
-    buffer_store16<SRGD_CONV3_OUT_NT != 0>(u32x4{pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])}, rso, o_voff, so_); \
-    buffer_store16<SRGD_CONV3_OUT_NT != 0>(u32x4{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]), pack_bf16x2(v3[0], v3[1]), pack_bf16x2(v3[2], v3[3])}, rso, o_voff, so_ + 16); \
+    buffer_store16(u32x4{pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])}, rso, o_voff, so_); \
+    buffer_store16(u32x4{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]), pack_bf16x2(v3[0], v3[1]), pack_bf16x2(v3[2], v3[3])}, rso, o_voff, so_ + 16); \
   } while (0)
   K_EMIT(0, c00, c01, c02, c03);
   K_EMIT(1, c10, c11, c12, c13);
@@ -536,13 +525,6 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   p.gn_in_a = gn_in_a;
   p.gn_in_b_off = gnin ? (int)((const char*)gn_in_b - (const char*)gn_in_a) : 0;
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
-  {
-    // SRGD_CONV3_XCD_PIN_KB: minimum packed-weight bytes of a layer for the n-tile-per-XCD map (0 = never)
-    static const long pin_min = (long)env_int("SRGD_CONV3_XCD_PIN_KB", CONV3_XCD_PIN_KB_DEFAULT) * 1024L;
-    const int n_tiles = a.Cout / BN3, m_tiles = grid / n_tiles;
-    const long wbytes = 9L * (a.C0 + a.C1) * a.Cout * 2;
-    p.xcd_pin_ntiles = pin_min > 0 && wbytes >= pin_min && (n_tiles == 2 || n_tiles == 4 || n_tiles == 8) && m_tiles % (8 / n_tiles) == 0;
-  }
   p.stamps = nullptr;
   if (STAMPS) {
     SRGD_HIP(hipGetSymbolAddress((void**)&p.stamps, HIP_SYMBOL(g_conv3_stamps)));

@@ -1,6 +1,6 @@
 # Profile collection on the GPU box (gpurun): kernel-trace stats and separate PMC passes, as MI355X_MICROARCH.md prescribes
 # (FETCH_SIZE and WRITE_SIZE in passes of their own, never combined with sys/hip tracing).
-R=$GRAFT_REPO_ROOT; TAG=${1:-r3}; O=$R/gpurun_out/${TAG}prof; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r5}; O=$R/gpurun_out/${TAG}prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for MODE in bf16 fp8 fp8_mixed; do
   EXTRA=""; [ $MODE != bf16 ] && EXTRA="--precision $MODE --ddpm_steps 100 --class_cond_scale 2.0"
