@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 TFLOP_PER_HR_TILE = 813.6          # BASELINE.md section 3 (1,025 tile-forwards x 793.8 GFLOP)
 TILE_FORWARDS_PER_HR_TILE = 1025
-PMC_TRAFFIC_FILE = "r4_pmc_traffic.json"     # newest committed PMC summary (tools/pmc_traffic.py)
+PMC_TRAFFIC_FILE = "r5_pmc_traffic.json"     # newest committed PMC summary (tools/pmc_traffic.py)
 # MI355X_MICROARCH.md: dense MFMA peaks of the dominant kernel's instruction (fp8 = block-scaled MX e4m3, 2x the bf16 rate)
 PEAK_TFLOPS = {"conv3x3_bf16": 2500.0, "conv3x3_mxfp8": 5000.0, "conv_igemm:bf16": 2500.0, "conv_igemm:fp32": 157.3}
 KERNEL_OF = {"conv3x3_bf16": "conv3x3_bf16_kernel", "conv3x3_mxfp8": "conv3x3_mxfp8_kernel", "conv_igemm": "conv_igemm_kernel"}
