@@ -41,6 +41,9 @@ namespace {
 #ifndef SRGD_MXFP8_STAMPS
 #define SRGD_MXFP8_STAMPS 0
 #endif
+#ifndef SRGD_MXFP8_DIAG_GNVALU
+#define SRGD_MXFP8_DIAG_GNVALU 0
+#endif
 constexpr bool QSTAMPS = SRGD_MXFP8_STAMPS != 0;
 constexpr int QPH = 8, QPW = 32;                 // output patch
 constexpr int QHP = QPH + 2, QWP = QPW + 2;      // halo patch: 10 x 34 = 340 pixels
@@ -226,6 +229,25 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
   // One K-step: the 4 weight fragments (64 output channels of this wave) stay in registers, the 8 pixel fragments stream
   // through one at a time - 24 ds_read_b128 per 32 MFMAs, and 128 + 32 + 16 operand/accumulator registers.
   auto compute = [&](int tap, int slot) {
+#if SRGD_MXFP8_DIAG_GNVALU
+    // Pricing build (tools/build_variant.py -DSRGD_MXFP8_DIAG_GNVALU=1; results unchanged - the arithmetic runs on dummy registers):
+    // the vector work a GroupNorm-apply + SiLU + MX quantisation of the staged halo patch would add to this kernel.  Per 128-channel
+    // chunk a wave would rewrite 340 x 128 / 4 = 10,880 elements = 170 per lane; the bf16 kernel's transform costs 28 instructions
+    // per 4 elements (8 of them v_exp / v_rcp), the 32-channel maximum + scale + e4m3 pack ~10 more per 4: ~1,600 per chunk and
+    // lane = ~180 per tap, issued here as four independent chains of the same instruction mix.
+    {
+      float g0 = (float)tap, g1 = g0 + 1.f, g2 = g0 + 2.f, g3 = g0 + 3.f;
+      asm volatile(".rept 6\n\t"
+                   "v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %1, %1, %2, %3\n\tv_fma_f32 %2, %2, %3, %0\n\tv_fma_f32 %3, %3, %0, %1\n\t"
+                   "v_mul_f32 %0, 0xbfb8aa3b, %0\n\tv_mul_f32 %1, 0xbfb8aa3b, %1\n\tv_mul_f32 %2, 0xbfb8aa3b, %2\n\tv_mul_f32 %3, 0xbfb8aa3b, %3\n\t"
+                   "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
+                   "v_add_f32 %0, 1.0, %0\n\tv_add_f32 %1, 1.0, %1\n\tv_add_f32 %2, 1.0, %2\n\tv_add_f32 %3, 1.0, %3\n\t"
+                   "v_rcp_f32 %0, %0\n\tv_rcp_f32 %1, %1\n\tv_rcp_f32 %2, %2\n\tv_rcp_f32 %3, %3\n\t"
+                   "v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %1, %1, %2, %3\n\tv_mul_f32 %2, %2, %0\n\tv_mul_f32 %3, %3, %1\n\t"
+                   "v_cvt_pk_bf16_f32 %0, %0, %1\n\tv_cvt_pk_bf16_f32 %2, %2, %3\n\tv_and_b32 %1, 0xffff0000, %0\n\tv_lshlrev_b32 %3, 16, %2\n\t"
+                   ".endr" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));
+    }
+#endif
     const char* Bt = sB0 + slot * QB_BYTES;
     const int dy = tap / 3, dx = tap - dy * 3;
     v8i b0, b1, b2, b3;
