@@ -268,7 +268,6 @@ struct srgd_engine {
   bool no_attn_w8 = false;    // SRGD_FP8_ATTN_W=0: fp8 modes keep the attention projections' weights in bf16 (A/B switch)
   unsigned attn_bf16_zones = 1;   // zones whose attention weights stay bf16 on top of fp8_bf16_zones: the first down stage's 256x256 LinearAttention
                                   // site (round 5, tools/fp8_attn_site_study.py); SRGD_FP8_ATTN_BF16_ZONES=<mask> overrides
-  bool attn_w8_rowscale = false;  // SRGD_FP8_ATTN_ROWSCALE=1: one power-of-two scale per output channel instead of per 32 input channels (study only)
   int attn_w8_tensors = 0;    // attention weight tensors carried as MX-fp8 (weight-only) after srgd_finalize_weights
   int attn_w8_skipped = 0;    // ... and attention weight tensors left in bf16 because Cin % 32 != 0 (dim-16 test models)
   int mx1x1_min_cin = 0;      // SRGD_MX1X1_MIN_CIN: pointwise layers with fewer input channels stay on conv1x1_bf16
@@ -1094,7 +1093,6 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   if (const char* v = getenv("SRGD_MX1X1_MIN_CIN")) e->mx1x1_min_cin = atoi(v);
   if (const char* v = getenv("SRGD_FP8_ATTN_W")) e->no_attn_w8 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_FP8_ATTN_BF16_ZONES")) e->attn_bf16_zones = (unsigned)strtoul(v, nullptr, 0);
-  if (const char* v = getenv("SRGD_FP8_ATTN_ROWSCALE")) e->attn_w8_rowscale = atoi(v) != 0;
   if (const char* v = getenv("SRGD_LA256")) e->no_la256 = atoi(v) == 0;
   if (const char* v = getenv("SRGD_FINAL_FUSION")) e->no_final_fusion = atoi(v) == 0;
   if (const char* v = getenv("SRGD_Q_FUSED")) e->no_twin_fusion = atoi(v) == 0;
@@ -1207,13 +1205,11 @@ int srgd_finalize_weights(srgd_engine* e) {
       if ((e->fp8_bf16_zones | e->attn_bf16_zones) & (1u << zone)) continue;
       const int64_t O = t.shape[0], I = t.shape[1];
       for (int64_t o = 0; o < O; ++o) {
-        float row_amax = 0.f;
-        for (int64_t k = 0; k < I; ++k) row_amax = std::max(row_amax, std::fabs(t.data[(size_t)o * I + k]));
         for (int64_t k0 = 0; k0 < I; k0 += 32) {
           float* w = t.data.data() + (size_t)o * I + k0;
           float amax = 0.f;
           for (int k = 0; k < 32; ++k) amax = std::max(amax, std::fabs(w[k]));
-          const int ex = mx_block_exponent(e->attn_w8_rowscale ? row_amax : amax);
+          const int ex = mx_block_exponent(amax);
           const float inv = std::ldexp(1.0f, -ex), sc = std::ldexp(1.0f, ex);
           for (int k = 0; k < 32; ++k) w[k] = round_through_e4m3(w[k] * inv) * sc;
         }
