@@ -1,5 +1,7 @@
 # Round 5: register-direct epilogue of conv3x3_bf16 against the round-4 kernel (srgd_amd/variants/libsrgd_hip_base.so built
-# from a worktree of a9bfeba), one box: kernel tests, two alternating rounds of tools/bench_conv.py, phase stamps.
+# from a worktree of a9bfeba: `git worktree add /tmp/base a9bfeba; SRGD_CSRC=/tmp/base/srgd_amd/csrc python tools/build_variant.py base`;
+# the round-4 library takes its stamps from the environment, SRGD_CONV3_STAMPS=1), one box: kernel tests, two alternating rounds of
+# tools/bench_conv.py, phase stamps.
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r5_regepi; mkdir -p $O
 V=$PWD/srgd_amd/variants
 timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py -x -q > $O/pytest_kernels.log 2>&1; echo "rc=$?" >> $O/pytest_kernels.log; tail -5 $O/pytest_kernels.log
