@@ -26,8 +26,11 @@ extern "C" {
  * pixel-unshuffle + 1x1 == 2x2/stride-2), PixelShuffleUpsample (:70-98, kind 2: 1x1 + SiLU + PixelShuffle),
  * and torch.cat on the skip path (:713,:716,:722: two channel-concatenated sources in0|in1).
  * weight_oihw_host / bias_host: PyTorch-layout fp32 on the HOST (packed + uploaded inside; this entry
- * point synchronises).  gn_partial: optional device [B][groups][Hout*Wout/128][2] receiving per-tile
- * (sum, sum of squares) of the output for a following GroupNorm. */
+ * point synchronises).  gn_partial: optional device [B][groups][nslots][2] receiving partial (sum, sum of squares)
+ * of the output for a following GroupNorm.  nslots depends on the kernel the call selects (srgd_k_conv2d_timed reports it):
+ * the generic kernel writes Hout*Wout/128 slots, the 3x3 fast paths one per contributing WAVE of a 256-pixel patch (4, or 8 per
+ * 128-channel tile of a group that spans whole tiles).  Size the buffer for the largest:
+ *     nslots_capacity = (Hout*Wout / 32) * max(1, (Cout / groups) / 64). */
 int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int Hin, int Win, int KS, int stride,
                   int pad, int kind, const float* weight_oihw_host, const float* bias_host, int Cout, void* out,
                   const void* residual, float* gn_partial, int groups, int is_bf16, void* stream);
@@ -38,8 +41,7 @@ int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int H
  * weights per (output channel, tap, 32 input channels); C0, C1, Cout % 128 == 0; error if not eligible),
  * 5 = impl 2 with the PRODUCER's GroupNorm + SiLU applied while the input is staged (Block.forward model.py:250-259 between
  * two convolutions): conv(silu(gn_tail_a[b][c] * in0 + gn_tail_b[b][c])), zero padding applied after the activation; one source,
- * gn_tail_a / gn_tail_b = device fp32 [B][C0] in ONE allocation (shift behind scale), gn_tail_src must be NULL,
- * 6 = impl 3 on its 256-pixel x 256-channel tile (one 16-wave workgroup per CU; Cout % 256 == 0; error if not eligible).
+ * gn_tail_a / gn_tail_b = device fp32 [B][C0] in ONE allocation (shift behind scale), gn_tail_src must be NULL.
  * gn_tail_src (nullable, NHWC like out): out = silu(gn_tail_a[b][c] * gn_tail_src + gn_tail_b[b][c]) + conv(in) -
  * the second GroupNorm+SiLU of a ResnetBlock and its residual add folded into the 1x1 res_conv (model.py:250-259,:285);
  * gn_tail_a / gn_tail_b: device fp32 [B][Cout].  May alias out.
@@ -68,7 +70,7 @@ int srgd_k_conv3x3_mxfp8(const void* in0, const void* in1, int C0, int C1, int B
 /* GroupNorm (from the conv's partial statistics) -> x*(scale+1)+shift -> SiLU (+ residual).
  * replaces: Block.forward after the conv (model.py:250-259) and the ResnetBlock residual add (:285).
  * gamma, beta: device [C]; scale_shift: device [B][2C] (scale | shift) or NULL; in place if y == x.
- * gn_partial: [B][groups][nslots][2] as written by the conv (nslots from srgd_k_conv2d_timed; generic kernel: hw/128). */
+ * gn_partial: [B][groups][nslots][2] as written by the conv (nslots from srgd_k_conv2d_timed / srgd_k_conv3x3_mxfp8). */
 int srgd_k_groupnorm_silu(const void* x, void* y, const void* residual, const float* gn_partial, int B, int hw,
                           int C, int groups, const float* gamma, const float* beta, const float* scale_shift,
                           int nslots, int is_bf16, void* stream);
