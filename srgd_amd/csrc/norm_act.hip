@@ -2,8 +2,23 @@
 // Memory-bound element-wise kernels: 16-byte vector accesses along the NHWC channel axis.
 #include "kernels.hpp"
 
+// gn_apply streams tensors far larger than the caches (0.5-4 GB per launch) once: non-temporal loads of x / residual and
+// non-temporal stores of y.  Round 5, same box, alternating: 5.27 -> 5.40 (loads) -> 5.58 TB/s (loads + stores), GroupNorm share of
+// a step 5.1 -> 4.84 %, +0.2 % end to end.  (A/B builds: -DSRGD_GN_NT=0 default policy, 1 loads only.)
+#ifndef SRGD_GN_NT
+#define SRGD_GN_NT 2
+#endif
 namespace srgd {
 namespace {
+
+template <typename V> __device__ __forceinline__ V ld_stream(const V* p) {
+  if (SRGD_GN_NT >= 1) { V r; r.v = __builtin_nontemporal_load(&p->v); return r; }
+  return *p;
+}
+template <typename V> __device__ __forceinline__ void st_stream(V* p, const V& x) {
+  if (SRGD_GN_NT >= 2) __builtin_nontemporal_store(x.v, &p->v);
+  else *p = x;
+}
 
 // One wave per (sample, group): sums the per-tile partials the conv epilogue wrote (fixed
 // order, fp64) and folds GroupNorm's affine and the ResnetBlock's (scale+1, shift)
@@ -102,7 +117,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       if (rs) t += r.get(j);
       o.set(j, t);
     }
-    ys[i] = o;
+    st_stream(&ys[i], o);
     if constexpr (sizeof(T) == 2) {
       if (oq) mx_store_twin(o.v, oq, os, (base + i) * 8, threadIdx.x & 3);      // MX-fp8 twin of the stored bf16 values
     }
@@ -112,9 +127,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   const unsigned stride = gridDim.x * 256u, n = (unsigned)vec_per_sample;
   unsigned i = blockIdx.x * 256u + threadIdx.x;
   for (; i + 3u * stride < n; i += 4u * stride) {
-    const Vec16<T> v0 = xs[i], v1 = xs[i + stride], v2 = xs[i + 2u * stride], v3 = xs[i + 3u * stride];
+    const Vec16<T> v0 = ld_stream(&xs[i]), v1 = ld_stream(&xs[i + stride]), v2 = ld_stream(&xs[i + 2u * stride]), v3 = ld_stream(&xs[i + 3u * stride]);
     Vec16<T> r0, r1, r2, r3;
-    if (rs) { r0 = rs[i]; r1 = rs[i + stride]; r2 = rs[i + 2u * stride]; r3 = rs[i + 3u * stride]; }
+    if (rs) { r0 = ld_stream(&rs[i]); r1 = ld_stream(&rs[i + stride]); r2 = ld_stream(&rs[i + 2u * stride]); r3 = ld_stream(&rs[i + 3u * stride]); }
     finish(i, v0, r0);
     finish(i + stride, v1, r1);
     finish(i + 2u * stride, v2, r2);
