@@ -307,6 +307,7 @@ def main():
     conds = [synthetic_lr_condition(i if canvas_mode else rank + i * world, args.lr_size, args.lr_size).to(device)
              for i in range(total)]
     n_even = ((4 * args.lr_size + 255) // 256 + 1) ** 2 if args.lr_size * 4 > 256 else 1
+    from srgd_amd.lanes import lanes_wanted
 
     def sample_local(idx):
         """The local images ``idx`` in ONE lock-step tiled_sample call (each image sampled exactly as it would be alone)."""
@@ -402,6 +403,9 @@ def main():
                        "tiles_per_unet_launch": (lambda n, lim: -(-n // -(-n // lim)))(n_even * min(args.images, args.steps),
                                                                                         args.sub_batch or n_even * min(args.images, args.steps)),
                        "tile_forwards_per_step": TILE_FORWARDS_PER_HR_TILE,
+                       # srgd_amd.lanes: a step that is one small launch runs as two concurrent halves on two HIP streams
+                       "step_lanes": lanes_wanted(n_even * min(args.images, args.steps), 1 if args.class_cond_scale == 1.0 else 2,
+                                                  args.sub_batch or min(125, n_even * min(args.images, args.steps)), sampler.step_lanes),
                        "parallelism": f"image-sharded x{world}"},
             "tflops_effective": value * TFLOP_PER_HR_TILE,
         }
@@ -415,9 +419,13 @@ def main():
             line.pop("tflops_effective", None)
         if not args.no_profile:
             eng = sampler.model.engine(args.precision)
+            # the per-kernel events of the profiled pass time one kernel at a time: one lane (with two concurrent lanes -
+            # srgd_amd.lanes, small steps only - a kernel's bracket would include the other lane's work)
+            lanes_setting, sampler.step_lanes = sampler.step_lanes, 1
             eng.profile_begin()
             sample_local(list(range(args.warmup, args.warmup + min(args.images, args.steps))))
             prof = eng.profile_end()
+            sampler.step_lanes = lanes_setting
             # the dominant kernel: conv3x3_bf16_kernel in bf16 mode, conv3x3_mxfp8_kernel in fp8 mode, the generic implicit
             # GEMM in fp32 mode - whichever convolution family took the most time in the profiled pass
             fam = max(("conv3x3_bf16", "conv3x3_mxfp8", "conv_igemm"), key=lambda k: prof["ms"].get(k, 0.0))

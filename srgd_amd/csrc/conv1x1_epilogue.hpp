@@ -9,9 +9,8 @@
 namespace srgd {
 namespace {
 
-#ifndef SRGD_CONV1_NT
-#define SRGD_CONV1_NT 1     // non-temporal output stores and tail-operand loads (streamed once): pointwise share 13.86 -> 13.74 % of the step, same box
-#endif
+// Output stores and tail-operand loads are non-temporal (both tensors are streamed once): pointwise share 13.86 -> 13.74 % of a step,
+// same box (profiles/r5/nt_policy/r5_nt_c1.json).
 enum { EPI_PLAIN = 0, EPI_RESIDUAL = 1, EPI_GNTAIL = 2, EPI_PS_SILU = 3, EPI_GNTAIL_FINAL = 4 };
 constexpr int EPI_BM = 256, EPI_BN = 128, EPI_NT = 512;
 constexpr int EPI_ROW = EPI_BN * 2 + 16;           // transposed output row (272 B: conflict-free 2-byte column writes)
@@ -100,7 +99,7 @@ __device__ __forceinline__ void conv1x1_epilogue(const Args& p, char* smem, cons
     for (int i = 0; i < NCH; ++i) {
       const int q = tid + NT1 * i;
       const bf16x8* ap = reinterpret_cast<const bf16x8*>(p.aux + obase + (size_t)(q >> 4) * p.Cout + (q & 15) * 8);
-      auxv[i] = SRGD_CONV1_NT ? __builtin_nontemporal_load(ap) : *ap;
+      auxv[i] = __builtin_nontemporal_load(ap);
     }
     if (EPI != EPI_RESIDUAL) {
       const float* ga = p.gn_a + (size_t)b * p.Cout + col0 + (tid & 15) * 8;
@@ -119,8 +118,7 @@ __device__ __forceinline__ void conv1x1_epilogue(const Args& p, char* smem, cons
       const int oy = op / p.Wout, ox = op - oy * p.Wout;
       const size_t o = ((size_t)(b * 2 * p.Hout + 2 * oy + (ps_ij >> 1)) * (2 * p.Wout) + 2 * ox + (ps_ij & 1)) * CoutPS +
                        ps_c0 + c16 * 8;
-      if (SRGD_CONV1_NT) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.out + o));
-      else *reinterpret_cast<bf16x8*>(p.out + o) = v;
+      __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.out + o));
       if (p.oq) mx_store_twin(v, p.oq, p.os, o, tid & 3);
     } else {
       const size_t o = obase + (size_t)pix * p.Cout + c16 * 8;
@@ -152,8 +150,7 @@ __device__ __forceinline__ void conv1x1_epilogue(const Args& p, char* smem, cons
           *reinterpret_cast<f32x4*>(p.eps4 + ((size_t)m0 + pix) * 4) = f32x4{s0 + p.fin_b[0], s1 + p.fin_b[1], s2 + p.fin_b[2], 0.f};
         continue;
       }
-      if (SRGD_CONV1_NT) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.out + o));
-      else *reinterpret_cast<bf16x8*>(p.out + o) = v;
+      __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.out + o));
       if (p.oq) mx_store_twin(v, p.oq, p.os, o, tid & 3);
     }
   }

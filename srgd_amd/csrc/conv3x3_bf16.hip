@@ -36,6 +36,9 @@
 #ifndef SRGD_CONV3_STAMPS
 #define SRGD_CONV3_STAMPS 0
 #endif
+#if SRGD_CONV3_STAMPS
+#include "stamps.hpp"
+#endif
 namespace srgd {
 namespace {
 
@@ -67,11 +70,11 @@ struct Conv3Args {
   float* gn_partial; int groups;
   const float* gn_in_a;   // GNIN: y = silu(a[b][c] * x + b[b][c]) applied to the input while it is staged ([B][Cin] fp32)
   int gn_in_b_off;        // byte offset of the shift array from the scale array (same allocation)
-  unsigned long long* stamps;   // SRGD_CONV3_STAMPS builds: per-phase s_memtime deltas summed over waves 0 of the workgroups; null otherwise
 };
 
-// phase accumulators of the stamp build: [prologue, main loop, epilogue issue, store drain, -, total, workgroups, real time]
-__device__ unsigned long long g_conv3_stamps[8];
+#if SRGD_CONV3_STAMPS
+__device__ unsigned long long g_conv3_timeline[(size_t)STAMP_REC * STAMP_MAX_WAVES];       // stamps.hpp
+#endif
 
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 // Raw barrier (no vmcnt drain: LDS-DMA prefetches stay in flight) fenced for the instruction scheduler:
@@ -454,11 +457,9 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     t3 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     t4 = __builtin_amdgcn_s_memtime();
-    if (p.stamps && tidE == 0) {
-      atomicAdd(&p.stamps[0], t1 - t0); atomicAdd(&p.stamps[1], t2 - t1); atomicAdd(&p.stamps[2], t3 - t2);
-      atomicAdd(&p.stamps[3], t4 - t3); atomicAdd(&p.stamps[5], t4 - t0); atomicAdd(&p.stamps[6], 1ull);
-      atomicAdd(&p.stamps[7], __builtin_amdgcn_s_memrealtime() - r0);      // 100 MHz ticks: in-kernel clock = total / this * 100 MHz
-    }
+#if SRGD_CONV3_STAMPS
+    if (laneE == 0) stamp_record(g_conv3_timeline, blockIdx.x * (NT3 / 64) + wave, r0, t1 - t0, t2 - t1, t3 - t2, t4 - t3);
+#endif
   }
 }
 
@@ -525,11 +526,6 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   p.gn_in_a = gn_in_a;
   p.gn_in_b_off = gnin ? (int)((const char*)gn_in_b - (const char*)gn_in_a) : 0;
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
-  p.stamps = nullptr;
-  if (STAMPS) {
-    SRGD_HIP(hipGetSymbolAddress((void**)&p.stamps, HIP_SYMBOL(g_conv3_stamps)));
-    SRGD_HIP(hipMemsetAsync(p.stamps, 0, sizeof(unsigned long long) * 8, st));
-  }
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
 #define K_SET(S_, G_)                                                                                  \
@@ -546,16 +542,19 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   else if (gnin) K_GO(false, true); else K_GO(false, false);
 #undef K_GO
   SRGD_HIP(hipGetLastError());
-  if (STAMPS) {                                         // stamp build: synchronous, prints the mean ticks per workgroup and phase
-    unsigned long long h[8];
+#if SRGD_CONV3_STAMPS
+  {                                                     // stamp build: synchronous, prints the phase means and the slot timeline
     SRGD_HIP(hipStreamSynchronize(st));
-    SRGD_HIP(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));
-    const double n = h[6] ? (double)h[6] : 1.0;
-    fprintf(stderr, "[conv3x3_bf16 stamps] C %d+%d -> %d @%dx%d grid %d: prologue %.0f  main %.0f  epilogue (wave 0: bias, pack, "
-                    "stores issued, statistics) %.0f  store drain %.0f  total %.0f  (s_memtime ticks per workgroup)  in-kernel clock %.3f GHz\n",
-            a.C0, a.C1, a.Cout, a.Hin, a.Win, grid, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[5] / n,
-            h[7] ? 0.1 * (double)h[5] / (double)h[7] : 0.0);
+    unsigned long long* dtl = nullptr;
+    SRGD_HIP(hipGetSymbolAddress((void**)&dtl, HIP_SYMBOL(g_conv3_timeline)));
+    const StampSummary r = stamp_summary(dtl, grid, NT3 / 64, 2);
+    fprintf(stderr, "[conv3x3_bf16 stamps] C %d+%d -> %d @%dx%d grid %d%s: prologue %.0f  main %.0f  epilogue (wave 0: bias, pack, stores issued, "
+                    "statistics) %.0f  store drain %.0f  total %.0f  (s_memtime ticks per workgroup)  in-kernel clock %.3f GHz | launch span %.1f us, "
+                    "workgroup %.2f us (wave-exit skew %.2f us), slot gap exit -> next entry %.2f us, slot occupancy %.3f on %zu CUs\n",
+            a.C0, a.C1, a.Cout, a.Hin, a.Win, grid, gnin ? " GNIN" : "", r.phase[0], r.phase[1], r.phase[2], r.phase[3],
+            r.phase[0] + r.phase[1] + r.phase[2] + r.phase[3], r.clock_ghz, r.span_us, r.wg_us, r.skew_us, r.gap_us, r.occupancy, r.cus);
   }
+#endif
   return 0;
 }
 

@@ -34,6 +34,9 @@
 #include <cstring>
 
 #include "kernels.hpp"
+#if SRGD_MXFP8_STAMPS
+#include "stamps.hpp"
+#endif
 
 namespace srgd {
 namespace {
@@ -80,11 +83,11 @@ struct ConvQArgs {
   bf16* out;
   float* gn_partial; int groups;
   unsigned char* oq; unsigned char* os;   // optional MX-fp8 twin of the output (ConvArgs::out_q / out_s)
-  unsigned long long* stamps;             // SRGD_MXFP8_STAMPS builds: per-phase s_memtime deltas summed over workgroups; null otherwise
 };
 
-// phase accumulators of the diagnostic mode: [prologue, main loop, epilogue, total, workgroups, s_memrealtime ticks]
-__device__ unsigned long long g_convq_stamps[8];
+#if SRGD_MXFP8_STAMPS
+__device__ unsigned long long g_convq_timeline[(size_t)STAMP_REC * STAMP_MAX_WAVES];      // stamps.hpp
+#endif
 
 // lane id from v_mbcnt, as volatile asm: never hoisted or CSE'd, so no VGPR carries it (or the thread id) across the K loop
 __device__ __forceinline__ int lane_id_opaque() {
@@ -448,11 +451,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
   }
   if constexpr (QSTAMPS) {
     t3 = __builtin_amdgcn_s_memtime();
-    if (p.stamps && wave == 0 && laneE == 0) {
-      atomicAdd(&p.stamps[0], t1 - t0); atomicAdd(&p.stamps[1], t2 - t1); atomicAdd(&p.stamps[2], t3 - t2);
-      atomicAdd(&p.stamps[3], t3 - t0); atomicAdd(&p.stamps[4], 1ull);
-      atomicAdd(&p.stamps[5], __builtin_amdgcn_s_memrealtime() - r0);
-    }
+#if SRGD_MXFP8_STAMPS
+    if (laneE == 0) stamp_record(g_convq_timeline, blockIdx.x * NW + wave, r0, t1 - t0, t2 - t1, t3 - t2, 0);
+#endif
   }
 }
 
@@ -551,11 +552,6 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   p.oq = (unsigned char*)a.out_q; p.os = (unsigned char*)a.out_s;
   const int grid = a.B * (a.Hin / QPH) * (a.Win / QPW) * (a.Cout / QBN);
   if (a.bias && ((size_t)a.bias & 15)) SRGD_FAIL("conv3x3_mxfp8: the bias array must be 16-byte aligned");
-  p.stamps = nullptr;
-  if (QSTAMPS) {
-    SRGD_HIP(hipGetSymbolAddress((void**)&p.stamps, HIP_SYMBOL(g_convq_stamps)));
-    SRGD_HIP(hipMemsetAsync(p.stamps, 0, sizeof(unsigned long long) * 8, st));
-  }
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
     SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
@@ -565,17 +561,20 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true>), dim3(grid), dim3(NW * 64), QLDS, st, p);
   else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false>), dim3(grid), dim3(NW * 64), QLDS, st, p);
   SRGD_HIP(hipGetLastError());
-  if (QSTAMPS) {                                        // stamp build: synchronous, prints the mean ticks per workgroup and phase
-    unsigned long long h[8];
+#if SRGD_MXFP8_STAMPS
+  {                                                     // stamp build: synchronous, prints the phase means and the slot timeline
     SRGD_HIP(hipStreamSynchronize(st));
-    SRGD_HIP(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));
-    const double n = h[4] ? (double)h[4] : 1.0;
+    unsigned long long* dtl = nullptr;
+    SRGD_HIP(hipGetSymbolAddress((void**)&dtl, HIP_SYMBOL(g_convq_timeline)));
+    const StampSummary r = stamp_summary(dtl, grid, NW, 2);
     const int steps = 9 * ((a.C0 + a.C1) / QKC);
     fprintf(stderr, "[conv3x3_mxfp8 stamps] C %d+%d -> %d @%dx%d grid %d: prologue %.0f  main %.0f (%.0f per K-step)  epilogue %.0f  total %.0f  "
-                    "(s_memtime ticks per workgroup)  in-kernel clock %.3f GHz\n",
-            a.C0, a.C1, a.Cout, a.Hin, a.Win, grid, h[0] / n, h[1] / n, h[1] / n / steps, h[2] / n, h[3] / n,
-            h[5] ? 0.1 * (double)h[3] / (double)h[5] : 0.0);
+                    "(s_memtime ticks per workgroup)  in-kernel clock %.3f GHz | launch span %.1f us, workgroup %.2f us (wave-exit skew %.2f us), "
+                    "slot gap exit -> next entry %.2f us, slot occupancy %.3f on %zu CUs\n",
+            a.C0, a.C1, a.Cout, a.Hin, a.Win, grid, r.phase[0], r.phase[1], r.phase[1] / steps, r.phase[2], r.phase[0] + r.phase[1] + r.phase[2],
+            r.clock_ghz, r.span_us, r.wg_us, r.skew_us, r.gap_us, r.occupancy, r.cus);
   }
+#endif
   return 0;
 }
 

@@ -143,7 +143,7 @@ void linattn_fused_pack(const float* to_qkv, const float* norm_g, const float* t
 int linattn_fused(const void* x, void* y, int B, int N, int C, const void* wkv_img, const void* wq, const void* wout,
                   const float* bout, const float* g2_scaled, float* ws, hipStream_t st, void* y_q = nullptr,
                   void* y_s = nullptr);          // y_q / y_s: optional MX-fp8 twin of y (see ConvArgs::out_q)
-// linattn_fused256.hip: the 32-pixel-tile kernels (C = 256 always; C = 128 when SRGD_LA128_TM32=1) behind the entry points above
+// linattn_fused256.hip: the 32-pixel-tile kernels (C = 256) behind the entry points above
 bool linattn_fused256_eligible(int C, int heads, int dh, int N, bool is_bf16);
 void linattn_fused256_pack(const float* to_qkv, const float* norm_g, const float* to_out, int C, std::vector<unsigned short>& wkv,
                            std::vector<unsigned short>& wq, std::vector<unsigned short>& wout);

@@ -27,9 +27,8 @@
 namespace srgd {
 namespace {
 
-#ifndef SRGD_LA_NT
-#define SRGD_LA_NT 1      // non-temporal x-tile DMAs and y stores (x and y are streamed once): kernel share 6.47 -> 6.40 % of the step, same box
-#endif
+// x-tile DMAs and y stores are non-temporal (x and y are streamed once per pass): kernel share 6.47 -> 6.40 % of a step, same box
+// (profiles/r5/nt_policy/r5_nt_la.json)
 #ifndef SRGD_LA_STAMPS
 #define SRGD_LA_STAMPS 0  // diagnostic build: per-phase s_memtime ticks of la1's tile loop (wave 0 of every workgroup), printed per launch
 #endif
@@ -47,7 +46,7 @@ __device__ unsigned long long g_la1_stamps[8];   // [norms + sync, k/v GEMM, sca
 __device__ __forceinline__ int swz(int row, int chunk16) { return row * 256 + ((chunk16 ^ (row & 15)) << 4); }
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voffset, 0, 0, SRGD_LA_NT ? 2 : 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voffset, 0, 0, 2 /* nt */);
 }
 
 #define LA_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
@@ -464,8 +463,7 @@ __global__ __launch_bounds__(NTH, 2) void la2_kernel(La2Args p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) yv[e] = (bf16)((float)ov[e] + (float)xv[e]);
       const size_t yo = ((size_t)b * p.N + px0 + row) * 128 + c16 * 8;
-      if (SRGD_LA_NT) __builtin_nontemporal_store(yv, reinterpret_cast<bf16x8*>(p.y + yo));
-      else *reinterpret_cast<bf16x8*>(p.y + yo) = yv;
+      __builtin_nontemporal_store(yv, reinterpret_cast<bf16x8*>(p.y + yo));
       if (p.yq) mx_store_twin(yv, p.yq, p.ys, yo, tid & 3);
     }
     // Tile t+1 (issued one iteration ago) must have landed before the next iteration reads it; this iteration's DMA of

@@ -4,20 +4,17 @@
 
 // gn_apply streams tensors far larger than the caches (0.5-4 GB per launch) once: non-temporal loads of x / residual and
 // non-temporal stores of y.  Round 5, same box, alternating: 5.27 -> 5.40 (loads) -> 5.58 TB/s (loads + stores), GroupNorm share of
-// a step 5.1 -> 4.84 %, +0.2 % end to end.  (A/B builds: -DSRGD_GN_NT=0 default policy, 1 loads only.)
-#ifndef SRGD_GN_NT
-#define SRGD_GN_NT 2
-#endif
+// a step 5.1 -> 4.84 %, +0.2 % end to end (profiles/r5/nt_policy/r5_gnnt.json).
 namespace srgd {
 namespace {
 
 template <typename V> __device__ __forceinline__ V ld_stream(const V* p) {
-  if (SRGD_GN_NT >= 1) { V r; r.v = __builtin_nontemporal_load(&p->v); return r; }
-  return *p;
+  V r;
+  r.v = __builtin_nontemporal_load(&p->v);
+  return r;
 }
 template <typename V> __device__ __forceinline__ void st_stream(V* p, const V& x) {
-  if (SRGD_GN_NT >= 2) __builtin_nontemporal_store(x.v, &p->v);
-  else *p = x;
+  __builtin_nontemporal_store(x.v, &p->v);
 }
 
 // One wave per (sample, group): sums the per-tile partials the conv epilogue wrote (fixed

@@ -16,10 +16,9 @@ namespace {
 // (a flat 64-bit index costs a 64-bit division + remainder per 16-byte vector and makes the pass VALU-bound).
 // HOIST (round 4, as gn_apply_kernel): the grid stride is a multiple of the vectors per pixel, so a thread's channels - and its 16
 // coefficients - are the same in every trip: loaded once instead of four 16-byte loads per vector.
-#ifndef SRGD_QUANT_NT
-#define SRGD_QUANT_NT 1     // non-temporal loads of x and stores of q (norm_act.hip: the same tensors, streamed once): configs[4] fp8 0.4575 -> 0.4608 (+0.7 %), same box
-#endif
-__device__ __forceinline__ bf16x8 ld_x(const bf16x8* p) { return SRGD_QUANT_NT ? __builtin_nontemporal_load(p) : *p; }
+// Non-temporal loads of x and stores of q (as gn_apply in norm_act.hip: the same tensors, streamed once): configs[4] fp8
+// 0.4575 -> 0.4608 HR tiles/s (+0.7 %), same box (profiles/r5/nt_policy/r5_qnt.json).
+__device__ __forceinline__ bf16x8 ld_x(const bf16x8* p) { return __builtin_nontemporal_load(p); }
 
 template <bool GN, bool HOIST>
 __global__ __launch_bounds__(256) void quant_mxfp8_kernel(const bf16* __restrict__ x, unsigned char* __restrict__ q,
@@ -58,8 +57,7 @@ __global__ __launch_bounds__(256) void quant_mxfp8_kernel(const bf16* __restrict
     int sb;
     const uint2 w = mx_quant8(y, &sb);
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-    if (SRGD_QUANT_NT) __builtin_nontemporal_store(u32x2_t{w.x, w.y}, reinterpret_cast<u32x2_t*>(&qs[i]));
-    else qs[i] = w;
+    __builtin_nontemporal_store(u32x2_t{w.x, w.y}, reinterpret_cast<u32x2_t*>(&qs[i]));
     if ((threadIdx.x & 3) == 0) ss[i >> 2] = (unsigned char)sb;
   };
   // four vectors per trip, loads first (norm_act.hip: one load per trip leaves half of HBM's latency-bandwidth product unused);

@@ -1,0 +1,69 @@
+"""Two concurrent lanes for small steps.
+
+One HR tile of BASELINE configs[1] is 25 (even grid) / 16 (odd grid) U-Net tiles per step.  As ONE launch per layer that is
+1.56 "waves" of workgroups on the 32x32 layers and 3.1 on the 64x64 ones: the last, partial wave of every kernel leaves a
+fifth of the chip idle, and nothing else is queued behind it because the next layer depends on this one.  Tiles of a step are
+independent (disjoint canvas regions; the odd-step ring lies outside all of them - the property the sharded canvas of
+``srgd_amd.parallel`` relies on), so the step is run as two halves on two HIP streams through two engines: while one half
+drains the tail of a kernel, the other half's kernels fill the idle CUs.  Measured on one MI355X (profiles/r5/step_lanes_ab.txt,
+`bench.py --images 1`, same box): one lane 1.231 HR tiles/s, two lanes 1.273 (+3.4 %), three / four lanes 1.184 / 1.183 (the
+parts get too small to fill the chip on the shallow layers); configs[4] fp8 with one HR tile 0.4438 -> 0.4583 (+3.3 %).  Two
+lanes do NOT pay for large steps (125 tiles: 1.334 vs 1.331), which keep one lane.  Results are bit-identical either way
+(tests/test_engine_gpu.py::test_two_step_lanes_are_bitwise_identical_to_one).
+
+The second engine is a second instance of the same C-ABI engine (its own scratch, graphs and packed weights); it is created
+the first time a step wants two lanes."""
+import os
+from typing import Callable, Optional
+
+import torch
+
+MAX_SAMPLES_FOR_TWO_LANES = 64      # tiles x guidance passes of one launch
+MAX_LANES = 2                       # three and four lanes measured 4 % SLOWER than one (25 tiles per step)
+
+
+def lanes_wanted(n_tiles: int, passes: int, sub_batch: int, setting: Optional[int]) -> int:
+    """Number of concurrent lanes of a step.  ``setting``: None = automatic (two lanes when the whole step is ONE launch of at
+    most 64 samples), an integer = forced (never more lanes than tiles)."""
+    if n_tiles < 2:
+        return 1
+    if setting is not None:
+        return max(1, min(int(setting), MAX_LANES, n_tiles))
+    one_launch = sub_batch >= n_tiles
+    return 2 if (one_launch and n_tiles * passes <= MAX_SAMPLES_FOR_TWO_LANES) else 1
+
+
+def lanes_setting_from_env() -> Optional[int]:
+    v = os.environ.get("SRGD_STEP_LANES", "").strip()
+    return int(v) if v.isdigit() and 1 <= int(v) <= MAX_LANES else None
+
+
+def lane_slices(n_tiles: int, lanes: int):
+    """Contiguous, near-equal parts [(first, count)] of a step's tile list, larger parts first."""
+    base, extra = divmod(n_tiles, lanes)
+    out, first = [], 0
+    for k in range(lanes):
+        count = base + (1 if k < extra else 0)
+        out.append((first, count))
+        first += count
+    return out
+
+
+class StepLanes:
+    """Runs ``call(engine, tile_first, tile_count, do_ring)`` for the parts of a step on their own streams and joins them."""
+
+    def __init__(self, engines, device: torch.device):
+        self.engines = tuple(engines)
+        self.device = device
+        self._side = [torch.cuda.Stream(device=device) for _ in self.engines[1:]]
+
+    def run(self, n_tiles: int, call: Callable) -> None:
+        parts = lane_slices(n_tiles, len(self.engines))
+        main = torch.cuda.current_stream(self.device)
+        for k, side in enumerate(self._side, start=1):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                call(self.engines[k], parts[k][0], parts[k][1], False)
+        call(self.engines[0], parts[0][0], parts[0][1], True)     # the odd-step ring (outside every tile) rides with the first part
+        for side in self._side:
+            main.wait_stream(side)

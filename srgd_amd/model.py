@@ -24,6 +24,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import SamplerGeometry, StepScalars
 from .engine import HipEngine
+from .lanes import StepLanes, lanes_setting_from_env, lanes_wanted
 
 __all__ = ["get_coord_and_pad", "get_coords", "get_area", "beta_linear_log_snr", "ConditionalSRUnet",
            "ConditionalContinuousTimeGaussianDiffusionSR", "ConditionalElucidatedDiffusionSR", "ModelEma", "get_model"]
@@ -276,12 +277,13 @@ class ConditionalSRUnet(nn.Module):
         new._engines = {}
         return new
 
-    def engine(self, precision: str = "fp32") -> HipEngine:
+    def engine(self, precision: str = "fp32", lane: int = 0) -> HipEngine:
+        """The C-ABI engine of this U-Net for one precision; ``lane`` > 0: a further instance (srgd_amd.lanes)."""
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise _lib.SrgdHipError("ConditionalSRUnet runs on MI355X only: move the model to the GPU "
                                     "(the CPU restatement under oracle/ is test infrastructure, not a fallback)")
-        key = (dev.index if dev.index is not None else torch.cuda.current_device(), precision)
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), precision) + ((lane,) if lane else ())
         if key not in self._engines:
             eng = HipEngine(dim=self.dim, dim_mults=self.dim_mults, full_attn=self.full_attn, channels=self.channels,
                             groups=self.groups, heads=self.heads, dim_head=self.dim_head, sinus_dim=self.sinus_dim,
@@ -334,6 +336,7 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
                                        # reference); a torch.Generator makes a run independent of other threads' draws
         self.device_noise_seed = 0
         self.max_tiles_per_launch = None   # None: use the caller's batch_size as the reference does
+        self.step_lanes = lanes_setting_from_env()   # None: automatic - small steps run as two concurrent halves (srgd_amd.lanes)
         # engine precision: "fp32" (default: the reference's numerics - upstream ignores ``amp`` and always computes fp32,
         # SURVEY App. E), "bf16" (throughput mode), "bf16_w8" (bf16 kernels, fp8-e4m3-rounded conv weights),
         # "fp8" (MX-fp8 3x3 convolutions, BASELINE configs[4]), "fp8_mixed" (fp8 below the top resolution only: 53 dB vs
@@ -421,6 +424,7 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
 
         sub_batch = self.max_tiles_per_launch or batch_size
         grids = (coords0, coords1)
+        lanes = None
         for i in range(num_sample_steps):
             if i < generation_start_steps:
                 continue
@@ -442,7 +446,19 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
                     noise_tiles = _host_randn(self.host_generator, n_tiles, 3, tile_size, tile_size).to(dev, non_blocking=True)
                 if i % 2 == 1:
                     noise_canvas = _host_randn(self.host_generator, 1, 3, hp, wp).to(dev, non_blocking=True)
-            if self.canvas_group is None:
+            n_step = n_tiles * batch
+            n_lanes = lanes_wanted(n_step, passes, sub_batch, self.step_lanes) if self.canvas_group is None else 1
+            if n_lanes > 1:
+                if lanes is None or len(lanes.engines) != n_lanes:   # further engines: same run geometry, own copies of the condition canvas
+                    more = [self.model.engine(precision or self.precision, lane=k) for k in range(1, n_lanes)]
+                    for e_ in more:
+                        e_.sampler_begin(geo, cond01, torch.empty_like(cond_canvas), [(a, c_) for (a, _, c_, _) in coords0],
+                                         [(a, c_) for (a, _, c_, _) in coords1], scalars, log_snrs, class_id)
+                    lanes = StepLanes([eng] + more, dev)
+                lanes.run(n_step, lambda e_, first, count, ring: e_.sampler_step_tiles(
+                    i, first, count, ring, img, cond_canvas, x_start, noise_tiles, noise_canvas, passes, kind, scale, sub_batch,
+                    seed=self.device_noise_seed))
+            elif self.canvas_group is None:
                 eng.sampler_step(i, img, cond_canvas, x_start, noise_tiles, noise_canvas, passes, kind, scale, sub_batch,
                                  seed=self.device_noise_seed)
             else:
@@ -584,6 +600,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         self.host_generator = None         # as in the DDPM wrapper: None = torch's global CPU generator
         self.device_noise_seed = 0
         self.max_tiles_per_launch = None
+        self.step_lanes = lanes_setting_from_env()   # as in the DDPM wrapper
         self.precision = "fp32"            # as in the DDPM wrapper
         self.canvas_group = None           # set by srgd_amd.parallel.shard_canvas: tiles of every step split over its ranks
 
@@ -693,6 +710,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
         x0_image_list = [img[:, :, top:bottom, left:right].clone().cpu()] if with_x0_images else None
         work = torch.empty(2, batch, 3, hp, wp, device=dev, dtype=torch.float32)
         sub_batch = self.max_tiles_per_launch or batch_size
+        lanes = None
         for i in range(n):
             if i < generation_start_steps:
                 continue
@@ -709,7 +727,18 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
                 raise IndexError(f"index {i} is out of bounds for dimension 0 with size {len(noised_sigmas)}")
             z = canvas_noise(None) if host_noise else None              # eps of the step (:2386), before the ring draw
             ring = canvas_noise(None) if (host_noise and i % 2 == 1) else None
-            if self.canvas_group is None:
+            n_step = (len(coords1) if i % 2 else len(coords0)) * batch
+            n_lanes = lanes_wanted(n_step, passes, sub_batch, self.step_lanes) if self.canvas_group is None else 1
+            if n_lanes > 1:
+                if lanes is None or len(lanes.engines) != n_lanes:   # further engines (srgd_amd.lanes): same run geometry
+                    more = [self.net.engine(precision or self.precision, lane=k) for k in range(1, n_lanes)]
+                    for e_ in more:
+                        e_.edm_begin(geo, cond01, torch.empty_like(cond_canvas), [(a, c_) for (a, _, c_, _) in coords0],
+                                     [(a, c_) for (a, _, c_, _) in coords1], scalars, c_noise, class_id)
+                    lanes = StepLanes([eng] + more, dev)
+                lanes.run(n_step, lambda e_, first, count, do_ring: e_.edm_step_tiles(
+                    i, first, count, do_ring, img, cond_canvas, x_start, work, z, ring, passes, kind, scale, sub_batch, seed))
+            elif self.canvas_group is None:
                 eng.edm_step(i, img, cond_canvas, x_start, work, z, ring, passes, kind, scale, sub_batch, seed=seed)
             else:
                 from .parallel import sharded_edm_step

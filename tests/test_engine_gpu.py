@@ -153,6 +153,45 @@ def test_result_is_independent_of_batch_size_and_bitwise_repeatable():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
 
 
+def test_two_step_lanes_are_bitwise_identical_to_one():
+    # srgd_amd.lanes: a small step runs as two concurrent halves on two HIP streams through two engines.  Tiles of a step are
+    # independent, so the images must not change - in both noise modes, with and without guidance (two passes per tile), in
+    # the eager and the hipGraph path (device noise, >= 3 steps: direct launch, capture, replay), DDPM and EDM.
+    sampler = build_sampler(16)
+    cond = C.synthetic_lr_condition(0, 256, 256).cuda()          # configs[1] geometry: 25 / 16 tiles per step
+    label = torch.tensor([0]).cuda()
+    keep = sampler.step_lanes
+    try:
+        for noise, scale, prec in (("device", 1.0, "bf16"), ("host", 2.0, "fp32"), ("device", 2.0, "fp8")):
+            sampler.noise_source = noise
+            outs = []
+            for lanes in (1, 2, None):                            # None: automatic (two lanes here: one launch of <= 64 samples)
+                sampler.step_lanes = lanes
+                sampler.device_noise_seed = 5
+                torch.manual_seed(5)
+                outs.append(sampler.tiled_sample(batch_size=25, condition_x=cond, class_label=label, class_cond_scale=scale,
+                                                 num_sample_steps=5, precision=prec).cpu())
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (noise, scale, prec)
+    finally:
+        sampler.step_lanes = keep
+        sampler.noise_source = "host"
+    edm = build_edm_sampler(16)
+    keep = edm.step_lanes
+    try:
+        for noise in ("device", "host"):
+            edm.noise_source = noise
+            outs = []
+            for lanes in (1, 2):
+                edm.step_lanes = lanes
+                edm.device_noise_seed = 9
+                torch.manual_seed(9)
+                outs.append(edm.tiled_sample(batch_size=25, condition_x=cond, class_label=label, num_sample_steps=5, precision="bf16").cpu())
+            assert torch.equal(outs[0], outs[1]), noise
+    finally:
+        edm.step_lanes = keep
+        edm.noise_source = "host"
+
+
 def test_device_noise_mode_full_size_properties():
     # BASELINE config-2 geometry (256^2 LR -> 1024^2, canvas 1280^2, 25/16 tiles), few steps:
     # size-independent properties - output range, determinism per seed, seed sensitivity.

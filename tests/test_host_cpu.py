@@ -273,3 +273,14 @@ def test_edm_step_tables_accept_more_call_steps_than_constructor_steps():
                 assert math.isnan(s.ring_sigma)                            # tiled_sample raises IndexError at this step
     _, _, scalars, _ = edm._step_tables(8, True)                            # in range: every odd step carries its sigma
     assert all(s.ring_sigma > 0 for s in scalars[1::2])
+
+
+def test_step_lanes_rule():
+    # srgd_amd.lanes: two concurrent halves only when the whole step is ONE launch of at most 64 samples (tiles x passes)
+    from srgd_amd.lanes import lanes_wanted
+    assert lanes_wanted(25, 1, 25, None) == 2 and lanes_wanted(16, 1, 25, None) == 2        # configs[1], one HR tile
+    assert lanes_wanted(25, 2, 25, None) == 2                                                # configs[4]: 50 samples
+    assert lanes_wanted(125, 1, 125, None) == 1                                              # five tiles in lock-step
+    assert lanes_wanted(25, 1, 4, None) == 1                                                 # several launches per step
+    assert lanes_wanted(1, 1, 4, None) == 1 and lanes_wanted(1, 1, 4, 2) == 1                # a single tile cannot be split
+    assert lanes_wanted(125, 1, 125, 2) == 2 and lanes_wanted(25, 1, 25, 1) == 1             # forced

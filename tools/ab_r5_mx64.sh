@@ -1,0 +1,12 @@
+# Round 5: conv3x3_mxfp8 with two taps x 64 channels per MFMA and double-buffered halo patches against the 128-channel-chunk kernel
+# (variants/libsrgd_hip_base_mx128.so), one box: kernel tests, per-shape bench, whole bench (configs[4] fp8)
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r5_mx64; mkdir -p $O
+V=$PWD/srgd_amd/variants
+timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "mxfp8 or fp8 or quant" > $O/pytest_kernels.log 2>&1; echo "rc=$?" >> $O/pytest_kernels.log; tail -5 $O/pytest_kernels.log
+grep -q "rc=0" $O/pytest_kernels.log || exit 1
+for R in 1 2; do
+  SRGD_HIP_LIB=$V/libsrgd_hip_base_mx128.so python tools/bench_conv_fp8.py --batch 125 --iters 10 --out $O/base_$R.json > $O/base_$R.txt 2>&1 || { tail $O/base_$R.txt; exit 1; }
+  python tools/bench_conv_fp8.py --batch 125 --iters 10 --out $O/new_$R.json > $O/new_$R.txt 2>&1 || { tail $O/new_$R.txt; exit 1; }
+done
+for R in 1 2; do paste -d'|' $O/base_$R.txt $O/new_$R.txt | grep -v amdgpu.ids | cut -c1-190; done
+[ "$1" = "full" ] && bash tools/ab_bench.sh r5_mx64 base_mx128 default --precision fp8 --ddpm_steps 100 --class_cond_scale 2.0 2>&1 | cut -c1-330

@@ -26,7 +26,7 @@ def run_group(sampler, conds, stream, reps, out):
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    s0, _ = build_sampler(128, dev, 1, 0)
+    s0, _ = build_sampler(128, dev, False, 0)
     s0.noise_source = "device"
     s1 = copy.deepcopy(s0)
     s1.noise_source = "device"
