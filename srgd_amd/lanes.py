@@ -7,8 +7,9 @@ independent (disjoint canvas regions; the odd-step ring lies outside all of them
 ``srgd_amd.parallel`` relies on), so the step is run as two halves on two HIP streams through two engines: while one half
 drains the tail of a kernel, the other half's kernels fill the idle CUs.  Measured on one MI355X (profiles/r5/step_lanes_ab.txt,
 `bench.py --images 1`, same box): one lane 1.231 HR tiles/s, two lanes 1.273 (+3.4 %), three / four lanes 1.184 / 1.183 (the
-parts get too small to fill the chip on the shallow layers); configs[4] fp8 with one HR tile 0.4438 -> 0.4583 (+3.3 %).  Two
-lanes do NOT pay for large steps (125 tiles: 1.334 vs 1.331), which keep one lane.  Results are bit-identical either way
+parts get too small to fill the chip on the shallow layers); configs[4] fp8 with one HR tile 0.4438 -> 0.4583 (+3.3 %).  With
+more HR tiles in lock-step the gain shrinks - 50 tiles per step 1.329 -> 1.365 (+2.8 %), 75: 1.351 -> 1.366 (+1.1 %), 100:
+1.361 -> 1.366 (+0.4 %), 125: 1.334 vs 1.331 - so steps of more than 100 samples keep one lane.  Results are bit-identical either way
 (tests/test_engine_gpu.py::test_two_step_lanes_are_bitwise_identical_to_one).
 
 The second engine is a second instance of the same C-ABI engine (its own scratch, graphs and packed weights); it is created
@@ -18,13 +19,13 @@ from typing import Callable, Optional
 
 import torch
 
-MAX_SAMPLES_FOR_TWO_LANES = 64      # tiles x guidance passes of one launch
+MAX_SAMPLES_FOR_TWO_LANES = 100     # tiles x guidance passes of one launch
 MAX_LANES = 2                       # three and four lanes measured 4 % SLOWER than one (25 tiles per step)
 
 
 def lanes_wanted(n_tiles: int, passes: int, sub_batch: int, setting: Optional[int]) -> int:
     """Number of concurrent lanes of a step.  ``setting``: None = automatic (two lanes when the whole step is ONE launch of at
-    most 64 samples), an integer = forced (never more lanes than tiles)."""
+    most 100 samples), an integer = forced (never more lanes than tiles)."""
     if n_tiles < 2:
         return 1
     if setting is not None:

@@ -165,7 +165,7 @@ def test_two_step_lanes_are_bitwise_identical_to_one():
         for noise, scale, prec in (("device", 1.0, "bf16"), ("host", 2.0, "fp32"), ("device", 2.0, "fp8")):
             sampler.noise_source = noise
             outs = []
-            for lanes in (1, 2, None):                            # None: automatic (two lanes here: one launch of <= 64 samples)
+            for lanes in (1, 2, None):                            # None: automatic (two lanes here: one launch of <= 100 samples)
                 sampler.step_lanes = lanes
                 sampler.device_noise_seed = 5
                 torch.manual_seed(5)

@@ -276,11 +276,12 @@ def test_edm_step_tables_accept_more_call_steps_than_constructor_steps():
 
 
 def test_step_lanes_rule():
-    # srgd_amd.lanes: two concurrent halves only when the whole step is ONE launch of at most 64 samples (tiles x passes)
+    # srgd_amd.lanes: two concurrent halves only when the whole step is ONE launch of at most 100 samples (tiles x passes)
     from srgd_amd.lanes import lanes_wanted
     assert lanes_wanted(25, 1, 25, None) == 2 and lanes_wanted(16, 1, 25, None) == 2        # configs[1], one HR tile
     assert lanes_wanted(25, 2, 25, None) == 2                                                # configs[4]: 50 samples
-    assert lanes_wanted(125, 1, 125, None) == 1                                              # five tiles in lock-step
+    assert lanes_wanted(100, 1, 100, None) == 2 and lanes_wanted(125, 1, 125, None) == 1     # four / five HR tiles in lock-step
+    assert lanes_wanted(75, 2, 75, None) == 1                                                # 150 samples
     assert lanes_wanted(25, 1, 4, None) == 1                                                 # several launches per step
     assert lanes_wanted(1, 1, 4, None) == 1 and lanes_wanted(1, 1, 4, 2) == 1                # a single tile cannot be split
     assert lanes_wanted(125, 1, 125, 2) == 2 and lanes_wanted(25, 1, 25, 1) == 1             # forced
