@@ -42,8 +42,11 @@ TFLOP_PER_HR_TILE = 813.6          # BASELINE.md section 3 (1,025 tile-forwards 
 TILE_FORWARDS_PER_HR_TILE = 1025
 PMC_TRAFFIC_FILE = "r5_pmc_traffic.json"     # newest committed PMC summary (tools/pmc_traffic.py)
 # MI355X_MICROARCH.md: dense MFMA peaks of the dominant kernel's instruction (fp8 = block-scaled MX e4m3, 2x the bf16 rate)
-PEAK_TFLOPS = {"conv3x3_bf16": 2500.0, "conv3x3_mxfp8": 5000.0, "conv_igemm:bf16": 2500.0, "conv_igemm:fp32": 157.3}
-KERNEL_OF = {"conv3x3_bf16": "conv3x3_bf16_kernel", "conv3x3_mxfp8": "conv3x3_mxfp8_kernel", "conv_igemm": "conv_igemm_kernel"}
+# conv3x3_split (f16x3 mode): the f16 MFMA peak; the kernel issues THREE MFMAs per algorithmic product, so its algorithmic ceiling is
+# a third of it (roofline.mfma_per_product, roofline.frac_of_issue_peak)
+PEAK_TFLOPS = {"conv3x3_bf16": 2500.0, "conv3x3_mxfp8": 5000.0, "conv3x3_split": 2500.0, "conv_igemm:bf16": 2500.0, "conv_igemm:fp32": 157.3}
+KERNEL_OF = {"conv3x3_bf16": "conv3x3_bf16_kernel", "conv3x3_mxfp8": "conv3x3_mxfp8_kernel", "conv_igemm": "conv_igemm_kernel",
+             "conv3x3_split": "conv3x3_split_kernel"}
 
 
 def parse():
@@ -57,8 +60,9 @@ def parse():
                     help="tiles: BASELINE configs[1] units, images sharded over ranks (weak scaling, the headline); "
                          "canvas: ONE --lr_size^2 image per step whose tiles are sharded over all ranks with a per-step "
                          "tile all-gather (configs[3] with --lr_size 2048; strong scaling, secondary)")
-    ap.add_argument("--precision", choices=["bf16", "fp32", "bf16_w8", "fp8", "fp8_mixed"], default="bf16",
-                    help="fp8: 3x3 convolutions on the block-scaled MX-fp8 matrix cores, e4m3 weights AND activations with a "
+    ap.add_argument("--precision", choices=["bf16", "fp32", "f16x3", "bf16_w8", "fp8", "fp8_mixed"], default="bf16",
+                    help="f16x3: fp32 tensors, every convolution product as three f16 MFMAs on (hi, lo) operand pairs - meets the 1e-3 "
+                         "parity bar like fp32; fp8: 3x3 convolutions on the block-scaled MX-fp8 matrix cores, e4m3 weights AND activations with a "
                          "scale per 32 channels (BASELINE configs[4] compute path; use with --ddpm_steps 100 "
                          "--class_cond_scale 2.0); fp8_mixed: fp8 below the top resolution, bf16 3x3 convolutions at 256x256 (53 dB vs bf16 "
                          "instead of 34 dB); bf16_w8: bf16 kernels with fp8-e4m3-rounded conv weights (numerics only)")
@@ -379,7 +383,10 @@ def main():
             "forced_dist": force_dist, "tile_allgathers": sampler.canvas_group.exchanges if sampler.canvas_group else 0,
             # per DDPM step of the timed region, max over ranks: pack + all-gather + unpack of the canvas tiles (HIP events on
             # the engine's stream); exchange_share = that / the wall time, i.e. what strong scaling loses to the collective
+            # since round 5 the first half-slice's gather runs on a side stream under the second half's compute: these are the
+            # EXPOSED part only (second half's gather + both unpacks on the compute stream) - not comparable with round 4's
             "exchange_ms": exchange_ms / max(1, args.steps * args.ddpm_steps),
+            "exchange_exposed_ms": exchange_ms / max(1, args.steps * args.ddpm_steps),
             "exchange_share": exchange_ms / (1e3 * dt),
             "exchange_mb_per_step": (3 * 256 * 256 * 4 * ((ne + no) / 2.0) / 1e6) if sampler.canvas_group else 0.0,
             "hr_tile_equivalents_per_s": args.steps * tf / dt / TILE_FORWARDS_PER_HR_TILE,
@@ -387,6 +394,9 @@ def main():
     elif rank == 0:
         tiles = args.steps * n_ranks
         value = tiles / dt
+        n_step = n_even * min(args.images, args.steps)                 # samples of an even step of one lock-step group
+        launch_limit = args.sub_batch or min(125, n_step)              # = sample_local's batch_size
+        step_lanes = lanes_wanted(n_step, 1 if args.class_cond_scale == 1.0 else 2, launch_limit, sampler.step_lanes, args.precision)
         line = {
             "metric": "HR tiles/sec (256->1024 x4, 50 steps, CFG=1.0)", "value": value, "unit": "HR tiles/s",
             "n_gpus": n_ranks, "rccl_ranks": n_ranks, "dist_backend": backend if dist else None, "forced_dist": force_dist,
@@ -394,18 +404,17 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (seeded LR images, seeded weights with the reference state_dict schema)",
-            "config": {"workload": f"{'BASELINE configs[1]' if (args.ddpm_steps == 50 and args.class_cond_scale == 1.0 and args.lr_size == 256 and args.precision == 'bf16') else 'BASELINE configs[4] (MX-fp8 3x3 convolutions: e4m3 weights + activations, E8M0 scale per 32 channels)' if args.precision == 'fp8' else 'BASELINE configs[4], mixed (MX-fp8 3x3 convolutions below the top resolution, bf16 at 256x256)' if args.precision == 'fp8_mixed' else 'BASELINE configs[4] numerics (fp8-rounded weights on bf16 kernels)' if args.precision == 'bf16_w8' else 'variant'}: one {args.lr_size}x{args.lr_size} LR tile x4 SR per step, "
+            "config": {"workload": f"{'BASELINE configs[1]' if (args.ddpm_steps == 50 and args.class_cond_scale == 1.0 and args.lr_size == 256 and args.precision == 'bf16') else 'BASELINE configs[4] (MX-fp8 3x3 convolutions: e4m3 weights + activations, E8M0 scale per 32 channels)' if args.precision == 'fp8' else 'BASELINE configs[4], mixed (MX-fp8 3x3 convolutions below the top resolution, bf16 at 256x256)' if args.precision == 'fp8_mixed' else 'BASELINE configs[4] numerics (fp8-rounded weights on bf16 kernels)' if args.precision == 'bf16_w8' else 'split-operand parity mode (fp32 tensors, three f16 MFMAs per product)' if args.precision == 'f16x3' else 'variant'}: one {args.lr_size}x{args.lr_size} LR tile x4 SR per step, "
                                    f"{args.ddpm_steps} DDPM steps, class_cond_scale={args.class_cond_scale}, dim-{args.dim} U-Net, "
                                    f"{args.precision}, device Philox noise; {min(args.images, args.steps)} steps "
                                    f"(HR tiles) advance in lock-step so their U-Net tiles share launches",
                        "images_in_lockstep": min(args.images, args.steps),
-                       # the engine's balanced-launch rule (engine.hip: cdiv(n, cdiv(n, limit))) for the even-step tile count
-                       "tiles_per_unet_launch": (lambda n, lim: -(-n // -(-n // lim)))(n_even * min(args.images, args.steps),
-                                                                                        args.sub_batch or n_even * min(args.images, args.steps)),
+                       # what the engine really launches: the step's samples split over the lanes (srgd_amd.lanes), each lane's part
+                       # cut by the engine's balanced-launch rule (engine.hip: cdiv(n, cdiv(n, limit))) under the SAME limit
+                       # sample_local passes as batch_size
+                       "step_lanes": step_lanes,
+                       "tiles_per_unet_launch": (lambda n, lim: -(-n // -(-n // lim)))(-(-n_step // step_lanes), launch_limit),
                        "tile_forwards_per_step": TILE_FORWARDS_PER_HR_TILE,
-                       # srgd_amd.lanes: a step that is one small launch runs as two concurrent halves on two HIP streams
-                       "step_lanes": lanes_wanted(n_even * min(args.images, args.steps), 1 if args.class_cond_scale == 1.0 else 2,
-                                                  args.sub_batch or min(125, n_even * min(args.images, args.steps)), sampler.step_lanes),
                        "parallelism": f"image-sharded x{world}"},
             "tflops_effective": value * TFLOP_PER_HR_TILE,
         }
@@ -428,7 +437,7 @@ def main():
             sampler.step_lanes = lanes_setting
             # the dominant kernel: conv3x3_bf16_kernel in bf16 mode, conv3x3_mxfp8_kernel in fp8 mode, the generic implicit
             # GEMM in fp32 mode - whichever convolution family took the most time in the profiled pass
-            fam = max(("conv3x3_bf16", "conv3x3_mxfp8", "conv_igemm"), key=lambda k: prof["ms"].get(k, 0.0))
+            fam = max(("conv3x3_bf16", "conv3x3_mxfp8", "conv3x3_split", "conv_igemm"), key=lambda k: prof["ms"].get(k, 0.0))
             conv_ms, n_launch, fl = prof["ms"][fam], prof["launches"][fam], prof["flops"][fam]
             achieved = fl / (conv_ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS.get(fam) or PEAK_TFLOPS["conv_igemm:" + ("fp32" if args.precision == "fp32" else "bf16")]
@@ -448,7 +457,10 @@ def main():
                                 "avg_launch_ms": conv_ms / max(n_launch, 1),
                                 "algorithmic_gflop_per_launch": fl / max(n_launch, 1) / 1e9,
                                 "family_time_share": conv_ms / sum(prof["ms"].values())}
-            conv_fams = ("conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "conv3x3_mxfp8", "conv1x1_mxfp8")
+            if fam == "conv3x3_split":
+                line["roofline"]["mfma_per_product"] = 3
+                line["roofline"]["frac_of_issue_peak"] = 3.0 * achieved / peak
+            conv_fams = ("conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "conv3x3_mxfp8", "conv1x1_mxfp8", "conv3x3_split", "conv_igemm_split")
             all_conv_ms = sum(prof["ms"].get(k, 0.0) for k in conv_fams)
             line["conv_all_tflops"] = sum(prof["flops"].get(k, 0.0) for k in conv_fams) / (all_conv_ms * 1e-3) / 1e12
             tot = sum(prof["ms"].values())

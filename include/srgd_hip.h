@@ -46,6 +46,14 @@ typedef struct srgd_engine srgd_engine;
                                     * convolutions on the bf16 kernel.  Measured on BASELINE configs[4]: 53.5 dB vs the bf16
                                     * engine (all-fp8: 36.6 dB) at 1.16x its throughput (all-fp8: 1.32x). */
 
+#define SRGD_PRECISION_F16X3 5 /* split-operand precision: fp32 activations, statistics, attention and sampler arithmetic exactly as
+                                * SRGD_PRECISION_FP32; the convolutions (Block.proj model.py:246, res_conv :271, to_qkv / to_out, the
+                                * resamplers) contract on the 16-bit matrix cores with every operand carried as an f16 (hi, lo) pair -
+                                * x*w ~= x_hi*w_hi + x_lo*w_hi + x_hi*w_lo, fp32 accumulate, weights pre-scaled by a power of two
+                                * per layer: 2^-22 per product instead of fp32's 2^-24 (plain bf16: 2^-9).  Meets the 1e-3 parity
+                                * bar like SRGD_PRECISION_FP32 at three 16-bit MFMAs per product instead of the 1/16-rate fp32
+                                * MFMA.  Layers whose input channels are not a multiple of 32 stay on the exact-fp32 kernel. */
+
 /* Constructor arguments of ConditionalSRUnet (model.py:537-556) as get_model passes them
  * (model.py:3504-3514).  Unsupported combinations are rejected by srgd_create. */
 typedef struct srgd_unet_config {

@@ -1,0 +1,49 @@
+"""CPU emulation of the split-operand convolution arithmetic (TEST INFRASTRUCTURE, like everything under oracle/).
+
+The product's f16x3 precision (srgd_amd/csrc/conv3x3_split.hip, conv_igemm.hip) evaluates a convolution on fp32 tensors as
+
+    x = x_hi + x_lo,  w * s = w_hi + w_lo          (hi = 16-bit round-to-nearest of the value, lo = round(value - hi))
+    conv(x, w) ~= [conv(x_hi, w_hi) + conv(x_lo, w_hi) + conv(x_hi, w_lo)] / s             (fp32 accumulation)
+
+with f16 halves and s = the power of two that puts max|w| into [2^10, 2^11) (bf16 halves: s = 1).  A product of two 16-bit values
+is exact in fp32, so three fp32 convolutions on the rounded operands reproduce the three MFMAs up to summation order.  There is
+no reference code for this (the reference computes plain fp32, model.py:246): the emulation pins the KERNELS to the documented
+arithmetic, and tools/split_numerics_study.py uses it to price the precision against the reference's fixtures.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def halves(x: torch.Tensor, kind: str):
+    dt = torch.float16 if kind == "f16" else torch.bfloat16
+    if kind == "f16":
+        x = x.clamp(-65504.0, 65504.0)          # the kernels saturate instead of producing inf - inf
+    hi = x.to(dt).float()
+    lo = (x - hi).to(dt).float()
+    return hi, lo
+
+
+def weight_scale(w: torch.Tensor, kind: str) -> float:
+    if kind != "f16":
+        return 1.0
+    m = float(w.abs().max())
+    if not (m > 0.0) or not math.isfinite(m):
+        return 1.0
+    return 2.0 ** (10 - math.floor(math.log2(m)))
+
+
+def split_conv2d(x, w, b=None, stride=1, padding=0, kind="f16", terms=3, scale=True):
+    s = weight_scale(w, kind) if scale else 1.0
+    wh, wl = halves(w * s, kind)
+    xh, xl = halves(x, kind)
+    y = F.conv2d(xl, wh, None, stride=stride, padding=padding) + F.conv2d(xh, wl, None, stride=stride, padding=padding)
+    if terms == 4:
+        y = y + F.conv2d(xl, wl, None, stride=stride, padding=padding)
+    y = (y + F.conv2d(xh, wh, None, stride=stride, padding=padding)) * (1.0 / s)
+    if b is not None:
+        y = y + b.view(1, -1, 1, 1)
+    return y

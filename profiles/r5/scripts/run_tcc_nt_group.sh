@@ -1,4 +1,6 @@
 # n-tile grouping inside an XCD band (SRGD_CONV3_NT_GROUP): TCC misses, throughput and in-kernel clock on the deep 3x3 layers
+# ARCHIVED (round 6): needs profiles/r5/conv3x3_bf16_nt_group_and_nt_policy_knobs.patch applied - see README.md here.
+grep -q SRGD_CONV3_NT_GROUP srgd_amd/csrc/conv3x3_bf16.hip || { echo "apply profiles/r5/conv3x3_bf16_nt_group_and_nt_policy_knobs.patch first: the knobs this script drives are not in this tree"; exit 1; }
 # (needs the knobs of profiles/r5/conv3x3_bf16_nt_group_and_nt_policy_knobs.patch applied to srgd_amd/csrc/conv3x3_bf16.hip: they were removed after this measurement)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5_tcc2; mkdir -p $O; V=$R/srgd_amd/variants
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,6 @@
 # Round 5 (review item 2): does the weight stream of the deep 3x3 layers stay in the XCDs' L2?  TCC hit / miss and fabric read
+# ARCHIVED (round 6): needs profiles/r5/conv3x3_bf16_nt_group_and_nt_policy_knobs.patch applied - see README.md here.
+grep -q SRGD_CONV3_NT_GROUP srgd_amd/csrc/conv3x3_bf16.hip || { echo "apply profiles/r5/conv3x3_bf16_nt_group_and_nt_policy_knobs.patch first: the knobs this script drives are not in this tree"; exit 1; }
 # (needs the knobs of profiles/r5/conv3x3_bf16_nt_group_and_nt_policy_knobs.patch applied to srgd_amd/csrc/conv3x3_bf16.hip: they were removed after this measurement)
 # requests of conv3x3_bf16_kernel on 1024 -> 1024 @32^2 (18.9 MB of weights, 125 tiles) for: production tile map; n-tiles pinned
 # to XCDs (SRGD_CONV3_XCD_PIN_KB=1024); pinned + non-temporal halo DMAs and output stores (variant build `nt`); next to the

@@ -238,6 +238,8 @@ enum KClass {
   KC_CONVQ,        // conv3x3_mxfp8_kernel: block-scaled MX-fp8 3x3 convolution (fp8 mode)
   KC_QUANT,        // bf16 -> MX-fp8 quantisation passes (fp8 mode)
   KC_CONV1Q,       // conv1x1_mxfp8_kernel: pointwise layers on the MX matrix cores (fp8 mode)
+  KC_CONV3S,       // conv3x3_split_kernel: 3x3 convolutions in split-operand precision (f16x3 mode)
+  KC_CONVS,        // conv_igemm_split_kernel: the other convolutions of the f16x3 mode
   KC_COUNT
 };
 

@@ -1,0 +1,464 @@
+// 3x3 / stride 1 / pad 1 convolution in SPLIT-OPERAND precision for gfx950 (MI355X): fp32 activations and fp32 results in HBM,
+// the contraction on the 16-bit matrix cores with every operand carried as a (hi, lo) pair of 16-bit values,
+//     x = x_hi + x_lo,   w = w_hi + w_lo,   x * w ~= x_hi * w_hi + x_lo * w_hi + x_hi * w_lo      (fp32 accumulate),
+// i.e. three v_mfma_f32_16x16x32_{f16,bf16} per fragment pair.  The dropped x_lo * w_lo term and the rounding of the lo halves are
+// 2^-22 (f16 halves, 11 + 11 significand bits) or 2^-16 (bf16 halves) of a product - against 2^-9 for plain bf16 operands.
+// The purpose: a precision that meets the reference's 1e-3 parity bar (reference Block.proj, model.py:246,
+// computes in fp32) at a third of the bf16 MFMA rate instead of the 1/16 of the exact-fp32 MFMA (conv_igemm.hip).
+//
+// Same implicit GEMM and the same LDS images as conv3x3_bf16.hip (M = an 8 x 32 pixel patch, N = 128 output channels, K walked
+// channel-chunk-major with the (8+2) x (32+2) halo patch of a 32-channel chunk staged once for all nine taps; 64-byte LDS rows,
+// XOR-swizzled; weights as srcA so that the epilogue is register-direct), with these differences:
+//   * the halo patch arrives as fp32 through VGPRs (buffer_load_dwordx4, out-of-image pixels zero-filled by the descriptor's range
+//     check), is split in registers (v_cvt_pk + v_sub: ~3 VALU per element, 24 elements per thread and chunk against 432 MFMAs per
+//     wave and chunk) and written to LDS as TWO 16-bit images (hi | lo) in the bf16 kernel's layout;
+//   * the weights are split once on the host (pack_conv3x3_split): per K-step one 16 KB unit = hi tile | lo tile, each already in
+//     its swizzled LDS image, streamed by LDS-DMA into a 3-deep ring exactly as in the bf16 kernel.  f16 halves: the whole weight
+//     tensor is scaled by a power of two so that max|w| sits at 2^10 (w_lo then stays clear of f16's subnormal range); the
+//     epilogue multiplies the accumulators by the inverse (exact);
+//   * LDS: 2 x (24 + 24) KB of A + 3 x 16 KB of B = 144 KB - one 512-thread workgroup per CU, two waves per SIMD, up to 256
+//     VGPRs per wave (64 accumulators + 64 operand-fragment registers + 24 staging registers);
+//   * epilogue: + bias, fp32 stores (four 16-byte stores per 16-pixel block straight from the accumulators), GroupNorm partial sums
+//     in the bf16 kernel's slot layout (conv3x3_bf16_stats_slots applies).
+// Roofline: MFMA.  3 x (2 * 9 * Cin * Cout) FLOP of 16-bit MFMA work per output pixel; counted as ALGORITHMIC flops (one product
+// per multiply-add) the ceiling is 2.5 PF / 3 = 833 TFLOP/s.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "kernels.hpp"
+
+namespace srgd {
+namespace {
+
+constexpr int PH = 8, PW = 32;                 // output patch
+constexpr int HP = PH + 2, WP = PW + 2;        // halo patch: 10 x 34 = 340 pixels
+constexpr int KC = 32;                         // channels per chunk (64-byte rows of 16-bit values)
+constexpr int BN3 = 128;
+constexpr int NT3 = 512;
+constexpr int A_IMG = 24 * 1024;               // one 16-bit halo image (340 px * 64 B = 21,760 used; 1,536 16-byte pieces)
+constexpr int A_BUF = 2 * A_IMG;               // hi | lo
+constexpr int B_TILE = BN3 * KC * 2;           // 8 KiB: one 16-bit weight tile
+constexpr int B_SLOT = 2 * B_TILE;             // hi | lo
+constexpr int LDS_BYTES = 2 * A_BUF + 3 * B_SLOT;   // 147,456: one workgroup per CU
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct Split3Args {
+  const float* in0; const float* in1; int C0, C1;
+  int B, H, W;
+  const void* w;          // pack_conv3x3_split
+  const float* bias;
+  float w_inv_scale;      // 1 / (power-of-two weight scale)
+  int Cout;
+  float* out;
+  float* gn_partial; int groups;
+};
+
+#define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define BARRIER()                        \
+  do {                                   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+
+__device__ __forceinline__ int row_swz(int row) { return (row >> 1) & 3; }
+
+// 8 fp32 -> 8 hi + 8 lo 16-bit values (each a 16-byte vector).  F16: values beyond f16's range saturate (finite garbage instead
+// of inf - inf = NaN; activations on this path are O(1..100)).
+template <bool F16>
+__device__ __forceinline__ void split8(const u32x4& r0, const u32x4& r1, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a = __builtin_bit_cast(float, k < 2 ? r0[2 * k] : r1[2 * k - 4]);
+    float b = __builtin_bit_cast(float, k < 2 ? r0[2 * k + 1] : r1[2 * k - 3]);
+    if constexpr (F16) {
+      a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+      b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+      const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+      const f32x2 hf = __builtin_convertvector(h, f32x2);
+      const f16x2 l = __builtin_convertvector(f32x2{a - hf[0], b - hf[1]}, f16x2);
+      hi[k] = __builtin_bit_cast(unsigned, h);
+      lo[k] = __builtin_bit_cast(unsigned, l);
+    } else {
+      const bf16x2 h = __builtin_convertvector(f32x2{a, b}, bf16x2);
+      const unsigned hb = __builtin_bit_cast(unsigned, h);
+      const float h0 = __uint_as_float(hb << 16), h1 = __uint_as_float(hb & 0xffff0000u);
+      const bf16x2 l = __builtin_convertvector(f32x2{a - h0, b - h1}, bf16x2);
+      hi[k] = hb;
+      lo[k] = __builtin_bit_cast(unsigned, l);
+    }
+  }
+}
+
+template <bool STATS, bool F16>
+__global__ __launch_bounds__(NT3, 2) void conv3x3_split_kernel(Split3Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, q16 = lane >> 4;
+
+  // ---- tile coordinates: the bf16 kernel's XCD-aware map (each XCD a contiguous band of tiles, n-tiles fastest)
+  const int n_tiles = p.Cout / BN3;
+  const int tiles_x = p.W / PW, tiles_y = p.H / PH;
+  const int m_tiles = p.B * tiles_y * tiles_x;
+  const int nwg = m_tiles * n_tiles;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, rem = nwg & 7, x = wg & 7, k = wg >> 3;
+    wg = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + k;
+  }
+  const int nt = wg % n_tiles, mt = wg / n_tiles;
+  const int b = mt / (tiles_y * tiles_x);
+  const int trem = mt - b * tiles_y * tiles_x;
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int y0 = ty * PH, x0 = tx * PW;
+  const int Cin = p.C0 + p.C1;
+  const int CC = Cin / KC;
+
+  // ---- A staging: 1,536 16-byte LDS pieces per image (1,360 used); thread t owns pieces t, t + 512, t + 1024.  Piece g = halo
+  // pixel P = g >> 2, stored chunk position g & 3, which holds SOURCE chunk (g & 3) ^ row_swz(P) (8 channels = 32 bytes of fp32).
+  int a_pix0, a_pix1, a_pix2;
+#define K_A_DECL(J)                                                           \
+  {                                                                           \
+    const int g = tid + NT3 * J;                                              \
+    const int P = g >> 2;                                                     \
+    const int py = P / WP, px = P - py * WP;                                  \
+    const int y = y0 + py - 1, x = x0 + px - 1;                               \
+    const bool ok = P < HP * WP && y >= 0 && y < p.H && x >= 0 && x < p.W;    \
+    a_pix##J = ok ? y * p.W + x : -1;                                         \
+  }
+  K_A_DECL(0) K_A_DECL(1) K_A_DECL(2)
+#undef K_A_DECL
+  // (tid + 512 J) >> 2 = (tid >> 2) + 128 J and 128 J vanishes from row_swz: one source chunk for the three pieces
+  const int a_sub = (tid & 3) ^ row_swz(tid >> 2);
+  const size_t img_elems0 = (size_t)p.H * p.W * p.C0, img_elems1 = (size_t)p.H * p.W * p.C1;
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (size_t)b * img_elems0), 0, (int)(img_elems0 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.in1 ? p.in1 + (size_t)b * img_elems1 : p.in0), 0, p.in1 ? (int)(img_elems1 * 4) : 0, 0x00020000);
+  const size_t w_tile_stride = (size_t)n_tiles * B_SLOT;              // bytes between consecutive (tap, cc) units
+  const char* w_base = (const char*)p.w + (size_t)nt * B_SLOT;
+  const __amdgpu_buffer_rsrc_t rsw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, (int)((size_t)(9 * CC - 1) * w_tile_stride + B_SLOT), 0x00020000);
+
+  char* const sA0 = smem;
+  char* const sB0 = smem + 2 * A_BUF;
+
+  // fp32 halo pieces of the NEXT chunk in flight (24 registers)
+  u32x4 ra00, ra01, ra10, ra11, ra20, ra21;
+  auto load_piece = [&](int cc, int a_pix, u32x4& lo16, u32x4& hi16) {
+    const int c = cc * KC;
+    const bool first = c < p.C0;
+    const int Cs = first ? p.C0 : p.C1;
+    const int coff = first ? c : c - p.C0;
+    const int voff = a_pix >= 0 ? (a_pix * Cs + coff + a_sub * 8) * 4 : 0x7ffffff0;
+    if (first) {
+      lo16 = __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, 0, 0);
+      hi16 = __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, 16, 0);
+    } else {
+      lo16 = __builtin_amdgcn_raw_buffer_load_b128(rs1, voff, 0, 0);
+      hi16 = __builtin_amdgcn_raw_buffer_load_b128(rs1, voff, 16, 0);
+    }
+  };
+  auto load_a = [&](int cc) {
+    load_piece(cc, a_pix0, ra00, ra01);
+    load_piece(cc, a_pix1, ra10, ra11);
+    load_piece(cc, a_pix2, ra20, ra21);
+  };
+  auto store_piece = [&](int cc, int j, const u32x4& r0, const u32x4& r1) {
+    u32x4 hi, lo;
+    split8<F16>(r0, r1, hi, lo);
+    char* dst = sA0 + (cc & 1) * A_BUF + (tid + NT3 * j) * 16;
+    *reinterpret_cast<u32x4*>(dst) = hi;
+    *reinterpret_cast<u32x4*>(dst + A_IMG) = lo;
+  };
+  // K-step (cc, tap) -> weight unit (tap, cc) into ring slot tap % 3 (9 % 3 == 0); every wave copies 1 KiB of the hi tile and
+  // 1 KiB of the lo tile.  `tap` is a compile-time constant (0..10: 9 and 10 are taps 0 and 1 of the next chunk).
+  const int w_tap_stride = (int)(CC * w_tile_stride);
+  const int tid16 = tid * 16;
+  auto issue_b = [&](int cc, int tap) {
+    if (tap >= 9) { tap -= 9; cc += 1; }
+    char* dst = sB0 + (tap % 3) * B_SLOT + wave * 1024;
+    const int so = tap * w_tap_stride + cc * (int)w_tile_stride;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)dst, 16, tid16, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(dst + B_TILE), 16, tid16, so + B_TILE, 0, 0);
+  };
+
+  f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c10 = 0, c11 = 0, c12 = 0, c13 = 0,
+        c20 = 0, c21 = 0, c22 = 0, c23 = 0, c30 = 0, c31 = 0, c32 = 0, c33 = 0;
+
+  // operand addresses: conv3x3_bf16.hip's (weight row n = wn*64 + j*16 + r16, chunk q16; halo pixel P = lp + Pc)
+  const int b_base = (wn * 64 + r16) * 64 + ((q16 ^ row_swz(r16)) << 4);
+  const int lp = 2 * wm * WP + r16, lp8 = lp << 3, lp64 = lp * 64, q16s = q16 << 4;
+  auto a_addr = [&](int tap, int i) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int Pc = ((i >> 1) + dy) * WP + (i & 1) * 16 + dx;
+    return lp64 + (((lp8 + Pc * 8) & 0x30) ^ q16s) + Pc * 64;
+  };
+  typedef u32x4 frag;      // 8 x 16-bit
+  auto mma = [&](f32x4& c, const frag& wt, const frag& px) {
+    if constexpr (F16) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wt), __builtin_bit_cast(f16x8, px), c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wt), __builtin_bit_cast(bf16x8, px), c, 0, 0, 0);
+  };
+  auto compute = [&](int cc, int tap) {
+    const char* A = sA0 + (cc & 1) * A_BUF;
+    const char* Bt = sB0 + (tap % 3) * B_SLOT;
+    const frag bh0 = *reinterpret_cast<const frag*>(Bt + b_base), bh1 = *reinterpret_cast<const frag*>(Bt + b_base + 1024),
+               bh2 = *reinterpret_cast<const frag*>(Bt + b_base + 2048), bh3 = *reinterpret_cast<const frag*>(Bt + b_base + 3072);
+    const frag bl0 = *reinterpret_cast<const frag*>(Bt + B_TILE + b_base), bl1 = *reinterpret_cast<const frag*>(Bt + B_TILE + b_base + 1024),
+               bl2 = *reinterpret_cast<const frag*>(Bt + B_TILE + b_base + 2048), bl3 = *reinterpret_cast<const frag*>(Bt + B_TILE + b_base + 3072);
+#define K_ROW(I, C0_, C1_, C2_, C3_)                                                          \
+  {                                                                                            \
+    const frag ah = *reinterpret_cast<const frag*>(A + a_addr(tap, I));                        \
+    const frag al = *reinterpret_cast<const frag*>(A + A_IMG + a_addr(tap, I));                \
+    mma(C0_, bh0, al); mma(C1_, bh1, al); mma(C2_, bh2, al); mma(C3_, bh3, al);                \
+    mma(C0_, bl0, ah); mma(C1_, bl1, ah); mma(C2_, bl2, ah); mma(C3_, bl3, ah);                \
+    mma(C0_, bh0, ah); mma(C1_, bh1, ah); mma(C2_, bh2, ah); mma(C3_, bh3, ah);                \
+  }
+    K_ROW(0, c00, c01, c02, c03)
+    K_ROW(1, c10, c11, c12, c13)
+    K_ROW(2, c20, c21, c22, c23)
+    K_ROW(3, c30, c31, c32, c33)
+#undef K_ROW
+  };
+
+  // ---- prologue: A(0) through registers, B[0], B[1]
+  issue_b(0, 0);
+  issue_b(0, 1);
+  load_a(0);
+  store_piece(0, 0, ra00, ra01);
+  store_piece(0, 1, ra10, ra11);
+  store_piece(0, 2, ra20, ra21);
+  WAIT_VM(2);                                    // B[0] landed (B[1]'s two copies may still fly)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BARRIER();
+
+  // ---- main loop.  Per K-step s = (cc, tap): issue B[s+2]; tap 0 additionally issues the six fp32 loads of chunk cc+1 (after the
+  // weight copies: they are then younger than B[s+2] and the counted waits of taps 0 and 1 let them fly); compute(s); taps 3..5 split
+  // one piece each into the other A buffer; wait until B[s+1] has landed; barrier.
+  // vmcnt bookkeeping (loads retire in order): at the end of tap t the requests younger than B[s+1] are
+  //   tap 0: B[s+2] (2) + A (6) = 8;   tap 1: A (6) + B[s+2] (2) = 8;   taps 2..8: B[s+2] (2)   (tap 2's wait retires the A loads).
+  for (int cc = 0; cc < CC - 1; ++cc) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      issue_b(cc, tap + 2);
+      if (tap == 0) {
+        __builtin_amdgcn_sched_barrier(0);         // the six loads stay BEHIND the weight copies (the counted waits assume it)
+        load_a(cc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      compute(cc, tap);
+      if (tap == 3) store_piece(cc + 1, 0, ra00, ra01);
+      if (tap == 4) store_piece(cc + 1, 1, ra10, ra11);
+      if (tap == 5) store_piece(cc + 1, 2, ra20, ra21);
+      if (tap < 2) WAIT_VM(8); else WAIT_VM(2);
+      if (tap == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's A pieces are in LDS before the barrier publishes them
+      BARRIER();
+    }
+  }
+  {
+    const int cc = CC - 1;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 7) issue_b(cc, tap + 2);
+      compute(cc, tap);
+      if (tap < 7) WAIT_VM(2); else WAIT_VM(0);
+      if (tap < 8) BARRIER();
+    }
+  }
+
+  // ------------------------------- epilogue (register-direct, fp32) --------------------------
+  // Accumulator block (mi, J), register e of lane (r16, g) = pixel (patch row 2 wm + (mi >> 1), x = 16 (mi & 1) + r16), output channel
+  // 64 wn + 16 g + 4 J + e (regepi_row_channel): a lane's sixteen registers of a pixel block are 16 consecutive channels = 64 bytes.
+  const int chw = nt * BN3 + wn * 64;
+  const int chl = q16 * 16;
+  f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0, bs2 = bs0, bs3 = bs0;
+  if (p.bias) {
+    const float* bp = p.bias + chw + chl;
+    bs0 = *reinterpret_cast<const f32x4*>(bp);
+    bs1 = *reinterpret_cast<const f32x4*>(bp + 4);
+    bs2 = *reinterpret_cast<const f32x4*>(bp + 8);
+    bs3 = *reinterpret_cast<const f32x4*>(bp + 12);
+  }
+  const u32x4 rso = make_raw_rsrc(p.out + ((size_t)(b * p.H + y0 + 2 * wm) * p.W + x0) * p.Cout + chw, (unsigned)(2 * p.W * p.Cout * 4));
+  const int o_voff = (r16 * p.Cout + chl) * 4;
+  const float ws = p.w_inv_scale;
+  f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = s1v;
+  asm volatile("" : "+v"(bs0), "+v"(bs1), "+v"(bs2), "+v"(bs3));
+#define K_EMIT(MI, C0_, C1_, C2_, C3_)                                                          \
+  do {                                                                                             \
+    const int so_ = ((((MI) >> 1) * p.W + ((MI) & 1) * 16) * p.Cout) * 4;                          \
+    const f32x4 v0 = C0_ * ws + bs0, v1 = C1_ * ws + bs1, v2 = C2_ * ws + bs2, v3 = C3_ * ws + bs3; \
+    if (STATS) {                                                                                   \
+      s1v += (v0 + v1) + (v2 + v3);                                                                \
+      s2v = __builtin_elementwise_fma(v0, v0, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v1, v1, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v2, v2, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v3, v3, s2v);                                                \
+    }                                                                                              \
+    buffer_store16(__builtin_bit_cast(u32x4, v0), rso, o_voff, so_);                               \
+    buffer_store16(__builtin_bit_cast(u32x4, v1), rso, o_voff, so_ + 16);                          \
+    buffer_store16(__builtin_bit_cast(u32x4, v2), rso, o_voff, so_ + 32);                          \
+    buffer_store16(__builtin_bit_cast(u32x4, v3), rso, o_voff, so_ + 48);                          \
+  } while (0)
+  K_EMIT(0, c00, c01, c02, c03);
+  K_EMIT(1, c10, c11, c12, c13);
+  K_EMIT(2, c20, c21, c22, c23);
+  K_EMIT(3, c30, c31, c32, c33);
+#undef K_EMIT
+  if (STATS) {
+    // same slot layout and reduction order as conv3x3_bf16.hip (gn_finalize sums the slots in index order)
+    const int cpg = p.Cout / p.groups;                    // 16, 32, 64 or a multiple of 128
+    float a1 = row16_sum((s1v[0] + s1v[1]) + (s1v[2] + s1v[3]));
+    float a2 = row16_sum((s2v[0] + s2v[1]) + (s2v[2] + s2v[3]));
+    if (cpg >= 32) { a1 = xor16_sum(a1); a2 = xor16_sum(a2); }
+    if (cpg >= 64) { a1 = xor32_sum(a1); a2 = xor32_sum(a2); }
+    const int rows_per_group = cpg >= 64 ? 4 : cpg >> 4;
+    if (r16 == 0 && (q16 & (rows_per_group - 1)) == 0) {
+      const int tpg = cpg >= BN3 ? cpg / BN3 : 1;
+      const int wpt = cpg >= BN3 ? 8 : 4;
+      const int nslots = tiles_y * tiles_x * tpg * wpt;
+      const int slot = (trem * tpg + (cpg >= BN3 ? nt % tpg : 0)) * wpt + (cpg >= BN3 ? wave : wm);
+      const int g = cpg >= BN3 ? chw / cpg : (chw + chl) >> __builtin_ctz(cpg);
+      float* dst = p.gn_partial + ((size_t)(b * p.groups + g) * nslots + slot) * 2;
+      *reinterpret_cast<f32x2*>(dst) = f32x2{a1, a2};
+    }
+  }
+}
+
+}  // namespace
+
+bool conv3x3_split_eligible(const ConvArgs& a) {
+  if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.mode != CONV_PLAIN || a.residual || a.gn_res_src) return false;
+  if (a.ps0 != a.C0 || (a.C1 && a.ps1 != a.C1)) return false;
+  if (a.C0 % KC || a.C1 % KC || a.Cout % BN3 || a.Cout != a.CoutPad) return false;
+  if (a.Hin % PH || a.Win % PW) return false;
+  if (a.gn_partial) {
+    const int cpg = a.Cout / a.groups;
+    if (a.Cout % a.groups) return false;
+    if (!(cpg == 16 || cpg == 32 || cpg == 64 || cpg % BN3 == 0)) return false;
+  }
+  if ((size_t)a.Hin * a.Win * (size_t)std::max(a.C0, a.C1) * 4 >= (1ull << 31)) return false;
+  if ((size_t)a.Hin * a.Win * (size_t)a.Cout * 4 >= (1ull << 31)) return false;
+  if ((size_t)9 * ((a.C0 + a.C1) / KC) * (a.Cout / BN3) * B_SLOT >= (1ull << 31)) return false;
+  return true;
+}
+
+// ---- host-side split of the weights ---------------------------------------------------------------------------------------------
+// f16: round-to-nearest-even conversion of a float (finite, |x| < 65520) to IEEE binary16 bits, subnormals kept.
+static unsigned short f32_to_f16_host(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const uint32_t au = u & 0x7fffffffu;
+  if (au >= 0x7f800000u) return (unsigned short)(sign | (au > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (au >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);           // >= 65520 rounds to infinity
+  if (au < 0x33000001u) return (unsigned short)sign;                        // <= 2^-25: rounds to zero
+  int e = (int)(au >> 23) - 127;
+  uint32_t m = (au & 0x7fffffu) | 0x800000u;                                // 24-bit significand
+  int shift;                                                                // bits to drop
+  uint32_t base;
+  if (e >= -14) { shift = 13; base = (uint32_t)(e + 15) << 10; m &= 0x7fffffu; }
+  else { shift = 13 + (-14 - e); base = 0; }                                // subnormal: keep the leading bit in m
+  const uint32_t keep = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  uint32_t h = base + keep;
+  if (rem > half || (rem == half && (keep & 1u))) h += 1;                   // carries into the exponent correctly
+  return (unsigned short)(sign | h);
+}
+static float f16_bits_to_f32(unsigned short h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  const int e = (h >> 10) & 31;
+  const uint32_t m = h & 0x3ffu;
+  float v;
+  if (e == 0) v = std::ldexp((float)m, -24);
+  else if (e == 31) v = m ? NAN : INFINITY;
+  else v = std::ldexp((float)(m | 0x400u), e - 25);
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  u |= sign;
+  std::memcpy(&v, &u, 4);
+  return v;
+}
+static float bf16_bits_to_f32(unsigned short h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float v;
+  std::memcpy(&v, &u, 4);
+  return v;
+}
+
+// The weight scale of a layer: the power of two that puts max|w| into [2^10, 2^11) for f16 halves (w_lo = w - w_hi then sits at
+// 2^-1 or above for the largest weights and loses nothing to f16's subnormal spacing of 2^-24 until |w| is 2^-13 of the maximum);
+// 1 for bf16 halves (fp32's exponent range).
+float split_weight_scale(const float* w, size_t n, bool f16) {
+  if (!f16) return 1.0f;
+  float m = 0.f;
+  for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(w[i]));
+  if (!(m > 0.f) || !std::isfinite(m)) return 1.0f;
+  int e;
+  (void)std::frexp(m, &e);                       // m = f * 2^e, f in [0.5, 1)  ->  floor(log2 m) = e - 1
+  return std::ldexp(1.0f, 10 - (e - 1));
+}
+void split_halves_host(float v, bool f16, unsigned short* hi, unsigned short* lo) {
+  if (f16) {
+    *hi = f32_to_f16_host(v);
+    *lo = f32_to_f16_host(v - f16_bits_to_f32(*hi));
+  } else {
+    *hi = f32_to_bf16_host(v);
+    *lo = f32_to_bf16_host(v - bf16_bits_to_f32(*hi));
+  }
+}
+
+// OIHW fp32 -> [tap][cc][ntile][hi tile | lo tile], each tile 128 rows x 64 B in conv3x3_bf16's swizzled LDS image and row order
+void pack_conv3x3_split(const float* src_oihw, int Cin, int Cout, bool f16, float scale, std::vector<unsigned short>& out) {
+  const int CC = Cin / KC, NTL = Cout / BN3;
+  out.assign((size_t)9 * CC * NTL * 2 * BN3 * KC, 0);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int cc = 0; cc < CC; ++cc)
+      for (int nt = 0; nt < NTL; ++nt) {
+        unsigned short* hi_t = out.data() + ((size_t)(tap * CC + cc) * NTL + nt) * 2 * BN3 * KC;
+        unsigned short* lo_t = hi_t + BN3 * KC;
+        for (int n = 0; n < BN3; ++n)
+          for (int c = 0; c < 4; ++c) {
+            const int cs = c ^ ((n >> 1) & 3);
+            for (int e = 0; e < 8; ++e) {
+              const int ci = cc * KC + c * 8 + e, o = nt * BN3 + regepi_row_channel(n);
+              const float v = src_oihw[(((size_t)o * Cin + ci) * 3 + tap / 3) * 3 + tap % 3] * scale;
+              split_halves_host(v, f16, &hi_t[n * KC + cs * 8 + e], &lo_t[n * KC + cs * 8 + e]);
+            }
+          }
+      }
+}
+
+int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bool f16, hipStream_t st) {
+  if (!conv3x3_split_eligible(a)) SRGD_FAIL("conv3x3_split: shape not eligible");
+  if (a.bias && ((size_t)a.bias & 15)) SRGD_FAIL("conv3x3_split: the bias array must be 16-byte aligned");
+  Split3Args p;
+  p.in0 = (const float*)a.in0; p.in1 = (const float*)a.in1; p.C0 = a.C0; p.C1 = a.C1;
+  p.B = a.B; p.H = a.Hin; p.W = a.Win; p.w = packed_w; p.bias = a.bias; p.w_inv_scale = w_inv_scale; p.Cout = a.Cout;
+  p.out = (float*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
+  const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
+  static bool attr_set[64] = {};
+  if (DeviceSetup once(attr_set); once.need) {
+#define K_SET(S_, F_)                                                                                  \
+  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<S_, F_>),              \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    K_SET(true, true) K_SET(false, true) K_SET(true, false) K_SET(false, false)
+#undef K_SET
+    once.done();
+  }
+  const bool stats = a.gn_partial != nullptr;
+#define K_GO(S_, F_) hipLaunchKernelGGL((conv3x3_split_kernel<S_, F_>), dim3(grid), dim3(NT3), LDS_BYTES, st, p)
+  if (stats && f16) K_GO(true, true); else if (stats) K_GO(true, false);
+  else if (f16) K_GO(false, true); else K_GO(false, false);
+#undef K_GO
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace srgd

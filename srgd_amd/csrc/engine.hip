@@ -114,6 +114,9 @@ struct ConvW {
   void* w1 = nullptr;         // conv1x1_bf16 packing (bf16 mode: 1x1 / pixel-shuffle / space-to-depth layers)
   void* wq = nullptr;         // conv3x3_mxfp8 packing (fp8 mode: e4m3 weights + E8M0 block scales)
   void* wq1 = nullptr;        // conv1x1_mxfp8 packing (fp8 mode: the pointwise layers whose inputs have MX-fp8 twins)
+  void* ws3 = nullptr;        // conv3x3_split packing (f16x3 mode: (hi, lo) f16 tiles of the scaled weights)
+  void* ws = nullptr;         // conv_igemm_split packing (f16x3 mode: every other layer with Cin % 32 == 0)
+  float ws_inv = 1.f;         // 1 / the layer's power-of-two weight scale (f16x3 mode)
   float* bias = nullptr;
 };
 struct Lin {
@@ -211,7 +214,7 @@ struct ProfRec { int kc; hipEvent_t a, b; };
 
 const char* kFamilyNames[KC_COUNT] = {"conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "init_conv7x7", "groupnorm_silu", "rmsnorm", "linear_attention",
                                       "full_attention", "final_conv_ddpm_step", "canvas_rng", "conditioning", "conv3x3_mxfp8",
-                                      "quantize_mxfp8", "conv1x1_mxfp8"};
+                                      "quantize_mxfp8", "conv1x1_mxfp8", "conv3x3_split", "conv_igemm_split"};
 
 }  // namespace
 }  // namespace srgd
@@ -253,6 +256,7 @@ struct srgd_engine {
   // 1.2931 HR tiles/s, and with gn_apply's hoisted coefficient loads 1.3657 / 1.3677 and 1.3660 / 1.3676 on a faster box: two
   // tiles is ahead by 0.1 % and takes the GroupNorm share from 6.0 to 5.0 % (one HBM pass less over every 256-channel tensor),
   // so the limit is two now.
+  bool split = false;         // SRGD_PRECISION_F16X3: fp32 tensors, convolutions as three f16 MFMAs per product (conv3x3_split.hip)
   bool fp8 = false;           // SRGD_PRECISION_FP8: 3x3 convolutions on the block-scaled MX-fp8 matrix cores, the rest as bf16
   bool w8 = false;            // SRGD_PRECISION_BF16_W8: conv weights rounded through fp8 e4m3 (per-output-channel scale)
   bool no_gn_fusion = false;
@@ -394,8 +398,9 @@ int build_topology(srgd_engine* e) {
   if (c.sinus_dim < 2 || c.sinus_dim % 2) SRGD_FAIL("learned_sinusoidal_dim must be even");
   if (c.dim % 16 != 0) SRGD_FAIL("unet_dim must be a multiple of 16");
   if (c.groups < 1 || c.dim % c.groups != 0) SRGD_FAIL("unet_dim must be divisible by resnet_block_groups");
-  if (c.precision < SRGD_PRECISION_FP32 || c.precision > SRGD_PRECISION_FP8_MIXED) SRGD_FAIL("unknown precision mode");
-  e->bf16 = c.precision != SRGD_PRECISION_FP32;
+  if (c.precision < SRGD_PRECISION_FP32 || c.precision > SRGD_PRECISION_F16X3) SRGD_FAIL("unknown precision mode");
+  e->split = c.precision == SRGD_PRECISION_F16X3;
+  e->bf16 = c.precision != SRGD_PRECISION_FP32 && !e->split;
   e->w8 = c.precision == SRGD_PRECISION_BF16_W8;
   e->fp8 = c.precision == SRGD_PRECISION_FP8 || c.precision == SRGD_PRECISION_FP8_MIXED;
   // mixed mode: the zones at the tile's own resolution (Ctx::zone 0, 2n, 2n+1) stay on the bf16 3x3 kernel - their
@@ -475,6 +480,18 @@ int pack_conv(srgd_engine* e, ConvW& c) {
     std::vector<unsigned short> p3;
     pack_conv3x3_bf16(e->wt[c.wi].data.data(), c.Cin, c.Cout, p3, f32_to_bf16_host);
     SRGD_TRY(upload(e, p3.data(), p3.size() * 2, &c.w3));
+  }
+  if (e->split && c.Cin % 32 == 0) {
+    // f16x3 mode: one power-of-two scale per layer, (hi, lo) f16 halves of the scaled weights in both kernels' layouts
+    const float scale = split_weight_scale(e->wt[c.wi].data.data(), e->wt[c.wi].numel(), true);
+    c.ws_inv = 1.0f / scale;
+    std::vector<unsigned short> ps;
+    if (c.kind == CK_NORMAL && c.KS == 3 && c.Cout % 128 == 0) {
+      pack_conv3x3_split(e->wt[c.wi].data.data(), c.Cin, c.Cout, true, scale, ps);
+      SRGD_TRY(upload(e, ps.data(), ps.size() * 2, &c.ws3));
+    }
+    pack_conv_weights_split(reinterpret_cast<const float*>(packed.data()), c.KS * c.KS, c.Cin, c.CoutPad, true, scale, ps);
+    SRGD_TRY(upload(e, ps.data(), ps.size() * 2, &c.ws));
   }
   if (e->fp8 && c.kind == CK_NORMAL && c.KS == 3 && c.Cin % 128 == 0 && c.Cout % 128 == 0) {
     std::vector<unsigned char> pq;
@@ -630,7 +647,9 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
     SRGD_TRY(q_twin(x, in0, C0, Hin * Win, &mq0));
     if (in1) SRGD_TRY(q_twin(x, in1, C1, Hin * Win, &mq1));
   }
-  const int fam = fast ? KC_CONV3 : fastq1 ? KC_CONV1Q : fast1 ? KC_CONV1 : KC_CONV;
+  const bool split3 = e->split && c.ws3 && !e->force_generic_conv && conv3x3_split_eligible(a);
+  const bool splitg = e->split && !split3 && c.ws && conv_igemm_split_eligible(a);
+  const int fam = split3 ? KC_CONV3S : splitg ? KC_CONVS : fast ? KC_CONV3 : fastq1 ? KC_CONV1Q : fast1 ? KC_CONV1 : KC_CONV;
   Prof p(e, fam, x.st);
   if (e->prof_on) {
     e->fam_flops[fam] += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
@@ -663,7 +682,12 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
     return conv3x3_bf16(a, c.w3, gn_in ? e->coefA : nullptr, gn_in ? e->coefB : nullptr, x.st);
   }
   if (gn_in) SRGD_FAIL("internal: fused input GroupNorm requested on the generic conv path");
+  if (split3) {
+    if (stats) e->stats_slots = conv3x3_bf16_stats_slots(a);
+    return conv3x3_split(a, c.ws3, c.ws_inv, true, x.st);
+  }
   if (stats) e->stats_slots = cdiv(a.Hout * a.Wout, conv_tile_m());
+  if (splitg) return conv_igemm_split(a, c.ws, c.ws_inv, true, x.st);
   return conv_igemm(a, e->bf16, x.st);
 }
 

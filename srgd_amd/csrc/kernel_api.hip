@@ -95,8 +95,27 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
     SRGD_TRY(dw3.alloc(p3.size() * 2));
     SRGD_HIP(hipMemcpy(dw3.p, p3.data(), p3.size() * 2, hipMemcpyHostToDevice));
   }
-  if (stats_slots) *stats_slots = fast ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
+  // impl 6 / 7: the split-operand kernels (fp32 tensors; f16 (hi, lo) operand pairs): 6 = conv3x3_split, 7 = conv_igemm_split;
+  // impl 8 / 9: the same two kernels with bf16 halves (numerics comparison only - the engine uses f16)
+  const bool split3 = impl == 6 || impl == 8, splitg = impl == 7 || impl == 9, split_f16 = impl == 6 || impl == 7;
+  DevBuf dws;
+  float ws_inv = 1.f;
+  if (split3 || splitg) {
+    if (is_bf16) SRGD_FAIL("srgd_k_conv2d: the split-operand kernels take fp32 tensors (is_bf16 = 0)");
+    if (split3 ? !conv3x3_split_eligible(a) || kind != 0 : !conv_igemm_split_eligible(a))
+      SRGD_FAIL("srgd_k_conv2d: the split-operand kernel does not cover this shape");
+    const float scale = split_weight_scale(weight_oihw_host, (size_t)Cout * Cin * KS * KS, split_f16);
+    ws_inv = 1.0f / scale;
+    std::vector<unsigned short> ps;
+    if (split3) pack_conv3x3_split(weight_oihw_host, Cin, Cout, split_f16, scale, ps);
+    else pack_conv_weights_split(reinterpret_cast<const float*>(packed.data()), KS * KS, Cin, CoutPad, split_f16, scale, ps);
+    SRGD_TRY(dws.alloc(ps.size() * 2));
+    SRGD_HIP(hipMemcpy(dws.p, ps.data(), ps.size() * 2, hipMemcpyHostToDevice));
+  }
+  if (stats_slots) *stats_slots = (fast || split3) ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
   auto run = [&]() -> int {
+    if (split3) return conv3x3_split(a, dws.p, ws_inv, split_f16, st);
+    if (splitg) return conv_igemm_split(a, dws.p, ws_inv, split_f16, st);
     if (fastq1) return conv1x1_mxfp8(a, q0.p, s0.p, q1.p, s1.p, dwq1.p, st);
     return fast ? conv3x3_bf16(a, dw3.p, gnin ? gn_tail_a : nullptr, gnin ? gn_tail_b : nullptr, st) : fast1 ? conv1x1_bf16(a, dw1.p, st) : conv_igemm(a, is_bf16 != 0, st);
   };

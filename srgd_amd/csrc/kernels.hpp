@@ -75,6 +75,21 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
                  hipStream_t st);
 unsigned short f32_to_bf16_host(float f);
 
+// ---------------------------------------------------------------- conv3x3_split.hip / conv_igemm.hip (split-operand precision)
+// fp32 tensors in HBM, contraction as three 16-bit MFMAs per product on (hi, lo) operand pairs (f16 halves, or bf16 halves for
+// the numerics comparison).  Weights are split on the host after scaling by split_weight_scale (a power of two; 1 for bf16).
+float split_weight_scale(const float* w, size_t n, bool f16);
+void split_halves_host(float v, bool f16, unsigned short* hi, unsigned short* lo);
+bool conv3x3_split_eligible(const ConvArgs& a);          // same shapes and GroupNorm slot layout as conv3x3_bf16
+void pack_conv3x3_split(const float* src_oihw, int Cin, int Cout, bool f16, float scale, std::vector<unsigned short>& out);
+int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bool f16, hipStream_t st);
+// generic implicit GEMM of that mode (a.w ignored; every epilogue of the fp32 conv_igemm); weights from pack_conv_weights_split,
+// which takes pack_conv_weights' fp32 [tap][CoutPad][Cin] order
+bool conv_igemm_split_eligible(const ConvArgs& a);
+void pack_conv_weights_split(const float* src_tap_o_i, int taps, int Cin, int CoutPad, bool f16, float scale,
+                             std::vector<unsigned short>& out);
+int conv_igemm_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bool f16, hipStream_t st);
+
 // ---------------------------------------------------------------- conv3x3_mxfp8.hip / quant_mxfp8.hip
 // Block-scaled MX-fp8 path (v_mfma_scale_f32_16x16x128_f8f6f4, BASELINE configs[4]): the 3x3 convolutions take e4m3
 // activations [B,H,W,C] + E8M0 scales [B,H,W,C/32] (one per 32 channels) and e4m3 weights with one scale per

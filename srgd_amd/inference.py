@@ -6,7 +6,7 @@ Differences that are deliberate and documented: torchvision/log
 ``T.Resize`` on a PIL image, ``ToTensor`` and ``ToPILImage`` do; ``pil_to_unit_tensor`` / ``unit_tensor_to_pil`` are
 the host-side equivalents kept for tests); ``--no_amp`` is accepted and, as upstream (whose sampler ignores ``amp`` and
 always computes fp32), changes nothing: the default run reproduces the reference's fp32 numerics.
-Engine-only switches: ``--precision {fp32,bf16,bf16_w8,fp8,fp8_mixed}`` opts into a throughput mode, ``--device_noise`` switches from
+Engine-only switches: ``--precision {fp32,f16x3,bf16,bf16_w8,fp8,fp8_mixed}`` opts into a throughput mode, ``--device_noise`` switches from
 the reference-compatible host noise stream to on-device Philox.
 """
 from __future__ import annotations
@@ -49,7 +49,7 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=71)
     p.add_argument("--backend", type=str, default="ddp")
     # engine-only switches (absent upstream)
-    p.add_argument("--precision", choices=["fp32", "bf16", "bf16_w8", "fp8", "fp8_mixed"], default="fp32",
+    p.add_argument("--precision", choices=["fp32", "f16x3", "bf16", "bf16_w8", "fp8", "fp8_mixed"], default="fp32",
                    help="fp32 (default): the reference's numerics (<= 1e-3 of its CPU path); bf16 / bf16_w8 / fp8 / fp8_mixed: "
                         "throughput modes of the MI355X engine (explicit opt-in)")
     p.add_argument("--device_noise", action="store_true",
@@ -255,6 +255,11 @@ def main(argv=None):
     t_pack = time.perf_counter()
     unet = getattr(sr_model, "model", None) or sr_model.net
     unet.engine(args.precision)                         # pack + upload the weights now, not inside the first image
+    from .lanes import AUTO_LANE_PRECISIONS
+    if (sr_model.step_lanes is None and args.precision in AUTO_LANE_PRECISIONS) or (sr_model.step_lanes or 1) > 1:
+        # small steps run as two concurrent halves through a second engine instance (srgd_amd.lanes: a second copy of the packed
+        # weights, scratch and graphs): built here, not inside the first image's sampling loop
+        unet.engine(args.precision, lane=1)
     torch.cuda.synchronize()
     print(f"engine ready: {len(sr_model.state_dict())} tensors packed and uploaded in {time.perf_counter() - t_pack:.2f} s")
     print(args)

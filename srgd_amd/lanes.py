@@ -21,22 +21,31 @@ import torch
 
 MAX_SAMPLES_FOR_TWO_LANES = 100     # tiles x guidance passes of one launch
 MAX_LANES = 2                       # three and four lanes measured 4 % SLOWER than one (25 tiles per step)
+# Automatic two-lane mode only where it was A/B-measured (profiles/r5/step_lanes_ab.txt: bf16 and fp8; profiles/r6 adds f16x3 when
+# measured).  fp32 (parity mode, 10x the kernel time per launch: the partial last wave is a rounding error there) keeps one lane
+# unless forced: a second engine is a second copy of the packed weights, scratch and graphs (memory note).
+AUTO_LANE_PRECISIONS = ("bf16", "bf16_w8", "fp8", "fp8_mixed")
 
 
-def lanes_wanted(n_tiles: int, passes: int, sub_batch: int, setting: Optional[int]) -> int:
+def lanes_wanted(n_tiles: int, passes: int, sub_batch: int, setting: Optional[int], precision: str = "bf16") -> int:
     """Number of concurrent lanes of a step.  ``setting``: None = automatic (two lanes when the whole step is ONE launch of at
-    most 100 samples), an integer = forced (never more lanes than tiles)."""
+    most 100 samples, in a precision of AUTO_LANE_PRECISIONS), an integer = forced (never more lanes than tiles)."""
     if n_tiles < 2:
         return 1
     if setting is not None:
         return max(1, min(int(setting), MAX_LANES, n_tiles))
+    if precision not in AUTO_LANE_PRECISIONS:
+        return 1
     one_launch = sub_batch >= n_tiles
     return 2 if (one_launch and n_tiles * passes <= MAX_SAMPLES_FOR_TWO_LANES) else 1
 
 
 def lanes_setting_from_env() -> Optional[int]:
+    """SRGD_STEP_LANES: 0 or 1 = one lane (off), 2 = two lanes forced, unset / anything else = automatic."""
     v = os.environ.get("SRGD_STEP_LANES", "").strip()
-    return int(v) if v.isdigit() and 1 <= int(v) <= MAX_LANES else None
+    if not v.isdigit():
+        return None
+    return max(1, min(int(v), MAX_LANES))
 
 
 def lane_slices(n_tiles: int, lanes: int):

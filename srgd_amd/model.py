@@ -447,7 +447,7 @@ class ConditionalContinuousTimeGaussianDiffusionSR(nn.Module):
                 if i % 2 == 1:
                     noise_canvas = _host_randn(self.host_generator, 1, 3, hp, wp).to(dev, non_blocking=True)
             n_step = n_tiles * batch
-            n_lanes = lanes_wanted(n_step, passes, sub_batch, self.step_lanes) if self.canvas_group is None else 1
+            n_lanes = lanes_wanted(n_step, passes, sub_batch, self.step_lanes, precision or self.precision) if self.canvas_group is None else 1
             if n_lanes > 1:
                 if lanes is None or len(lanes.engines) != n_lanes:   # further engines: same run geometry, own copies of the condition canvas
                     more = [self.model.engine(precision or self.precision, lane=k) for k in range(1, n_lanes)]
@@ -728,7 +728,7 @@ class ConditionalElucidatedDiffusionSR(nn.Module):
             z = canvas_noise(None) if host_noise else None              # eps of the step (:2386), before the ring draw
             ring = canvas_noise(None) if (host_noise and i % 2 == 1) else None
             n_step = (len(coords1) if i % 2 else len(coords0)) * batch
-            n_lanes = lanes_wanted(n_step, passes, sub_batch, self.step_lanes) if self.canvas_group is None else 1
+            n_lanes = lanes_wanted(n_step, passes, sub_batch, self.step_lanes, precision or self.precision) if self.canvas_group is None else 1
             if n_lanes > 1:
                 if lanes is None or len(lanes.engines) != n_lanes:   # further engines (srgd_amd.lanes): same run geometry
                     more = [self.net.engine(precision or self.precision, lane=k) for k in range(1, n_lanes)]

@@ -291,23 +291,27 @@ def _step_and_exchange(eng, shard: CanvasShard, step: int, n_tiles: int, canvase
             _scatter_part(eng, shard, step, n_tiles, w, 0, w, (canvas,), g)
         shard._timed_end(ev)
         return
-    main = torch.cuda.current_stream()
-    side = shard.side_stream(main.device)
-    run_tiles(a0, a1 - a0, False)
-    first_done = torch.cuda.Event()
-    first_done.record(main)
-    with torch.cuda.stream(side):
-        side.wait_event(first_done)
-        g0 = _gather_part(eng, shard, step, a0, a1 - a0, 0, h, canvases)
-        gathered = torch.cuda.Event()
-        gathered.record(side)
-    run_tiles(a1, mine.stop - a1, True)                  # overlaps the first half's exchange
-    ev = shard._timed_begin()                            # what is left on the compute stream is the EXPOSED exchange time
-    g1 = _gather_part(eng, shard, step, a1, mine.stop - a1, 1, w - h, canvases)
-    main.wait_event(gathered)
-    _scatter_part(eng, shard, step, n_tiles, w, 0, h, canvases, g0)
-    _scatter_part(eng, shard, step, n_tiles, w, h, w - h, canvases, g1)
-    shard._timed_end(ev)
+    # streams and events of the CANVASES' device: the caller's current device may be another one, and a side stream
+    # made on it would neither carry the pack / all-gather nor order against the engine's stream
+    dev = next(c.device for c in canvases if c is not None and c.is_cuda)
+    with torch.cuda.device(dev):
+        main = torch.cuda.current_stream(dev)
+        side = shard.side_stream(dev)
+        run_tiles(a0, a1 - a0, False)
+        first_done = torch.cuda.Event()
+        first_done.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(first_done)
+            g0 = _gather_part(eng, shard, step, a0, a1 - a0, 0, h, canvases)
+            gathered = torch.cuda.Event()
+            gathered.record(side)
+        run_tiles(a1, mine.stop - a1, True)                  # overlaps the first half's exchange
+        ev = shard._timed_begin()                            # what is left on the compute stream is the EXPOSED exchange time
+        g1 = _gather_part(eng, shard, step, a1, mine.stop - a1, 1, w - h, canvases)
+        main.wait_event(gathered)
+        _scatter_part(eng, shard, step, n_tiles, w, 0, h, canvases, g0)
+        _scatter_part(eng, shard, step, n_tiles, w, h, w - h, canvases, g1)
+        shard._timed_end(ev)
 
 
 def sharded_step(eng, shard: CanvasShard, step: int, n_tiles: int, img, cond_canvas, x_start, noise_tiles, noise_canvas,

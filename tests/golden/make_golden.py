@@ -247,8 +247,46 @@ def make_long(cases=None):
         print("long", case["name"], "done", tuple(img.shape), float(img.mean()))
 
 
+def make_full(cases=None):
+    """BASELINE configs[1] at full length, with the reference's own trajectory (with_images / with_x0_images)."""
+    ref = refshim.load_reference()
+    assert ref is not None, "reference not present"
+    rm, rc = ref
+    torch.set_num_threads(int(os.environ.get("SRGD_GOLDEN_THREADS", "8")))
+    for case in (C.FULL_CASES if cases is None else cases):
+        sampler, _ = refshim.build_reference_sampler(rm, rc, dim=case["dim"], num_sample_steps=case["steps"])
+        schema = {k: tuple(v.shape) for k, v in sampler.state_dict().items()}
+        sd = synth_state_dict(schema, seed=case["weight_seed"])
+        sampler.load_state_dict(sd, strict=True)
+        cond = C.sampler_condition(case)
+        label = torch.tensor([case["label"]])
+        torch.manual_seed(case["seed"])
+        with torch.inference_mode():
+            img, xt_list, x0_list = sampler.tiled_sample(
+                batch_size=case["batch_size"], condition_x=cond.clone(), class_label=label,
+                cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
+                num_sample_steps=case["steps"], with_images=True, with_x0_images=True)
+        # entry 0 of both lists is the cropped start image (model.py:3319, :3323); entry i + 1 is the canvas after step i
+        arrays = dict(cond_sum=np.float64(cond.double().sum().item()),
+                      w_sum=np.float64(sum(v.double().abs().sum().item() for v in sd.values())),
+                      image_u16=torch.round(img.clamp(0, 1) * 65535.0).to(torch.int32).numpy().astype(np.uint16),
+                      checksum=np.float64(img.double().sum().item()),
+                      xt_sum=np.array([t.double().sum().item() for t in xt_list[1:]]),
+                      xt_abs=np.array([t.double().abs().sum().item() for t in xt_list[1:]]),
+                      x0_sum=np.array([t.double().sum().item() for t in x0_list[1:]]),
+                      x0_abs=np.array([t.double().abs().sum().item() for t in x0_list[1:]]),
+                      trace_steps=np.array(C.FULL_TRACE_STEPS))
+        for i in C.FULL_TRACE_STEPS:
+            arrays[f"xt_{i}"] = C.trace_planes(xt_list[i + 1]).numpy().copy()
+            arrays[f"x0_{i}"] = C.trace_planes(x0_list[i + 1]).numpy().copy()
+        np.savez_compressed(os.path.join(HERE, f"sample_{case['name']}.npz"), **arrays)
+        print("full", case["name"], "done", tuple(img.shape), float(img.mean()), flush=True)
+
+
 if __name__ == "__main__":
-    if "--sample-only" in sys.argv:
+    if "--config2-full" in sys.argv:
+        make_full()
+    elif "--sample-only" in sys.argv:
         make_sample()
     elif "--modules-only" in sys.argv:
         make_modules()

@@ -70,7 +70,7 @@ def test_library_is_loaded_in_process():
 
 
 @pytest.mark.parametrize("case", C.UNET_CASES, ids=lambda c: c["name"])
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "bf16"])
 def test_unet_forward_matches_reference(case, precision):
     z = np.load(os.path.join(G, "unet_eps.npz"))
     sampler = build_sampler(case["dim"], weight_seed=case["weight_seed"])
@@ -88,13 +88,16 @@ def test_unet_forward_matches_reference(case, precision):
             _report(test="unet_forward", case=case["name"], mode=mode, precision=precision, max_abs=err, ref_max=scale)
             assert torch.isfinite(got).all()
             # bf16 measured on MI355X: 2.4e-2 (dim 16) / 1.3e-2 (dim 128) of the eps range; gate at ~1.7x that
-            assert err <= (1e-4 if precision == "fp32" else 4e-2) * scale, (mode, err)
+            assert err <= (4e-2 if precision == "bf16" else 1e-4) * scale, (mode, err)
     finally:
         unet.precision = "fp32"
 
 
+# The two precisions that claim the north-star bar (<= 1e-3 max-abs against the reference's output): exact-fp32 MFMA, and the
+# split-operand mode (three f16 MFMAs per product on fp32 tensors; dim-16 cases mix it with fp32 layers where Cin % 32 != 0).
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("case", C.SAMPLER_CASES, ids=lambda c: c["name"])
-def test_tiled_sample_fp32_matches_reference(case):
+def test_tiled_sample_fp32_matches_reference(case, precision):
     z = np.load(os.path.join(G, f"sample_{case['name']}.npz"))
     sampler = build_sampler(case["dim"], weight_seed=case["weight_seed"])
     cond = C.sampler_condition(case)
@@ -105,12 +108,12 @@ def test_tiled_sample_fp32_matches_reference(case):
     sampler.noise_source = "host"
     got = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond.cuda(), class_label=label,
                                cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
-                               num_sample_steps=case["steps"], precision="fp32", **C.extra_kwargs(case))
+                               num_sample_steps=case["steps"], precision=precision, **C.extra_kwargs(case))
     torch.cuda.synchronize()
     want = torch.from_numpy(z["image"])
     assert got.shape == want.shape and got.dtype == torch.float32
     err = (got.cpu() - want).abs().max().item()
-    _report(test="tiled_sample", case=case["name"], precision="fp32", max_abs=err)
+    _report(test="tiled_sample", case=case["name"], precision=precision, max_abs=err)
     assert err <= 1e-3, err           # north-star bar
     assert err <= 2e-4, err           # and in practice an order of magnitude inside it
 
@@ -647,14 +650,16 @@ def test_config5_cfg2_100_steps_fp32_parity_and_bf16_fp8_weight_reports():
     assert abs(cond.double().sum().item() - float(z["cond_sum"])) < 1e-6
     label = torch.tensor([case["label"]]).cuda()
     outs = {}
-    for mode in ("fp32", "bf16", "bf16_w8", "fp8", "fp8_mixed"):
+    for mode in ("fp32", "f16x3", "bf16", "bf16_w8", "fp8", "fp8_mixed"):
         torch.manual_seed(case["seed"])
         outs[mode] = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label,
                                           class_cond_scale=case["class_cond_scale"], num_sample_steps=case["steps"],
                                           precision=mode).cpu()
     psnr = lambda a, b: float(10 * np.log10(1.0 / max(float(((a - b) ** 2).mean()), 1e-20)))
     err32 = (outs["fp32"] - want).abs().max().item()
-    _report(test="config5_256", fp32_max_abs=err32, bf16_psnr_vs_ref=psnr(outs["bf16"], want),
+    errx3 = (outs["f16x3"] - want).abs().max().item()
+    assert errx3 <= 1e-3, errx3
+    _report(test="config5_256", fp32_max_abs=err32, f16x3_max_abs=errx3, bf16_psnr_vs_ref=psnr(outs["bf16"], want),
             w8_psnr_vs_ref=psnr(outs["bf16_w8"], want), w8_psnr_vs_bf16=psnr(outs["bf16_w8"], outs["bf16"]),
             w8_max_abs_vs_bf16=(outs["bf16_w8"] - outs["bf16"]).abs().max().item(),
             fp8_psnr_vs_ref=psnr(outs["fp8"], want), fp8_mixed_psnr_vs_ref=psnr(outs["fp8_mixed"], want),
@@ -815,15 +820,17 @@ def test_config2_geometry_dim128_matches_reference_fp32_and_bf16():
     label = torch.tensor([case["label"]]).cuda()
     sampler.noise_source = "host"
     outs = {}
-    for prec in ("fp32", "bf16", "fp8", "fp8_mixed"):
+    for prec in ("fp32", "f16x3", "bf16", "fp8", "fp8_mixed"):
         torch.manual_seed(case["seed"])
         outs[prec] = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label,
                                           num_sample_steps=case["steps"], precision=prec).cpu()
     e32 = (outs["fp32"] - want).abs()
+    ex3 = (outs["f16x3"] - want).abs()
+    assert float(ex3.max()) <= 1e-3 and float(ex3.max()) <= 3e-4, float(ex3.max())     # the split-operand mode: same bar, same guard
     ebf = (outs["bf16"] - want).abs()
     psnr_of = lambda a: float(10 * np.log10(1.0 / max(float(((a - want) ** 2).mean()), 1e-20)))
     psnr = psnr_of(outs["bf16"])
-    _report(test="config2_geometry_2steps", case=case["name"], fp32_max_abs=float(e32.max()), bf16_max_abs=float(ebf.max()),
+    _report(test="config2_geometry_2steps", case=case["name"], fp32_max_abs=float(e32.max()), f16x3_max_abs=float(ex3.max()), bf16_max_abs=float(ebf.max()),
             bf16_mean_abs=float(ebf.mean()), bf16_psnr_vs_reference=psnr, fp8_psnr_vs_reference=psnr_of(outs["fp8"]),
             fp8_mixed_psnr_vs_reference=psnr_of(outs["fp8_mixed"]))
     # MX-fp8 modes against the reference at configs[1]'s real geometry; gates within 3 dB of the measurement

@@ -285,3 +285,18 @@ def test_step_lanes_rule():
     assert lanes_wanted(25, 1, 4, None) == 1                                                 # several launches per step
     assert lanes_wanted(1, 1, 4, None) == 1 and lanes_wanted(1, 1, 4, 2) == 1                # a single tile cannot be split
     assert lanes_wanted(125, 1, 125, 2) == 2 and lanes_wanted(25, 1, 25, 1) == 1             # forced
+    # automatic only in the precisions it was A/B-measured in: the parity modes keep one lane unless forced
+    assert lanes_wanted(25, 1, 25, None, "fp32") == 1 and lanes_wanted(25, 1, 25, None, "f16x3") == 1
+    assert lanes_wanted(25, 1, 25, 2, "fp32") == 2 and lanes_wanted(25, 1, 25, None, "fp8") == 2
+    import os
+    from srgd_amd.lanes import lanes_setting_from_env
+    keep = os.environ.get("SRGD_STEP_LANES")
+    try:
+        for v, want in (("0", 1), ("1", 1), ("2", 2), ("7", 2), ("", None), ("auto", None)):
+            os.environ["SRGD_STEP_LANES"] = v
+            assert lanes_setting_from_env() == want, v
+    finally:
+        if keep is None:
+            os.environ.pop("SRGD_STEP_LANES", None)
+        else:
+            os.environ["SRGD_STEP_LANES"] = keep

@@ -1,0 +1,170 @@
+"""GPU tests of the split-operand precision (SRGD_PRECISION_F16X3): fp32 tensors, every convolution product as three f16 MFMAs on
+(hi, lo) operand pairs (srgd_amd/csrc/conv3x3_split.hip, conv_igemm.hip: conv_igemm_split_kernel), through the kernel-level C ABI.
+
+Three kinds of check:
+  * against torch's float64 convolution (the quantity the reference's fp32 Block.proj approximates, model.py:246), with the
+    tolerance of an fp32 convolution - the mode's claim;
+  * against the CPU emulation of the documented arithmetic (oracle/split_emulation.py) to fp32 summation-order noise - the kernels
+    compute what the header says, nothing looser;
+  * exactness on small integers (every fragment map, swizzle and tap shift).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.split_emulation import split_conv2d
+from tests.test_kernels_gpu import DEV, L, from_dev_nhwc, ptr, run_conv, stream, to_dev_nhwc, _report_k
+
+pytestmark = pytest.mark.gpu
+
+IMPL3 = {"f16": 6, "bf16": 8}       # conv3x3_split
+IMPLG = {"f16": 7, "bf16": 9}       # conv_igemm_split
+
+
+def conv64(x, w, b, **kw):
+    return F.conv2d(x.double(), w.double(), None if b is None else b.double(), **kw)
+
+
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+def test_conv3x3_split_integer_exact(kind):
+    g = torch.Generator().manual_seed(12)
+    x = torch.randint(-3, 4, (2, 64, 16, 64), generator=g).float()
+    w = torch.randint(-2, 3, (128, 64, 3, 3), generator=g).float()
+    b = torch.randint(-4, 5, (128,), generator=g).float()
+    got, _ = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, impl=IMPL3[kind])
+    assert torch.equal(got, F.conv2d(x, w, b, padding=1))
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 0, 128, 8, 32), (1, 64, 32, 256, 16, 64), (3, 128, 0, 128, 32, 32),
+                                 (1, 256, 128, 1024, 8, 32), (1, 32, 0, 2048, 8, 32), (2, 32, 0, 512, 16, 32), (1, 32, 0, 2048, 16, 32, 8)],
+                         ids=lambda s: "B%d_C%d+%d_Cout%d_%dx%d" % s[:6] + ("_g%d" % s[6] if len(s) > 6 else ""))
+def test_conv3x3_split_borders_sources_stats(cfg):
+    # the shapes of test_conv3x3_bf16_fast_path_borders_sources_stats: tiles touching every image border, two sources, every
+    # channels-per-group class of the register-direct epilogue
+    B, c0, c1, cout, H, W = cfg[:6]
+    lib = L().lib()
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(B, c0, H, W, generator=g)
+    x1 = torch.randn(B, c1, H, W, generator=g) if c1 else None
+    w = torch.randn(cout, c0 + c1, 3, 3, generator=g) / (3 * (c0 + c1) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    groups = cfg[6] if len(cfg) > 6 else (8 if cout <= 1024 else 0)
+    xin = x0 if x1 is None else torch.cat((x0, x1), 1)
+    want64 = conv64(xin, w, b, padding=1)
+    scale = max(1.0, float(want64.abs().max()))
+    err = {}
+    for kind in ("f16", "bf16"):
+        got, part, nslots = run_conv(x0, x1, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, groups=groups, impl=IMPL3[kind],
+                                     want_slots=True)
+        err[kind] = float((got.double() - want64).abs().max())
+        emu = split_conv2d(xin, w, b, padding=1, kind=kind)
+        assert (got - emu).abs().max() <= 4e-6 * scale, (kind, float((got - emu).abs().max()))      # summation order only
+        if kind == "f16" and groups:
+            assert torch.isfinite(part).all()
+            s = part.sum(2).cpu().double()
+            want_s1 = want64.reshape(B, groups, -1).sum(-1)
+            want_s2 = (want64 ** 2).reshape(B, groups, -1).sum(-1)
+            assert (s[..., 0] - want_s1).abs().max() <= 1e-4 * max(1.0, float(want_s1.abs().max()))
+            assert (s[..., 1] - want_s2).abs().max() <= 1e-4 * float(want_s2.abs().max())
+            gamma, beta = 1 + 0.2 * torch.randn(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
+            d = to_dev_nhwc(got, False)
+            dg, db_ = gamma.to(DEV), beta.to(DEV)
+            part = part.contiguous()
+            L().check(lib.srgd_k_groupnorm_silu(ptr(d), ptr(d), ptr(None), ptr(part), B, H * W, cout, groups, ptr(dg),
+                                                ptr(db_), ptr(None), nslots, 0, stream()), "groupnorm")
+            y = F.silu(F.group_norm(want64.float(), groups, gamma, beta, eps=1e-5))
+            assert (from_dev_nhwc(d) - y).abs().max() <= 2e-5 * max(1.0, float(y.abs().max()))
+    e32 = float((F.conv2d(xin, w, b, padding=1).double() - want64).abs().max())
+    _report_k(test="conv3x3_split", cfg=list(cfg), f16x3_max_abs=err["f16"], bf16x3_max_abs=err["bf16"], torch_fp32_max_abs=e32,
+              ref_max=scale)
+    assert err["f16"] <= 4e-6 * scale, err          # an fp32 convolution's own error on these shapes is ~1e-6 of the range
+    assert err["bf16"] <= 3e-4 * scale, err
+    assert err["f16"] < err["bf16"]
+
+
+def test_conv3x3_split_small_and_large_magnitudes():
+    # what the power-of-two weight scale is for: weights of 1e-3 (w_lo deep in f16's subnormal range without it), activations
+    # spanning 1e-3 .. 1e2 in one tensor; and saturation instead of NaN beyond f16's range
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 8, 32, generator=g) * torch.logspace(-3, 2, 64).view(1, 64, 1, 1)
+    w = torch.randn(128, 64, 3, 3, generator=g) * 1e-3
+    want64 = conv64(x, w, None, padding=1)
+    got, _ = run_conv(x, None, w, None, ks=3, stride=1, pad=1, kind=0, bf16=False, impl=6)
+    assert (got.double() - want64).abs().max() <= 4e-6 * float(want64.abs().max())
+    x[0, 0, 0, 0] = 1e6
+    got, _ = run_conv(x, None, w, None, ks=3, stride=1, pad=1, kind=0, bf16=False, impl=6)
+    assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("variant", ["plain", "residual", "two_sources", "pixel_shuffle", "unshuffle", "stats", "k_heavy", "ragged_m"])
+def test_conv_igemm_split_variants(variant):
+    g = torch.Generator().manual_seed(21)
+    B, H, W = 2, 16, 24
+    kw = dict(ks=1, stride=1, pad=0, kind=0)
+    c0, c1, cout = 64, 0, 128
+    residual, groups = None, 0
+    if variant == "two_sources":
+        c0, c1, cout = 96, 32, 192
+    elif variant == "k_heavy":
+        c0, cout, H, W = 1024, 256, 8, 8
+    elif variant == "ragged_m":
+        B, H, W, cout = 3, 10, 10, 96                   # 100 pixels per sample: a masked 128-row tile; Cout < CoutPad
+    elif variant == "stats":
+        groups, cout = 8, 256
+    elif variant == "unshuffle":
+        kw = dict(ks=2, stride=2, pad=0, kind=1)
+    elif variant == "pixel_shuffle":
+        kw = dict(ks=1, stride=1, pad=0, kind=2)
+        cout = 256
+    x0 = torch.randn(B, c0, H, W, generator=g)
+    x1 = torch.randn(B, c1, H, W, generator=g) if c1 else None
+    cin = c0 + c1
+    if variant == "unshuffle":
+        w = torch.randn(cout, 4 * cin, 1, 1, generator=g) / (4 * cin) ** 0.5
+    else:
+        w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g)
+    xin = x0 if x1 is None else torch.cat((x0, x1), 1)
+    if variant == "unshuffle":
+        want64 = conv64(F.pixel_unshuffle(xin, 2), w, b)
+    else:
+        want64 = conv64(xin, w, b)
+    if variant == "pixel_shuffle":
+        want64 = F.pixel_shuffle(F.silu(want64), 2)
+    if variant == "residual":
+        residual = torch.randn(B, cout, H, W, generator=g)
+        want64 = want64 + residual.double()
+    scale = max(1.0, float(want64.abs().max()))
+    for impl, tolr in ((7, 4e-6), (9, 3e-4)):
+        got, part = run_conv(x0, x1, w, b, bf16=False, residual=residual, groups=groups, impl=impl, **kw)
+        err = float((got.double() - want64).abs().max())
+        _report_k(test="conv_igemm_split", variant=variant, impl=impl, max_abs=err, ref_max=scale)
+        assert err <= tolr * scale, (variant, impl, err)
+        if groups and impl == 7:
+            s = part.sum(2).cpu().double()
+            pre = conv64(xin, w, b)
+            assert (s[..., 0] - pre.reshape(B, groups, -1).sum(-1)).abs().max() <= 1e-4 * float(pre.abs().sum(1).max())
+            assert (s[..., 1] - (pre ** 2).reshape(B, groups, -1).sum(-1)).abs().max() <= 1e-4 * float((pre ** 2).reshape(B, groups, -1).sum(-1).max())
+
+
+def test_conv_igemm_split_3x3_equals_the_halo_kernel_to_summation_order():
+    # the same 3x3 layer through both split kernels (different tiling and K order, same arithmetic)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 16, 32, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    b = torch.randn(128, generator=g)
+    a, _ = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, impl=6)
+    c, _ = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, impl=7)
+    assert (a - c).abs().max() <= 3e-6 * float(a.abs().max())
+
+
+def test_split_kernels_reject_what_they_do_not_cover():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 48, 8, 32, generator=g)          # Cin % 32 != 0
+    w = torch.randn(128, 48, 3, 3, generator=g)
+    for impl in (6, 7):
+        with pytest.raises(Exception):
+            run_conv(x, None, w, None, ks=3, stride=1, pad=1, kind=0, bf16=False, impl=impl)
+    with pytest.raises(Exception):                      # bf16 tensors
+        run_conv(torch.randn(1, 64, 8, 32), None, torch.randn(128, 64, 3, 3), None, ks=3, stride=1, pad=1, kind=0, bf16=True, impl=6)

@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--stats", type=int, default=1)
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     ap.add_argument("--impls", default="1,0")
+    ap.add_argument("--fp32", action="store_true",
+                    help="fp32 tensors (is_bf16 = 0): impl 1 = exact-fp32 MFMA, 6 / 7 = the split-operand kernels (f16x3 mode)")
     args = ap.parse_args()
     lib = _lib.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -65,13 +67,14 @@ def main():
             continue
         g = torch.Generator(device="cuda").manual_seed(0)
         B = args.batch
-        x0 = torch.randn(B, hw, hw, c0, device="cuda", generator=g).to(torch.bfloat16)
-        x1 = torch.randn(B, hw, hw, c1, device="cuda", generator=g).to(torch.bfloat16) if c1 else None
+        adt = torch.float32 if args.fp32 else torch.bfloat16
+        x0 = torch.randn(B, hw, hw, c0, device="cuda", generator=g).to(adt)
+        x1 = torch.randn(B, hw, hw, c1, device="cuda", generator=g).to(adt) if c1 else None
         w = (torch.randn(cout, c0 + c1, ks, ks) / (ks * (c0 + c1) ** 0.5)).float().contiguous()
         bias = torch.randn(cout).float()
         outs, res = [], {}
         for impl in [int(v) for v in args.impls.split(',')]:
-            out = torch.empty(B, hw, hw, cout, device="cuda", dtype=torch.bfloat16)
+            out = torch.empty(B, hw, hw, cout, device="cuda", dtype=adt)
             groups = 8 if (args.stats and ks == 3) else 0
             part = torch.zeros(B * 8 * (hw * hw // 32) * 2, device="cuda") if groups else None
             ms = C.c_float()
@@ -82,10 +85,10 @@ def main():
             rc = lib.srgd_k_conv2d_timed(C.c_void_p(x0.data_ptr()), C.c_void_p(x1.data_ptr() if c1 else 0), c0, c1, B, hw, hw,
                                          ks, 1, ks // 2, 0, C.c_void_p(w.data_ptr()), C.c_void_p(bias.data_ptr()), cout,
                                          C.c_void_p(out.data_ptr()), C.c_void_p(0),
-                                         C.c_void_p(part.data_ptr() if groups else 0), groups, 1, impl, args.iters,
+                                         C.c_void_p(part.data_ptr() if groups else 0), groups, 0 if args.fp32 else 1, impl, args.iters,
                                          C.byref(ms), C.byref(slots), C.c_void_p(0), C.c_void_p(coef[0].data_ptr() if impl == 5 else 0),
                                          C.c_void_p(coef[1].data_ptr() if impl == 5 else 0), st)
-            if rc != 0 and impl == 4:               # the MX pointwise kernel does not cover every shape: skip the shape
+            if rc != 0 and impl in (4, 6, 7):               # the MX pointwise kernel does not cover every shape: skip the shape
                 print(f"{name:28s} impl {impl}: not eligible", flush=True)
                 res = None
                 break
@@ -106,7 +109,7 @@ def main():
         ia, ib = [int(v) for v in args.impls.split(',')][:2]        # first = the reference arm (default: generic), second = the arm under test
         rows.append(dict(shape=name, impl_a=ia, impl_b=ib, generic_tflops=round(res[ia], 1), engine_tflops=round(res[ib], 1),
                          max_abs_diff=d, ref_max=ref, stats_rel_diff=ds))
-        gb = 2.0 * B * hw * hw * (c0 + c1 + cout) / 1e9           # bf16 in + out, once
+        gb = (4.0 if args.fp32 else 2.0) * B * hw * hw * (c0 + c1 + cout) / 1e9           # in + out, once
         ms0 = 2.0 * B * hw * hw * cout * ks * ks * (c0 + c1) / (res[ib] * 1e12) * 1e3
         print(f"{name:28s} impl {ia} {res[ia]:7.1f} TF   impl {ib} {res[ib]:7.1f} TF ({ms0:.3f} ms, {gb / ms0:.2f} TB/s in+out)   |diff| {d:.3g} (max {ref:.3g})  stats {ds:.2g}", flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
