@@ -460,7 +460,7 @@ def main():
             if fam == "conv3x3_split":
                 line["roofline"]["mfma_per_product"] = 3
                 line["roofline"]["frac_of_issue_peak"] = 3.0 * achieved / peak
-            conv_fams = ("conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "conv3x3_mxfp8", "conv1x1_mxfp8", "conv3x3_split", "conv_igemm_split")
+            conv_fams = ("conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "conv3x3_mxfp8", "conv1x1_mxfp8", "conv3x3_split", "conv_igemm_split", "conv1x1_split")
             all_conv_ms = sum(prof["ms"].get(k, 0.0) for k in conv_fams)
             line["conv_all_tflops"] = sum(prof["flops"].get(k, 0.0) for k in conv_fams) / (all_conv_ms * 1e-3) / 1e12
             tot = sum(prof["ms"].values())
@@ -469,7 +469,7 @@ def main():
             # SURVEY 8(d) secondary check: the HBM-bound kernel families, algorithmic bytes (every operand read once, every
             # result written once; summed by the engine per launch) / HIP-event time, against the 8 TB/s HBM3E peak
             hbm = {}
-            for k in ("groupnorm_silu", "rmsnorm", "linear_attention", "conv1x1_bf16", "conv1x1_mxfp8", "final_conv_ddpm_step", "quantize_mxfp8"):
+            for k in ("groupnorm_silu", "rmsnorm", "linear_attention", "conv1x1_bf16", "conv1x1_mxfp8", "conv1x1_split", "final_conv_ddpm_step", "quantize_mxfp8"):
                 if prof["ms"].get(k, 0.0) > 0 and prof["bytes"].get(k, 0.0) > 0:
                     gbps = prof["bytes"][k] / (prof["ms"][k] * 1e-3) / 1e9
                     hbm[k] = {"achieved": round(gbps, 1), "unit": "GB/s", "peak": 8000.0, "frac": round(gbps / 8000.0, 4),

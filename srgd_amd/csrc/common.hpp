@@ -240,6 +240,7 @@ enum KClass {
   KC_CONV1Q,       // conv1x1_mxfp8_kernel: pointwise layers on the MX matrix cores (fp8 mode)
   KC_CONV3S,       // conv3x3_split_kernel: 3x3 convolutions in split-operand precision (f16x3 mode)
   KC_CONVS,        // conv_igemm_split_kernel: the other convolutions of the f16x3 mode
+  KC_CONV1S,       // conv1x1_split_kernel: pointwise layers of the f16x3 mode (streaming GEMM, LDS-DMA ring)
   KC_COUNT
 };
 

@@ -1,0 +1,321 @@
+// Pointwise (1x1) convolutions in SPLIT-OPERAND precision for gfx950 (MI355X): the layers conv1x1_bf16.hip serves in the bf16 modes -
+// ResnetBlock res_conv (reference model.py:271), to_qkv / to_out (:300-303, :338-340), PixelShuffleUpsample's 1x1 + SiLU +
+// PixelShuffle (:70-98), Downsample's space-to-depth + 1x1 (:106-110, as a 2x2 / stride-2 gather) - on fp32 tensors, every product
+// as three f16 MFMAs on (hi, lo) operand pairs (arithmetic: conv3x3_split.hip).
+//
+// These layers are HBM-bound (fp32 in and out; <= 192 MFMA-FLOP per input byte at Cout = 128), so the kernel is a streaming GEMM built
+// for bytes in flight, like conv1x1_bf16.hip:
+//   * workgroup = 512 threads = 8 waves; output tile = 256 consecutive pixels x 128 channels; a wave owns 32 pixels x ALL 128
+//     channels (2 pixel blocks x 8 weight-row blocks of v_mfma_f32_16x16x32_f16: 64 accumulators);
+//   * every K-step (32 channels) is ONE 48 KB stage brought in by LDS-DMA (6 buffer_load ... lds per wave) into a 3-deep ring - two
+//     stages (96 KB: 64 KB of pixels) are always in flight per CU: the fp32 pixel rows (256 x 128 B, 16-byte chunks XOR-swizzled by
+//     the row so that the fragment reads are conflict-free; 8 lanes read one full 128-byte line) and the weight unit (hi tile | lo
+//     tile, split on the host, pre-swizzled);
+//   * a wave DMAs exactly the 32 pixel rows it consumes, reads its fp32 fragments from LDS (8 consecutive channels of a pixel = two
+//     ds_read_b128 per lane and block) and splits them in registers: every input element is split once.  (Round 6 first had every
+//     lane load its fragments straight from global memory - no LDS for the pixels at all.  Correct, but a quarter-wave then touches
+//     16 different 128-byte lines per instruction: 2.3-3.4 TB/s on the 256x256 layers, profiles/r6/conv1x1_split_direct_loads.txt);
+//   * weights as srcA with the tile's rows stored in the order (tile row 16 J + 4 g + e <- channel 32 g + 4 J + e), so that a
+//     lane's 32 accumulators of a pixel are 32 CONSECUTIVE channels: the epilogue (x inverse weight scale, + bias, + residual or
+//     SiLU + PixelShuffle scatter) is register-direct, eight 16-byte stores per pixel block, 512 contiguous bytes per pixel;
+//   * LDS 144 KB: one workgroup per CU, two waves per SIMD.
+// Roofline: HBM (algorithmic bytes = input once per n-tile + output once + weights); K-heavy shapes at 32x32 / 64x64 are MFMA-bound
+// at a third of the f16 peak like the 3x3 kernel.
+#include <cmath>
+#include <cstdlib>
+
+#include "kernels.hpp"
+
+namespace srgd {
+namespace {
+
+constexpr int BM = 256, BN = 128, KC = 32, NT = 512;
+constexpr int A_BYTES = BM * KC * 4;           // 32 KiB: 256 pixel rows x 128 B of fp32
+constexpr int B_TILE = BN * KC * 2;            // 8 KiB: one 16-bit weight tile
+constexpr int B_SLOT = 2 * B_TILE;             // hi | lo
+constexpr int STAGE = A_BYTES + B_SLOT;        // 48 KiB
+constexpr int RING = 3;
+constexpr int LDS_BYTES = RING * STAGE;        // 147,456: one workgroup per CU
+enum { SEPI_PLAIN = 0, SEPI_RESIDUAL = 1, SEPI_PS_SILU = 2 };
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+struct Split1Args {
+  const float* in0; const float* in1; int C0, C1;
+  int B, Hin, Win, Hout, Wout;
+  int KH, KW, stride;     // 1x1, or 2x2 / stride 2 (space-to-depth folded into the K walk)
+  int ps0, ps1;           // pixel stride of each source in elements
+  const void* w;          // pack_conv1x1_split
+  const float* bias;
+  float w_inv_scale;
+  int Cout;
+  float* out;
+  const float* aux;       // SEPI_RESIDUAL: tensor added to the output
+};
+
+#define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define BARRIER()                        \
+  do {                                   \
+    __builtin_amdgcn_s_barrier();        \
+    __builtin_amdgcn_sched_barrier(0);   \
+  } while (0)
+
+// 8 fp32 (two 16-byte loads) -> the hi and lo f16 fragments (saturating, as conv3x3_split.hip)
+__device__ __forceinline__ void split8(const u32x4& r0, const u32x4& r1, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a = __builtin_bit_cast(float, k < 2 ? r0[2 * k] : r1[2 * k - 4]);
+    float b = __builtin_bit_cast(float, k < 2 ? r0[2 * k + 1] : r1[2 * k - 3]);
+    a = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f);
+    b = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+    const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(f32x2{a - hf[0], b - hf[1]}, f16x2);
+    hi[k] = __builtin_bit_cast(unsigned, h);
+    lo[k] = __builtin_bit_cast(unsigned, l);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, q16 = lane >> 4;
+
+  const int n_tiles = p.Cout / BN;
+  const int HWo = p.Hout * p.Wout;
+  int wg = blockIdx.x;
+  {                                                // XCD-aware order: the n-tiles of one m-tile back to back on one XCD
+    const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, x = wg & 7, k = wg >> 3;
+    wg = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + k;
+  }
+  const int nt = wg % n_tiles;
+  const int mt = wg / n_tiles;
+  const long m0 = (long)mt * BM;                   // HWo % 256 == 0: a tile lies in one image
+  const int b = (int)(m0 / HWo);
+  const int p0 = (int)(m0 - (long)b * HWo);
+  const int Cin = p.C0 + p.C1;
+  const int CC = Cin / KC;
+  const int S = p.KH * p.KW * CC;
+
+  // ---- A staging: the wave's 32 pixel rows = 4 KiB = 4 wave-instructions per stage.  Instruction J covers rows 32 w + 8 J .. + 7;
+  // lane L fills 16-byte position L & 7 of row 8 J + (L >> 3), which holds SOURCE chunk (L & 7) ^ (row & 7) (4 channels).
+  // Per-lane byte offsets at tap (0,0), channel chunk 0, for each source; everything that changes per K-step is wave-uniform.
+  const int a_chunk = (lane & 7) ^ (lane >> 3);
+#define K_A1_DECL(J)                                                      \
+  int a_b0##J, a_b1##J;                                                      \
+  {                                                                          \
+    const int op = p0 + wave * 32 + 8 * J + (lane >> 3);                     \
+    const int oy = op / p.Wout, ox = op - oy * p.Wout;                       \
+    const int pix = oy * p.stride * p.Win + ox * p.stride;                   \
+    a_b0##J = (pix * p.ps0 + a_chunk * 4) * 4;                               \
+    a_b1##J = (pix * p.ps1 + a_chunk * 4) * 4;                               \
+  }
+  K_A1_DECL(0) K_A1_DECL(1) K_A1_DECL(2) K_A1_DECL(3)
+#undef K_A1_DECL
+  const size_t img0 = (size_t)p.Hin * p.Win * p.ps0, img1 = (size_t)p.Hin * p.Win * p.ps1;
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (size_t)b * img0), 0, (int)(img0 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.in1 ? p.in1 + (size_t)b * img1 : p.in0), 0, p.in1 ? (int)(img1 * 4) : 0, 0x00020000);
+  const size_t w_tile_stride = (size_t)n_tiles * B_SLOT;
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.w + (size_t)nt * B_SLOT), 0, (int)((size_t)(S - 1) * w_tile_stride + B_SLOT), 0x00020000);
+
+  // issue stream: the next K-step to request - tap (ty, tx), channel chunk, ring slot, weight offset - advanced incrementally
+  int i_ty = 0, i_tx = 0, i_cc = 0, i_slot = 0, i_w = 0;
+  const int tid16 = tid * 16;
+  auto dma = [&](__amdgpu_buffer_rsrc_t rs, char* dst, int voff, int soff) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, voff, soff, 0, 0);
+  };
+  auto issue = [&]() __attribute__((always_inline)) {
+    const int c = i_cc * KC;
+    const bool first = c < p.C0;
+    const int soff = first ? ((i_ty * p.Win + i_tx) * p.ps0 + c) * 4 : ((i_ty * p.Win + i_tx) * p.ps1 + c - p.C0) * 4;
+    char* st = smem + i_slot * STAGE;
+    char* sa = st + wave * 4096;
+    // (per-lane offsets selected with v_cndmask, the descriptors by two branches: see conv1x1_bf16.hip)
+    const int v0 = first ? a_b00 : a_b10, v1 = first ? a_b01 : a_b11, v2 = first ? a_b02 : a_b12, v3 = first ? a_b03 : a_b13;
+    if (first) { dma(rs0, sa, v0, soff); dma(rs0, sa + 1024, v1, soff); dma(rs0, sa + 2048, v2, soff); dma(rs0, sa + 3072, v3, soff); }
+    else { dma(rs1, sa, v0, soff); dma(rs1, sa + 1024, v1, soff); dma(rs1, sa + 2048, v2, soff); dma(rs1, sa + 3072, v3, soff); }
+    dma(rsw, st + A_BYTES + wave * 1024, tid16, i_w);                       // hi tile: 8 waves x 1 KiB
+    dma(rsw, st + A_BYTES + B_TILE + wave * 1024, tid16, i_w + B_TILE);     // lo tile
+    i_w += (int)w_tile_stride;
+    i_slot = i_slot == RING - 1 ? 0 : i_slot + 1;
+    if (++i_cc == CC) {
+      i_cc = 0;
+      if (++i_tx == p.KW) { i_tx = 0; ++i_ty; }
+    }
+  };
+
+  f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c04 = 0, c05 = 0, c06 = 0, c07 = 0,
+        c10 = 0, c11 = 0, c12 = 0, c13 = 0, c14 = 0, c15 = 0, c16 = 0, c17 = 0;
+  // fragment addresses.  Pixel P = 32 w + 16 mi + r16 (P & 7 = r16 & 7): channels 8 q16 .. + 7 are source chunks 2 q16, 2 q16 + 1
+  const int sw = r16 & 7;
+  const int a_row0 = (wave * 32 + r16) * 128, a_row1 = a_row0 + 16 * 128;
+  const int a_c0 = ((2 * q16) ^ sw) << 4, a_c1 = ((2 * q16 + 1) ^ sw) << 4;
+  const int b_base = A_BYTES + r16 * 64 + ((q16 ^ ((r16 >> 1) & 3)) << 4);       // weight row 16 J + r16, chunk q16 (the swizzle ignores J)
+  int c_slot = 0;
+  auto mma = [&](f32x4& c, const u32x4& wt, const u32x4& px) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wt), __builtin_bit_cast(f16x8, px), c, 0, 0, 0);
+  };
+  auto compute = [&]() __attribute__((always_inline)) {
+    const char* st = smem + c_slot * STAGE;
+    c_slot = c_slot == RING - 1 ? 0 : c_slot + 1;
+    u32x4 ah0, al0, ah1, al1;
+    split8(*reinterpret_cast<const u32x4*>(st + a_row0 + a_c0), *reinterpret_cast<const u32x4*>(st + a_row0 + a_c1), ah0, al0);
+    split8(*reinterpret_cast<const u32x4*>(st + a_row1 + a_c0), *reinterpret_cast<const u32x4*>(st + a_row1 + a_c1), ah1, al1);
+#define K_COL(J, C0_, C1_)                                                                         \
+  {                                                                                                \
+    const u32x4 bh = *reinterpret_cast<const u32x4*>(st + b_base + J * 1024);                      \
+    const u32x4 bl = *reinterpret_cast<const u32x4*>(st + B_TILE + b_base + J * 1024);             \
+    mma(C0_, bh, al0); mma(C1_, bh, al1);                                                          \
+    mma(C0_, bl, ah0); mma(C1_, bl, ah1);                                                          \
+    mma(C0_, bh, ah0); mma(C1_, bh, ah1);                                                          \
+  }
+    K_COL(0, c00, c10) K_COL(1, c01, c11) K_COL(2, c02, c12) K_COL(3, c03, c13)
+    K_COL(4, c04, c14) K_COL(5, c05, c15) K_COL(6, c06, c16) K_COL(7, c07, c17)
+#undef K_COL
+  };
+
+  // ---- pipeline: stages s+1 and s+2 in flight while stage s is consumed (6 DMA instructions per wave and stage)
+  issue();
+  if (S > 1) issue();
+  if (S > 1) WAIT_VM(6); else WAIT_VM(0);
+  BARRIER();
+  for (int s = 0; s < S; ++s) {
+    if (s + 2 < S) issue();
+    compute();
+    if (s + 2 < S) WAIT_VM(6); else WAIT_VM(0);     // stage s+1 has landed (this wave's part; the barrier covers the rest)
+    if (s + 1 < S) BARRIER();
+  }
+
+  // ------------------------------- epilogue (register-direct, fp32) --------------------------
+  // lane (r16, g = q16), pixel block mi, weight block J, register e  ->  pixel wave * 32 + mi * 16 + r16, channel 32 g + 4 J + e
+  const int n0 = nt * BN;
+  const float ws = p.w_inv_scale;
+  // all bias vectors (and, per pixel block, all residual vectors) are loaded AHEAD of the first store: stores count in vmcnt too, so
+  // a load issued behind a store would be waited for together with that store's completion
+  f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0, bs2 = bs0, bs3 = bs0, bs4 = bs0, bs5 = bs0, bs6 = bs0, bs7 = bs0;
+  if (p.bias) {
+    const float* bp = p.bias + n0 + q16 * 32;
+    bs0 = *reinterpret_cast<const f32x4*>(bp); bs1 = *reinterpret_cast<const f32x4*>(bp + 4);
+    bs2 = *reinterpret_cast<const f32x4*>(bp + 8); bs3 = *reinterpret_cast<const f32x4*>(bp + 12);
+    bs4 = *reinterpret_cast<const f32x4*>(bp + 16); bs5 = *reinterpret_cast<const f32x4*>(bp + 20);
+    bs6 = *reinterpret_cast<const f32x4*>(bp + 24); bs7 = *reinterpret_cast<const f32x4*>(bp + 28);
+  }
+  asm volatile("" : "+v"(bs0), "+v"(bs1), "+v"(bs2), "+v"(bs3), "+v"(bs4), "+v"(bs5), "+v"(bs6), "+v"(bs7));
+  size_t o0, o1;
+#define K_OFF(MI, O_)                                                                                                  \
+  {                                                                                                                    \
+    const int op = p0 + wave * 32 + MI * 16 + r16;                                                                     \
+    if (EPI == SEPI_PS_SILU) {                                                                                         \
+      const int CoutPS = p.Cout >> 2, ij = n0 / CoutPS, ch0 = n0 - ij * CoutPS;                                        \
+      const int oy = op / p.Wout, ox = op - oy * p.Wout;                                                               \
+      O_ = ((size_t)(b * 2 * p.Hout + 2 * oy + (ij >> 1)) * (2 * p.Wout) + 2 * ox + (ij & 1)) * CoutPS + ch0 + q16 * 32; \
+    } else {                                                                                                           \
+      O_ = ((size_t)b * HWo + op) * p.Cout + n0 + q16 * 32;                                                            \
+    }                                                                                                                  \
+  }
+  K_OFF(0, o0) K_OFF(1, o1)
+#undef K_OFF
+  f32x4 v0_[8] = {c00 * ws + bs0, c01 * ws + bs1, c02 * ws + bs2, c03 * ws + bs3, c04 * ws + bs4, c05 * ws + bs5, c06 * ws + bs6, c07 * ws + bs7};
+  f32x4 v1_[8] = {c10 * ws + bs0, c11 * ws + bs1, c12 * ws + bs2, c13 * ws + bs3, c14 * ws + bs4, c15 * ws + bs5, c16 * ws + bs6, c17 * ws + bs7};
+  if (EPI == SEPI_RESIDUAL) {
+    f32x4 r0_[8], r1_[8];
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+      r0_[J] = *reinterpret_cast<const f32x4*>(p.aux + o0 + 4 * J);
+      r1_[J] = *reinterpret_cast<const f32x4*>(p.aux + o1 + 4 * J);
+    }
+    asm volatile("" : "+v"(r0_[0]), "+v"(r0_[1]), "+v"(r0_[2]), "+v"(r0_[3]), "+v"(r0_[4]), "+v"(r0_[5]), "+v"(r0_[6]), "+v"(r0_[7]));
+    asm volatile("" : "+v"(r1_[0]), "+v"(r1_[1]), "+v"(r1_[2]), "+v"(r1_[3]), "+v"(r1_[4]), "+v"(r1_[5]), "+v"(r1_[6]), "+v"(r1_[7]));
+#pragma unroll
+    for (int J = 0; J < 8; ++J) { v0_[J] += r0_[J]; v1_[J] += r1_[J]; }
+  }
+  if (EPI == SEPI_PS_SILU) {
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v0_[J][e] = silu<true>(v0_[J][e]); v1_[J][e] = silu<true>(v1_[J][e]); }
+    }
+  }
+#pragma unroll
+  for (int J = 0; J < 8; ++J) *reinterpret_cast<f32x4*>(p.out + o0 + 4 * J) = v0_[J];
+#pragma unroll
+  for (int J = 0; J < 8; ++J) *reinterpret_cast<f32x4*>(p.out + o1 + 4 * J) = v1_[J];
+}
+
+}  // namespace
+
+bool conv1x1_split_eligible(const ConvArgs& a) {
+  if (a.pad != 0 || a.stride < 1 || a.KH < 1 || a.KW < 1) return false;
+  if ((a.Hout - 1) * a.stride + a.KH > a.Hin || (a.Wout - 1) * a.stride + a.KW > a.Win) return false;   // the gather stays inside
+  if (a.ps0 != a.C0 || (a.C1 && a.ps1 != a.C1)) return false;
+  if (a.C1 && (a.KH != 1 || a.KW != 1)) return false;
+  if (a.C0 % KC || a.C1 % KC || a.Cout % BN || a.Cout != a.CoutPad) return false;
+  if (((long)a.Hout * a.Wout) % BM) return false;
+  if (a.gn_partial || a.gn_res_src || a.out_q || a.eps4) return false;
+  if (a.mode == CONV_PIXEL_SHUFFLE_SILU && ((a.Cout / 4) % BN || a.residual)) return false;
+  if (a.mode != CONV_PLAIN && a.mode != CONV_PIXEL_SHUFFLE_SILU) return false;
+  if ((size_t)a.Hin * a.Win * (size_t)std::max(a.ps0, a.ps1) * 4 >= (1ull << 31)) return false;
+  if ((size_t)a.KH * a.KW * ((a.C0 + a.C1) / KC) * (a.Cout / BN) * B_SLOT >= (1ull << 31)) return false;
+  return true;
+}
+
+// fp32 [tap][Cout][Cin] (pack_conv_weights' order incl. its pixel-shuffle column permutation) -> [tap][cc][ntile][hi tile | lo tile];
+// a tile = 128 rows x 64 B, XOR-swizzled, row 16 J + 4 g + e holding output channel 32 g + 4 J + e of the n-tile
+void pack_conv1x1_split(const float* src_tap_o_i, int taps, int Cin, int Cout, float scale, std::vector<unsigned short>& out) {
+  const int CC = Cin / KC, NTL = Cout / BN;
+  out.assign((size_t)taps * CC * NTL * 2 * BN * KC, 0);
+  for (int tap = 0; tap < taps; ++tap)
+    for (int cc = 0; cc < CC; ++cc)
+      for (int nt = 0; nt < NTL; ++nt) {
+        unsigned short* hi_t = out.data() + ((size_t)(tap * CC + cc) * NTL + nt) * 2 * BN * KC;
+        unsigned short* lo_t = hi_t + BN * KC;
+        for (int n = 0; n < BN; ++n) {
+          const int J = n >> 4, g = (n >> 2) & 3, e = n & 3;
+          const int o = nt * BN + 32 * g + 4 * J + e;
+          for (int c = 0; c < 4; ++c) {
+            const int cs = c ^ ((n >> 1) & 3);
+            for (int k = 0; k < 8; ++k) {
+              const float v = src_tap_o_i[((size_t)tap * Cout + o) * Cin + cc * KC + c * 8 + k] * scale;
+              split_halves_host(v, true, &hi_t[n * KC + cs * 8 + k], &lo_t[n * KC + cs * 8 + k]);
+            }
+          }
+        }
+      }
+}
+
+int conv1x1_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, hipStream_t st) {
+  if (!conv1x1_split_eligible(a)) SRGD_FAIL("conv1x1_split: shape not eligible");
+  if (a.bias && ((size_t)a.bias & 15)) SRGD_FAIL("conv1x1_split: the bias array must be 16-byte aligned");
+  Split1Args p;
+  p.in0 = (const float*)a.in0; p.in1 = (const float*)a.in1; p.C0 = a.C0; p.C1 = a.C1;
+  p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Hout = a.Hout; p.Wout = a.Wout;
+  p.KH = a.KH; p.KW = a.KW; p.stride = a.stride; p.ps0 = a.ps0; p.ps1 = a.C1 ? a.ps1 : 0;
+  p.w = packed_w; p.bias = a.bias; p.w_inv_scale = w_inv_scale; p.Cout = a.Cout; p.out = (float*)a.out;
+  p.aux = (const float*)a.residual;
+  const long grid = (long)a.B * a.Hout * a.Wout / BM * (a.Cout / BN);
+  if (grid <= 0 || grid > 0x7fffffffL) SRGD_FAIL("conv1x1_split: bad grid");
+  static bool attr_set[64] = {};
+  if (DeviceSetup once(attr_set); once.need) {
+#define K_SET(E_) SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<E_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    K_SET(SEPI_PLAIN) K_SET(SEPI_RESIDUAL) K_SET(SEPI_PS_SILU)
+#undef K_SET
+    once.done();
+  }
+#define K_GO(E_) hipLaunchKernelGGL((conv1x1_split_kernel<E_>), dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, p)
+  if (a.mode == CONV_PIXEL_SHUFFLE_SILU) K_GO(SEPI_PS_SILU);
+  else if (a.residual) K_GO(SEPI_RESIDUAL);
+  else K_GO(SEPI_PLAIN);
+#undef K_GO
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace srgd

@@ -56,6 +56,8 @@ struct Split3Args {
   int Cout;
   float* out;
   float* gn_partial; int groups;
+  const float* gn_in_a;   // GNIN: y = silu(a[b][c] * x + b[b][c]) applied to the input while it is staged ([B][Cin] fp32 each)
+  const float* gn_in_b;
 };
 
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
@@ -94,7 +96,11 @@ __device__ __forceinline__ void split8(const u32x4& r0, const u32x4& r1, u32x4& 
   }
 }
 
-template <bool STATS, bool F16>
+// GNIN instances: the PRODUCER's GroupNorm-apply + SiLU (reference Block.forward model.py:250-259 between two convolutions) is applied
+// to the fp32 halo pieces in registers, ahead of the split - the separate gn_apply pass over that tensor (4 B read + 4 B written per
+// element) disappears.  Out-of-image halo pixels stay zero (the convolution pads the ACTIVATED tensor).  v_exp_f32 / v_rcp_f32
+// (1 ulp each) instead of gn_apply's expf and IEEE division: ~3e-7 relative, far inside the mode's 2^-22 per product.
+template <bool STATS, bool F16, bool GNIN>
 __global__ __launch_bounds__(NT3, 2) void conv3x3_split_kernel(Split3Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -166,12 +172,29 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_split_kernel(Split3Args p) {
       hi16 = __builtin_amdgcn_raw_buffer_load_b128(rs1, voff, 16, 0);
     }
   };
+  f32x4 ga0, ga1, gb0, gb1;                        // GNIN: scale / shift of the thread's 8 channels of the chunk in flight
   auto load_a = [&](int cc) {
     load_piece(cc, a_pix0, ra00, ra01);
     load_piece(cc, a_pix1, ra10, ra11);
     load_piece(cc, a_pix2, ra20, ra21);
+    if constexpr (GNIN) {                          // one source (launcher); the same 8 channels for all three pieces
+      const float* ca = p.gn_in_a + (size_t)b * Cin + cc * KC + a_sub * 8;
+      const float* cb = p.gn_in_b + (size_t)b * Cin + cc * KC + a_sub * 8;
+      ga0 = *reinterpret_cast<const f32x4*>(ca); ga1 = *reinterpret_cast<const f32x4*>(ca + 4);
+      gb0 = *reinterpret_cast<const f32x4*>(cb); gb1 = *reinterpret_cast<const f32x4*>(cb + 4);
+    }
   };
-  auto store_piece = [&](int cc, int j, const u32x4& r0, const u32x4& r1) {
+  auto act4 = [&](u32x4& r, const f32x4& ga, const f32x4& gb) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float t = __builtin_fmaf(ga[k], __builtin_bit_cast(float, r[k]), gb[k]);
+      r[k] = __builtin_bit_cast(unsigned, t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)));
+    }
+  };
+  auto store_piece = [&](int cc, int j, u32x4 r0, u32x4 r1) {
+    if constexpr (GNIN) {
+      if ((j == 0 ? a_pix0 : (j == 1 ? a_pix1 : a_pix2)) >= 0) { act4(r0, ga0, gb0); act4(r1, ga1, gb1); }
+    }
     u32x4 hi, lo;
     split8<F16>(r0, r1, hi, lo);
     char* dst = sA0 + (cc & 1) * A_BUF + (tid + NT3 * j) * 16;
@@ -243,7 +266,8 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_split_kernel(Split3Args p) {
   // weight copies: they are then younger than B[s+2] and the counted waits of taps 0 and 1 let them fly); compute(s); taps 3..5 split
   // one piece each into the other A buffer; wait until B[s+1] has landed; barrier.
   // vmcnt bookkeeping (loads retire in order): at the end of tap t the requests younger than B[s+1] are
-  //   tap 0: B[s+2] (2) + A (6) = 8;   tap 1: A (6) + B[s+2] (2) = 8;   taps 2..8: B[s+2] (2)   (tap 2's wait retires the A loads).
+  //   tap 0: B[s+2] (2) + A (6) = 8;   tap 1: A (6) + B[s+2] (2) = 8;   taps 2..8: B[s+2] (2)   (tap 2's wait retires the A loads);
+  //   GNIN: the chunk's four coefficient loads ride with the A loads (12 instead of 8).
   for (int cc = 0; cc < CC - 1; ++cc) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -257,7 +281,8 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_split_kernel(Split3Args p) {
       if (tap == 3) store_piece(cc + 1, 0, ra00, ra01);
       if (tap == 4) store_piece(cc + 1, 1, ra10, ra11);
       if (tap == 5) store_piece(cc + 1, 2, ra20, ra21);
-      if (tap < 2) WAIT_VM(8); else WAIT_VM(2);
+      if (tap < 2) { if constexpr (GNIN) WAIT_VM(12); else WAIT_VM(8); }        // GNIN: + the four coefficient loads of tap 0
+      else WAIT_VM(2);
       if (tap == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's A pieces are in LDS before the barrier publishes them
       BARRIER();
     }
@@ -435,27 +460,34 @@ void pack_conv3x3_split(const float* src_oihw, int Cin, int Cout, bool f16, floa
       }
 }
 
-int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bool f16, hipStream_t st) {
+int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bool f16, hipStream_t st, const float* gn_in_a,
+                  const float* gn_in_b) {
   if (!conv3x3_split_eligible(a)) SRGD_FAIL("conv3x3_split: shape not eligible");
+  const bool gnin = gn_in_a != nullptr;
+  if (gnin && (a.C1 != 0 || !gn_in_b || !f16 || ((size_t)gn_in_a & 15) || ((size_t)gn_in_b & 15)))
+    SRGD_FAIL("conv3x3_split: fused input GroupNorm needs one source, f16 halves and 16-byte aligned scale / shift arrays");
   if (a.bias && ((size_t)a.bias & 15)) SRGD_FAIL("conv3x3_split: the bias array must be 16-byte aligned");
   Split3Args p;
   p.in0 = (const float*)a.in0; p.in1 = (const float*)a.in1; p.C0 = a.C0; p.C1 = a.C1;
   p.B = a.B; p.H = a.Hin; p.W = a.Win; p.w = packed_w; p.bias = a.bias; p.w_inv_scale = w_inv_scale; p.Cout = a.Cout;
   p.out = (float*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
+  p.gn_in_a = gn_in_a; p.gn_in_b = gn_in_b;
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-#define K_SET(S_, F_)                                                                                  \
-  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<S_, F_>),              \
+#define K_SET(S_, F_, G_)                                                                              \
+  SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<S_, F_, G_>),          \
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    K_SET(true, true) K_SET(false, true) K_SET(true, false) K_SET(false, false)
+    K_SET(true, true, false) K_SET(false, true, false) K_SET(true, false, false) K_SET(false, false, false)
+    K_SET(true, true, true) K_SET(false, true, true)
 #undef K_SET
     once.done();
   }
   const bool stats = a.gn_partial != nullptr;
-#define K_GO(S_, F_) hipLaunchKernelGGL((conv3x3_split_kernel<S_, F_>), dim3(grid), dim3(NT3), LDS_BYTES, st, p)
-  if (stats && f16) K_GO(true, true); else if (stats) K_GO(true, false);
-  else if (f16) K_GO(false, true); else K_GO(false, false);
+#define K_GO(S_, F_, G_) hipLaunchKernelGGL((conv3x3_split_kernel<S_, F_, G_>), dim3(grid), dim3(NT3), LDS_BYTES, st, p)
+  if (gnin) { if (stats) K_GO(true, true, true); else K_GO(false, true, true); }
+  else if (stats && f16) K_GO(true, true, false); else if (stats) K_GO(true, false, false);
+  else if (f16) K_GO(false, true, false); else K_GO(false, false, false);
 #undef K_GO
   SRGD_HIP(hipGetLastError());
   return 0;

@@ -116,6 +116,7 @@ struct ConvW {
   void* wq1 = nullptr;        // conv1x1_mxfp8 packing (fp8 mode: the pointwise layers whose inputs have MX-fp8 twins)
   void* ws3 = nullptr;        // conv3x3_split packing (f16x3 mode: (hi, lo) f16 tiles of the scaled weights)
   void* ws = nullptr;         // conv_igemm_split packing (f16x3 mode: every other layer with Cin % 32 == 0)
+  void* ws1 = nullptr;        // conv1x1_split packing (f16x3 mode: 1x1 / pixel-shuffle / space-to-depth layers with Cout % 128 == 0)
   float ws_inv = 1.f;         // 1 / the layer's power-of-two weight scale (f16x3 mode)
   float* bias = nullptr;
 };
@@ -214,7 +215,7 @@ struct ProfRec { int kc; hipEvent_t a, b; };
 
 const char* kFamilyNames[KC_COUNT] = {"conv_igemm", "conv3x3_bf16", "conv1x1_bf16", "init_conv7x7", "groupnorm_silu", "rmsnorm", "linear_attention",
                                       "full_attention", "final_conv_ddpm_step", "canvas_rng", "conditioning", "conv3x3_mxfp8",
-                                      "quantize_mxfp8", "conv1x1_mxfp8", "conv3x3_split", "conv_igemm_split"};
+                                      "quantize_mxfp8", "conv1x1_mxfp8", "conv3x3_split", "conv_igemm_split", "conv1x1_split"};
 
 }  // namespace
 }  // namespace srgd
@@ -260,6 +261,7 @@ struct srgd_engine {
   bool fp8 = false;           // SRGD_PRECISION_FP8: 3x3 convolutions on the block-scaled MX-fp8 matrix cores, the rest as bf16
   bool w8 = false;            // SRGD_PRECISION_BF16_W8: conv weights rounded through fp8 e4m3 (per-output-channel scale)
   bool no_gn_fusion = false;
+  int split_gn_fusion_max_ntiles = 64;  // f16x3 mode: three MFMAs per staged product make the transform relatively cheaper (SRGD_GN_FUSION_NTILES overrides)
   int gn_fusion_max_ntiles = 2;         // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile); round 4: 2 (was 1)
   bool no_final_fusion = false;   // SRGD_FINAL_FUSION=0: the last ResnetBlock stores its output and final_step applies the 1x1 (A/B switch)
   bool no_la256 = false;      // SRGD_LA256=0: the C = 256 LinearAttention sites run the unfused chain (A/B switch)
@@ -492,6 +494,10 @@ int pack_conv(srgd_engine* e, ConvW& c) {
     }
     pack_conv_weights_split(reinterpret_cast<const float*>(packed.data()), c.KS * c.KS, c.Cin, c.CoutPad, true, scale, ps);
     SRGD_TRY(upload(e, ps.data(), ps.size() * 2, &c.ws));
+    if ((c.KS == 1 || c.kind == CK_UNSHUFFLE) && c.Cout % 128 == 0 && c.CoutPad == c.Cout) {
+      pack_conv1x1_split(reinterpret_cast<const float*>(packed.data()), c.KS * c.KS, c.Cin, c.Cout, scale, ps);
+      SRGD_TRY(upload(e, ps.data(), ps.size() * 2, &c.ws1));
+    }
   }
   if (e->fp8 && c.kind == CK_NORMAL && c.KS == 3 && c.Cin % 128 == 0 && c.Cout % 128 == 0) {
     std::vector<unsigned char> pq;
@@ -588,6 +594,14 @@ bool final_fusion_possible(const srgd_engine* e) {
 // gn_in: the input is a raw conv output whose GroupNorm+SiLU (coefA/coefB) the fast 3x3 kernel applies while
 // staging; *gn_in_done tells the caller whether that happened (otherwise it must run gn_apply first).
 bool conv_can_fuse_gn_in(srgd_engine* e, const ConvW& c, int nb, int H, int W) {
+  if (e->split) {       // f16x3 mode: conv3x3_split applies it to the fp32 halo pieces in registers, ahead of the split
+    if (!c.ws3 || e->force_generic_conv || e->no_gn_fusion || c.Cout / 128 > e->split_gn_fusion_max_ntiles) return false;
+    ConvArgs a{};
+    a.C0 = c.Cin; a.C1 = 0; a.ps0 = c.Cin; a.B = nb; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W;
+    a.KH = a.KW = c.KS; a.stride = c.stride; a.pad = c.pad; a.Cout = c.Cout; a.CoutPad = c.CoutPad; a.mode = c.mode;
+    a.groups = e->cfg.groups; a.gn_partial = e->gn_partial;
+    return conv3x3_split_eligible(a);
+  }
   if (!e->bf16 || !c.w3 || e->force_generic_conv || e->no_gn_fusion) return false;
   if (c.Cout / 128 > e->gn_fusion_max_ntiles) return false;
   ConvArgs a{};
@@ -648,8 +662,9 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
     if (in1) SRGD_TRY(q_twin(x, in1, C1, Hin * Win, &mq1));
   }
   const bool split3 = e->split && c.ws3 && !e->force_generic_conv && conv3x3_split_eligible(a);
-  const bool splitg = e->split && !split3 && c.ws && conv_igemm_split_eligible(a);
-  const int fam = split3 ? KC_CONV3S : splitg ? KC_CONVS : fast ? KC_CONV3 : fastq1 ? KC_CONV1Q : fast1 ? KC_CONV1 : KC_CONV;
+  const bool split1 = e->split && !split3 && c.ws1 && !stats && !e->force_generic_conv && !e->no_conv1x1 && conv1x1_split_eligible(a);
+  const bool splitg = e->split && !split3 && !split1 && c.ws && conv_igemm_split_eligible(a);
+  const int fam = split3 ? KC_CONV3S : split1 ? KC_CONV1S : splitg ? KC_CONVS : fast ? KC_CONV3 : fastq1 ? KC_CONV1Q : fast1 ? KC_CONV1 : KC_CONV;
   Prof p(e, fam, x.st);
   if (e->prof_on) {
     e->fam_flops[fam] += 2.0 * (double)x.nb * a.Hout * a.Wout * c.Cout * (double)(c.KS * c.KS * c.Cin);
@@ -681,11 +696,12 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
     if (stats) e->stats_slots = conv3x3_bf16_stats_slots(a);
     return conv3x3_bf16(a, c.w3, gn_in ? e->coefA : nullptr, gn_in ? e->coefB : nullptr, x.st);
   }
-  if (gn_in) SRGD_FAIL("internal: fused input GroupNorm requested on the generic conv path");
   if (split3) {
     if (stats) e->stats_slots = conv3x3_bf16_stats_slots(a);
-    return conv3x3_split(a, c.ws3, c.ws_inv, true, x.st);
+    return conv3x3_split(a, c.ws3, c.ws_inv, true, x.st, gn_in ? e->coefA : nullptr, gn_in ? e->coefB : nullptr);
   }
+  if (gn_in) SRGD_FAIL("internal: fused input GroupNorm requested on the generic conv path");
+  if (split1) return conv1x1_split(a, c.ws1, c.ws_inv, x.st);
   if (stats) e->stats_slots = cdiv(a.Hout * a.Wout, conv_tile_m());
   if (splitg) return conv_igemm_split(a, c.ws, c.ws_inv, true, x.st);
   return conv_igemm(a, e->bf16, x.st);
@@ -1107,7 +1123,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   e->cfg = *cfg;
   SRGD_TRY(build_topology(e.get()));
   if (const char* v = getenv("SRGD_GN_FUSION")) e->no_gn_fusion = atoi(v) == 0;   // experiment switch (see no_gn_fusion)
-  if (const char* v = getenv("SRGD_GN_FUSION_NTILES")) e->gn_fusion_max_ntiles = atoi(v);
+  if (const char* v = getenv("SRGD_GN_FUSION_NTILES")) e->gn_fusion_max_ntiles = e->split_gn_fusion_max_ntiles = atoi(v);
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
   // fp8_mixed is the quality-oriented fp8 mode: its pointwise layers stay on conv1x1_bf16 unless asked for (the MX pointwise

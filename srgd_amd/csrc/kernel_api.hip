@@ -97,24 +97,33 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   }
   // impl 6 / 7: the split-operand kernels (fp32 tensors; f16 (hi, lo) operand pairs): 6 = conv3x3_split, 7 = conv_igemm_split;
   // impl 8 / 9: the same two kernels with bf16 halves (numerics comparison only - the engine uses f16)
-  const bool split3 = impl == 6 || impl == 8, splitg = impl == 7 || impl == 9, split_f16 = impl == 6 || impl == 7;
+  // impl 10: the streaming pointwise kernel of that mode (conv1x1_split.hip; f16 halves)
+  // impl 11: impl 6 with the producer's GroupNorm + SiLU applied while the input is staged (gn_tail_a / gn_tail_b = [B][C0] scale / shift)
+  const bool split_gnin = impl == 11;
+  if (split_gnin) {
+    if (!gn_tail_a || !gn_tail_b || C1) SRGD_FAIL("srgd_k_conv2d: impl 11 (GroupNorm-in-staging) needs one source and gn_tail_a / gn_tail_b");
+    a.gn_res_src = nullptr; a.gn_res_a = nullptr; a.gn_res_b = nullptr;
+  }
+  const bool split3 = impl == 6 || impl == 8 || split_gnin, splitg = impl == 7 || impl == 9, split1 = impl == 10, split_f16 = impl == 6 || impl == 7 || split1 || split_gnin;
   DevBuf dws;
   float ws_inv = 1.f;
-  if (split3 || splitg) {
+  if (split3 || splitg || split1) {
     if (is_bf16) SRGD_FAIL("srgd_k_conv2d: the split-operand kernels take fp32 tensors (is_bf16 = 0)");
-    if (split3 ? !conv3x3_split_eligible(a) || kind != 0 : !conv_igemm_split_eligible(a))
+    if (split3 ? !conv3x3_split_eligible(a) || kind != 0 : split1 ? !conv1x1_split_eligible(a) : !conv_igemm_split_eligible(a))
       SRGD_FAIL("srgd_k_conv2d: the split-operand kernel does not cover this shape");
     const float scale = split_weight_scale(weight_oihw_host, (size_t)Cout * Cin * KS * KS, split_f16);
     ws_inv = 1.0f / scale;
     std::vector<unsigned short> ps;
     if (split3) pack_conv3x3_split(weight_oihw_host, Cin, Cout, split_f16, scale, ps);
+    else if (split1) pack_conv1x1_split(reinterpret_cast<const float*>(packed.data()), KS * KS, Cin, Cout, scale, ps);
     else pack_conv_weights_split(reinterpret_cast<const float*>(packed.data()), KS * KS, Cin, CoutPad, split_f16, scale, ps);
     SRGD_TRY(dws.alloc(ps.size() * 2));
     SRGD_HIP(hipMemcpy(dws.p, ps.data(), ps.size() * 2, hipMemcpyHostToDevice));
   }
   if (stats_slots) *stats_slots = (fast || split3) ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
   auto run = [&]() -> int {
-    if (split3) return conv3x3_split(a, dws.p, ws_inv, split_f16, st);
+    if (split3) return conv3x3_split(a, dws.p, ws_inv, split_f16, st, split_gnin ? gn_tail_a : nullptr, split_gnin ? gn_tail_b : nullptr);
+    if (split1) return conv1x1_split(a, dws.p, ws_inv, st);
     if (splitg) return conv_igemm_split(a, dws.p, ws_inv, split_f16, st);
     if (fastq1) return conv1x1_mxfp8(a, q0.p, s0.p, q1.p, s1.p, dwq1.p, st);
     return fast ? conv3x3_bf16(a, dw3.p, gnin ? gn_tail_a : nullptr, gnin ? gn_tail_b : nullptr, st) : fast1 ? conv1x1_bf16(a, dw1.p, st) : conv_igemm(a, is_bf16 != 0, st);

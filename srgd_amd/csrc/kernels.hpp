@@ -82,13 +82,22 @@ float split_weight_scale(const float* w, size_t n, bool f16);
 void split_halves_host(float v, bool f16, unsigned short* hi, unsigned short* lo);
 bool conv3x3_split_eligible(const ConvArgs& a);          // same shapes and GroupNorm slot layout as conv3x3_bf16
 void pack_conv3x3_split(const float* src_oihw, int Cin, int Cout, bool f16, float scale, std::vector<unsigned short>& out);
-int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bool f16, hipStream_t st);
+// gn_in_a / gn_in_b (nullable, f16 halves only): [B][Cin] fp32 coefficients of y = silu(a*x + b) applied to the INPUT while it is
+// staged (the producer's GroupNorm + SiLU, fused; single source)
+int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bool f16, hipStream_t st,
+                  const float* gn_in_a = nullptr, const float* gn_in_b = nullptr);
 // generic implicit GEMM of that mode (a.w ignored; every epilogue of the fp32 conv_igemm); weights from pack_conv_weights_split,
 // which takes pack_conv_weights' fp32 [tap][CoutPad][Cin] order
 bool conv_igemm_split_eligible(const ConvArgs& a);
 void pack_conv_weights_split(const float* src_tap_o_i, int taps, int Cin, int CoutPad, bool f16, float scale,
                              std::vector<unsigned short>& out);
 int conv_igemm_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bool f16, hipStream_t st);
+// conv1x1_split.hip: the pointwise layers of that mode as a streaming kernel (3-deep LDS-DMA ring of fp32 pixel rows + split weights; plain,
+// + residual, SiLU + PixelShuffle epilogues; 1x1 incl. two sources, 2x2 / stride-2 gather); f16 halves; weights from
+// pack_conv1x1_split, which takes pack_conv_weights' fp32 [tap][Cout][Cin] order
+bool conv1x1_split_eligible(const ConvArgs& a);
+void pack_conv1x1_split(const float* src_tap_o_i, int taps, int Cin, int Cout, float scale, std::vector<unsigned short>& out);
+int conv1x1_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, hipStream_t st);
 
 // ---------------------------------------------------------------- conv3x3_mxfp8.hip / quant_mxfp8.hip
 // Block-scaled MX-fp8 path (v_mfma_scale_f32_16x16x128_f8f6f4, BASELINE configs[4]): the 3x3 convolutions take e4m3

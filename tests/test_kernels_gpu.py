@@ -84,9 +84,10 @@ def run_conv(x0, x1, w, b, *, ks, stride, pad, kind, bf16, residual=None, groups
     bh = None if b is None else b.contiguous().float()
     slots = C.c_int()
     tail_src = tail_a = tail_b = None
-    if gn_tail is not None:                 # (h [B,C,H,W], a [B,C], b [B,C]): out = silu(a*h + b) + conv(x)
-        tail_src = to_dev_nhwc(gn_tail[0], bf16)
-        tail_a, tail_b = gn_tail[1].float().contiguous().to(DEV), gn_tail[2].float().contiguous().to(DEV)
+    if gn_tail is not None:                 # (h [B,C,H,W], a [B,C], b [B,C]): out = silu(a*h + b) + conv(x); h None: impl 5 / 11 (GNIN)
+        tail_src = None if gn_tail[0] is None else to_dev_nhwc(gn_tail[0], bf16)
+        tail_a = gn_tail[1] if gn_tail[1].is_cuda else gn_tail[1].float().contiguous().to(DEV)
+        tail_b = gn_tail[2] if gn_tail[2].is_cuda else gn_tail[2].float().contiguous().to(DEV)
     L().check(lib.srgd_k_conv2d_timed(ptr(d0), ptr(d1), C0, C1, B, H, W, ks, stride, pad, kind, ptr(wh), ptr(bh), cout,
                                       ptr(out), ptr(dres), ptr(part), groups, int(bf16), impl, 0, None,
                                       C.byref(slots), ptr(tail_src), ptr(tail_a), ptr(tail_b), stream()),

@@ -83,6 +83,30 @@ def test_conv3x3_split_borders_sources_stats(cfg):
     assert err["f16"] < err["bf16"]
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 128, 16, 32), (1, 128, 256, 16, 64), (3, 32, 128, 8, 32)], ids=lambda s: "B%d_C%d_Cout%d_%dx%d" % s)
+def test_conv3x3_split_groupnorm_in_staging(cfg):
+    # impl 11: conv(silu(a[b][c] * x + b[b][c])) with the activation applied to the fp32 halo pieces in registers; the zero padding
+    # applies to the ACTIVATED tensor (silu(b) != 0 must not leak into the halo)
+    B, cin, cout, H, W = cfg
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, cin, H, W, generator=g) * 2
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cout, generator=g)
+    ca = 1 + 0.3 * torch.randn(B, cin, generator=g)
+    cb = 0.5 * torch.randn(B, cin, generator=g)
+    coef = torch.stack([ca, cb]).contiguous().to(DEV)          # one allocation, 16-byte aligned rows
+    act = F.silu(ca.double()[:, :, None, None] * x.double() + cb.double()[:, :, None, None])
+    want64 = F.conv2d(act, w.double(), b.double(), padding=1)
+    got, part, nslots = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, groups=8, impl=11, want_slots=True,
+                                 gn_tail=(None, coef[0], coef[1]))
+    scale = max(1.0, float(want64.abs().max()))
+    err = float((got.double() - want64).abs().max())
+    _report_k(test="conv3x3_split_gnin", cfg=list(cfg), max_abs=err, ref_max=scale)
+    assert err <= 6e-6 * scale, err
+    s = part.sum(2).cpu().double()
+    assert (s[..., 0] - want64.reshape(B, 8, -1).sum(-1)).abs().max() <= 1e-4 * max(1.0, float(want64.abs().sum(1).max()))
+
+
 def test_conv3x3_split_small_and_large_magnitudes():
     # what the power-of-two weight scale is for: weights of 1e-3 (w_lo deep in f16's subnormal range without it), activations
     # spanning 1e-3 .. 1e2 in one tensor; and saturation instead of NaN beyond f16's range
@@ -146,6 +170,56 @@ def test_conv_igemm_split_variants(variant):
             pre = conv64(xin, w, b)
             assert (s[..., 0] - pre.reshape(B, groups, -1).sum(-1)).abs().max() <= 1e-4 * float(pre.abs().sum(1).max())
             assert (s[..., 1] - (pre ** 2).reshape(B, groups, -1).sum(-1)).abs().max() <= 1e-4 * float((pre ** 2).reshape(B, groups, -1).sum(-1).max())
+
+
+@pytest.mark.parametrize("variant", ["plain", "residual", "two_sources", "pixel_shuffle", "unshuffle", "k_heavy", "one_step", "integers"])
+def test_conv1x1_split_streaming_kernel(variant):
+    # conv1x1_split.hip (fp32 pixel rows and split weights through a 3-deep LDS-DMA ring, split in registers, register-direct epilogue)
+    # against float64 and against the generic split kernel (same arithmetic, different tiling)
+    g = torch.Generator().manual_seed(31)
+    B, H, W = 2, 16, 32                                     # 512 pixels per image: two 256-pixel tiles
+    kw = dict(ks=1, stride=1, pad=0, kind=0)
+    c0, c1, cout = 64, 0, 128
+    residual = None
+    if variant == "two_sources":
+        c0, c1, cout = 96, 32, 256
+    elif variant == "k_heavy":
+        c0, cout, H, W = 1024, 256, 16, 16
+    elif variant == "one_step":
+        c0 = 32                                             # a single K-step: prologue and last step only
+    elif variant == "unshuffle":
+        kw = dict(ks=2, stride=2, pad=0, kind=1)
+        H, W = 32, 32                                       # output 16 x 16 = 256 pixels per image
+    elif variant == "pixel_shuffle":
+        kw = dict(ks=1, stride=1, pad=0, kind=2)
+        cout = 1024                                         # Cout / 4 = 256: two n-tiles per sub-pixel
+    cin = c0 + c1
+    if variant == "integers":
+        x0 = torch.randint(-3, 4, (B, c0, H, W), generator=g).float()
+        w = torch.randint(-2, 3, (cout, cin, 1, 1), generator=g).float()
+        b = torch.randint(-4, 5, (cout,), generator=g).float()
+    else:
+        x0 = torch.randn(B, c0, H, W, generator=g)
+        w = torch.randn(cout, (4 if variant == "unshuffle" else 1) * cin, 1, 1, generator=g) / ((4 if variant == "unshuffle" else 1) * cin) ** 0.5
+        b = torch.randn(cout, generator=g)
+    x1 = torch.randn(B, c1, H, W, generator=g) if c1 else None
+    xin = x0 if x1 is None else torch.cat((x0, x1), 1)
+    want64 = conv64(F.pixel_unshuffle(xin, 2), w, b) if variant == "unshuffle" else conv64(xin, w, b)
+    if variant == "pixel_shuffle":
+        want64 = F.pixel_shuffle(F.silu(want64), 2)
+    if variant == "residual":
+        residual = torch.randn(B, cout, H, W, generator=g)
+        want64 = want64 + residual.double()
+    got, _ = run_conv(x0, x1, w, b, bf16=False, residual=residual, impl=10, **kw)
+    if variant == "integers":
+        assert torch.equal(got.double(), want64)
+        return
+    scale = max(1.0, float(want64.abs().max()))
+    err = float((got.double() - want64).abs().max())
+    gen, _ = run_conv(x0, x1, w, b, bf16=False, residual=residual, impl=7, **kw)
+    _report_k(test="conv1x1_split", variant=variant, max_abs=err, ref_max=scale, vs_generic_split=float((got - gen).abs().max()))
+    assert err <= 4e-6 * scale, (variant, err)
+    assert (got - gen).abs().max() <= 3e-6 * scale
 
 
 def test_conv_igemm_split_3x3_equals_the_halo_kernel_to_summation_order():
