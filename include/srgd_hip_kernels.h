@@ -47,7 +47,8 @@ int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int H
  * (conv_igemm.hip; C0, C1 % 32 == 0); 8 / 9 = the same two kernels with bf16 halves (numerics comparison only); 10 = the streaming
  * pointwise kernel of that mode (conv1x1_split.hip: 1x1 incl. two sources, 2x2 / stride-2 gather, + residual, SiLU + PixelShuffle;
  * C0, C1 % 32 == 0, Cout % 128 == 0, Hout * Wout % 256 == 0); 11 = impl 6 with the producer's GroupNorm + SiLU applied while the input
- * is staged, as impl 5 (gn_tail_a / gn_tail_b = device fp32 [B][C0], 16-byte aligned; one source; gn_tail_src NULL).
+ * is staged, as impl 5 (gn_tail_a / gn_tail_b = device fp32 [B][C0], 16-byte aligned; one source; gn_tail_src NULL); 12 / 13 = impl
+ * 6 / 11 on the 512-thread form of that kernel (one workgroup per CU) instead of the engine's default (256 threads, two per CU).
  * gn_tail_src (nullable, NHWC like out): out = silu(gn_tail_a[b][c] * gn_tail_src + gn_tail_b[b][c]) + conv(in) -
  * the second GroupNorm+SiLU of a ResnetBlock and its residual add folded into the 1x1 res_conv (model.py:250-259,:285);
  * gn_tail_a / gn_tail_b: device fp32 [B][Cout].  May alias out.

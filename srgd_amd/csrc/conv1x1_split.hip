@@ -1,6 +1,7 @@
 // Pointwise (1x1) convolutions in SPLIT-OPERAND precision for gfx950 (MI355X): the layers conv1x1_bf16.hip serves in the bf16 modes -
 // ResnetBlock res_conv (reference model.py:271), to_qkv / to_out (:300-303, :338-340), PixelShuffleUpsample's 1x1 + SiLU +
-// PixelShuffle (:70-98), Downsample's space-to-depth + 1x1 (:106-110, as a 2x2 / stride-2 gather) - on fp32 tensors, every product
+// PixelShuffle (:70-98), Downsample's space-to-depth + 1x1 (:106-110, as a 2x2 / stride-2 gather), and the 7x7 input convolution as
+// a 7x1 gather over 64-element windows (:597) - on fp32 tensors, every product
 // as three f16 MFMAs on (hi, lo) operand pairs (arithmetic: conv3x3_split.hip).
 //
 // These layers are HBM-bound (fp32 in and out; <= 192 MFMA-FLOP per input byte at Cout = 128), so the kernel is a streaming GEMM built
@@ -255,7 +256,10 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
 bool conv1x1_split_eligible(const ConvArgs& a) {
   if (a.pad != 0 || a.stride < 1 || a.KH < 1 || a.KW < 1) return false;
   if ((a.Hout - 1) * a.stride + a.KH > a.Hin || (a.Wout - 1) * a.stride + a.KW > a.Win) return false;   // the gather stays inside
-  if (a.ps0 != a.C0 || (a.C1 && a.ps1 != a.C1)) return false;
+  if (a.ps0 % 4 || (a.C1 && (a.ps1 % 4 || a.ps1 < a.C1))) return false;                              // 16-byte aligned rows
+  // a pixel stride below the channel count = the overlapping-window view of the 7x7 input convolution (kernels.hpp): one source,
+  // and the last output pixel's window must stay inside its row
+  if (a.ps0 != a.C0 && (a.C1 || (long)(a.Win - (a.Wout - 1) * a.stride - a.KW) * a.ps0 + a.ps0 < a.C0)) return false;
   if (a.C1 && (a.KH != 1 || a.KW != 1)) return false;
   if (a.C0 % KC || a.C1 % KC || a.Cout % BN || a.Cout != a.CoutPad) return false;
   if (((long)a.Hout * a.Wout) % BM) return false;

@@ -187,8 +187,11 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_split_kernel(Split3Args p) {
   auto act4 = [&](u32x4& r, const f32x4& ga, const f32x4& gb) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float t = __builtin_fmaf(ga[k], __builtin_bit_cast(float, r[k]), gb[k]);
-      r[k] = __builtin_bit_cast(unsigned, t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)));
+      // (element copied out first: __builtin_bit_cast applied directly to the vector-element lvalue r[k] read element 0 for every
+      // k with this toolchain - hipcc 7.2 - which the kernel test caught)
+      const unsigned u = r[k];
+      const float t = __builtin_fmaf(ga[k], __uint_as_float(u), gb[k]);
+      r[k] = __float_as_uint(t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)));
     }
   };
   auto store_piece = [&](int cc, int j, u32x4 r0, u32x4 r1) {
@@ -357,6 +360,269 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_split_kernel(Split3Args p) {
   }
 }
 
+
+// ---- the two-workgroups-per-CU form -----------------------------------------------------------------------------------------------
+// Same arithmetic, LDS images and weight stream; the tile is an 8 x 16 pixel patch (M = 128) x 128 channels on 256 threads (4 waves,
+// 2 along M x 2 along N, each still 64 pixels x 64 channels = 4 patch rows of 16), the A image is SINGLE-buffered (hi | lo, 24 KB;
+// the next chunk's pieces wait in registers and are split + written at the chunk boundary, between two barriers) and the weight ring
+// stays 3 deep: 72 KB per workgroup - TWO workgroups per CU.  Why: with one workgroup per CU every barrier of the K loop (one per
+// K-step) leaves the matrix pipe idle until the first operand fragments are back from LDS, and so do the prologue, the chunk boundary
+// and the epilogue; a second, independent workgroup on the same SIMDs fills those gaps (the bf16 kernel's arrangement).  Price: the
+// weight stream is fetched per 128 pixels instead of per 256 (L2 -> LDS), the halo overhead rises from 1.33 to 1.41.
+constexpr int PW2 = 16, WP2 = PW2 + 2;            // halo patch 10 x 18 = 180 pixels
+constexpr int NT2 = 256;
+constexpr int A_IMG2 = 12 * 1024;                 // 768 16-byte pieces (720 used)
+constexpr int A_BUF2 = 2 * A_IMG2;                // hi | lo
+constexpr int LDS2_BYTES = A_BUF2 + 3 * B_SLOT;   // 73,728: two workgroups per CU
+
+template <bool STATS, bool GNIN>
+__global__ __launch_bounds__(NT2, 2) void conv3x3_split2_kernel(Split3Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, q16 = lane >> 4;
+
+  const int n_tiles = p.Cout / BN3;
+  const int tiles_x = p.W / PW2, tiles_y = p.H / PH;
+  const int m_tiles = p.B * tiles_y * tiles_x;
+  const int nwg = m_tiles * n_tiles;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, rem = nwg & 7, x = wg & 7, k = wg >> 3;
+    wg = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + k;
+  }
+  const int nt = wg % n_tiles, mt = wg / n_tiles;
+  const int b = mt / (tiles_y * tiles_x);
+  const int trem = mt - b * tiles_y * tiles_x;
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int y0 = ty * PH, x0 = tx * PW2;
+  const int Cin = p.C0 + p.C1;
+  const int CC = Cin / KC;
+
+  // ---- A staging: 768 pieces per image (720 used); thread t owns pieces t, t + 256, t + 512 (same source chunk for all three)
+  int a_pix0, a_pix1, a_pix2;
+#define K_A_DECL(J)                                                           \
+  {                                                                           \
+    const int g = tid + NT2 * J;                                              \
+    const int P = g >> 2;                                                     \
+    const int py = P / WP2, px = P - py * WP2;                                \
+    const int y = y0 + py - 1, x = x0 + px - 1;                               \
+    const bool ok = P < HP * WP2 && y >= 0 && y < p.H && x >= 0 && x < p.W;   \
+    a_pix##J = ok ? y * p.W + x : -1;                                         \
+  }
+  K_A_DECL(0) K_A_DECL(1) K_A_DECL(2)
+#undef K_A_DECL
+  const int a_sub = (tid & 3) ^ row_swz(tid >> 2);
+  const size_t img_elems0 = (size_t)p.H * p.W * p.C0, img_elems1 = (size_t)p.H * p.W * p.C1;
+  const __amdgpu_buffer_rsrc_t rs0 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (size_t)b * img_elems0), 0, (int)(img_elems0 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.in1 ? p.in1 + (size_t)b * img_elems1 : p.in0), 0, p.in1 ? (int)(img_elems1 * 4) : 0, 0x00020000);
+  const size_t w_tile_stride = (size_t)n_tiles * B_SLOT;
+  const char* w_base = (const char*)p.w + (size_t)nt * B_SLOT;
+  const __amdgpu_buffer_rsrc_t rsw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, (int)((size_t)(9 * CC - 1) * w_tile_stride + B_SLOT), 0x00020000);
+
+  char* const sA = smem;
+  char* const sB0 = smem + A_BUF2;
+
+  u32x4 ra00, ra01, ra10, ra11, ra20, ra21;
+  f32x4 ga0, ga1, gb0, gb1;
+  auto load_piece = [&](int cc, int a_pix, u32x4& lo16, u32x4& hi16) {
+    const int c = cc * KC;
+    const bool first = c < p.C0;
+    const int Cs = first ? p.C0 : p.C1;
+    const int coff = first ? c : c - p.C0;
+    const int voff = a_pix >= 0 ? (a_pix * Cs + coff + a_sub * 8) * 4 : 0x7ffffff0;
+    if (first) {
+      lo16 = __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, 0, 0);
+      hi16 = __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, 16, 0);
+    } else {
+      lo16 = __builtin_amdgcn_raw_buffer_load_b128(rs1, voff, 0, 0);
+      hi16 = __builtin_amdgcn_raw_buffer_load_b128(rs1, voff, 16, 0);
+    }
+  };
+  auto load_a = [&](int cc) {
+    load_piece(cc, a_pix0, ra00, ra01);
+    load_piece(cc, a_pix1, ra10, ra11);
+    load_piece(cc, a_pix2, ra20, ra21);
+    if constexpr (GNIN) {
+      const float* ca = p.gn_in_a + (size_t)b * Cin + cc * KC + a_sub * 8;
+      const float* cb = p.gn_in_b + (size_t)b * Cin + cc * KC + a_sub * 8;
+      ga0 = *reinterpret_cast<const f32x4*>(ca); ga1 = *reinterpret_cast<const f32x4*>(ca + 4);
+      gb0 = *reinterpret_cast<const f32x4*>(cb); gb1 = *reinterpret_cast<const f32x4*>(cb + 4);
+    }
+  };
+  auto act4 = [&](u32x4& r, const f32x4& ga, const f32x4& gb) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned u = r[k];                       // (see conv3x3_split_kernel: no bit_cast on the element lvalue)
+      const float t = __builtin_fmaf(ga[k], __uint_as_float(u), gb[k]);
+      r[k] = __float_as_uint(t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)));
+    }
+  };
+  auto store_piece = [&](int j, u32x4 r0, u32x4 r1) {
+    if constexpr (GNIN) {
+      if ((j == 0 ? a_pix0 : (j == 1 ? a_pix1 : a_pix2)) >= 0) { act4(r0, ga0, gb0); act4(r1, ga1, gb1); }
+    }
+    u32x4 hi, lo;
+    split8<true>(r0, r1, hi, lo);
+    char* dst = sA + (tid + NT2 * j) * 16;
+    *reinterpret_cast<u32x4*>(dst) = hi;
+    *reinterpret_cast<u32x4*>(dst + A_IMG2) = lo;
+  };
+  // weight unit of K-step (cc, tap) -> ring slot tap % 3; every wave copies 2 x 1 KiB of the hi tile and 2 x 1 KiB of the lo tile
+  const int w_tap_stride = (int)(CC * w_tile_stride);
+  const int tid16 = tid * 16;
+  auto issue_b = [&](int cc, int tap) {
+    if (tap >= 9) { tap -= 9; cc += 1; }
+    char* dst = sB0 + (tap % 3) * B_SLOT + wave * 1024;
+    const int so = tap * w_tap_stride + cc * (int)w_tile_stride;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)dst, 16, tid16, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(dst + 4096), 16, tid16, so + 4096, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(dst + B_TILE), 16, tid16, so + B_TILE, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(dst + B_TILE + 4096), 16, tid16, so + B_TILE + 4096, 0, 0);
+  };
+
+  f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c10 = 0, c11 = 0, c12 = 0, c13 = 0,
+        c20 = 0, c21 = 0, c22 = 0, c23 = 0, c30 = 0, c31 = 0, c32 = 0, c33 = 0;
+  const int b_base = (wn * 64 + r16) * 64 + ((q16 ^ row_swz(r16)) << 4);
+  // the wave's pixel block i (0..3) = patch row 4 wm + i, x = r16: halo pixel P = lp + Pc, lp = 4 wm WP2 + r16, Pc = (i + dy) WP2 + dx
+  const int lp = 4 * wm * WP2 + r16, lp8 = lp << 3, lp64 = lp * 64, q16s = q16 << 4;
+  auto a_addr = [&](int tap, int i) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int Pc = (i + dy) * WP2 + dx;
+    return lp64 + (((lp8 + Pc * 8) & 0x30) ^ q16s) + Pc * 64;
+  };
+  typedef u32x4 frag;
+  auto mma = [&](f32x4& c, const frag& wt, const frag& px) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wt), __builtin_bit_cast(f16x8, px), c, 0, 0, 0);
+  };
+  auto compute = [&](int tap) {
+    const char* Bt = sB0 + (tap % 3) * B_SLOT;
+    const frag bh0 = *reinterpret_cast<const frag*>(Bt + b_base), bh1 = *reinterpret_cast<const frag*>(Bt + b_base + 1024),
+               bh2 = *reinterpret_cast<const frag*>(Bt + b_base + 2048), bh3 = *reinterpret_cast<const frag*>(Bt + b_base + 3072);
+    const frag bl0 = *reinterpret_cast<const frag*>(Bt + B_TILE + b_base), bl1 = *reinterpret_cast<const frag*>(Bt + B_TILE + b_base + 1024),
+               bl2 = *reinterpret_cast<const frag*>(Bt + B_TILE + b_base + 2048), bl3 = *reinterpret_cast<const frag*>(Bt + B_TILE + b_base + 3072);
+#define K_ROW(I, C0_, C1_, C2_, C3_)                                                          \
+  {                                                                                            \
+    const frag ah = *reinterpret_cast<const frag*>(sA + a_addr(tap, I));                       \
+    const frag al = *reinterpret_cast<const frag*>(sA + A_IMG2 + a_addr(tap, I));              \
+    mma(C0_, bh0, al); mma(C1_, bh1, al); mma(C2_, bh2, al); mma(C3_, bh3, al);                \
+    mma(C0_, bl0, ah); mma(C1_, bl1, ah); mma(C2_, bl2, ah); mma(C3_, bl3, ah);                \
+    mma(C0_, bh0, ah); mma(C1_, bh1, ah); mma(C2_, bh2, ah); mma(C3_, bh3, ah);                \
+  }
+    K_ROW(0, c00, c01, c02, c03)
+    K_ROW(1, c10, c11, c12, c13)
+    K_ROW(2, c20, c21, c22, c23)
+    K_ROW(3, c30, c31, c32, c33)
+#undef K_ROW
+  };
+
+  // ---- prologue
+  issue_b(0, 0);
+  issue_b(0, 1);
+  load_a(0);
+  store_piece(0, ra00, ra01);
+  store_piece(1, ra10, ra11);
+  store_piece(2, ra20, ra21);
+  WAIT_VM(4);                                    // B[0] landed (B[1]'s four copies may still fly)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  BARRIER();
+
+  // ---- main loop.  vmcnt bookkeeping: B[s+2] is four requests, the A loads six (+ four coefficient loads with GNIN), all of them
+  // younger than B[s+1] at the end of taps 0 and 1; tap 2's wait (4) retires them.  At the chunk boundary (after tap 8's barrier:
+  // every wave has finished reading the A image) the next chunk's pieces are split and written, then a second barrier publishes them.
+  for (int cc = 0; cc < CC - 1; ++cc) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      issue_b(cc, tap + 2);
+      if (tap == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(cc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      compute(tap);
+      if (tap < 2) { if constexpr (GNIN) WAIT_VM(14); else WAIT_VM(10); }
+      else WAIT_VM(4);
+      BARRIER();
+      if (tap == 8) {
+        store_piece(0, ra00, ra01);
+        store_piece(1, ra10, ra11);
+        store_piece(2, ra20, ra21);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BARRIER();
+      }
+    }
+  }
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    if (tap < 7) issue_b(CC - 1, tap + 2);
+    compute(tap);
+    if (tap < 7) WAIT_VM(4); else WAIT_VM(0);
+    if (tap < 8) BARRIER();
+  }
+
+  // ---- epilogue (register-direct, fp32): block mi = patch row 4 wm + mi, pixel x = r16, channels 64 wn + 16 g + 4 J + e
+  const int chw = nt * BN3 + wn * 64;
+  const int chl = q16 * 16;
+  f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0, bs2 = bs0, bs3 = bs0;
+  if (p.bias) {
+    const float* bp = p.bias + chw + chl;
+    bs0 = *reinterpret_cast<const f32x4*>(bp);
+    bs1 = *reinterpret_cast<const f32x4*>(bp + 4);
+    bs2 = *reinterpret_cast<const f32x4*>(bp + 8);
+    bs3 = *reinterpret_cast<const f32x4*>(bp + 12);
+  }
+  const u32x4 rso = make_raw_rsrc(p.out + ((size_t)(b * p.H + y0 + 4 * wm) * p.W + x0) * p.Cout + chw, (unsigned)(4 * p.W * p.Cout * 4));
+  const int o_voff = (r16 * p.Cout + chl) * 4;
+  const float ws = p.w_inv_scale;
+  f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = s1v;
+  asm volatile("" : "+v"(bs0), "+v"(bs1), "+v"(bs2), "+v"(bs3));
+#define K_EMIT(MI, C0_, C1_, C2_, C3_)                                                          \
+  do {                                                                                             \
+    const int so_ = ((MI) * p.W * p.Cout) * 4;                                                     \
+    const f32x4 v0 = C0_ * ws + bs0, v1 = C1_ * ws + bs1, v2 = C2_ * ws + bs2, v3 = C3_ * ws + bs3; \
+    if (STATS) {                                                                                   \
+      s1v += (v0 + v1) + (v2 + v3);                                                                \
+      s2v = __builtin_elementwise_fma(v0, v0, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v1, v1, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v2, v2, s2v);                                                \
+      s2v = __builtin_elementwise_fma(v3, v3, s2v);                                                \
+    }                                                                                              \
+    buffer_store16(__builtin_bit_cast(u32x4, v0), rso, o_voff, so_);                               \
+    buffer_store16(__builtin_bit_cast(u32x4, v1), rso, o_voff, so_ + 16);                          \
+    buffer_store16(__builtin_bit_cast(u32x4, v2), rso, o_voff, so_ + 32);                          \
+    buffer_store16(__builtin_bit_cast(u32x4, v3), rso, o_voff, so_ + 48);                          \
+  } while (0)
+  K_EMIT(0, c00, c01, c02, c03);
+  K_EMIT(1, c10, c11, c12, c13);
+  K_EMIT(2, c20, c21, c22, c23);
+  K_EMIT(3, c30, c31, c32, c33);
+#undef K_EMIT
+  if (STATS) {
+    // slots: per (sample, group) tiles_y * tiles_x * tpg * wpt with wpt = 2 (4 when a group spans whole 128-channel tiles) - twice
+    // the patches of the 512-thread kernel with half the waves each: the same count (conv3x3_bf16_stats_slots)
+    const int cpg = p.Cout / p.groups;
+    float a1 = row16_sum((s1v[0] + s1v[1]) + (s1v[2] + s1v[3]));
+    float a2 = row16_sum((s2v[0] + s2v[1]) + (s2v[2] + s2v[3]));
+    if (cpg >= 32) { a1 = xor16_sum(a1); a2 = xor16_sum(a2); }
+    if (cpg >= 64) { a1 = xor32_sum(a1); a2 = xor32_sum(a2); }
+    const int rows_per_group = cpg >= 64 ? 4 : cpg >> 4;
+    if (r16 == 0 && (q16 & (rows_per_group - 1)) == 0) {
+      const int tpg = cpg >= BN3 ? cpg / BN3 : 1;
+      const int wpt = cpg >= BN3 ? 4 : 2;
+      const int nslots = tiles_y * tiles_x * tpg * wpt;
+      const int slot = (trem * tpg + (cpg >= BN3 ? nt % tpg : 0)) * wpt + (cpg >= BN3 ? wave : wm);
+      const int g = cpg >= BN3 ? chw / cpg : (chw + chl) >> __builtin_ctz(cpg);
+      float* dst = p.gn_partial + ((size_t)(b * p.groups + g) * nslots + slot) * 2;
+      *reinterpret_cast<f32x2*>(dst) = f32x2{a1, a2};
+    }
+  }
+}
+
 }  // namespace
 
 bool conv3x3_split_eligible(const ConvArgs& a) {
@@ -461,7 +727,7 @@ void pack_conv3x3_split(const float* src_oihw, int Cin, int Cout, bool f16, floa
 }
 
 int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bool f16, hipStream_t st, const float* gn_in_a,
-                  const float* gn_in_b) {
+                  const float* gn_in_b, int form) {
   if (!conv3x3_split_eligible(a)) SRGD_FAIL("conv3x3_split: shape not eligible");
   const bool gnin = gn_in_a != nullptr;
   if (gnin && (a.C1 != 0 || !gn_in_b || !f16 || ((size_t)gn_in_a & 15) || ((size_t)gn_in_b & 15)))
@@ -484,6 +750,24 @@ int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bo
     once.done();
   }
   const bool stats = a.gn_partial != nullptr;
+  // SRGD_SPLIT3_WG=1: the 512-thread kernel (one workgroup per CU); default: the 256-thread kernel (two per CU), f16 halves only
+  static const int env_form = env_int("SRGD_SPLIT3_WG", 2);
+  const int wg_form = form ? form : env_form;
+  if (f16 && wg_form != 1) {
+    static bool attr_set2[64] = {};
+    if (DeviceSetup once(attr_set2); once.need) {
+#define K_SET2(S_, G_) SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split2_kernel<S_, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_BYTES));
+      K_SET2(true, false) K_SET2(false, false) K_SET2(true, true) K_SET2(false, true)
+#undef K_SET2
+      once.done();
+    }
+    const int grid2 = a.B * (a.Hin / PH) * (a.Win / PW2) * (a.Cout / BN3);
+#define K_GO2(S_, G_) hipLaunchKernelGGL((conv3x3_split2_kernel<S_, G_>), dim3(grid2), dim3(NT2), LDS2_BYTES, st, p)
+    if (stats && gnin) K_GO2(true, true); else if (stats) K_GO2(true, false); else if (gnin) K_GO2(false, true); else K_GO2(false, false);
+#undef K_GO2
+    SRGD_HIP(hipGetLastError());
+    return 0;
+  }
 #define K_GO(S_, F_, G_) hipLaunchKernelGGL((conv3x3_split_kernel<S_, F_, G_>), dim3(grid), dim3(NT3), LDS_BYTES, st, p)
   if (gnin) { if (stats) K_GO(true, true, true); else K_GO(false, true, true); }
   else if (stats && f16) K_GO(true, true, false); else if (stats) K_GO(true, false, false);

@@ -237,6 +237,8 @@ struct srgd_engine {
   void* init7_w = nullptr;      // 7x1 x 64-virtual-channel packing of init_conv for the MFMA route
   int init7_coutpad = 0;
   void* init7_w1 = nullptr;     // same weights in the conv1x1_bf16 tile order
+  void* init7_ws1 = nullptr;    // f16x3 mode: the same weights split into (hi, lo) f16 tiles for conv1x1_split
+  float init7_ws_inv = 1.f;
   float *init_b = nullptr, *final_w = nullptr, *final_b = nullptr, *sin_w = nullptr, *cls_emb = nullptr;
   int init_wi = -1, init_bi = -1, final_wi = -1, final_bi = -1, sin_wi = -1, cls_emb_i = -1;
   Lin time1, time3, cls1, cls3;
@@ -926,6 +928,8 @@ int run_init7(srgd_engine* e, const void* padded, int entries, int H, int W, voi
   a.w = e->init7_w; a.bias = e->init_b; a.Cout = e->dim; a.CoutPad = e->init7_coutpad;
   a.out = out; a.residual = nullptr; a.mode = CONV_PLAIN; a.gn_partial = nullptr; a.groups = e->cfg.groups;
   a.gn_res_src = nullptr; a.gn_res_a = a.gn_res_b = nullptr;
+  if (e->split && e->init7_ws1 && !e->no_conv1x1 && !e->force_generic_conv && conv1x1_split_eligible(a))
+    return conv1x1_split(a, e->init7_ws1, e->init7_ws_inv, st);
   if (e->bf16 && e->init7_w1 && !e->no_conv1x1 && !e->force_generic_conv && conv1x1_bf16_eligible(a)) {
     QTensor tw;                                    // fp8 mode: x0 feeds the first and the last ResnetBlock's 3x3 convolutions
     const bool x0q = e->fp8 && (!((e->fp8_bf16_zones >> 0) & 1u) || !((e->fp8_bf16_zones >> (2 * e->n_stages + 1)) & 1u));
@@ -1283,6 +1287,13 @@ int srgd_finalize_weights(srgd_engine* e) {
       }
     } else {
       SRGD_TRY(upload(e, q.data(), q.size() * 4, &e->init7_w));
+      if (e->split && e->init7_coutpad == e->dim) {
+        const float scale = split_weight_scale(q.data(), q.size(), true);
+        e->init7_ws_inv = 1.0f / scale;
+        std::vector<unsigned short> ps;
+        pack_conv1x1_split(q.data(), 7, 64, e->dim, scale, ps);
+        SRGD_TRY(upload(e, ps.data(), ps.size() * 2, &e->init7_ws1));
+      }
     }
   }
   SRGD_TRY(upload_f32(e, e->final_wi, &e->final_w));

@@ -99,12 +99,14 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   // impl 8 / 9: the same two kernels with bf16 halves (numerics comparison only - the engine uses f16)
   // impl 10: the streaming pointwise kernel of that mode (conv1x1_split.hip; f16 halves)
   // impl 11: impl 6 with the producer's GroupNorm + SiLU applied while the input is staged (gn_tail_a / gn_tail_b = [B][C0] scale / shift)
-  const bool split_gnin = impl == 11;
+  const bool split_gnin = impl == 11 || impl == 13;
   if (split_gnin) {
     if (!gn_tail_a || !gn_tail_b || C1) SRGD_FAIL("srgd_k_conv2d: impl 11 (GroupNorm-in-staging) needs one source and gn_tail_a / gn_tail_b");
     a.gn_res_src = nullptr; a.gn_res_a = nullptr; a.gn_res_b = nullptr;
   }
-  const bool split3 = impl == 6 || impl == 8 || split_gnin, splitg = impl == 7 || impl == 9, split1 = impl == 10, split_f16 = impl == 6 || impl == 7 || split1 || split_gnin;
+  // impl 12 / 13: impl 6 / 11 on the 512-thread form of the kernel (one workgroup per CU) instead of the engine's default
+  const bool split_form1 = impl == 12 || impl == 13;
+  const bool split3 = impl == 6 || impl == 8 || impl == 12 || split_gnin, splitg = impl == 7 || impl == 9, split1 = impl == 10, split_f16 = impl == 6 || impl == 7 || impl == 12 || split1 || split_gnin;
   DevBuf dws;
   float ws_inv = 1.f;
   if (split3 || splitg || split1) {
@@ -122,7 +124,7 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   }
   if (stats_slots) *stats_slots = (fast || split3) ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
   auto run = [&]() -> int {
-    if (split3) return conv3x3_split(a, dws.p, ws_inv, split_f16, st, split_gnin ? gn_tail_a : nullptr, split_gnin ? gn_tail_b : nullptr);
+    if (split3) return conv3x3_split(a, dws.p, ws_inv, split_f16, st, split_gnin ? gn_tail_a : nullptr, split_gnin ? gn_tail_b : nullptr, split_form1 ? 1 : 0);
     if (split1) return conv1x1_split(a, dws.p, ws_inv, st);
     if (splitg) return conv_igemm_split(a, dws.p, ws_inv, split_f16, st);
     if (fastq1) return conv1x1_mxfp8(a, q0.p, s0.p, q1.p, s1.p, dwq1.p, st);

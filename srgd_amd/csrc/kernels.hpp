@@ -84,8 +84,10 @@ bool conv3x3_split_eligible(const ConvArgs& a);          // same shapes and Grou
 void pack_conv3x3_split(const float* src_oihw, int Cin, int Cout, bool f16, float scale, std::vector<unsigned short>& out);
 // gn_in_a / gn_in_b (nullable, f16 halves only): [B][Cin] fp32 coefficients of y = silu(a*x + b) applied to the INPUT while it is
 // staged (the producer's GroupNorm + SiLU, fused; single source)
+// form: 0 = the engine's choice (SRGD_SPLIT3_WG, default 2), 1 = the 512-thread kernel (one workgroup per CU), 2 = the 256-thread
+// kernel (two workgroups per CU; f16 halves only)
 int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bool f16, hipStream_t st,
-                  const float* gn_in_a = nullptr, const float* gn_in_b = nullptr);
+                  const float* gn_in_a = nullptr, const float* gn_in_b = nullptr, int form = 0);
 // generic implicit GEMM of that mode (a.w ignored; every epilogue of the fp32 conv_igemm); weights from pack_conv_weights_split,
 // which takes pack_conv_weights' fp32 [tap][CoutPad][Cin] order
 bool conv_igemm_split_eligible(const ConvArgs& a);

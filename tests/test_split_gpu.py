@@ -18,7 +18,7 @@ from tests.test_kernels_gpu import DEV, L, from_dev_nhwc, ptr, run_conv, stream,
 
 pytestmark = pytest.mark.gpu
 
-IMPL3 = {"f16": 6, "bf16": 8}       # conv3x3_split
+IMPL3 = {"f16": 6, "bf16": 8, "f16_512": 12}       # conv3x3_split (6: the engine's form, 256 threads; 12: the 512-thread form)
 IMPLG = {"f16": 7, "bf16": 9}       # conv_igemm_split
 
 
@@ -26,7 +26,7 @@ def conv64(x, w, b, **kw):
     return F.conv2d(x.double(), w.double(), None if b is None else b.double(), **kw)
 
 
-@pytest.mark.parametrize("kind", ["f16", "bf16"])
+@pytest.mark.parametrize("kind", ["f16", "bf16", "f16_512"])
 def test_conv3x3_split_integer_exact(kind):
     g = torch.Generator().manual_seed(12)
     x = torch.randint(-3, 4, (2, 64, 16, 64), generator=g).float()
@@ -54,13 +54,13 @@ def test_conv3x3_split_borders_sources_stats(cfg):
     want64 = conv64(xin, w, b, padding=1)
     scale = max(1.0, float(want64.abs().max()))
     err = {}
-    for kind in ("f16", "bf16"):
+    for kind in ("f16", "bf16", "f16_512"):
         got, part, nslots = run_conv(x0, x1, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, groups=groups, impl=IMPL3[kind],
                                      want_slots=True)
         err[kind] = float((got.double() - want64).abs().max())
-        emu = split_conv2d(xin, w, b, padding=1, kind=kind)
+        emu = split_conv2d(xin, w, b, padding=1, kind=kind[:4].rstrip("_"))
         assert (got - emu).abs().max() <= 4e-6 * scale, (kind, float((got - emu).abs().max()))      # summation order only
-        if kind == "f16" and groups:
+        if kind.startswith("f16") and groups:
             assert torch.isfinite(part).all()
             s = part.sum(2).cpu().double()
             want_s1 = want64.reshape(B, groups, -1).sum(-1)
@@ -78,7 +78,7 @@ def test_conv3x3_split_borders_sources_stats(cfg):
     e32 = float((F.conv2d(xin, w, b, padding=1).double() - want64).abs().max())
     _report_k(test="conv3x3_split", cfg=list(cfg), f16x3_max_abs=err["f16"], bf16x3_max_abs=err["bf16"], torch_fp32_max_abs=e32,
               ref_max=scale)
-    assert err["f16"] <= 4e-6 * scale, err          # an fp32 convolution's own error on these shapes is ~1e-6 of the range
+    assert err["f16"] <= 4e-6 * scale and err["f16_512"] <= 4e-6 * scale, err          # an fp32 convolution's own error on these shapes is ~1e-6 of the range
     assert err["bf16"] <= 3e-4 * scale, err
     assert err["f16"] < err["bf16"]
 
@@ -97,14 +97,15 @@ def test_conv3x3_split_groupnorm_in_staging(cfg):
     coef = torch.stack([ca, cb]).contiguous().to(DEV)          # one allocation, 16-byte aligned rows
     act = F.silu(ca.double()[:, :, None, None] * x.double() + cb.double()[:, :, None, None])
     want64 = F.conv2d(act, w.double(), b.double(), padding=1)
-    got, part, nslots = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, groups=8, impl=11, want_slots=True,
-                                 gn_tail=(None, coef[0], coef[1]))
     scale = max(1.0, float(want64.abs().max()))
-    err = float((got.double() - want64).abs().max())
-    _report_k(test="conv3x3_split_gnin", cfg=list(cfg), max_abs=err, ref_max=scale)
-    assert err <= 6e-6 * scale, err
-    s = part.sum(2).cpu().double()
-    assert (s[..., 0] - want64.reshape(B, 8, -1).sum(-1)).abs().max() <= 1e-4 * max(1.0, float(want64.abs().sum(1).max()))
+    for impl in (11, 13):                            # the engine's form (256 threads) and the 512-thread form
+        got, part, nslots = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, groups=8, impl=impl, want_slots=True,
+                                     gn_tail=(None, coef[0], coef[1]))
+        err = float((got.double() - want64).abs().max())
+        _report_k(test="conv3x3_split_gnin", cfg=list(cfg), impl=impl, max_abs=err, ref_max=scale)
+        assert err <= 6e-6 * scale, (impl, err)
+        s = part.sum(2).cpu().double()
+        assert (s[..., 0] - want64.reshape(B, 8, -1).sum(-1)).abs().max() <= 1e-4 * max(1.0, float(want64.abs().sum(1).max()))
 
 
 def test_conv3x3_split_small_and_large_magnitudes():
