@@ -48,7 +48,7 @@ int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int H
  * pointwise kernel of that mode (conv1x1_split.hip: 1x1 incl. two sources, 2x2 / stride-2 gather, + residual, SiLU + PixelShuffle;
  * C0, C1 % 32 == 0, Cout % 128 == 0, Hout * Wout % 256 == 0); 11 = impl 6 with the producer's GroupNorm + SiLU applied while the input
  * is staged, as impl 5 (gn_tail_a / gn_tail_b = device fp32 [B][C0], 16-byte aligned; one source; gn_tail_src NULL); 12 / 13 = impl
- * 6 / 11 on the 512-thread form of that kernel (one workgroup per CU) instead of the engine's default (256 threads, two per CU).
+ * 6 / 11 on the 256-thread form of that kernel (two workgroups per CU) instead of the engine's default (512 threads, one per CU).
  * gn_tail_src (nullable, NHWC like out): out = silu(gn_tail_a[b][c] * gn_tail_src + gn_tail_b[b][c]) + conv(in) -
  * the second GroupNorm+SiLU of a ResnetBlock and its residual add folded into the 1x1 res_conv (model.py:250-259,:285);
  * gn_tail_a / gn_tail_b: device fp32 [B][Cout].  May alias out.
@@ -98,6 +98,16 @@ int srgd_k_full_attention(const void* qkv, void* out, int B, int N, int heads, i
 int srgd_k_linattn_block_fused(const void* x, void* y, int B, int N, int C, const float* to_qkv_host,
                                const float* norm_g_host, const float* to_out_w_host, const float* to_out_b_host,
                                const float* out_g_host, void* stream);
+
+/* f16x3 mode: a pointwise projection with an RMSNorm folded into its kernel (conv1x1_split.hip), fp32 NHWC tensors, N % 256 == 0.
+ *   pre_norm_g_host  != NULL:  out = W . RMSNorm_g(x)                      replaces: self.norm(x) -> self.to_qkv (model.py:311-312, :348-349)
+ *   post_norm_g_host != NULL:  out = RMSNorm_g(W . x + bias) + residual    replaces: LinearAttention.to_out (Conv2d, RMSNorm; model.py:300-303)
+ *                              and the block's `attn(x) + x` (:703); Cout == 128, residual required.
+ * RMSNorm_g(v) = v / max(||v||_2, 1e-12) * g * sqrt(C) over the channels of a pixel (model.py:201-207).  Weights [Cout][Cin], gains and
+ * bias fp32 on the HOST (the gain of the pre-norm is folded into the weights before they are split); synchronises. */
+int srgd_k_conv1x1_split_rms(const void* x, int Cin, int B, int N, const float* weight_oi_host, const float* bias_host, int Cout,
+                             const float* pre_norm_g_host, const float* post_norm_g_host, const void* residual, void* out,
+                             void* stream);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

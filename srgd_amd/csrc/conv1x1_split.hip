@@ -37,7 +37,7 @@ constexpr int B_SLOT = 2 * B_TILE;             // hi | lo
 constexpr int STAGE = A_BYTES + B_SLOT;        // 48 KiB
 constexpr int RING = 3;
 constexpr int LDS_BYTES = RING * STAGE;        // 147,456: one workgroup per CU
-enum { SEPI_PLAIN = 0, SEPI_RESIDUAL = 1, SEPI_PS_SILU = 2 };
+enum { SEPI_PLAIN = 0, SEPI_RESIDUAL = 1, SEPI_PS_SILU = 2, SEPI_RMS_RESIDUAL = 3 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -53,7 +53,8 @@ struct Split1Args {
   float w_inv_scale;
   int Cout;
   float* out;
-  const float* aux;       // SEPI_RESIDUAL: tensor added to the output
+  const float* aux;       // SEPI_RESIDUAL / SEPI_RMS_RESIDUAL: tensor added to the output
+  const float* rms_g;     // SEPI_RMS_RESIDUAL: [Cout] gain of the RMSNorm applied to the result, already times sqrt(Cout)
 };
 
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
@@ -79,7 +80,12 @@ __device__ __forceinline__ void split8(const u32x4& r0, const u32x4& r1, u32x4& 
   }
 }
 
-template <int EPI>
+// RMS_IN: the convolution reads RMSNorm(x) (reference RMSNorm.forward model.py:206-207 ahead of to_qkv, :312 / :349): the gain and
+// sqrt(C) are folded into the weights on the host, and the per-pixel 1 / max(||x||, 1e-12) - a wave sees every channel of its 32
+// pixels on their way through the K loop - multiplies the accumulators in the epilogue.  SEPI_RMS_RESIDUAL (one n-tile: Cout ==
+// 128): out = RMSNorm(acc + bias) * g + aux, the tail of LinearAttention.to_out and the block's residual add (:303, :703).
+// Both remove a separate rms_norm pass (4 B read + 4 B written per element, + the residual read).
+template <int EPI, bool RMS_IN>
 __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -161,6 +167,16 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
   const int a_c0 = ((2 * q16) ^ sw) << 4, a_c1 = ((2 * q16 + 1) ^ sw) << 4;
   const int b_base = A_BYTES + r16 * 64 + ((q16 ^ ((r16 >> 1) & 3)) << 4);       // weight row 16 J + r16, chunk q16 (the swizzle ignores J)
   int c_slot = 0;
+  float ss0 = 0.f, ss1 = 0.f;                       // RMS_IN: sum of squares of the lane's 8 channels of its two pixels
+  auto sumsq8 = [&](const u32x4& r0, const u32x4& r1, float acc) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned u0 = r0[k], u1 = r1[k];
+      acc = __builtin_fmaf(__uint_as_float(u0), __uint_as_float(u0), acc);
+      acc = __builtin_fmaf(__uint_as_float(u1), __uint_as_float(u1), acc);
+    }
+    return acc;
+  };
   auto mma = [&](f32x4& c, const u32x4& wt, const u32x4& px) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wt), __builtin_bit_cast(f16x8, px), c, 0, 0, 0);
   };
@@ -168,8 +184,11 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
     const char* st = smem + c_slot * STAGE;
     c_slot = c_slot == RING - 1 ? 0 : c_slot + 1;
     u32x4 ah0, al0, ah1, al1;
-    split8(*reinterpret_cast<const u32x4*>(st + a_row0 + a_c0), *reinterpret_cast<const u32x4*>(st + a_row0 + a_c1), ah0, al0);
-    split8(*reinterpret_cast<const u32x4*>(st + a_row1 + a_c0), *reinterpret_cast<const u32x4*>(st + a_row1 + a_c1), ah1, al1);
+    const u32x4 x00 = *reinterpret_cast<const u32x4*>(st + a_row0 + a_c0), x01 = *reinterpret_cast<const u32x4*>(st + a_row0 + a_c1);
+    const u32x4 x10 = *reinterpret_cast<const u32x4*>(st + a_row1 + a_c0), x11 = *reinterpret_cast<const u32x4*>(st + a_row1 + a_c1);
+    if constexpr (RMS_IN) { ss0 = sumsq8(x00, x01, ss0); ss1 = sumsq8(x10, x11, ss1); }
+    split8(x00, x01, ah0, al0);
+    split8(x10, x11, ah1, al1);
 #define K_COL(J, C0_, C1_)                                                                         \
   {                                                                                                \
     const u32x4 bh = *reinterpret_cast<const u32x4*>(st + b_base + J * 1024);                      \
@@ -224,8 +243,41 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
   }
   K_OFF(0, o0) K_OFF(1, o1)
 #undef K_OFF
-  f32x4 v0_[8] = {c00 * ws + bs0, c01 * ws + bs1, c02 * ws + bs2, c03 * ws + bs3, c04 * ws + bs4, c05 * ws + bs5, c06 * ws + bs6, c07 * ws + bs7};
-  f32x4 v1_[8] = {c10 * ws + bs0, c11 * ws + bs1, c12 * ws + bs2, c13 * ws + bs3, c14 * ws + bs4, c15 * ws + bs5, c16 * ws + bs6, c17 * ws + bs7};
+  float ws0 = ws, ws1 = ws;
+  if constexpr (RMS_IN) {
+    // the four lanes of a pixel (r16, q16 = 0..3) hold its channels 8 q16 .. of every chunk: sum over them, then F.normalize's
+    // x / max(||x||, 1e-12)
+    ss0 = xor32_sum(xor16_sum(ss0));
+    ss1 = xor32_sum(xor16_sum(ss1));
+    ws0 = ws / fmaxf(sqrtf(ss0), 1e-12f);
+    ws1 = ws / fmaxf(sqrtf(ss1), 1e-12f);
+  }
+  f32x4 v0_[8] = {c00 * ws0 + bs0, c01 * ws0 + bs1, c02 * ws0 + bs2, c03 * ws0 + bs3, c04 * ws0 + bs4, c05 * ws0 + bs5, c06 * ws0 + bs6, c07 * ws0 + bs7};
+  f32x4 v1_[8] = {c10 * ws1 + bs0, c11 * ws1 + bs1, c12 * ws1 + bs2, c13 * ws1 + bs3, c14 * ws1 + bs4, c15 * ws1 + bs5, c16 * ws1 + bs6, c17 * ws1 + bs7};
+  if (EPI == SEPI_RMS_RESIDUAL) {
+    // RMSNorm over the pixel's 128 output channels (one n-tile): 32 of them in this lane, the rest in the pixel's other three lanes
+    f32x4 r0_[8], r1_[8], g_[8];
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+      r0_[J] = *reinterpret_cast<const f32x4*>(p.aux + o0 + 4 * J);
+      r1_[J] = *reinterpret_cast<const f32x4*>(p.aux + o1 + 4 * J);
+      g_[J] = *reinterpret_cast<const f32x4*>(p.rms_g + n0 + q16 * 32 + 4 * J);
+    }
+    asm volatile("" : "+v"(r0_[0]), "+v"(r0_[1]), "+v"(r0_[2]), "+v"(r0_[3]), "+v"(r0_[4]), "+v"(r0_[5]), "+v"(r0_[6]), "+v"(r0_[7]));
+    asm volatile("" : "+v"(r1_[0]), "+v"(r1_[1]), "+v"(r1_[2]), "+v"(r1_[3]), "+v"(r1_[4]), "+v"(r1_[5]), "+v"(r1_[6]), "+v"(r1_[7]));
+    asm volatile("" : "+v"(g_[0]), "+v"(g_[1]), "+v"(g_[2]), "+v"(g_[3]), "+v"(g_[4]), "+v"(g_[5]), "+v"(g_[6]), "+v"(g_[7]));
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { t0 = __builtin_fmaf(v0_[J][e], v0_[J][e], t0); t1 = __builtin_fmaf(v1_[J][e], v1_[J][e], t1); }
+    }
+    t0 = xor32_sum(xor16_sum(t0));
+    t1 = xor32_sum(xor16_sum(t1));
+    const float i0 = 1.0f / fmaxf(sqrtf(t0), 1e-12f), i1 = 1.0f / fmaxf(sqrtf(t1), 1e-12f);
+#pragma unroll
+    for (int J = 0; J < 8; ++J) { v0_[J] = v0_[J] * i0 * g_[J] + r0_[J]; v1_[J] = v1_[J] * i1 * g_[J] + r1_[J]; }
+  }
   if (EPI == SEPI_RESIDUAL) {
     f32x4 r0_[8], r1_[8];
 #pragma unroll
@@ -264,6 +316,8 @@ bool conv1x1_split_eligible(const ConvArgs& a) {
   if (a.C0 % KC || a.C1 % KC || a.Cout % BN || a.Cout != a.CoutPad) return false;
   if (((long)a.Hout * a.Wout) % BM) return false;
   if (a.gn_partial || a.gn_res_src || a.out_q || a.eps4) return false;
+  if (a.rms_out_g && (a.Cout != BN || !a.residual || a.mode != CONV_PLAIN || a.rms_in)) return false;
+  if (a.rms_in && (a.mode != CONV_PLAIN || a.residual)) return false;
   if (a.mode == CONV_PIXEL_SHUFFLE_SILU && ((a.Cout / 4) % BN || a.residual)) return false;
   if (a.mode != CONV_PLAIN && a.mode != CONV_PIXEL_SHUFFLE_SILU) return false;
   if ((size_t)a.Hin * a.Win * (size_t)std::max(a.ps0, a.ps1) * 4 >= (1ull << 31)) return false;
@@ -304,19 +358,25 @@ int conv1x1_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, hi
   p.KH = a.KH; p.KW = a.KW; p.stride = a.stride; p.ps0 = a.ps0; p.ps1 = a.C1 ? a.ps1 : 0;
   p.w = packed_w; p.bias = a.bias; p.w_inv_scale = w_inv_scale; p.Cout = a.Cout; p.out = (float*)a.out;
   p.aux = (const float*)a.residual;
+  p.rms_g = a.rms_out_g;
+  if (a.rms_out_g && (a.Cout != BN || !a.residual || a.mode != CONV_PLAIN)) SRGD_FAIL("conv1x1_split: the RMSNorm tail needs Cout == 128 and the residual tensor");
   const long grid = (long)a.B * a.Hout * a.Wout / BM * (a.Cout / BN);
   if (grid <= 0 || grid > 0x7fffffffL) SRGD_FAIL("conv1x1_split: bad grid");
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-#define K_SET(E_) SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<E_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    K_SET(SEPI_PLAIN) K_SET(SEPI_RESIDUAL) K_SET(SEPI_PS_SILU)
+#define K_SET(E_, R_) SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<E_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    K_SET(SEPI_PLAIN, false) K_SET(SEPI_RESIDUAL, false) K_SET(SEPI_PS_SILU, false) K_SET(SEPI_RMS_RESIDUAL, false) K_SET(SEPI_PLAIN, true)
 #undef K_SET
     once.done();
   }
-#define K_GO(E_) hipLaunchKernelGGL((conv1x1_split_kernel<E_>), dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, p)
-  if (a.mode == CONV_PIXEL_SHUFFLE_SILU) K_GO(SEPI_PS_SILU);
-  else if (a.residual) K_GO(SEPI_RESIDUAL);
-  else K_GO(SEPI_PLAIN);
+#define K_GO(E_, R_) hipLaunchKernelGGL((conv1x1_split_kernel<E_, R_>), dim3((unsigned)grid), dim3(NT), LDS_BYTES, st, p)
+  if (a.rms_in) {
+    if (a.mode != CONV_PLAIN || a.residual || a.rms_out_g) SRGD_FAIL("conv1x1_split: the RMSNorm-on-input form has the plain epilogue only");
+    K_GO(SEPI_PLAIN, true);
+  } else if (a.mode == CONV_PIXEL_SHUFFLE_SILU) K_GO(SEPI_PS_SILU, false);
+  else if (a.rms_out_g) K_GO(SEPI_RMS_RESIDUAL, false);
+  else if (a.residual) K_GO(SEPI_RESIDUAL, false);
+  else K_GO(SEPI_PLAIN, false);
 #undef K_GO
   SRGD_HIP(hipGetLastError());
   return 0;

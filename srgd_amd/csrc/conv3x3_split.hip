@@ -750,8 +750,10 @@ int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bo
     once.done();
   }
   const bool stats = a.gn_partial != nullptr;
-  // SRGD_SPLIT3_WG=1: the 512-thread kernel (one workgroup per CU); default: the 256-thread kernel (two per CU), f16 halves only
-  static const int env_form = env_int("SRGD_SPLIT3_WG", 2);
+  // default: the 512-thread kernel (one workgroup per CU); SRGD_SPLIT3_WG=2: the 256-thread kernel (two per CU; f16 halves only).
+  // Same-box A/B (profiles/r6/conv3x3_split_forms_ab.txt): bit-identical results, 0.3873 vs 0.3854 HR tiles/s - the kernel is not
+  // waiting on its barriers, it runs at the matrix pipe's sustained rate like conv3x3_bf16 - so the form with half the weight traffic stays
+  static const int env_form = env_int("SRGD_SPLIT3_WG", 1);
   const int wg_form = form ? form : env_form;
   if (f16 && wg_form != 1) {
     static bool attr_set2[64] = {};

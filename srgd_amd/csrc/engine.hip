@@ -139,6 +139,10 @@ struct AttnW {
   int ngi = -1, ogi = -1;
   float *norm_g = nullptr, *out_g = nullptr;
   ConvW qkv, out;
+  // f16x3 mode: to_qkv for conv1x1_split with the pre-norm's gain * sqrt(C) folded into the weights (the kernel supplies the
+  // per-pixel 1 / ||x||), and the post-norm's gain * sqrt(C) for the RMSNorm tail of to_out (C == 128 sites)
+  void* qkv_ws1n = nullptr; float qkv_wsn_inv = 1.f;
+  float* out_gs = nullptr;
   // fused LinearAttention block operands (bf16, C = 128 / 256): see linattn_fused.hip, linattn_fused256.hip
   void *f_wkv = nullptr, *f_wq = nullptr, *f_wout = nullptr;
   float* f_g2 = nullptr;
@@ -267,6 +271,7 @@ struct srgd_engine {
   int gn_fusion_max_ntiles = 2;         // GNIN only where Cout / 128 <= this (the transform is repeated once per n-tile); round 4: 2 (was 1)
   bool no_final_fusion = false;   // SRGD_FINAL_FUSION=0: the last ResnetBlock stores its output and final_step applies the 1x1 (A/B switch)
   bool no_la256 = false;      // SRGD_LA256=0: the C = 256 LinearAttention sites run the unfused chain (A/B switch)
+  bool no_rms_fusion = false; // SRGD_RMS_FUSION=0: f16x3 mode runs the RMSNorms around the attention projections as separate passes (A/B switch)
   bool no_conv1x1 = false;    // SRGD_CONV1X1=0: route the pointwise layers through the generic implicit GEMM (A/B switch)
   // fp8 modes: pointwise layers with twinned inputs on the MX matrix cores (conv1x1_mxfp8, 128-pixel tiles: two workgroups
   // per CU).  Per shape +20-40 % over conv1x1_bf16; end to end it only paid once the shared epilogue loaded its tail operand up
@@ -543,6 +548,25 @@ int pack_attn(srgd_engine* e, AttnW& a) {
   if (a.ogi >= 0) SRGD_TRY(upload_f32(e, a.ogi, &a.out_g));
   SRGD_TRY(pack_conv(e, a.qkv));
   SRGD_TRY(pack_conv(e, a.out));
+  if (e->split && a.C % 32 == 0 && a.qkv.Cout % 128 == 0 && a.qkv.CoutPad == a.qkv.Cout) {
+    // to_qkv(RMSNorm(x)) = (1 / ||x||) * (W diag(g sqrt(C))) x : fold the gain into the weights, [1][Cout][Cin] order
+    const float* w = e->wt[a.qkv.wi].data.data();
+    const float* g = e->wt[a.ngi].data.data();
+    std::vector<float> wf((size_t)a.qkv.Cout * a.C);
+    const float rc = sqrtf((float)a.C);
+    for (int o = 0; o < a.qkv.Cout; ++o)
+      for (int c = 0; c < a.C; ++c) wf[(size_t)o * a.C + c] = w[(size_t)o * a.C + c] * g[c] * rc;
+    const float scale = split_weight_scale(wf.data(), wf.size(), true);
+    a.qkv_wsn_inv = 1.0f / scale;
+    std::vector<unsigned short> ps;
+    pack_conv1x1_split(wf.data(), 1, a.C, a.qkv.Cout, scale, ps);
+    SRGD_TRY(upload(e, ps.data(), ps.size() * 2, &a.qkv_ws1n));
+    if (a.ogi >= 0) {
+      std::vector<float> g2(a.C);
+      for (int c = 0; c < a.C; ++c) g2[c] = e->wt[a.ogi].data[c] * rc;
+      SRGD_TRY(upload(e, g2.data(), g2.size() * 4, (void**)&a.out_gs));
+    }
+  }
   if (!a.full && e->bf16 && (a.C == 128 || (a.C == 256 && !e->no_la256)) && e->cfg.heads == 4 && e->cfg.dim_head == 32) {
     std::vector<unsigned short> wkv, wq, wo;
     linattn_fused_pack(e->wt[a.qkv.wi].data.data(), e->wt[a.ngi].data.data(), e->wt[a.out.wi].data.data(), a.C, wkv, wq, wo);
@@ -868,10 +892,36 @@ int attn_block(Ctx& x, const AttnW& a, const void* in, void** out, bool want_twi
   void* qkv = e->pool.get((size_t)npix * 3 * e->hid * e->es);
   void* att = e->pool.get((size_t)npix * e->hid * e->es);
   if (!nrm || !qkv || !att) return -1;
-  { Prof p(e, KC_RMS, x.st);
-    if (e->prof_on) e->fam_bytes[KC_RMS] += (double)npix * a.C * e->es * 2.0;
-    SRGD_TRY(rms_norm(in, nrm, nullptr, a.norm_g, npix, a.C, e->bf16, x.st)); }
-  SRGD_TRY(run_conv(x, a.qkv, nrm, a.C, nullptr, 0, x.H, x.W, qkv, nullptr, false));
+  // f16x3 mode: both RMSNorms ride in the projections' kernels where conv1x1_split covers the shape (conv1x1_split.hip: RMS_IN,
+  // SEPI_RMS_RESIDUAL); SRGD_RMS_FUSION=0 keeps the separate passes (A/B switch)
+  auto split1_args = [&](const ConvW& c, const void* src, int Cin, void* dst) {
+    ConvArgs q;
+    q.in0 = src; q.in1 = nullptr; q.C0 = Cin; q.C1 = 0; q.ps0 = Cin; q.ps1 = 0;
+    q.B = x.nb; q.Hin = x.H; q.Win = x.W; q.Hout = x.H; q.Wout = x.W; q.KH = q.KW = 1; q.stride = 1; q.pad = 0;
+    q.w = nullptr; q.bias = c.bias; q.Cout = c.Cout; q.CoutPad = c.CoutPad; q.out = dst; q.residual = nullptr; q.mode = CONV_PLAIN;
+    q.gn_partial = nullptr; q.groups = e->cfg.groups; q.gn_res_src = nullptr; q.gn_res_a = q.gn_res_b = nullptr;
+    return q;
+  };
+  bool qkv_done = false;
+  if (e->split && a.qkv_ws1n && !e->no_rms_fusion && !e->no_conv1x1 && !e->force_generic_conv) {
+    ConvArgs q = split1_args(a.qkv, in, a.C, qkv);
+    q.rms_in = true;
+    if (conv1x1_split_eligible(q)) {
+      Prof p(e, KC_CONV1S, x.st);
+      if (e->prof_on) {
+        e->fam_flops[KC_CONV1S] += 2.0 * (double)npix * a.qkv.Cout * a.C;
+        e->fam_bytes[KC_CONV1S] += (double)npix * (a.C + a.qkv.Cout) * 4.0 + (double)a.C * a.qkv.Cout * 4.0;
+      }
+      SRGD_TRY(conv1x1_split(q, a.qkv_ws1n, a.qkv_wsn_inv, x.st));
+      qkv_done = true;
+    }
+  }
+  if (!qkv_done) {
+    { Prof p(e, KC_RMS, x.st);
+      if (e->prof_on) e->fam_bytes[KC_RMS] += (double)npix * a.C * e->es * 2.0;
+      SRGD_TRY(rms_norm(in, nrm, nullptr, a.norm_g, npix, a.C, e->bf16, x.st)); }
+    SRGD_TRY(run_conv(x, a.qkv, nrm, a.C, nullptr, 0, x.H, x.W, qkv, nullptr, false));
+  }
   if (a.full) {
     Prof p(e, KC_FULLATTN, x.st);
     if (e->prof_on) e->fam_bytes[KC_FULLATTN] += (double)npix * e->hid * e->es * 4.0;      // q, k, v read, o written
@@ -887,10 +937,26 @@ int attn_block(Ctx& x, const AttnW& a, const void* in, void** out, bool want_twi
   if (a.full) {
     SRGD_TRY(run_conv(x, a.out, att, e->hid, nullptr, 0, x.H, x.W, nrm, in, false, false, nullptr, want_twin));   // + bias + residual x
   } else {
-    SRGD_TRY(run_conv(x, a.out, att, e->hid, nullptr, 0, x.H, x.W, nrm, nullptr, false));
-    Prof p(e, KC_RMS, x.st);
-    if (e->prof_on) e->fam_bytes[KC_RMS] += (double)npix * a.C * e->es * 3.0;
-    SRGD_TRY(rms_norm(nrm, nrm, in, a.out_g, npix, a.C, e->bf16, x.st));                     // RMSNorm then + x
+    bool out_done = false;
+    if (e->split && a.out.ws1 && a.out_gs && a.C == 128 && !e->no_rms_fusion && !e->no_conv1x1 && !e->force_generic_conv) {
+      ConvArgs q = split1_args(a.out, att, e->hid, nrm);
+      q.residual = in; q.rms_out_g = a.out_gs;
+      if (conv1x1_split_eligible(q)) {
+        Prof p(e, KC_CONV1S, x.st);
+        if (e->prof_on) {
+          e->fam_flops[KC_CONV1S] += 2.0 * (double)npix * a.C * e->hid;
+          e->fam_bytes[KC_CONV1S] += (double)npix * (e->hid + 2.0 * a.C) * 4.0 + (double)a.C * e->hid * 4.0;
+        }
+        SRGD_TRY(conv1x1_split(q, a.out.ws1, a.out.ws_inv, x.st));
+        out_done = true;
+      }
+    }
+    if (!out_done) {
+      SRGD_TRY(run_conv(x, a.out, att, e->hid, nullptr, 0, x.H, x.W, nrm, nullptr, false));
+      Prof p(e, KC_RMS, x.st);
+      if (e->prof_on) e->fam_bytes[KC_RMS] += (double)npix * a.C * e->es * 3.0;
+      SRGD_TRY(rms_norm(nrm, nrm, in, a.out_g, npix, a.C, e->bf16, x.st));                     // RMSNorm then + x
+    }
   }
   e->pool.put(att);
   *out = nrm;
@@ -1130,6 +1196,7 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   if (const char* v = getenv("SRGD_GN_FUSION_NTILES")) e->gn_fusion_max_ntiles = e->split_gn_fusion_max_ntiles = atoi(v);
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
+  if (const char* v = getenv("SRGD_RMS_FUSION")) e->no_rms_fusion = atoi(v) == 0;
   // fp8_mixed is the quality-oriented fp8 mode: its pointwise layers stay on conv1x1_bf16 unless asked for (the MX pointwise
   // kernel buys ~3 % there and costs 1.2 dB against the reference; round-3 advisor finding).  fp8 keeps them on the MX cores.
   e->no_mx1x1 = e->cfg.precision == SRGD_PRECISION_FP8_MIXED;

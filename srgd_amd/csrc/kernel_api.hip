@@ -1,6 +1,7 @@
 // Kernel-level C ABI (include/srgd_hip_kernels.h): thin wrappers that let each kernel family be
 // driven - and parity-tested - in isolation.  Convenience allocations here are per call; the
 // engine itself (engine.hip) never allocates on its hot path.
+#include <cmath>
 #include <vector>
 
 #include "../../include/srgd_hip_kernels.h"
@@ -104,8 +105,8 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
     if (!gn_tail_a || !gn_tail_b || C1) SRGD_FAIL("srgd_k_conv2d: impl 11 (GroupNorm-in-staging) needs one source and gn_tail_a / gn_tail_b");
     a.gn_res_src = nullptr; a.gn_res_a = nullptr; a.gn_res_b = nullptr;
   }
-  // impl 12 / 13: impl 6 / 11 on the 512-thread form of the kernel (one workgroup per CU) instead of the engine's default
-  const bool split_form1 = impl == 12 || impl == 13;
+  // impl 12 / 13: impl 6 / 11 on the 256-thread form of the kernel (two workgroups per CU) instead of the engine's default
+  const bool split_form2 = impl == 12 || impl == 13;
   const bool split3 = impl == 6 || impl == 8 || impl == 12 || split_gnin, splitg = impl == 7 || impl == 9, split1 = impl == 10, split_f16 = impl == 6 || impl == 7 || impl == 12 || split1 || split_gnin;
   DevBuf dws;
   float ws_inv = 1.f;
@@ -124,7 +125,7 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   }
   if (stats_slots) *stats_slots = (fast || split3) ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
   auto run = [&]() -> int {
-    if (split3) return conv3x3_split(a, dws.p, ws_inv, split_f16, st, split_gnin ? gn_tail_a : nullptr, split_gnin ? gn_tail_b : nullptr, split_form1 ? 1 : 0);
+    if (split3) return conv3x3_split(a, dws.p, ws_inv, split_f16, st, split_gnin ? gn_tail_a : nullptr, split_gnin ? gn_tail_b : nullptr, split_form2 ? 2 : 0);
     if (split1) return conv1x1_split(a, dws.p, ws_inv, st);
     if (splitg) return conv_igemm_split(a, dws.p, ws_inv, split_f16, st);
     if (fastq1) return conv1x1_mxfp8(a, q0.p, s0.p, q1.p, s1.p, dwq1.p, st);
@@ -209,6 +210,45 @@ int srgd_k_linattn_block_fused(const void* x, void* y, int B, int N, int C, cons
   SRGD_HIP(hipMemcpy(db.p, to_out_b_host, C * 4, hipMemcpyHostToDevice));
   SRGD_HIP(hipMemcpy(dg.p, g2.data(), C * 4, hipMemcpyHostToDevice));
   SRGD_TRY(linattn_fused(x, y, B, N, C, dkv.p, dq.p, dout.p, (const float*)db.p, (const float*)dg.p, (float*)ws.p, st));
+  SRGD_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int srgd_k_conv1x1_split_rms(const void* x, int Cin, int B, int N, const float* weight_oi_host, const float* bias_host, int Cout,
+                             const float* pre_norm_g_host, const float* post_norm_g_host, const void* residual, void* out,
+                             void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!x || !weight_oi_host || !out || Cin <= 0 || Cout <= 0) SRGD_FAIL("srgd_k_conv1x1_split_rms: null argument");
+  if (pre_norm_g_host && post_norm_g_host) SRGD_FAIL("srgd_k_conv1x1_split_rms: one RMSNorm per call");
+  std::vector<float> wf((size_t)Cout * Cin);
+  const float rc = sqrtf((float)Cin);
+  for (int o = 0; o < Cout; ++o)
+    for (int c = 0; c < Cin; ++c)
+      wf[(size_t)o * Cin + c] = weight_oi_host[(size_t)o * Cin + c] * (pre_norm_g_host ? pre_norm_g_host[c] * rc : 1.0f);
+  const float scale = split_weight_scale(wf.data(), wf.size(), true);
+  std::vector<unsigned short> ps;
+  ConvArgs a{};
+  a.in0 = x; a.C0 = Cin; a.ps0 = Cin; a.B = B; a.Hin = 1; a.Win = N; a.Hout = 1; a.Wout = N; a.KH = a.KW = 1; a.stride = 1;
+  a.Cout = Cout; a.CoutPad = Cout; a.out = out; a.mode = CONV_PLAIN; a.residual = residual;
+  a.rms_in = pre_norm_g_host != nullptr;
+  DevBuf dw, db, dg;
+  if (bias_host) {
+    SRGD_TRY(db.alloc((size_t)Cout * 4));
+    SRGD_HIP(hipMemcpy(db.p, bias_host, (size_t)Cout * 4, hipMemcpyHostToDevice));
+    a.bias = (const float*)db.p;
+  }
+  if (post_norm_g_host) {
+    std::vector<float> g2(Cout);
+    for (int c = 0; c < Cout; ++c) g2[c] = post_norm_g_host[c] * sqrtf((float)Cout);
+    SRGD_TRY(dg.alloc((size_t)Cout * 4));
+    SRGD_HIP(hipMemcpy(dg.p, g2.data(), (size_t)Cout * 4, hipMemcpyHostToDevice));
+    a.rms_out_g = (const float*)dg.p;
+  }
+  if (!conv1x1_split_eligible(a)) SRGD_FAIL("srgd_k_conv1x1_split_rms: needs Cin % 32 == 0, Cout % 128 == 0 (== 128 with a post-norm, and a residual), N % 256 == 0");
+  pack_conv1x1_split(wf.data(), 1, Cin, Cout, scale, ps);
+  SRGD_TRY(dw.alloc(ps.size() * 2));
+  SRGD_HIP(hipMemcpy(dw.p, ps.data(), ps.size() * 2, hipMemcpyHostToDevice));
+  SRGD_TRY(conv1x1_split(a, dw.p, 1.0f / scale, st));
   SRGD_HIP(hipStreamSynchronize(st));
   return 0;
 }

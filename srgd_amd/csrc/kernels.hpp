@@ -45,6 +45,11 @@ struct ConvArgs {
   float* eps4 = nullptr;
   const float* fin_w = nullptr;
   const float* fin_b = nullptr;
+  // conv1x1_split only (f16x3 mode), the RMSNorms around the attention projections (model.py:201-207):
+  //   rms_in: the convolution reads RMSNorm(in) - the caller folded gain * sqrt(Cin) into the weights, the kernel supplies the
+  //   per-pixel 1 / max(||x||, 1e-12);  rms_out_g ([Cout], gain * sqrt(Cout); Cout == 128, residual set): out = RMSNorm(conv) * g + residual
+  bool rms_in = false;
+  const float* rms_out_g = nullptr;
 };
 int conv_igemm(const ConvArgs& a, bool is_bf16, hipStream_t st);
 int conv_tile_m();
@@ -84,7 +89,7 @@ bool conv3x3_split_eligible(const ConvArgs& a);          // same shapes and Grou
 void pack_conv3x3_split(const float* src_oihw, int Cin, int Cout, bool f16, float scale, std::vector<unsigned short>& out);
 // gn_in_a / gn_in_b (nullable, f16 halves only): [B][Cin] fp32 coefficients of y = silu(a*x + b) applied to the INPUT while it is
 // staged (the producer's GroupNorm + SiLU, fused; single source)
-// form: 0 = the engine's choice (SRGD_SPLIT3_WG, default 2), 1 = the 512-thread kernel (one workgroup per CU), 2 = the 256-thread
+// form: 0 = the engine's choice (SRGD_SPLIT3_WG, default 1), 1 = the 512-thread kernel (one workgroup per CU), 2 = the 256-thread
 // kernel (two workgroups per CU; f16 halves only)
 int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bool f16, hipStream_t st,
                   const float* gn_in_a = nullptr, const float* gn_in_b = nullptr, int form = 0);

@@ -18,7 +18,7 @@ from tests.test_kernels_gpu import DEV, L, from_dev_nhwc, ptr, run_conv, stream,
 
 pytestmark = pytest.mark.gpu
 
-IMPL3 = {"f16": 6, "bf16": 8, "f16_512": 12}       # conv3x3_split (6: the engine's form, 256 threads; 12: the 512-thread form)
+IMPL3 = {"f16": 6, "bf16": 8, "f16_256": 12}       # conv3x3_split (6: the engine's form, 512 threads; 12: the 256-thread form)
 IMPLG = {"f16": 7, "bf16": 9}       # conv_igemm_split
 
 
@@ -26,7 +26,7 @@ def conv64(x, w, b, **kw):
     return F.conv2d(x.double(), w.double(), None if b is None else b.double(), **kw)
 
 
-@pytest.mark.parametrize("kind", ["f16", "bf16", "f16_512"])
+@pytest.mark.parametrize("kind", ["f16", "bf16", "f16_256"])
 def test_conv3x3_split_integer_exact(kind):
     g = torch.Generator().manual_seed(12)
     x = torch.randint(-3, 4, (2, 64, 16, 64), generator=g).float()
@@ -54,7 +54,7 @@ def test_conv3x3_split_borders_sources_stats(cfg):
     want64 = conv64(xin, w, b, padding=1)
     scale = max(1.0, float(want64.abs().max()))
     err = {}
-    for kind in ("f16", "bf16", "f16_512"):
+    for kind in ("f16", "bf16", "f16_256"):
         got, part, nslots = run_conv(x0, x1, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, groups=groups, impl=IMPL3[kind],
                                      want_slots=True)
         err[kind] = float((got.double() - want64).abs().max())
@@ -78,7 +78,7 @@ def test_conv3x3_split_borders_sources_stats(cfg):
     e32 = float((F.conv2d(xin, w, b, padding=1).double() - want64).abs().max())
     _report_k(test="conv3x3_split", cfg=list(cfg), f16x3_max_abs=err["f16"], bf16x3_max_abs=err["bf16"], torch_fp32_max_abs=e32,
               ref_max=scale)
-    assert err["f16"] <= 4e-6 * scale and err["f16_512"] <= 4e-6 * scale, err          # an fp32 convolution's own error on these shapes is ~1e-6 of the range
+    assert err["f16"] <= 4e-6 * scale and err["f16_256"] <= 4e-6 * scale, err          # an fp32 convolution's own error on these shapes is ~1e-6 of the range
     assert err["bf16"] <= 3e-4 * scale, err
     assert err["f16"] < err["bf16"]
 
@@ -98,7 +98,7 @@ def test_conv3x3_split_groupnorm_in_staging(cfg):
     act = F.silu(ca.double()[:, :, None, None] * x.double() + cb.double()[:, :, None, None])
     want64 = F.conv2d(act, w.double(), b.double(), padding=1)
     scale = max(1.0, float(want64.abs().max()))
-    for impl in (11, 13):                            # the engine's form (256 threads) and the 512-thread form
+    for impl in (11, 13):                            # the engine's form (512 threads) and the 256-thread form
         got, part, nslots = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, groups=8, impl=impl, want_slots=True,
                                      gn_tail=(None, coef[0], coef[1]))
         err = float((got.double() - want64).abs().max())
@@ -221,6 +221,47 @@ def test_conv1x1_split_streaming_kernel(variant):
     _report_k(test="conv1x1_split", variant=variant, max_abs=err, ref_max=scale, vs_generic_split=float((got - gen).abs().max()))
     assert err <= 4e-6 * scale, (variant, err)
     assert (got - gen).abs().max() <= 3e-6 * scale
+
+
+@pytest.mark.parametrize("cfg", [("pre", 128, 384, 1, 512), ("pre", 256, 384, 2, 256), ("pre", 1024, 384, 1, 1024), ("post", 128, 128, 2, 512)],
+                         ids=lambda c: "%s_C%d_Cout%d_B%d_N%d" % c)
+def test_conv1x1_split_with_rmsnorm_folded_in(cfg):
+    # the RMSNorms around the attention projections inside the projection's kernel (reference model.py:201-207, :300-303, :311-312)
+    kind, cin, cout, B, N = cfg
+    import ctypes as C
+    lib = L().lib()
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, N, cin, generator=g) * torch.logspace(-1, 1, N).view(1, N, 1)      # pixel norms over two decades
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    gain = 1 + 0.3 * torch.randn(cin if kind == "pre" else cout, generator=g)
+    bias = None if kind == "pre" else torch.randn(cout, generator=g)
+    res = None if kind == "pre" else torch.randn(B, N, cout, generator=g)
+
+    def rms64(v, gg):
+        v = v.double()
+        return v / v.norm(dim=-1, keepdim=True).clamp_min(1e-12) * gg.double() * v.shape[-1] ** 0.5
+
+    if kind == "pre":
+        want = rms64(x, gain) @ w.double().t()
+    else:
+        want = rms64(x.double() @ w.double().t() + bias.double(), gain) + res.double()
+    dx = x.contiguous().to(DEV)
+    dres = None if res is None else res.contiguous().to(DEV)
+    out = torch.empty(B, N, cout, device=DEV)
+    wh, gh = w.contiguous(), gain.contiguous()
+    bh = None if bias is None else bias.contiguous()
+    L().check(lib.srgd_k_conv1x1_split_rms(ptr(dx), cin, B, N, ptr(wh), ptr(bh), cout, ptr(gh if kind == "pre" else None),
+                                          ptr(gh if kind == "post" else None), ptr(dres), ptr(out), stream()), "conv1x1_split_rms")
+    got = out.cpu().double()
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    _report_k(test="conv1x1_split_rms", cfg=list(cfg), max_abs=err, ref_max=scale)
+    assert err <= 6e-6 * scale, err
+    # a zero pixel stays finite (F.normalize's eps)
+    dx[0, 0].zero_()
+    L().check(lib.srgd_k_conv1x1_split_rms(ptr(dx), cin, B, N, ptr(wh), ptr(bh), cout, ptr(gh if kind == "pre" else None),
+                                          ptr(gh if kind == "post" else None), ptr(dres), ptr(out), stream()), "conv1x1_split_rms")
+    assert torch.isfinite(out).all()
 
 
 def test_conv_igemm_split_3x3_equals_the_halo_kernel_to_summation_order():
