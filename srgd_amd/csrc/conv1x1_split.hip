@@ -54,6 +54,7 @@ struct Split1Args {
   int Cout;
   float* out;
   const float* aux;       // SEPI_RESIDUAL / SEPI_RMS_RESIDUAL: tensor added to the output
+  int n_wg_tiles;         // m-tiles x n-tiles (the grid is persistent: at most one workgroup per CU)
   const float* rms_g;     // SEPI_RMS_RESIDUAL: [Cout] gain of the RMSNorm applied to the result, already times sqrt(Cout)
 };
 
@@ -95,28 +96,32 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
 
   const int n_tiles = p.Cout / BN;
   const int HWo = p.Hout * p.Wout;
-  int wg = blockIdx.x;
-  {                                                // XCD-aware order: the n-tiles of one m-tile back to back on one XCD
-    const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, x = wg & 7, k = wg >> 3;
-    wg = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + k;
-  }
-  const int nt = wg % n_tiles;
-  const int mt = wg / n_tiles;
-  const long m0 = (long)mt * BM;                   // HWo % 256 == 0: a tile lies in one image
-  const int b = (int)(m0 / HWo);
-  const int p0 = (int)(m0 - (long)b * HWo);
   const int Cin = p.C0 + p.C1;
   const int CC = Cin / KC;
   const int S = p.KH * p.KW * CC;
+  // ---- persistent workgroup: tiles v = blockIdx.x, + gridDim.x, ... of the T = m-tiles x n-tiles (gridDim.x is a multiple of 8 or
+  // equals T).  The XCD-aware renumbering (n-tiles of one m-tile back to back inside an XCD's contiguous band) is applied to v: the
+  // tiles of one workgroup stay on its XCD's band.
+  const int T = p.n_wg_tiles;
+  auto tile_of = [&](int v, int& nt_, int& b_, int& p0_) {
+    const int q = T >> 3, rem = T & 7, x = v & 7, k = v >> 3;
+    const int wg = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + k;
+    nt_ = wg % n_tiles;
+    const int mt = wg / n_tiles, tpi = HWo / BM;     // HWo % 256 == 0: a tile lies in one image (32-bit arithmetic throughout)
+    b_ = mt / tpi;
+    p0_ = (mt - b_ * tpi) * BM;
+  };
 
   // ---- A staging: the wave's 32 pixel rows = 4 KiB = 4 wave-instructions per stage.  Instruction J covers rows 32 w + 8 J .. + 7;
   // lane L fills 16-byte position L & 7 of row 8 J + (L >> 3), which holds SOURCE chunk (L & 7) ^ (row & 7) (4 channels).
-  // Per-lane byte offsets at tap (0,0), channel chunk 0, for each source; everything that changes per K-step is wave-uniform.
+  // Per-lane byte offsets RELATIVE to the tile's first pixel (launcher: 256 % Wout == 0 or Wout % 256 == 0, so a tile is whole rows
+  // or a piece of one and the offsets are the same for every tile), tap (0,0), channel chunk 0, for each source; everything that
+  // changes per tile or per K-step is wave-uniform and rides in the scalar offset.
   const int a_chunk = (lane & 7) ^ (lane >> 3);
 #define K_A1_DECL(J)                                                      \
   int a_b0##J, a_b1##J;                                                      \
   {                                                                          \
-    const int op = p0 + wave * 32 + 8 * J + (lane >> 3);                     \
+    const int op = wave * 32 + 8 * J + (lane >> 3);                          \
     const int oy = op / p.Wout, ox = op - oy * p.Wout;                       \
     const int pix = oy * p.stride * p.Win + ox * p.stride;                   \
     a_b0##J = (pix * p.ps0 + a_chunk * 4) * 4;                               \
@@ -125,24 +130,38 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
   K_A1_DECL(0) K_A1_DECL(1) K_A1_DECL(2) K_A1_DECL(3)
 #undef K_A1_DECL
   const size_t img0 = (size_t)p.Hin * p.Win * p.ps0, img1 = (size_t)p.Hin * p.Win * p.ps1;
-  const __amdgpu_buffer_rsrc_t rs0 =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (size_t)b * img0), 0, (int)(img0 * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.in1 ? p.in1 + (size_t)b * img1 : p.in0), 0, p.in1 ? (int)(img1 * 4) : 0, 0x00020000);
   const size_t w_tile_stride = (size_t)n_tiles * B_SLOT;
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const char*)p.w + (size_t)nt * B_SLOT), 0, (int)((size_t)(S - 1) * w_tile_stride + B_SLOT), 0x00020000);
 
-  // issue stream: the next K-step to request - tap (ty, tx), channel chunk, ring slot, weight offset - advanced incrementally
-  int i_ty = 0, i_tx = 0, i_cc = 0, i_slot = 0, i_w = 0;
+  // ---- issue stream: ONE continuous sequence of stages over all tiles of this workgroup, two stages ahead of the consumer - the
+  // first two stages of the next tile are in flight while this tile's epilogue stores drain.  Issue-side state: tile (descriptors,
+  // scalar base offsets), tap (ty, tx), channel chunk, ring slot, weight offset.
+  int i_v = blockIdx.x, i_ty = 0, i_tx = 0, i_cc = 0, i_slot = 0, i_w = 0, i_base0 = 0, i_base1 = 0;
+  __amdgpu_buffer_rsrc_t rs0, rs1, rsw;
+  auto issue_tile = [&]() __attribute__((always_inline)) {
+    int nt_, b_, p0_;
+    tile_of(i_v < T ? i_v : 0, nt_, b_, p0_);
+    const int oy = p0_ / p.Wout, ox = p0_ - oy * p.Wout;
+    const int pix0 = oy * p.stride * p.Win + ox * p.stride;
+    i_base0 = pix0 * p.ps0 * 4;
+    i_base1 = pix0 * p.ps1 * 4;
+    rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in0 + (size_t)b_ * img0), 0, (int)(img0 * 4), 0x00020000);
+    rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in1 ? p.in1 + (size_t)b_ * img1 : p.in0), 0, p.in1 ? (int)(img1 * 4) : 0, 0x00020000);
+    rsw = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.w + (size_t)nt_ * B_SLOT), 0,
+                                            (int)((size_t)(S - 1) * w_tile_stride + B_SLOT), 0x00020000);
+    i_ty = i_tx = i_cc = 0;
+    i_w = 0;
+  };
+  issue_tile();
   const int tid16 = tid * 16;
   auto dma = [&](__amdgpu_buffer_rsrc_t rs, char* dst, int voff, int soff) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)dst, 16, voff, soff, 0, 0);
   };
-  auto issue = [&]() __attribute__((always_inline)) {
+  // returns false when the stream is exhausted (nothing issued)
+  auto issue = [&]() __attribute__((always_inline)) -> bool {
+    if (i_v >= T) return false;
     const int c = i_cc * KC;
     const bool first = c < p.C0;
-    const int soff = first ? ((i_ty * p.Win + i_tx) * p.ps0 + c) * 4 : ((i_ty * p.Win + i_tx) * p.ps1 + c - p.C0) * 4;
+    const int soff = first ? i_base0 + ((i_ty * p.Win + i_tx) * p.ps0 + c) * 4 : i_base1 + ((i_ty * p.Win + i_tx) * p.ps1 + c - p.C0) * 4;
     char* st = smem + i_slot * STAGE;
     char* sa = st + wave * 4096;
     // (per-lane offsets selected with v_cndmask, the descriptors by two branches: see conv1x1_bf16.hip)
@@ -155,12 +174,18 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
     i_slot = i_slot == RING - 1 ? 0 : i_slot + 1;
     if (++i_cc == CC) {
       i_cc = 0;
-      if (++i_tx == p.KW) { i_tx = 0; ++i_ty; }
+      if (++i_tx == p.KW) {
+        i_tx = 0;
+        if (++i_ty == p.KH) {                       // this tile's last stage is out: on to the workgroup's next tile
+          i_v += gridDim.x;
+          issue_tile();
+        }
+      }
     }
+    return true;
   };
 
-  f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c04 = 0, c05 = 0, c06 = 0, c07 = 0,
-        c10 = 0, c11 = 0, c12 = 0, c13 = 0, c14 = 0, c15 = 0, c16 = 0, c17 = 0;
+  f32x4 c00, c01, c02, c03, c04, c05, c06, c07, c10, c11, c12, c13, c14, c15, c16, c17;
   // fragment addresses.  Pixel P = 32 w + 16 mi + r16 (P & 7 = r16 & 7): channels 8 q16 .. + 7 are source chunks 2 q16, 2 q16 + 1
   const int sw = r16 & 7;
   const int a_row0 = (wave * 32 + r16) * 128, a_row1 = a_row0 + 16 * 128;
@@ -202,16 +227,25 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
 #undef K_COL
   };
 
-  // ---- pipeline: stages s+1 and s+2 in flight while stage s is consumed (6 DMA instructions per wave and stage)
-  issue();
-  if (S > 1) issue();
-  if (S > 1) WAIT_VM(6); else WAIT_VM(0);
+  // ---- pipeline: stages g+1 and g+2 of the stream in flight while stage g is consumed (6 DMA instructions per wave and stage).
+  // The counted wait at the end of a K-step (stage g+1 landed: at most the 6 requests of stage g+2 outstanding) also covers the
+  // tile boundary: the epilogue's stores count in vmcnt as well, so the first K-step of the next tile waits until they have
+  // drained - while that tile's first two stages, issued before the stores, are already landing.
+  bool more = issue();
+  more = issue() && more;
+  if (more) WAIT_VM(6); else WAIT_VM(0);
   BARRIER();
+  for (int v = blockIdx.x; v < T; v += gridDim.x) {
+  int nt, b, p0;
+  tile_of(v, nt, b, p0);
+  c00 = 0; c01 = 0; c02 = 0; c03 = 0; c04 = 0; c05 = 0; c06 = 0; c07 = 0;
+  c10 = 0; c11 = 0; c12 = 0; c13 = 0; c14 = 0; c15 = 0; c16 = 0; c17 = 0;
+  ss0 = 0.f; ss1 = 0.f;
   for (int s = 0; s < S; ++s) {
-    if (s + 2 < S) issue();
+    const bool issued = issue();
     compute();
-    if (s + 2 < S) WAIT_VM(6); else WAIT_VM(0);     // stage s+1 has landed (this wave's part; the barrier covers the rest)
-    if (s + 1 < S) BARRIER();
+    if (issued) WAIT_VM(6); else WAIT_VM(0);        // stage g+1 has landed (this wave's part; the barrier covers the rest)
+    BARRIER();
   }
 
   // ------------------------------- epilogue (register-direct, fp32) --------------------------
@@ -301,6 +335,7 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
   for (int J = 0; J < 8; ++J) *reinterpret_cast<f32x4*>(p.out + o0 + 4 * J) = v0_[J];
 #pragma unroll
   for (int J = 0; J < 8; ++J) *reinterpret_cast<f32x4*>(p.out + o1 + 4 * J) = v1_[J];
+  }   // tiles of this workgroup
 }
 
 }  // namespace
@@ -315,6 +350,7 @@ bool conv1x1_split_eligible(const ConvArgs& a) {
   if (a.C1 && (a.KH != 1 || a.KW != 1)) return false;
   if (a.C0 % KC || a.C1 % KC || a.Cout % BN || a.Cout != a.CoutPad) return false;
   if (((long)a.Hout * a.Wout) % BM) return false;
+  if (BM % a.Wout != 0 && a.Wout % BM != 0) return false;          // a tile is whole output rows or a piece of one (tile-relative offsets)
   if (a.gn_partial || a.gn_res_src || a.out_q || a.eps4) return false;
   if (a.rms_out_g && (a.Cout != BN || !a.residual || a.mode != CONV_PLAIN || a.rms_in)) return false;
   if (a.rms_in && (a.mode != CONV_PLAIN || a.residual)) return false;
@@ -360,8 +396,20 @@ int conv1x1_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, hi
   p.aux = (const float*)a.residual;
   p.rms_g = a.rms_out_g;
   if (a.rms_out_g && (a.Cout != BN || !a.residual || a.mode != CONV_PLAIN)) SRGD_FAIL("conv1x1_split: the RMSNorm tail needs Cout == 128 and the residual tensor");
-  const long grid = (long)a.B * a.Hout * a.Wout / BM * (a.Cout / BN);
-  if (grid <= 0 || grid > 0x7fffffffL) SRGD_FAIL("conv1x1_split: bad grid");
+  const long tiles = (long)a.B * a.Hout * a.Wout / BM * (a.Cout / BN);
+  if (tiles <= 0 || tiles > 0x7fffffffL) SRGD_FAIL("conv1x1_split: bad grid");
+  p.n_wg_tiles = (int)tiles;
+  // persistent grid: one workgroup per CU (144 KB of LDS each), a multiple of 8 so that a workgroup's tiles stay on its XCD's band
+  static int cus[64] = {};
+  int dev = 0;
+  SRGD_HIP(hipGetDevice(&dev));
+  if (dev >= 0 && dev < 64 && cus[dev] == 0) {
+    int n = 0;
+    SRGD_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    __atomic_store_n(&cus[dev], n > 8 ? n & ~7 : 8, __ATOMIC_RELAXED);
+  }
+  const int n_cu = (dev >= 0 && dev < 64) ? cus[dev] : 256;
+  const long grid = tiles <= n_cu ? tiles : n_cu;
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
 #define K_SET(E_, R_) SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<E_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
