@@ -47,7 +47,7 @@ def test_dim128_checkpoint_file_through_the_cli_reproduces_the_reference_image(t
     Image.fromarray(lr, "RGB").save(indir / "tile.png")
     r = _cli(CONF, ckpt, indir, outdir, case)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert "engine precision: fp32" in r.stdout and "check: <All keys matched successfully>" in r.stderr + r.stdout
+    assert "engine precision: f16x3" in r.stdout and "check: <All keys matched successfully>" in r.stderr + r.stdout
     m = re.search(r"engine ready: 280 tensors packed and uploaded in ([0-9.]+) s", r.stdout)
     assert m, r.stdout[-2000:]
     # (no wall-clock bound here: a functional test must not flake on a loaded box; DESIGN section 8 quotes 0.35 s fp32 / 0.68 s

@@ -41,7 +41,7 @@ def test_inference_cli_writes_out_pngs_and_matches_the_oracle_pipeline(tmp_path)
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "Invalid image or unable to open image" in r.stdout
-    assert "engine precision: fp32" in r.stdout      # the DEFAULT run computes in the reference's precision (no --no_amp needed)
+    assert "engine precision: f16x3" in r.stdout     # the DEFAULT run computes at the reference's accuracy (split-operand mode; no --no_amp needed)
     out_png = outdir / "a_out.png"
     assert out_png.exists() and not (outdir / "broken_out.png").exists()
     got = np.asarray(Image.open(out_png).convert("RGB"))
@@ -58,6 +58,13 @@ def test_inference_cli_writes_out_pngs_and_matches_the_oracle_pipeline(tmp_path)
     # second run: everything already there -> "skip"
     r2 = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0 and "skip" in r2.stdout
+    # --precision fp32 (exact-fp32 MFMA, the CLI default until round 5): the same image up to truncation flips
+    out32 = tmp_path / "out_fp32"
+    cmd32 = [c if c != str(outdir) else str(out32) for c in cmd] + ["--precision", "fp32"]
+    r32 = subprocess.run(cmd32, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r32.returncode == 0 and "engine precision: fp32" in r32.stdout, r32.stderr[-2000:]
+    d32 = np.abs(np.asarray(Image.open(out32 / "a_out.png").convert("RGB")).astype(int) - want.astype(int))
+    assert d32.max() <= 1 and (d32 > 0).mean() < 2e-3
     # explicit opt-in to the throughput mode: same image within bf16's distance of the fp32 result
     out_bf = tmp_path / "out_bf16"
     cmd_bf = [c if c != str(outdir) else str(out_bf) for c in cmd] + ["--precision", "bf16", "--no_amp"]

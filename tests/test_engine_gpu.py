@@ -681,7 +681,7 @@ def test_config5_cfg2_100_steps_fp32_parity_and_bf16_fp8_weight_reports():
 
 # Gates of the throughput modes against the REFERENCE's configs[1] output at full length (50 steps): set 3 dB under the first
 # measurement on MI355X (profiles/r6_parity_report.jsonl); moved up only.
-CONFIG2_FULL_GATES_DB = {"bf16": 55.0, "fp8_mixed": 49.0, "fp8": 32.0}
+CONFIG2_FULL_GATES_DB = {"bf16": 55.5, "fp8_mixed": 49.5, "fp8": 33.7}      # measured 58.50 / 52.56 / 36.72 dB (round 6)
 
 
 def test_config2_full_length_against_the_reference():
