@@ -37,7 +37,7 @@ constexpr int B_SLOT = 2 * B_TILE;             // hi | lo
 constexpr int STAGE = A_BYTES + B_SLOT;        // 48 KiB
 constexpr int RING = 3;
 constexpr int LDS_BYTES = RING * STAGE;        // 147,456: one workgroup per CU
-enum { SEPI_PLAIN = 0, SEPI_RESIDUAL = 1, SEPI_PS_SILU = 2, SEPI_RMS_RESIDUAL = 3 };
+enum { SEPI_PLAIN = 0, SEPI_RESIDUAL = 1, SEPI_PS_SILU = 2, SEPI_RMS_RESIDUAL = 3, SEPI_GNTAIL = 4 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -53,7 +53,8 @@ struct Split1Args {
   float w_inv_scale;
   int Cout;
   float* out;
-  const float* aux;       // SEPI_RESIDUAL / SEPI_RMS_RESIDUAL: tensor added to the output
+  const float* aux;       // SEPI_RESIDUAL / SEPI_RMS_RESIDUAL: tensor added to the output; SEPI_GNTAIL: tensor the GroupNorm tail is applied to
+  const float* gn_a; const float* gn_b;   // SEPI_GNTAIL: [B][Cout] scale / shift of y = silu(a * aux + b)
   int n_wg_tiles;         // m-tiles x n-tiles (the grid is persistent: at most one workgroup per CU)
   const float* rms_g;     // SEPI_RMS_RESIDUAL: [Cout] gain of the RMSNorm applied to the result, already times sqrt(Cout)
 };
@@ -312,6 +313,32 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
 #pragma unroll
     for (int J = 0; J < 8; ++J) { v0_[J] = v0_[J] * i0 * g_[J] + r0_[J]; v1_[J] = v1_[J] * i1 * g_[J] + r1_[J]; }
   }
+  if (EPI == SEPI_GNTAIL) {
+    // out = conv(x) + silu(a[b][c] * h + b[b][c]): the second GroupNorm + SiLU of a ResnetBlock and its residual add folded into the
+    // 1x1 res_conv (reference model.py:250-259, :283-285); h may alias out (a lane reads exactly the addresses it writes)
+    f32x4 r0_[8], r1_[8], a_[8], b_[8];
+    const float* ga = p.gn_a + (size_t)b * p.Cout + n0 + q16 * 32;
+    const float* gb = p.gn_b + (size_t)b * p.Cout + n0 + q16 * 32;
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+      r0_[J] = *reinterpret_cast<const f32x4*>(p.aux + o0 + 4 * J);
+      r1_[J] = *reinterpret_cast<const f32x4*>(p.aux + o1 + 4 * J);
+      a_[J] = *reinterpret_cast<const f32x4*>(ga + 4 * J);
+      b_[J] = *reinterpret_cast<const f32x4*>(gb + 4 * J);
+    }
+    asm volatile("" : "+v"(r0_[0]), "+v"(r0_[1]), "+v"(r0_[2]), "+v"(r0_[3]), "+v"(r0_[4]), "+v"(r0_[5]), "+v"(r0_[6]), "+v"(r0_[7]));
+    asm volatile("" : "+v"(r1_[0]), "+v"(r1_[1]), "+v"(r1_[2]), "+v"(r1_[3]), "+v"(r1_[4]), "+v"(r1_[5]), "+v"(r1_[6]), "+v"(r1_[7]));
+    asm volatile("" : "+v"(a_[0]), "+v"(a_[1]), "+v"(a_[2]), "+v"(a_[3]), "+v"(a_[4]), "+v"(a_[5]), "+v"(a_[6]), "+v"(a_[7]));
+    asm volatile("" : "+v"(b_[0]), "+v"(b_[1]), "+v"(b_[2]), "+v"(b_[3]), "+v"(b_[4]), "+v"(b_[5]), "+v"(b_[6]), "+v"(b_[7]));
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v0_[J][e] += silu<true>(__builtin_fmaf(a_[J][e], r0_[J][e], b_[J][e]));
+        v1_[J][e] += silu<true>(__builtin_fmaf(a_[J][e], r1_[J][e], b_[J][e]));
+      }
+    }
+  }
   if (EPI == SEPI_RESIDUAL) {
     f32x4 r0_[8], r1_[8];
 #pragma unroll
@@ -351,7 +378,8 @@ bool conv1x1_split_eligible(const ConvArgs& a) {
   if (a.C0 % KC || a.C1 % KC || a.Cout % BN || a.Cout != a.CoutPad) return false;
   if (((long)a.Hout * a.Wout) % BM) return false;
   if (BM % a.Wout != 0 && a.Wout % BM != 0) return false;          // a tile is whole output rows or a piece of one (tile-relative offsets)
-  if (a.gn_partial || a.gn_res_src || a.out_q || a.eps4) return false;
+  if (a.gn_partial || a.out_q || a.eps4) return false;
+  if (a.gn_res_src && (!a.gn_res_a || !a.gn_res_b || a.residual || a.rms_in || a.rms_out_g || a.mode != CONV_PLAIN)) return false;
   if (a.rms_out_g && (a.Cout != BN || !a.residual || a.mode != CONV_PLAIN || a.rms_in)) return false;
   if (a.rms_in && (a.mode != CONV_PLAIN || a.residual)) return false;
   if (a.mode == CONV_PIXEL_SHUFFLE_SILU && ((a.Cout / 4) % BN || a.residual)) return false;
@@ -393,7 +421,8 @@ int conv1x1_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, hi
   p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.Hout = a.Hout; p.Wout = a.Wout;
   p.KH = a.KH; p.KW = a.KW; p.stride = a.stride; p.ps0 = a.ps0; p.ps1 = a.C1 ? a.ps1 : 0;
   p.w = packed_w; p.bias = a.bias; p.w_inv_scale = w_inv_scale; p.Cout = a.Cout; p.out = (float*)a.out;
-  p.aux = (const float*)a.residual;
+  p.aux = a.gn_res_src ? (const float*)a.gn_res_src : (const float*)a.residual;
+  p.gn_a = a.gn_res_a; p.gn_b = a.gn_res_b;
   p.rms_g = a.rms_out_g;
   if (a.rms_out_g && (a.Cout != BN || !a.residual || a.mode != CONV_PLAIN)) SRGD_FAIL("conv1x1_split: the RMSNorm tail needs Cout == 128 and the residual tensor");
   const long tiles = (long)a.B * a.Hout * a.Wout / BM * (a.Cout / BN);
@@ -414,6 +443,7 @@ int conv1x1_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, hi
   if (DeviceSetup once(attr_set); once.need) {
 #define K_SET(E_, R_) SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_split_kernel<E_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     K_SET(SEPI_PLAIN, false) K_SET(SEPI_RESIDUAL, false) K_SET(SEPI_PS_SILU, false) K_SET(SEPI_RMS_RESIDUAL, false) K_SET(SEPI_PLAIN, true)
+    K_SET(SEPI_GNTAIL, false)
 #undef K_SET
     once.done();
   }
@@ -422,6 +452,7 @@ int conv1x1_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, hi
     if (a.mode != CONV_PLAIN || a.residual || a.rms_out_g) SRGD_FAIL("conv1x1_split: the RMSNorm-on-input form has the plain epilogue only");
     K_GO(SEPI_PLAIN, true);
   } else if (a.mode == CONV_PIXEL_SHUFFLE_SILU) K_GO(SEPI_PS_SILU, false);
+  else if (a.gn_res_src) K_GO(SEPI_GNTAIL, false);
   else if (a.rms_out_g) K_GO(SEPI_RMS_RESIDUAL, false);
   else if (a.residual) K_GO(SEPI_RESIDUAL, false);
   else K_GO(SEPI_PLAIN, false);

@@ -826,6 +826,17 @@ int run_gn(Ctx& x, const float* gamma, const float* beta, int C, int hw, int ss_
   return 0;
 }
 
+// f16x3 mode: can this res_conv run on conv1x1_split with the GroupNorm2 + SiLU + residual tail in its epilogue?
+bool split_gntail_possible(const Ctx& x, const ConvW& c, int C0, int C1) {
+  const srgd_engine* e = x.e;
+  if (!c.ws1 || e->force_generic_conv || e->no_conv1x1) return false;
+  ConvArgs a{};
+  a.C0 = C0; a.C1 = C1; a.ps0 = C0; a.ps1 = C1; a.in1 = C1 ? (const void*)1 : nullptr; a.B = x.nb; a.Hin = x.H; a.Win = x.W; a.Hout = x.H; a.Wout = x.W;
+  a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.Cout = c.Cout; a.CoutPad = c.CoutPad; a.mode = CONV_PLAIN;
+  a.gn_res_src = (const void*)1; a.gn_res_a = (const float*)1; a.gn_res_b = (const float*)1;
+  return conv1x1_split_eligible(a);
+}
+
 // ResnetBlock (model.py:261-285); returns a pool buffer [nb,H,W,Cout]
 int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, int C1, void** out, bool want_twin = false,
               float* eps4 = nullptr) {
@@ -857,6 +868,10 @@ int res_block(Ctx& x, const ResW& r, const void* in0, int C0, const void* in1, i
     // GroupNorm2 + SiLU + (+ res_conv(x)) evaluated in the 1x1 res_conv's epilogue, in place over v
     SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, nullptr, true));
     SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, v, nullptr, false, false, v, want_twin, eps4, true));
+  } else if (r.has_res && e->split && !e->no_gn_fusion && split_gntail_possible(x, r.res, C0, C1)) {
+    // f16x3 mode: the same fusion in conv1x1_split's epilogue (SEPI_GNTAIL)
+    SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, nullptr, true));
+    SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, v, nullptr, false, false, v));
   } else if (r.has_res) {
     SRGD_TRY(run_conv(x, r.res, in0, C0, in1, C1, x.H, x.W, u, nullptr, false));   // u is free again: reuse it
     SRGD_TRY(run_gn(x, r.g2, r.b2, r.Cout, hw, -1, v, u));

@@ -128,8 +128,9 @@ def test_cli_flags_are_the_reference_flags():
         (0, None, None, True, True, 71, "ddp")
     a = parse_args(["-c", "x", "-m", "w", "--input_dir", "i", "--output_dir", "o", "--no_amp", "--test_label", "0"])
     assert a.amp is False and a.test_label == 0
-    # engine-only switch: the default precision is the reference's (fp32); throughput modes are explicit opt-ins
-    assert a.precision == "fp32"
+    # engine-only switch: the default precision is the one that meets the reference's 1e-3 bar at matrix-core speed (f16x3, round 6;
+    # fp32 = exact-fp32 MFMA stays selectable); throughput modes are explicit opt-ins
+    assert a.precision == "f16x3"
     assert parse_args(["-c", "x", "-m", "w", "--input_dir", "i", "--output_dir", "o", "--precision", "bf16"]).precision == "bf16"
 
 
@@ -286,7 +287,9 @@ def test_step_lanes_rule():
     assert lanes_wanted(1, 1, 4, None) == 1 and lanes_wanted(1, 1, 4, 2) == 1                # a single tile cannot be split
     assert lanes_wanted(125, 1, 125, 2) == 2 and lanes_wanted(25, 1, 25, 1) == 1             # forced
     # automatic only in the precisions it was A/B-measured in: the parity modes keep one lane unless forced
-    assert lanes_wanted(25, 1, 25, None, "fp32") == 1 and lanes_wanted(25, 1, 25, None, "f16x3") == 1
+    assert lanes_wanted(25, 1, 25, None, "fp32") == 1 and lanes_wanted(125, 1, 125, None, "fp32") == 1
+    assert lanes_wanted(25, 1, 25, None, "f16x3") == 2 and lanes_wanted(125, 1, 125, None, "f16x3") == 2      # measured in round 6
+    assert lanes_wanted(125, 2, 125, None, "f16x3") == 1 and lanes_wanted(125, 1, 64, None, "f16x3") == 1
     assert lanes_wanted(25, 1, 25, 2, "fp32") == 2 and lanes_wanted(25, 1, 25, None, "fp8") == 2
     import os
     from srgd_amd.lanes import lanes_setting_from_env

@@ -173,7 +173,7 @@ def test_conv_igemm_split_variants(variant):
             assert (s[..., 1] - (pre ** 2).reshape(B, groups, -1).sum(-1)).abs().max() <= 1e-4 * float((pre ** 2).reshape(B, groups, -1).sum(-1).max())
 
 
-@pytest.mark.parametrize("variant", ["plain", "residual", "two_sources", "pixel_shuffle", "unshuffle", "k_heavy", "one_step", "integers"])
+@pytest.mark.parametrize("variant", ["plain", "residual", "two_sources", "gn_tail", "pixel_shuffle", "unshuffle", "k_heavy", "one_step", "integers"])
 def test_conv1x1_split_streaming_kernel(variant):
     # conv1x1_split.hip (fp32 pixel rows and split weights through a 3-deep LDS-DMA ring, split in registers, register-direct epilogue)
     # against float64 and against the generic split kernel (same arithmetic, different tiling)
@@ -211,12 +211,21 @@ def test_conv1x1_split_streaming_kernel(variant):
     if variant == "residual":
         residual = torch.randn(B, cout, H, W, generator=g)
         want64 = want64 + residual.double()
-    got, _ = run_conv(x0, x1, w, b, bf16=False, residual=residual, impl=10, **kw)
+    gn_tail = None
+    if variant == "gn_tail":            # out = conv(x) + silu(a * h + b): the ResnetBlock tail (model.py:250-259, :285) in the res_conv's epilogue
+        hsrc = torch.randn(B, cout, H, W, generator=g) * 2
+        ta, tb = 1 + 0.3 * torch.randn(B, cout, generator=g), 0.5 * torch.randn(B, cout, generator=g)
+        gn_tail = (hsrc, ta, tb)
+        want64 = want64 + F.silu(ta.double()[:, :, None, None] * hsrc.double() + tb.double()[:, :, None, None])
+    got, _ = run_conv(x0, x1, w, b, bf16=False, residual=residual, impl=10, gn_tail=gn_tail, **kw)
     if variant == "integers":
         assert torch.equal(got.double(), want64)
         return
     scale = max(1.0, float(want64.abs().max()))
     err = float((got.double() - want64).abs().max())
+    if variant == "gn_tail":            # (the generic split kernel has no tail epilogue: float64 is the only check)
+        assert err <= 4e-6 * scale, (variant, err)
+        return
     gen, _ = run_conv(x0, x1, w, b, bf16=False, residual=residual, impl=7, **kw)
     _report_k(test="conv1x1_split", variant=variant, max_abs=err, ref_max=scale, vs_generic_split=float((got - gen).abs().max()))
     assert err <= 4e-6 * scale, (variant, err)
