@@ -229,9 +229,8 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
   };
 
   // ---- pipeline: stages g+1 and g+2 of the stream in flight while stage g is consumed (6 DMA instructions per wave and stage).
-  // The counted wait at the end of a K-step (stage g+1 landed: at most the 6 requests of stage g+2 outstanding) also covers the
-  // tile boundary: the epilogue's stores count in vmcnt as well, so the first K-step of the next tile waits until they have
-  // drained - while that tile's first two stages, issued before the stores, are already landing.
+  // The epilogue's stores count in vmcnt as well; the next tile's first two stages are issued before them and are already landing
+  // while they drain (see the wait below).
   bool more = issue();
   more = issue() && more;
   if (more) WAIT_VM(6); else WAIT_VM(0);
@@ -245,7 +244,14 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
   for (int s = 0; s < S; ++s) {
     const bool issued = issue();
     compute();
-    if (issued) WAIT_VM(6); else WAIT_VM(0);        // stage g+1 has landed (this wave's part; the barrier covers the rest)
+    // stage g+1 has landed (this wave's part; the barrier covers the rest) once only the requests younger than it are outstanding:
+    // the 6 of stage g+2 - and, in the first K-step of a later tile, the previous tile's 16 epilogue stores, which were issued
+    // after stage g+1 (vmcnt retires vector-memory requests of a wave in issue order, loads and stores alike, on gfx9-family
+    // parts).  Without the + 16 this wait would drain the stores before the tile's second K-step could start; with it the drain
+    // overlaps two K-steps and the loads of the next two stages.
+    if (s == 0 && v != (int)blockIdx.x) { if (issued) WAIT_VM(22); else WAIT_VM(16); }
+    else if (issued) WAIT_VM(6);
+    else WAIT_VM(0);
     BARRIER();
   }
 
