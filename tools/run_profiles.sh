@@ -1,15 +1,17 @@
 # Profile collection on the GPU box (gpurun): kernel-trace stats and separate PMC passes, as MI355X_MICROARCH.md prescribes
 # (FETCH_SIZE and WRITE_SIZE in passes of their own, never combined with sys/hip tracing).
-R=$GRAFT_REPO_ROOT; TAG=${1:-r5}; O=$R/gpurun_out/${TAG}prof; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r6}; O=$R/gpurun_out/${TAG}prof; mkdir -p $O
+MODES=${2:-"bf16 f16x3 fp8 fp8_mixed"}
 cd /tmp && export TMPDIR=/tmp
-for MODE in bf16 fp8 fp8_mixed; do
+for MODE in $MODES; do
   EXTRA=""; [ $MODE != bf16 ] && EXTRA="--precision $MODE --ddpm_steps 100 --class_cond_scale 2.0"
+  [ $MODE = f16x3 ] && EXTRA="--precision f16x3"       # the parity mode at the headline configuration (50 steps, CFG 1.0)
   STEPS=5; [ $MODE = fp8 ] && STEPS=5
   rocprofv3 --kernel-trace --stats -d $O/kt_$MODE -o k -- python3 $R/bench.py --steps $STEPS --warmup 0 --no_cpu_baseline --no_profile $EXTRA > $O/kt_$MODE.log 2>&1
   python3 $R/tools/rocprof_db_stats.py $(find $O/kt_$MODE -name "*.db" | head -1) $O/${MODE}_kernel_stats.csv > $O/${MODE}_kernel_stats.txt
   rm -rf $O/kt_$MODE
   [ $MODE = fp8_mixed ] && continue        # kernel-trace statistics only: its kernels are the bf16 and fp8 ones
-  PMCX="--steps 5 --warmup 0 --no_cpu_baseline --no_profile --ddpm_steps 2"; [ $MODE = fp8 ] && PMCX="$PMCX --precision fp8"
+  PMCX="--steps 5 --warmup 0 --no_cpu_baseline --no_profile --ddpm_steps 2"; [ $MODE != bf16 ] && PMCX="$PMCX --precision $MODE"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf_$MODE -o f -- python3 $R/bench.py $PMCX > $O/pf_$MODE.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw_$MODE -o w -- python3 $R/bench.py $PMCX > $O/pw_$MODE.log 2>&1
   python3 $R/tools/pmc_traffic.py $(find $O/pf_$MODE -name "*.db" | head -1) $(find $O/pw_$MODE -name "*.db" | head -1) $O/pmc_traffic_$MODE.json "bench.py $PMCX (125/80 tiles per launch)" > $O/pmc_traffic_$MODE.txt
@@ -22,4 +24,4 @@ SRGD_GRAPHS=0 rocprofv3 --kernel-trace --stats -d $O/kt_nograph -o k -- python3 
 python3 $R/tools/rocprof_db_stats.py $(find $O/kt_nograph -name "*.db" | head -1) $O/bf16_nograph_kernel_stats.csv > $O/bf16_nograph_kernel_stats.txt
 rm -rf $O/kt_nograph
 grep -h copyBuffer $O/bf16_kernel_stats.csv $O/bf16_nograph_kernel_stats.csv
-cd $R; head -22 $O/bf16_kernel_stats.csv; head -16 $O/fp8_kernel_stats.csv; head -16 $O/fp8_mixed_kernel_stats.csv; cat $O/pmc_traffic_bf16.txt $O/pmc_traffic_fp8.txt; cat $O/pmc_sq_bf16.txt $O/pmc_sq_fp8.txt | head -60
+cd $R; for M in $MODES; do head -16 $O/${M}_kernel_stats.csv; done; cat $O/pmc_traffic_*.txt; cat $O/pmc_sq_*.txt | head -80
