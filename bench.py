@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 TFLOP_PER_HR_TILE = 813.6          # BASELINE.md section 3 (1,025 tile-forwards x 793.8 GFLOP)
 TILE_FORWARDS_PER_HR_TILE = 1025
-PMC_TRAFFIC_FILE = "r5_pmc_traffic.json"     # newest committed PMC summary (tools/pmc_traffic.py)
+PMC_TRAFFIC_FILE = "r6_pmc_traffic.json"     # newest committed PMC summary (tools/pmc_traffic.py; bf16 and f16x3 passes of round 6, fp8 kernels from round 5)
 # MI355X_MICROARCH.md: dense MFMA peaks of the dominant kernel's instruction (fp8 = block-scaled MX e4m3, 2x the bf16 rate)
 # conv3x3_split (f16x3 mode): the f16 MFMA peak; the kernel issues THREE MFMAs per algorithmic product, so its algorithmic ceiling is
 # a third of it (roofline.mfma_per_product, roofline.frac_of_issue_peak)
@@ -446,7 +446,7 @@ def main():
             # cannot share a pass, and rocprofv3 cannot run inside the benchmark): the committed summary is quoted and labelled
             traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
-            if os.path.exists(pmc) and args.precision in ("bf16", "fp8", "fp8_mixed"):
+            if os.path.exists(pmc) and args.precision in ("bf16", "fp8", "fp8_mixed", "f16x3"):
                 t = json.load(open(pmc)).get(kname)
                 if t:   # gfx950: FETCH_SIZE counts half of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> x2
                     traffic = (2.0 * t["FETCH_SIZE"]["avg_kb"] + t["WRITE_SIZE"]["avg_kb"]) * 1024.0

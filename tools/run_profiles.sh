@@ -3,6 +3,10 @@
 R=$GRAFT_REPO_ROOT; TAG=${1:-r6}; O=$R/gpurun_out/${TAG}prof; mkdir -p $O
 MODES=${2:-"bf16 f16x3 fp8 fp8_mixed"}
 cd /tmp && export TMPDIR=/tmp
+# one step lane: the per-kernel durations of two concurrent lanes overlap (their sum exceeds the wall time) and the launch mix changes
+# (125 / 80 tiles per launch becomes 125 / 40 + 40 or 63 + 62 / 40 + 40); bench.py's profiled pass - the `roofline` numbers these
+# summaries must agree with - runs with one lane for the same reason
+export SRGD_STEP_LANES=1
 for MODE in $MODES; do
   EXTRA=""; [ $MODE != bf16 ] && EXTRA="--precision $MODE --ddpm_steps 100 --class_cond_scale 2.0"
   [ $MODE = f16x3 ] && EXTRA="--precision f16x3"       # the parity mode at the headline configuration (50 steps, CFG 1.0)
