@@ -247,8 +247,10 @@ def make_long(cases=None):
         print("long", case["name"], "done", tuple(img.shape), float(img.mean()))
 
 
-def make_full(cases=None):
-    """BASELINE configs[1] at full length, with the reference's own trajectory (with_images / with_x0_images)."""
+def make_full(cases=None, trace_steps=None):
+    """BASELINE configs[1] (or, --config5-full, configs[4]) at full length, with the reference's own trajectory (with_images /
+    with_x0_images)."""
+    trace_steps = C.FULL_TRACE_STEPS if trace_steps is None else trace_steps
     ref = refshim.load_reference()
     assert ref is not None, "reference not present"
     rm, rc = ref
@@ -275,8 +277,8 @@ def make_full(cases=None):
                       xt_abs=np.array([t.double().abs().sum().item() for t in xt_list[1:]]),
                       x0_sum=np.array([t.double().sum().item() for t in x0_list[1:]]),
                       x0_abs=np.array([t.double().abs().sum().item() for t in x0_list[1:]]),
-                      trace_steps=np.array(C.FULL_TRACE_STEPS))
-        for i in C.FULL_TRACE_STEPS:
+                      trace_steps=np.array(trace_steps))
+        for i in trace_steps:
             arrays[f"xt_{i}"] = C.trace_planes(xt_list[i + 1]).numpy().copy()
             arrays[f"x0_{i}"] = C.trace_planes(x0_list[i + 1]).numpy().copy()
         np.savez_compressed(os.path.join(HERE, f"sample_{case['name']}.npz"), **arrays)
@@ -286,6 +288,8 @@ def make_full(cases=None):
 if __name__ == "__main__":
     if "--config2-full" in sys.argv:
         make_full()
+    elif "--config5-full" in sys.argv:
+        make_full(C.FULL5_CASES, C.FULL5_TRACE_STEPS)
     elif "--sample-only" in sys.argv:
         make_sample()
     elif "--modules-only" in sys.argv:

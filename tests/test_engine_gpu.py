@@ -684,17 +684,13 @@ def test_config5_cfg2_100_steps_fp32_parity_and_bf16_fp8_weight_reports():
 CONFIG2_FULL_GATES_DB = {"bf16": 55.5, "fp8_mixed": 49.5, "fp8": 33.7}      # measured 58.50 / 52.56 / 36.72 dB (round 6)
 
 
-def test_config2_full_length_against_the_reference():
-    # BASELINE configs[1] exactly as written - 256^2 LR -> 1024^2, canvas 1280^2, 25 / 16 tiles, 50 DDPM steps, class_cond_scale 1.0,
-    # dim 128, batch_size 8, seed 71 - against the REFERENCE's own output and trajectory (tests/golden/make_golden.py
-    # --config2-full: 1,025 tile-forwards through /root/reference/model.py:3288-3413, about two hours of CPU in the build container).
-    # Until round 5 this run was checked engine-against-engine only.  The parity modes (fp32, f16x3) are gated at the north-star bar
-    # on the final image and followed through the trajectory (with_images / with_x0_images, model.py:3398-3401); the throughput
-    # modes are reported as PSNR against the reference.
-    case = C.FULL_CASES[0]
+def _full_length_check(case, gates, tag):
+    """A full-length run against the REFERENCE's own output and trajectory (tests/golden/make_golden.py --config2-full /
+    --config5-full): the parity modes (fp32, f16x3) gated at the north-star bar on the final image and followed through the
+    trajectory (with_images / with_x0_images, model.py:3398-3401); the throughput modes reported as PSNR against the reference."""
     path = os.path.join(G, f"sample_{case['name']}.npz")
     if not os.path.exists(path):
-        pytest.skip("full-length configs[1] fixture not generated in this tree")
+        pytest.skip(f"fixture {os.path.basename(path)} not generated in this tree")
     z = np.load(path)
     want = torch.from_numpy(z["image_u16"].astype(np.float32) / 65535.0)
     assert abs(want.double().sum().item() - float(z["checksum"])) < 3.2e6 * 7.7e-6
@@ -705,14 +701,15 @@ def test_config2_full_length_against_the_reference():
     sampler.noise_source = "host"
     psnr_of = lambda a: float(10 * np.log10(1.0 / max(float(((a - want) ** 2).mean()), 1e-20)))
     steps = [int(i) for i in z["trace_steps"]]
+    kw = dict(batch_size=case["batch_size"], condition_x=cond, class_label=label, num_sample_steps=case["steps"],
+              cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"])
     for prec in ("fp32", "f16x3"):
         torch.manual_seed(case["seed"])
-        out, xts, x0s = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label,
-                                             num_sample_steps=case["steps"], precision=prec, with_images=True, with_x0_images=True)
+        out, xts, x0s = sampler.tiled_sample(precision=prec, with_images=True, with_x0_images=True, **kw)
         out = out.cpu()
         assert len(xts) == case["steps"] + 1 and len(x0s) == case["steps"] + 1
         err = float((out - want).abs().max())
-        # trajectory: the reference's canvases after steps 0, 1, 10, 25, 49 (8x-subsampled planes) and fp64 checksums of every step
+        # trajectory: the reference's canvases after the traced steps (8x-subsampled planes) and fp64 checksums of every step
         xt_err = {i: float((C.trace_planes(xts[i + 1]) - torch.from_numpy(z[f"xt_{i}"])).abs().max()) for i in steps}
         x0_err = {i: float((C.trace_planes(x0s[i + 1]) - torch.from_numpy(z[f"x0_{i}"])).abs().max()) for i in steps}
         xt_abs = np.array([t.double().abs().sum().item() for t in xts[1:]])
@@ -720,9 +717,9 @@ def test_config2_full_length_against_the_reference():
         rel_xt = float(np.max(np.abs(xt_abs - z["xt_abs"]) / z["xt_abs"]))
         rel_x0 = float(np.max(np.abs(x0_abs - z["x0_abs"]) / z["x0_abs"]))
         del xts, x0s
-        _report(test="config2_full_vs_reference", precision=prec, max_abs=err, mean_abs=float((out - want).abs().mean()),
+        _report(test=tag, precision=prec, max_abs=err, mean_abs=float((out - want).abs().mean()),
                 xt_max_abs_at=xt_err, x0_max_abs_at=x0_err, xt_abs_checksum_rel=rel_xt, x0_abs_checksum_rel=rel_x0)
-        assert out.shape == (1, 3, 1024, 1024)
+        assert out.shape == (1, 3, case["h"], case["w"])
         assert err <= 1e-3, (prec, err)                              # north-star bar, against the reference itself, at full length
         # x_t carries N(0,1)-scale noise: summation-order differences stay ~1e-5; x_start = (x - sigma eps) / alpha amplifies eps
         # differences by 1 / alpha (148x at step 0) before the clamp
@@ -730,15 +727,31 @@ def test_config2_full_length_against_the_reference():
         assert max(x0_err.values()) <= 2e-2 and x0_err[steps[-1]] <= 2e-3, (prec, x0_err)
         assert rel_xt <= 1e-5 and rel_x0 <= 1e-4, (prec, rel_xt, rel_x0)
     rep = {}
-    for prec in ("bf16", "fp8_mixed", "fp8"):
+    for prec in gates:
         torch.manual_seed(case["seed"])
-        out = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label,
-                                   num_sample_steps=case["steps"], precision=prec).cpu()
+        out = sampler.tiled_sample(precision=prec, **kw).cpu()
         assert torch.isfinite(out).all() and out.min() >= 0 and out.max() <= 1
         rep[prec] = dict(psnr_db=psnr_of(out), max_abs=float((out - want).abs().max()), mean_abs=float((out - want).abs().mean()))
-    _report(test="config2_full_vs_reference", throughput_modes=rep)
-    for prec, gate in CONFIG2_FULL_GATES_DB.items():
+    _report(test=tag, throughput_modes=rep)
+    for prec, gate in gates.items():
         assert rep[prec]["psnr_db"] > gate, (prec, rep[prec])
+
+
+def test_config2_full_length_against_the_reference():
+    # BASELINE configs[1] exactly as written - 256^2 LR -> 1024^2, canvas 1280^2, 25 / 16 tiles, 50 DDPM steps, class_cond_scale 1.0,
+    # dim 128, batch_size 8, seed 71: 1,025 tile-forwards through /root/reference/model.py:3288-3413 (about two hours of CPU in the
+    # build container).  Until round 5 this run was checked engine-against-engine only.
+    _full_length_check(C.FULL_CASES[0], CONFIG2_FULL_GATES_DB, "config2_full_vs_reference")
+
+
+# configs[4] at its full geometry against the reference: gates to be set 3 dB under the first measurement
+CONFIG5_FULL_GATES_DB = {"bf16": 52.0, "fp8_mixed": 46.0, "fp8": 30.0}
+
+
+def test_config5_full_geometry_against_the_reference():
+    # BASELINE configs[4] at full geometry: the same 1024^2 image, 100 DDPM steps, class_cond_scale 2.0 (both passes in one launch) =
+    # 4,100 tile-forwards through the reference (about four hours of CPU: make_golden.py --config5-full)
+    _full_length_check(C.FULL5_CASES[0], CONFIG5_FULL_GATES_DB, "config5_full_vs_reference")
 
 
 def test_edm_lockstep_images_equal_their_solo_runs():
