@@ -155,6 +155,13 @@ int srgd_sampler_step_tiles(srgd_engine* e, int step, int tile_first, int tile_c
 int srgd_sampler_exchange_tiles(srgd_engine* e, int parity, int tile_first, int tile_count, float* canvas, float* tiles,
                                 int to_canvas, void* stream);
 
+/* Unpacks an all-gathered buffer [world * part_w, 3, tile, tile] into the canvas in ONE launch: ranks own contiguous slices of
+ * slice_w tiles of grid `parity`, each contributed tiles [part_off, part_off + part_w) of its slice, so row j of `gathered` is tile
+ * (j / part_w) * slice_w + part_off + j % part_w; rows past the end of the grid (short and empty slices) are skipped.  Equivalent to
+ * `world` calls of srgd_sampler_exchange_tiles(to_canvas = 1). */
+int srgd_sampler_unpack_gathered(srgd_engine* e, int parity, int world, int slice_w, int part_off, int part_w, float* canvas,
+                                 const float* gathered, void* stream);
+
 /* Optional start from the forward-diffused condition instead of white noise (generation_start_steps > 0 or
  * start_white_noise=False): img = reflect_pad(2*cond01-1) * alpha + noise * sigma over the whole canvas
  * (q_sample, model.py:3305-3308, :3312-3315, :3434-3442).  noise_canvas: device [3,Hp,Wp] or NULL (device RNG). */

@@ -70,6 +70,8 @@ PROTOTYPES = {
                                           C.c_void_p]),
     "srgd_sampler_exchange_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_void_p]),
+    "srgd_sampler_unpack_gathered": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]),
     "srgd_edm_begin": (C.c_int, [C.c_void_p, C.POINTER(SamplerGeometry), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32), C.c_int, C.POINTER(EdmScalars), C.POINTER(C.c_float), C.c_int,
                                  C.c_void_p]),

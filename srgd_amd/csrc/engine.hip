@@ -1858,6 +1858,19 @@ int srgd_sampler_exchange_tiles(srgd_engine* e, int parity, int tile_first, int 
   return canvas_exchange_tiles(canvas, tiles, tb, to_canvas != 0, (hipStream_t)stream);
 }
 
+int srgd_sampler_unpack_gathered(srgd_engine* e, int parity, int world, int slice_w, int part_off, int part_w, float* canvas,
+                                 const float* gathered, void* stream) {
+  if (!e || !e->run_active) SRGD_FAIL("srgd_sampler_unpack_gathered: call srgd_sampler_begin first");
+  if (!canvas || !gathered) SRGD_FAIL("srgd_sampler_unpack_gathered: null argument");
+  if (world < 1 || slice_w < 1 || part_w < 1 || part_off < 0 || part_off + part_w > slice_w)
+    SRGD_FAIL("srgd_sampler_unpack_gathered: the part [part_off, part_off + part_w) must lie inside a slice of slice_w tiles");
+  const srgd_sampler_geometry& g = e->geo;
+  const int n = (parity & 1 ? g.n_odd : g.n_even) * g.n_images;
+  Prof p(e, KC_CANVAS, (hipStream_t)stream);
+  TileBatch tb{parity & 1 ? e->d_tiles_odd : e->d_tiles_even, 0, world * part_w, g.Hp, g.Wp, g.tile, parity & 1 ? g.n_odd : g.n_even};
+  return canvas_unpack_gathered(canvas, gathered, tb, slice_w, part_off, part_w, n, (hipStream_t)stream);
+}
+
 int srgd_sampler_q_start(srgd_engine* e, const float* cond01, const float* noise_canvas, float alpha, float sigma,
                          float* img, uint64_t seed, void* stream) {
   if (!e || !e->run_active) SRGD_FAIL("srgd_sampler_q_start: call srgd_sampler_begin first");

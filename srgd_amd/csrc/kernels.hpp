@@ -267,6 +267,7 @@ int canvas_finish(const float* img, int planes, int Hp, int Wp, int left, int to
                   hipStream_t st);
 // copies the tiles [tb.first, tb.first+tb.ntiles) between a canvas and a packed [ntiles][3][tile][tile] buffer
 // (the exchange unit when one canvas is sharded over ranks: SURVEY section 8(e), config 4)
+int canvas_unpack_gathered(float* canvas, const float* gathered, const TileBatch& tb, int w, int off, int pw, int n_grid, hipStream_t st);
 int canvas_exchange_tiles(float* canvas, float* tiles, const TileBatch& tb, bool to_canvas, hipStream_t st);
 // counter-based Gaussian noise (Philox4x32-10 + Box-Muller), throughput mode only
 int philox_normal(float* dst, size_t n, uint64_t seed, uint64_t stream_id, const int* step_ptr, hipStream_t st);

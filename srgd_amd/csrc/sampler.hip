@@ -382,6 +382,29 @@ __global__ __launch_bounds__(256) void canvas_exchange_tiles_kernel(float* __res
   }
 }
 
+// unpack of an all-gathered buffer in ONE launch: row j of `gathered` ([world * pw][3][tile][tile]) is the i = j % pw -th tile of rank
+// r = j / pw 's part, i.e. tile r * w + off + i of the grid (ranks own slices of w tiles; a part is tiles [off, off + pw) of a slice);
+// rows past the end of the grid (short and empty slices) are skipped
+__global__ __launch_bounds__(256) void canvas_unpack_gathered_kernel(float* __restrict__ canvas, const float* __restrict__ gathered,
+                                                                     TileBatch tb, int w, int off, int pw, int n_grid) {
+  const int q4 = tb.tile / 4;
+  const long n = (long)tb.ntiles * 3 * tb.tile * q4;         // tb.ntiles = world * pw rows
+  const long plane = (long)tb.Hp * tb.Wp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int xq = (int)(i % q4);
+    long r = i / q4;
+    const int y = (int)(r % tb.tile);
+    r /= tb.tile;
+    const int c = (int)(r % 3), j = (int)(r / 3);
+    const int t = (j / pw) * w + off + (j % pw);
+    if (t >= n_grid) continue;
+    const int* tyx = tb.tile_yx + 3 * t;
+    float* cp = canvas + ((long)tyx[2] * 3 + c) * plane + (long)(tyx[0] + y) * tb.Wp + tyx[1] + xq * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(gathered + i * 4);
+    cp[0] = v[0]; cp[1] = v[1]; cp[2] = v[2]; cp[3] = v[3];
+  }
+}
+
 // ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
 __device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
   const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
@@ -530,6 +553,14 @@ int canvas_finish(const float* img, int planes, int Hp, int Wp, int left, int to
                   hipStream_t st) {
   hipLaunchKernelGGL(canvas_finish_kernel, dim3(grid_for((long)planes * H * W)), dim3(256), 0, st, img, planes, Hp, Wp,
                      left, top, H, W, out01);
+  SRGD_HIP(hipGetLastError());
+  return 0;
+}
+
+int canvas_unpack_gathered(float* canvas, const float* gathered, const TileBatch& tb, int w, int off, int pw, int n_grid, hipStream_t st) {
+  if (tb.tile % 4 != 0) SRGD_FAIL("canvas_unpack_gathered: tile edge must be a multiple of 4");
+  const long n = (long)tb.ntiles * 3 * tb.tile * (tb.tile / 4);
+  hipLaunchKernelGGL(canvas_unpack_gathered_kernel, dim3(grid_for(n)), dim3(256), 0, st, canvas, gathered, tb, w, off, pw, n_grid);
   SRGD_HIP(hipGetLastError());
   return 0;
 }

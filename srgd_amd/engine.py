@@ -144,6 +144,15 @@ class HipEngine:
                                                   float(guidance_scale), int(sub_batch), int(seed) & (2 ** 64 - 1),
                                                   _stream_ptr(self.device)), "srgd_sampler_step_tiles")
 
+    def sampler_unpack_gathered(self, parity: int, world: int, slice_w: int, part_off: int, part_w: int, canvas: torch.Tensor,
+                                gathered: torch.Tensor) -> None:
+        """One launch: rows of an all-gathered buffer [world * part_w, 3, T, T] back into the canvas (srgd_hip.h)."""
+        assert gathered.is_contiguous() and gathered.dtype == torch.float32 and gathered.shape[0] == world * part_w
+        with torch.cuda.device(self.device):
+            check(self._L.srgd_sampler_unpack_gathered(self._h, int(parity), int(world), int(slice_w), int(part_off), int(part_w),
+                                                       _dev_ptr(canvas), _dev_ptr(gathered), _stream_ptr(self.device)),
+                  "srgd_sampler_unpack_gathered")
+
     def sampler_exchange_tiles(self, parity: int, tile_first: int, tile_count: int, canvas: torch.Tensor,
                                tiles: torch.Tensor, to_canvas: bool) -> None:
         """Pack (canvas -> tiles) or unpack (tiles -> canvas) tiles [tile_first, tile_first+tile_count) of a grid."""

@@ -260,7 +260,10 @@ def _scatter_part(eng, shard: CanvasShard, step: int, n_tiles: int, w: int, off:
         if off == 0 and pw == w:                         # whole slices: the gathered buffer IS the grid in order - one launch
             eng.sampler_exchange_tiles(step & 1, 0, n_tiles, canvas, everyone, to_canvas=True)
             continue
-        for r in range(world):
+        if hasattr(eng, "sampler_unpack_gathered"):      # half-slices: still ONE launch (row -> tile mapping in the kernel)
+            eng.sampler_unpack_gathered(step & 1, world, w, off, pw, canvas, everyone)
+            continue
+        for r in range(world):                           # (engines without the strided unpack: one launch per rank)
             t0 = min(n_tiles, r * w + off)
             cnt = min(n_tiles, r * w + off + pw) - t0
             if cnt > 0:
