@@ -195,6 +195,46 @@ def test_two_step_lanes_are_bitwise_identical_to_one():
         edm.noise_source = "host"
 
 
+def test_f16x3_lanes_graphs_and_lockstep_are_bitwise_neutral_at_dim128():
+    # the split-operand kernels (persistent conv1x1_split, conv3x3_split with GroupNorm-in-staging, the RMSNorm / GroupNorm-tail
+    # epilogues) under everything the sampler does around them, at the production width: two concurrent step lanes (automatic for
+    # f16x3), hipGraph replay vs eager launches, two images in lock-step vs their solo runs - all bit-identical
+    import os
+    sampler = build_sampler(128)
+    conds = torch.cat([C.synthetic_lr_condition(i, 64, 64) for i in range(2)]).cuda()        # 256^2 images: one tile per step each
+    big = C.synthetic_lr_condition(0, 256, 256).cuda()                                       # configs[1] geometry: 25 / 16 tiles
+    label = torch.tensor([0]).cuda()
+    keep = sampler.step_lanes
+    try:
+        sampler.noise_source = "device"
+        sampler.device_noise_seed = 11
+        outs = []
+        for lanes in (1, 2, None):
+            sampler.step_lanes = lanes
+            outs.append(sampler.tiled_sample(batch_size=25, condition_x=big, class_label=label, num_sample_steps=5, precision="f16x3").cpu())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        sampler.step_lanes = None
+        for mode in ("0",):
+            os.environ["SRGD_GRAPHS"] = mode
+            sampler.model._invalidate_engines()
+            eager = sampler.tiled_sample(batch_size=25, condition_x=big, class_label=label, num_sample_steps=5, precision="f16x3").cpu()
+        assert torch.equal(eager, outs[0])
+        os.environ.pop("SRGD_GRAPHS", None)
+        sampler.model._invalidate_engines()
+        both = sampler.tiled_sample(batch_size=8, condition_x=conds, class_label=label, num_sample_steps=4, class_cond_scale=1.5,
+                                    precision="f16x3").cpu()
+        for i in range(2):
+            solo = sampler.tiled_sample(batch_size=8, condition_x=conds[i:i + 1], class_label=label, num_sample_steps=4,
+                                        class_cond_scale=1.5, precision="f16x3").cpu()
+            assert torch.equal(both[i:i + 1], solo), i
+        assert torch.isfinite(both).all()
+    finally:
+        os.environ.pop("SRGD_GRAPHS", None)
+        sampler.model._invalidate_engines()
+        sampler.step_lanes = keep
+        sampler.noise_source = "host"
+
+
 def test_device_noise_mode_full_size_properties():
     # BASELINE config-2 geometry (256^2 LR -> 1024^2, canvas 1280^2, 25/16 tiles), few steps:
     # size-independent properties - output range, determinism per seed, seed sensitivity.
@@ -496,8 +536,9 @@ def build_edm_sampler(dim, steps=32, weight_seed=0, fresh=False):
     return _EDM_MODELS.pop(key) if fresh else _EDM_MODELS[key]
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("case", C.EDM_CASES, ids=lambda c: c["name"])
-def test_edm_tiled_sample_fp32_matches_reference(case):
+def test_edm_tiled_sample_fp32_matches_reference(case, precision):
     z = np.load(os.path.join(G, f"sample_edm_{case['name']}.npz"))
     sampler = build_edm_sampler(case["dim"], weight_seed=case["weight_seed"])
     cond = C.sampler_condition(case).cuda()
@@ -509,12 +550,12 @@ def test_edm_tiled_sample_fp32_matches_reference(case):
         sampler.num_sample_steps = case.get("ctor_steps", case["steps"])
         got = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label,
                                    cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"],
-                                   num_sample_steps=case["steps"], precision="fp32", **C.edm_extra_kwargs(case)).cpu()
+                                   num_sample_steps=case["steps"], precision=precision, **C.edm_extra_kwargs(case)).cpu()
     finally:
         sampler.num_sample_steps = ctor_steps
     want = torch.from_numpy(z["image"])
     err = (got - want).abs().max().item()
-    _report(test="edm_tiled_sample", case=case["name"], precision="fp32", max_abs=err)
+    _report(test="edm_tiled_sample", case=case["name"], precision=precision, max_abs=err)
     assert got.shape == want.shape
     assert err <= 1e-3, err                 # north-star bar
     assert err <= 3e-4, err                 # regression guard
