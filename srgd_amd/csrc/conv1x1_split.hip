@@ -18,14 +18,25 @@
 //     16 different 128-byte lines per instruction: 2.3-3.4 TB/s on the 256x256 layers, profiles/r6/conv1x1_split_direct_loads.txt);
 //   * weights as srcA with the tile's rows stored in the order (tile row 16 J + 4 g + e <- channel 32 g + 4 J + e), so that a
 //     lane's 32 accumulators of a pixel are 32 CONSECUTIVE channels: the epilogue (x inverse weight scale, + bias, + residual or
-//     SiLU + PixelShuffle scatter) is register-direct, eight 16-byte stores per pixel block, 512 contiguous bytes per pixel;
-//   * LDS 144 KB: one workgroup per CU, two waves per SIMD.
+//     SiLU + PixelShuffle scatter) works on the accumulators directly; the finished values are transposed through a 2 KB per-wave
+//     LDS staging area so that every store instruction writes full 128-byte lines (the stores are what bounds this kernel);
+//   * LDS 160 KB (144 KB ring + 16 KB store staging): one workgroup per CU, two waves per SIMD - so the workgroup is PERSISTENT (grid = number of CUs) and walks its
+//     tiles with one continuous stage stream: the next tile's first two stages are in flight while this tile's stores drain
+//     (128 -> 128 @256x256: 3.8 -> 4.4 TB/s, profiles/r6/conv1x1_split_persistent.txt);
+//   * further epilogues fold whole passes of the f16x3 mode into this kernel: the GroupNorm2 + SiLU + residual tail of a ResnetBlock
+//     (SEPI_GNTAIL), RMSNorm(conv) * g + residual (SEPI_RMS_RESIDUAL) and RMSNorm of the INPUT (RMS_IN: gain folded into the weights).
 // Roofline: HBM (algorithmic bytes = input once per n-tile + output once + weights); K-heavy shapes at 32x32 / 64x64 are MFMA-bound
 // at a third of the f16 peak like the 3x3 kernel.
 #include <cmath>
 #include <cstdlib>
 
 #include "kernels.hpp"
+
+// Diagnostic builds (tools/build_variant.py only; results are wrong on purpose): -DSRGD_C1S_DIAG=1 issues no MFMAs (data movement only),
+// =2 no epilogue stores, =3 no pixel-row DMAs (weights + arithmetic + stores)
+#ifndef SRGD_C1S_DIAG
+#define SRGD_C1S_DIAG 0
+#endif
 
 namespace srgd {
 namespace {
@@ -36,7 +47,8 @@ constexpr int B_TILE = BN * KC * 2;            // 8 KiB: one 16-bit weight tile
 constexpr int B_SLOT = 2 * B_TILE;             // hi | lo
 constexpr int STAGE = A_BYTES + B_SLOT;        // 48 KiB
 constexpr int RING = 3;
-constexpr int LDS_BYTES = RING * STAGE;        // 147,456: one workgroup per CU
+constexpr int STG_BYTES = 2048;                // per-wave staging area of the store transposition (epilogue)
+constexpr int LDS_BYTES = RING * STAGE + (NT / 64) * STG_BYTES;   // 147,456 + 16,384 = 163,840: all of a CU's LDS, one workgroup per CU
 enum { SEPI_PLAIN = 0, SEPI_RESIDUAL = 1, SEPI_PS_SILU = 2, SEPI_RMS_RESIDUAL = 3, SEPI_GNTAIL = 4 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -167,8 +179,12 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
     char* sa = st + wave * 4096;
     // (per-lane offsets selected with v_cndmask, the descriptors by two branches: see conv1x1_bf16.hip)
     const int v0 = first ? a_b00 : a_b10, v1 = first ? a_b01 : a_b11, v2 = first ? a_b02 : a_b12, v3 = first ? a_b03 : a_b13;
+#if SRGD_C1S_DIAG == 3
+    dma(rsw, sa, tid16, i_w); dma(rsw, sa + 1024, tid16, i_w); dma(rsw, sa + 2048, tid16, i_w); dma(rsw, sa + 3072, tid16, i_w);   // (same request count, L2-resident source)
+#else
     if (first) { dma(rs0, sa, v0, soff); dma(rs0, sa + 1024, v1, soff); dma(rs0, sa + 2048, v2, soff); dma(rs0, sa + 3072, v3, soff); }
     else { dma(rs1, sa, v0, soff); dma(rs1, sa + 1024, v1, soff); dma(rs1, sa + 2048, v2, soff); dma(rs1, sa + 3072, v3, soff); }
+#endif
     dma(rsw, st + A_BYTES + wave * 1024, tid16, i_w);                       // hi tile: 8 waves x 1 KiB
     dma(rsw, st + A_BYTES + B_TILE + wave * 1024, tid16, i_w + B_TILE);     // lo tile
     i_w += (int)w_tile_stride;
@@ -204,7 +220,11 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
     return acc;
   };
   auto mma = [&](f32x4& c, const u32x4& wt, const u32x4& px) {
+#if SRGD_C1S_DIAG == 1
+    c[0] += __uint_as_float(wt[0] ^ px[0]);            // keeps the operand reads alive
+#else
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wt), __builtin_bit_cast(f16x8, px), c, 0, 0, 0);
+#endif
   };
   auto compute = [&]() __attribute__((always_inline)) {
     const char* st = smem + c_slot * STAGE;
@@ -322,27 +342,31 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
   if (EPI == SEPI_GNTAIL) {
     // out = conv(x) + silu(a[b][c] * h + b[b][c]): the second GroupNorm + SiLU of a ResnetBlock and its residual add folded into the
     // 1x1 res_conv (reference model.py:250-259, :283-285); h may alias out (a lane reads exactly the addresses it writes)
-    f32x4 r0_[8], r1_[8], a_[8], b_[8];
+    // (block 0's tail operand, then block 1's in the same registers: all of it ahead of the first store, which comes at the very end)
+    f32x4 r_[8], a_[8], b_[8];
     const float* ga = p.gn_a + (size_t)b * p.Cout + n0 + q16 * 32;
     const float* gb = p.gn_b + (size_t)b * p.Cout + n0 + q16 * 32;
 #pragma unroll
     for (int J = 0; J < 8; ++J) {
-      r0_[J] = *reinterpret_cast<const f32x4*>(p.aux + o0 + 4 * J);
-      r1_[J] = *reinterpret_cast<const f32x4*>(p.aux + o1 + 4 * J);
+      r_[J] = *reinterpret_cast<const f32x4*>(p.aux + o0 + 4 * J);
       a_[J] = *reinterpret_cast<const f32x4*>(ga + 4 * J);
       b_[J] = *reinterpret_cast<const f32x4*>(gb + 4 * J);
     }
-    asm volatile("" : "+v"(r0_[0]), "+v"(r0_[1]), "+v"(r0_[2]), "+v"(r0_[3]), "+v"(r0_[4]), "+v"(r0_[5]), "+v"(r0_[6]), "+v"(r0_[7]));
-    asm volatile("" : "+v"(r1_[0]), "+v"(r1_[1]), "+v"(r1_[2]), "+v"(r1_[3]), "+v"(r1_[4]), "+v"(r1_[5]), "+v"(r1_[6]), "+v"(r1_[7]));
+    asm volatile("" : "+v"(r_[0]), "+v"(r_[1]), "+v"(r_[2]), "+v"(r_[3]), "+v"(r_[4]), "+v"(r_[5]), "+v"(r_[6]), "+v"(r_[7]));
     asm volatile("" : "+v"(a_[0]), "+v"(a_[1]), "+v"(a_[2]), "+v"(a_[3]), "+v"(a_[4]), "+v"(a_[5]), "+v"(a_[6]), "+v"(a_[7]));
     asm volatile("" : "+v"(b_[0]), "+v"(b_[1]), "+v"(b_[2]), "+v"(b_[3]), "+v"(b_[4]), "+v"(b_[5]), "+v"(b_[6]), "+v"(b_[7]));
 #pragma unroll
     for (int J = 0; J < 8; ++J) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v0_[J][e] += silu<true>(__builtin_fmaf(a_[J][e], r0_[J][e], b_[J][e]));
-        v1_[J][e] += silu<true>(__builtin_fmaf(a_[J][e], r1_[J][e], b_[J][e]));
-      }
+      for (int e = 0; e < 4; ++e) v0_[J][e] += silu<true>(__builtin_fmaf(a_[J][e], r_[J][e], b_[J][e]));
+    }
+#pragma unroll
+    for (int J = 0; J < 8; ++J) r_[J] = *reinterpret_cast<const f32x4*>(p.aux + o1 + 4 * J);
+    asm volatile("" : "+v"(r_[0]), "+v"(r_[1]), "+v"(r_[2]), "+v"(r_[3]), "+v"(r_[4]), "+v"(r_[5]), "+v"(r_[6]), "+v"(r_[7]));
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v1_[J][e] += silu<true>(__builtin_fmaf(a_[J][e], r_[J][e], b_[J][e]));
     }
   }
   if (EPI == SEPI_RESIDUAL) {
@@ -364,10 +388,49 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
       for (int e = 0; e < 4; ++e) { v0_[J][e] = silu<true>(v0_[J][e]); v1_[J][e] = silu<true>(v1_[J][e]); }
     }
   }
+#if SRGD_C1S_DIAG == 2
+  if (v0_[0][0] == 123.456f && v1_[7][3] == 654.321f)           // (never true: the values stay live, nothing is stored)
+#endif
+  {
+    // Stores go through a 2 KB per-wave LDS staging area so that every store instruction writes FULL 128-byte lines.  Straight from
+    // the accumulators a lane owns one 128-byte segment (32 channels of one pixel) and needs eight 16-byte stores for it: every
+    // instruction touches 64 different lines, 16 bytes each - and the stores, not the loads or the MFMAs, were what bounded this
+    // kernel (diagnostic builds, profiles/r6/conv1x1_split_phase_diagnostics.txt: 128 -> 128 @256x256 0.390 ms, without the stores
+    // 0.206 ms, without the MFMAs 0.362 ms, without the pixel-row DMAs 0.353 ms).  Per pixel block, in four rounds: the 16 lanes
+    // holding channel quarter g' write their 16 pixels x 128 B into the staging area, all 64 lanes read it back 16 bytes at a time
+    // in memory order (8 lanes per pixel line) and store.  Wave-private: LDS executes a wave's instructions in order, no barrier.
+    char* const stg = smem + RING * STAGE + wave * STG_BYTES;
+    const int l8 = lane >> 3, c8 = lane & 7;                      // read-back: pixel row l8 (+ 8 for the second half), 16-byte chunk c8
+    auto pixel_out = [&](int mi, int row) -> size_t {             // element offset of channel n0 of pixel `row` of block mi
+      const int op = p0 + wave * 32 + mi * 16 + row;
+      if (EPI == SEPI_PS_SILU) {
+        const int CoutPS = p.Cout >> 2, ij = n0 / CoutPS, ch0 = n0 - ij * CoutPS;
+        const int oy = op / p.Wout, ox = op - oy * p.Wout;
+        return ((size_t)(b * 2 * p.Hout + 2 * oy + (ij >> 1)) * (2 * p.Wout) + 2 * ox + (ij & 1)) * CoutPS + ch0;
+      }
+      return ((size_t)b * HWo + op) * p.Cout + n0;
+    };
+    const size_t pa0 = pixel_out(0, l8), pa1 = pixel_out(0, l8 + 8), pb0 = pixel_out(1, l8), pb1 = pixel_out(1, l8 + 8);
 #pragma unroll
-  for (int J = 0; J < 8; ++J) *reinterpret_cast<f32x4*>(p.out + o0 + 4 * J) = v0_[J];
+    for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-  for (int J = 0; J < 8; ++J) *reinterpret_cast<f32x4*>(p.out + o1 + 4 * J) = v1_[J];
+      for (int gq = 0; gq < 4; ++gq) {
+        if (q16 == gq) {
+#pragma unroll
+          for (int J = 0; J < 8; ++J) *reinterpret_cast<f32x4*>(stg + r16 * 128 + J * 16) = mi == 0 ? v0_[J] : v1_[J];
+        }
+        // compiler-level fence: to the optimiser a lane that skipped the branch has not written the staging area, so it may reuse
+        // the previous round's read-back (it did: the reads were sunk INTO the branch and three quarters of the channels came out
+        // stale - caught by the kernel tests).  The hardware needs nothing here: LDS executes a wave's instructions in order.
+        asm volatile("" ::: "memory");
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(stg + lane * 16);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(stg + 1024 + lane * 16);
+        asm volatile("" ::: "memory");
+        *reinterpret_cast<f32x4*>(p.out + (mi == 0 ? pa0 : pb0) + gq * 32 + c8 * 4) = w0;
+        *reinterpret_cast<f32x4*>(p.out + (mi == 0 ? pa1 : pb1) + gq * 32 + c8 * 4) = w1;
+      }
+    }
+  }
   }   // tiles of this workgroup
 }
 
