@@ -19,10 +19,12 @@
 //   * the MFMAs take the WEIGHT fragment as their A operand and the PIXEL fragment as B (both fragments have the same register
 //     image, so the K loop does not change): D then holds, per lane, four consecutive weight rows of ONE pixel.  The host
 //     packs the weight rows of a tile in the order that makes a lane's sixteen values of a 16-pixel block sixteen consecutive
-//     output channels (common.hpp, regepi_row_channel) - the epilogue is register-direct: + bias, bf16 pack, two 16-byte stores
-//     per block straight from the accumulators, GroupNorm partial sums (reference Block.norm, model.py:250-259) by in-lane adds
-//     + a DPP row reduction (+ permlane swaps across rows), one slot per wave.  No LDS traffic, no barrier: the phase no longer competes with the co-resident workgroup's
-//     K loop for the LDS pipe (round 4's LDS transposition was 23 % of a 128 -> 128 @256^2 tile for that reason).
+//     output channels (common.hpp, regepi_row_channel) - the epilogue is register-direct: + bias, bf16 pack, GroupNorm partial sums
+//     (reference Block.norm, model.py:250-259) by in-lane adds + a DPP row reduction (+ permlane swaps across rows), one slot per
+//     wave, no barrier (round 4's workgroup-wide LDS transposition was 23 % of a 128 -> 128 @256^2 tile).  The packed values take
+//     one wave-private hop through the idle halo-patch buffer (2 ds_write_b128 + 2 ds_read_b128 per block) so that every store
+//     instruction writes 8 full 128-byte lines instead of 64 scattered 16-byte pieces: +0.9 % on the benchmark, same box
+//     (profiles/r6/conv3x3_full_line_stores_ab.txt).
 //   * blockIdx is remapped so each XCD (private L2) gets a contiguous band of tiles (halo reuse in L2).
 //   * GNIN instances (template parameter): the PRODUCER's GroupNorm-apply + SiLU is applied to a chunk's halo patch in LDS right
 //     after it lands (reference Block.forward model.py:250-259 between two convolutions), which removes a full HBM pass; these
@@ -52,6 +54,10 @@ constexpr int B_BYTES = BN3 * KC * 2;          // 8 KiB
 constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 73,728: two workgroups per CU
 constexpr int COEF_BYTES = 2 * 256;            // GNIN: 32 scales | 32 shifts (fp32) per channel chunk, double-buffered
 constexpr bool STAMPS = SRGD_CONV3_STAMPS != 0;
+#ifndef SRGD_CONV3_DIRECT_STORES           // A/B builds: 1 = the 16-byte stores straight from the accumulators (round 5)
+#define SRGD_CONV3_DIRECT_STORES 0
+#endif
+static_assert(8 * 16 * 144 <= A_BYTES, "store staging fits the idle A buffer");
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // Accumulator block (mi, J), register e of lane (r16, g) = pixel (patch row 2 wm + (mi >> 1), x = 16 (mi & 1) + r16), tile row
   // 64 wn + 16 J + 4 g + e = output channel 64 wn + 16 g + 4 J + e (the host's row order, common.hpp: regepi_row_channel): the
   // sixteen registers of a pixel block are 16 consecutive channels - two 16-byte stores, the four lanes of a pixel fill 128
-  // contiguous bytes.  No LDS and no barrier: every wave leaves on its own.
+  // contiguous bytes.  No barrier: every wave leaves on its own (the staging rows below are wave-private).
   if constexpr (GNIN) {
     // asm MFMAs: the compiler does not know the accumulators were written by the matrix pipe and inserts no wait states ahead of
     // their first VALU read (up to 18 for a 16x16 result)
@@ -407,6 +413,15 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
   // output descriptor: base of the wave's first pixel / channel, two patch rows in range
   const u32x4 rso = make_raw_rsrc(p.out + ((size_t)(b * p.H + y0 + 2 * wm) * p.W + x0) * p.Cout + chw, (unsigned)(2 * p.W * p.Cout * 2));
   const int o_voff = (r16E * p.Cout + chl) * 2;
+  // Stores leave as FULL 128-byte lines (the wave's 64 channels of a pixel): each 16-pixel block goes through 16 staging rows of the
+  // wave (144-byte pitch) in the A buffer the last chunk does NOT use - every wave is past the barriers that followed its last read,
+  // so no barrier here; LDS executes a wave's instructions in order, the fences are for the optimiser (conv1x1_split.hip).  Straight
+  // from the accumulators a store instruction writes 64 scattered 16-byte pieces (conv3x3_mxfp8.hip: +1-4 % on the mid-size layers).
+  constexpr int STG_ROW = 144;
+  char* const stg = smem + (CC & 1) * A_BYTES + wave * (16 * STG_ROW);
+  const int stg_w = r16E * STG_ROW + q16E * 32;
+  const int stg_r = (laneE >> 3) * STG_ROW + (laneE & 7) * 16;
+  const int line_off = (laneE >> 3) * p.Cout * 2 + (laneE & 7) * 16;
   f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = s1v;            // GroupNorm sums, per register position
   // all four bias vectors are waited for here: behind the first asm store the compiler (which cannot count it) would wait with
   // vmcnt(0) for the remaining ones - and so for that store's completion
@@ -422,8 +437,21 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
       s2v = __builtin_elementwise_fma(v2, v2, s2v);                                                \
       s2v = __builtin_elementwise_fma(v3, v3, s2v);                                                \
     }                                                                                              \
-    buffer_store16(u32x4{pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])}, rso, o_voff, so_); \
-    buffer_store16(u32x4{pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]), pack_bf16x2(v3[0], v3[1]), pack_bf16x2(v3[2], v3[3])}, rso, o_voff, so_ + 16); \
+    const u32x4 lo_ = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])}; \
+    const u32x4 hi_ = {pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]), pack_bf16x2(v3[0], v3[1]), pack_bf16x2(v3[2], v3[3])}; \
+    if (SRGD_CONV3_DIRECT_STORES) {                                                                \
+      buffer_store16(lo_, rso, o_voff, so_);                                                       \
+      buffer_store16(hi_, rso, o_voff, so_ + 16);                                                  \
+    } else {                                                                                       \
+      *reinterpret_cast<u32x4*>(stg + stg_w) = lo_;                                                \
+      *reinterpret_cast<u32x4*>(stg + stg_w + 16) = hi_;                                           \
+      asm volatile("" ::: "memory");                                                               \
+      const u32x4 w0_ = *reinterpret_cast<const u32x4*>(stg + stg_r);                              \
+      const u32x4 w1_ = *reinterpret_cast<const u32x4*>(stg + stg_r + 8 * STG_ROW);                \
+      asm volatile("" ::: "memory");                                                               \
+      buffer_store16(w0_, rso, line_off, so_);                                                     \
+      buffer_store16(w1_, rso, line_off, so_ + 8 * p.Cout * 2);                                    \
+    }                                                                                              \
   } while (0)
   K_EMIT(0, c00, c01, c02, c03);
   K_EMIT(1, c10, c11, c12, c13);
