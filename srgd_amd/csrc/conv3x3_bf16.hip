@@ -58,6 +58,9 @@ constexpr bool STAMPS = SRGD_CONV3_STAMPS != 0;
 #define SRGD_CONV3_DIRECT_STORES 0
 #endif
 static_assert(8 * 16 * 144 <= A_BYTES, "store staging fits the idle A buffer");
+#ifndef SRGD_CONV3_DIAG_LDS_PAD            // pricing builds: extra dynamic LDS per workgroup (16 KiB -> ONE workgroup per CU)
+#define SRGD_CONV3_DIAG_LDS_PAD 0
+#endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -558,14 +561,14 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   if (DeviceSetup once(attr_set); once.need) {
 #define K_SET(S_, G_)                                                                                  \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_>),               \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (G_ ? COEF_BYTES : 0)));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (G_ ? COEF_BYTES : 0) + SRGD_CONV3_DIAG_LDS_PAD));
     K_SET(true, false) K_SET(false, false) K_SET(true, true) K_SET(false, true)
 #undef K_SET
     once.done();
   }
   const bool stats = a.gn_partial != nullptr;
 #define K_GO(S_, G_) \
-  hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_>), dim3(grid), dim3(NT3), LDS_BYTES + (G_ ? COEF_BYTES : 0), st, p)
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_>), dim3(grid), dim3(NT3), LDS_BYTES + (G_ ? COEF_BYTES : 0) + SRGD_CONV3_DIAG_LDS_PAD, st, p)
   if (stats && gnin) K_GO(true, true); else if (stats) K_GO(true, false);
   else if (gnin) K_GO(false, true); else K_GO(false, false);
 #undef K_GO

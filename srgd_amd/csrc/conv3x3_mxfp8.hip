@@ -54,6 +54,9 @@ namespace {
 #ifndef SRGD_MXFP8_DIAG
 #define SRGD_MXFP8_DIAG 0
 #endif
+#ifndef SRGD_MXFP8_DIAG_LDS_PAD             // pricing builds: extra dynamic LDS per workgroup (16 KiB -> ONE workgroup per CU)
+#define SRGD_MXFP8_DIAG_LDS_PAD 0
+#endif
 #ifndef SRGD_MXFP8_DIRECT_STORES          // A/B builds: 1 = the 16-byte stores straight from the accumulators (rounds 4-5)
 #define SRGD_MXFP8_DIRECT_STORES 0
 #endif
@@ -598,12 +601,12 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   if (a.bias && ((size_t)a.bias & 15)) SRGD_FAIL("conv3x3_mxfp8: the bias array must be 16-byte aligned");
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
-    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS + SRGD_MXFP8_DIAG_LDS_PAD));
+    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS + SRGD_MXFP8_DIAG_LDS_PAD));
     once.done();
   }
-  if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true>), dim3(grid), dim3(NW * 64), QLDS, st, p);
-  else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false>), dim3(grid), dim3(NW * 64), QLDS, st, p);
+  if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true>), dim3(grid), dim3(NW * 64), QLDS + SRGD_MXFP8_DIAG_LDS_PAD, st, p);
+  else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false>), dim3(grid), dim3(NW * 64), QLDS + SRGD_MXFP8_DIAG_LDS_PAD, st, p);
   SRGD_HIP(hipGetLastError());
 #if SRGD_MXFP8_STAMPS
   {                                                     // stamp build: synchronous, prints the phase means and the slot timeline

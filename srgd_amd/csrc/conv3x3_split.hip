@@ -18,7 +18,8 @@
 //     epilogue multiplies the accumulators by the inverse (exact);
 //   * LDS: 2 x (24 + 24) KB of A + 3 x 16 KB of B = 144 KB - one 512-thread workgroup per CU, two waves per SIMD, up to 256
 //     VGPRs per wave (64 accumulators + 64 operand-fragment registers + 24 staging registers);
-//   * epilogue: + bias, fp32 stores (four 16-byte stores per 16-pixel block straight from the accumulators), GroupNorm partial sums
+//   * epilogue: + bias, fp32 stores (per 16-pixel block one wave-private hop through the idle A buffer, then four stores of four whole
+//     256-byte pixel rows each: +1.8 % on an f16x3 step against 16-byte stores straight from the accumulators), GroupNorm partial sums
 //     in the bf16 kernel's slot layout (conv3x3_bf16_stats_slots applies).
 // Roofline: MFMA.  3 x (2 * 9 * Cin * Cout) FLOP of 16-bit MFMA work per output pixel; counted as ALGORITHMIC flops (one product
 // per multiply-add) the ceiling is 2.5 PF / 3 = 833 TFLOP/s.
@@ -41,6 +42,9 @@ constexpr int A_BUF = 2 * A_IMG;               // hi | lo
 constexpr int B_TILE = BN3 * KC * 2;           // 8 KiB: one 16-bit weight tile
 constexpr int B_SLOT = 2 * B_TILE;             // hi | lo
 constexpr int LDS_BYTES = 2 * A_BUF + 3 * B_SLOT;   // 147,456: one workgroup per CU
+#ifndef SRGD_CONV3S_DIRECT_STORES          // A/B builds: 1 = four 16-byte stores per block straight from the accumulators
+#define SRGD_CONV3S_DIRECT_STORES 0
+#endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -316,6 +320,15 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_split_kernel(Split3Args p) {
   }
   const u32x4 rso = make_raw_rsrc(p.out + ((size_t)(b * p.H + y0 + 2 * wm) * p.W + x0) * p.Cout + chw, (unsigned)(2 * p.W * p.Cout * 4));
   const int o_voff = (r16 * p.Cout + chl) * 4;
+  // Stores leave as full lines (the wave's 64 fp32 channels of a pixel = 256 bytes): each 16-pixel block goes through 16 staging rows
+  // of the wave (272-byte pitch) in the A buffer the last chunk does not use, and every store instruction then writes four whole
+  // pixel rows instead of 64 scattered 16-byte pieces (conv3x3_bf16.hip; wave-private, no barrier, compiler fences only).
+  constexpr int STG_ROW = 272;
+  static_assert(8 * 16 * STG_ROW <= A_BUF, "store staging fits the idle A buffer");
+  char* const stg = smem + (CC & 1) * A_BUF + wave * (16 * STG_ROW);
+  const int stg_w = r16 * STG_ROW + q16 * 64;
+  const int stg_r = (lane >> 4) * STG_ROW + (lane & 15) * 16;       // read-back: pixel lane >> 4 (+ 4, 8, 12), 16-byte piece lane & 15
+  const int line_off = (lane >> 4) * p.Cout * 4 + (lane & 15) * 16;
   const float ws = p.w_inv_scale;
   f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = s1v;
   asm volatile("" : "+v"(bs0), "+v"(bs1), "+v"(bs2), "+v"(bs3));
@@ -330,10 +343,27 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_split_kernel(Split3Args p) {
       s2v = __builtin_elementwise_fma(v2, v2, s2v);                                                \
       s2v = __builtin_elementwise_fma(v3, v3, s2v);                                                \
     }                                                                                              \
-    buffer_store16(__builtin_bit_cast(u32x4, v0), rso, o_voff, so_);                               \
-    buffer_store16(__builtin_bit_cast(u32x4, v1), rso, o_voff, so_ + 16);                          \
-    buffer_store16(__builtin_bit_cast(u32x4, v2), rso, o_voff, so_ + 32);                          \
-    buffer_store16(__builtin_bit_cast(u32x4, v3), rso, o_voff, so_ + 48);                          \
+    if (SRGD_CONV3S_DIRECT_STORES) {                                                               \
+      buffer_store16(__builtin_bit_cast(u32x4, v0), rso, o_voff, so_);                             \
+      buffer_store16(__builtin_bit_cast(u32x4, v1), rso, o_voff, so_ + 16);                        \
+      buffer_store16(__builtin_bit_cast(u32x4, v2), rso, o_voff, so_ + 32);                        \
+      buffer_store16(__builtin_bit_cast(u32x4, v3), rso, o_voff, so_ + 48);                        \
+    } else {                                                                                       \
+      *reinterpret_cast<f32x4*>(stg + stg_w) = v0;                                                 \
+      *reinterpret_cast<f32x4*>(stg + stg_w + 16) = v1;                                            \
+      *reinterpret_cast<f32x4*>(stg + stg_w + 32) = v2;                                            \
+      *reinterpret_cast<f32x4*>(stg + stg_w + 48) = v3;                                            \
+      asm volatile("" ::: "memory");                                                               \
+      const u32x4 w0_ = *reinterpret_cast<const u32x4*>(stg + stg_r);                              \
+      const u32x4 w1_ = *reinterpret_cast<const u32x4*>(stg + stg_r + 4 * STG_ROW);                \
+      const u32x4 w2_ = *reinterpret_cast<const u32x4*>(stg + stg_r + 8 * STG_ROW);                \
+      const u32x4 w3_ = *reinterpret_cast<const u32x4*>(stg + stg_r + 12 * STG_ROW);               \
+      asm volatile("" ::: "memory");                                                               \
+      buffer_store16(w0_, rso, line_off, so_);                                                     \
+      buffer_store16(w1_, rso, line_off, so_ + 4 * p.Cout * 4);                                    \
+      buffer_store16(w2_, rso, line_off, so_ + 8 * p.Cout * 4);                                    \
+      buffer_store16(w3_, rso, line_off, so_ + 12 * p.Cout * 4);                                   \
+    }                                                                                              \
   } while (0)
   K_EMIT(0, c00, c01, c02, c03);
   K_EMIT(1, c10, c11, c12, c13);
