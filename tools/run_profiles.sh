@@ -11,6 +11,8 @@ for MODE in $MODES; do
   EXTRA=""; [ $MODE != bf16 ] && EXTRA="--precision $MODE --ddpm_steps 100 --class_cond_scale 2.0"
   [ $MODE = f16x3 ] && EXTRA="--precision f16x3"       # the parity mode at the headline configuration (50 steps, CFG 1.0)
   STEPS=5; [ $MODE = fp8 ] && STEPS=5
+  # the bench line of THIS box and lane setting (HIP-event time per launch of the dominant kernel: must agree with the rocprof average below)
+  python3 $R/bench.py --no_cpu_baseline $EXTRA > $O/bench_${MODE}_same_box.json 2>$O/bench_${MODE}_same_box.err
   rocprofv3 --kernel-trace --stats -d $O/kt_$MODE -o k -- python3 $R/bench.py --steps $STEPS --warmup 0 --no_cpu_baseline --no_profile $EXTRA > $O/kt_$MODE.log 2>&1
   python3 $R/tools/rocprof_db_stats.py $(find $O/kt_$MODE -name "*.db" | head -1) $O/${MODE}_kernel_stats.csv > $O/${MODE}_kernel_stats.txt
   rm -rf $O/kt_$MODE
