@@ -1,4 +1,5 @@
 #!/bin/bash
+[ -n "$GRAFT_REPO_ROOT" ] || { echo "archived GPU-box script (see README.md next to it)"; exit 2; }
 # conv3x3_mxfp8: full-line stores through LDS (shipped) against the direct 16-byte stores (variant mxdirect), same box
 set -e
 out=gpurun_out/mxs; mkdir -p $out

@@ -1,4 +1,5 @@
 #!/bin/bash
+[ -n "$GRAFT_REPO_ROOT" ] || { echo "archived GPU-box script (see README.md next to it)"; exit 2; }
 # Prices a persistent form of conv3x3_mxfp8 before building it (GPU box): diagnostic variants of the shipped kernel
 # (tools/build_variant.py mxdN -DSRGD_MXFP8_DIAG=N; 1 = the prologue does not wait for the halo patch, 2 = no epilogue stores, 3 = both)
 set -e

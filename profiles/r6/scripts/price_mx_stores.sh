@@ -1,4 +1,5 @@
 #!/bin/bash
+[ -n "$GRAFT_REPO_ROOT" ] || { echo "archived GPU-box script (see README.md next to it)"; exit 2; }
 # conv3x3_mxfp8: what do the epilogue's stores cost, and is it the requests or the HBM write stream?  (diagnostic variants, GPU box)
 set -e
 out=gpurun_out/mxw; mkdir -p $out

@@ -1,4 +1,5 @@
 #!/bin/bash
+[ -n "$GRAFT_REPO_ROOT" ] || { echo "archived GPU-box script (see README.md next to it)"; exit 2; }
 # 3x3 kernels with ONE workgroup per CU (LDS padded) against the shipped two: can one workgroup alone feed the matrix pipe?
 set -e
 out=gpurun_out/onewg; mkdir -p $out
