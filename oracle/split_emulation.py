@@ -47,3 +47,30 @@ def split_conv2d(x, w, b=None, stride=1, padding=0, kind="f16", terms=3, scale=T
     if b is not None:
         y = y + b.view(1, -1, 1, 1)
     return y
+
+
+def mixed_split_conv2d(x, w, b=None, stride=1, padding=0, mode="f16x2_w1"):
+    """Cheaper relatives of f16x3, for pricing only (no kernel computes these):
+    f16x2_w1  x = x_hi + x_lo, w rounded to ONE f16 value:   conv(x_hi, w_hi) + conv(x_lo, w_hi)                       (2 MFMAs)
+    f16x2_x1  x rounded to ONE f16 value, w = w_hi + w_lo:   conv(x_hi, w_hi) + conv(x_hi, w_lo)                       (2 MFMAs)
+    f16mx2    f16x3 with the two cross terms on MX-fp8 operands (e4m3 + E8M0 per 32 channels; the scaled MFMA runs at twice the
+              f16 rate, so the three products cost two): conv(x_hi, w_hi) + conv(Q(x_lo), Q(w_hi)) + conv(Q(x_hi), Q(w_lo))"""
+    from oracle import mxfp8
+    s = weight_scale(w, "f16")
+    wh, wl = halves(w * s, "f16")
+    xh, xl = halves(x, "f16")
+    y = F.conv2d(xh, wh, None, stride=stride, padding=padding)
+    if mode == "f16x2_w1":
+        y = y + F.conv2d(xl, wh, None, stride=stride, padding=padding)
+    elif mode == "f16x2_x1":
+        y = y + F.conv2d(xh, wl, None, stride=stride, padding=padding)
+    elif mode == "f16mx2":
+        qa = lambda t: mxfp8.quantize(t.permute(0, 2, 3, 1).contiguous())[2].permute(0, 3, 1, 2).contiguous()
+        y = y + F.conv2d(qa(xl), mxfp8.quantize_conv_weight(wh), None, stride=stride, padding=padding) \
+              + F.conv2d(qa(xh), mxfp8.quantize_conv_weight(wl), None, stride=stride, padding=padding)
+    else:
+        raise ValueError(mode)
+    y = y * (1.0 / s)
+    if b is not None:
+        y = y + b.view(1, -1, 1, 1)
+    return y

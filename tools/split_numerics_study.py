@@ -16,6 +16,7 @@ operands reproduce what three MFMAs accumulate up to summation order.  Variants:
              subnormal range (undone exactly after the accumulation)
     f16x3ns  f16 halves, no weight scaling (what the subnormal range costs)
     bf16     plain bf16 operands (one MFMA): the throughput mode's convolution arithmetic, for scale
+    f16x2_w1 / f16x2_x1 / f16mx2   cheaper relatives of f16x3 (two MFMAs' worth of matrix work; oracle/split_emulation.py), for pricing
 The report is the final-pixel max-abs / PSNR against the REFERENCE's fixture (tests/golden), next to the plain fp32 oracle's.
 """
 from __future__ import annotations
@@ -36,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import srgd_oracle as O                 # noqa: E402
 from srgd_amd.synth import synth_state_dict         # noqa: E402
-from oracle.split_emulation import split_conv2d    # noqa: E402
+from oracle.split_emulation import mixed_split_conv2d, split_conv2d    # noqa: E402
 from tests.golden import cases as C                 # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
@@ -50,6 +51,8 @@ def make_conv(variant):
         if variant == "bf16":
             y = TF.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), None, stride=stride, padding=padding)
             return y if b is None else y + b.view(1, -1, 1, 1)
+        if variant in ("f16x2_w1", "f16x2_x1", "f16mx2"):        # cheaper relatives of f16x3 (pricing only, no kernel)
+            return mixed_split_conv2d(x, w, b, stride=stride, padding=padding, mode=variant)
         kind = "bf16" if variant.startswith("bf16") else "f16"
         return split_conv2d(x, w, b, stride=stride, padding=padding, kind=kind, terms=4 if variant.endswith("x4") else 3,
                             scale=variant != "f16x3ns")
