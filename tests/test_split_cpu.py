@@ -72,3 +72,19 @@ def test_full_length_config2_fixture_is_intact():
     assert z["xt_abs"][0] > z["xt_abs"][-1] and abs(z["x0_abs"][-1] - z["x0_abs"][-2]) / z["x0_abs"][-1] < 1e-2
     cond = C.sampler_condition(case)
     assert abs(cond.double().sum().item() - float(z["cond_sum"])) < 1e-6             # the seeded input is reproducible here
+
+
+def test_cheaper_relatives_of_f16x3_rank_as_the_design_note_says():
+    # dropping a cross term costs 2^-12 of a product, cross terms on MX-fp8 operands 2^-15, all three on f16 2^-22
+    from oracle.split_emulation import mixed_split_conv2d
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 12, 12, generator=g)
+    w = torch.randn(32, 64, 3, 3, generator=g) / 24.0
+    want = F.conv2d(x.double(), w.double(), padding=1)
+    scale = float(want.abs().max())
+    err = lambda y: float((y.double() - want).abs().max()) / scale
+    e3 = err(split_conv2d(x, w, padding=1, kind="f16"))
+    emx = err(mixed_split_conv2d(x, w, padding=1, mode="f16mx2"))
+    ew1 = err(mixed_split_conv2d(x, w, padding=1, mode="f16x2_w1"))
+    ex1 = err(mixed_split_conv2d(x, w, padding=1, mode="f16x2_x1"))
+    assert e3 < 2e-6 and e3 < emx / 8 and emx < min(ew1, ex1) / 4 and max(ew1, ex1) < 2e-3, (e3, emx, ew1, ex1)
