@@ -33,7 +33,7 @@
 #include "kernels.hpp"
 
 // Diagnostic builds (tools/build_variant.py only; results are wrong on purpose): -DSRGD_C1S_DIAG=1 issues no MFMAs (data movement only),
-// =2 no epilogue stores, =3 no pixel-row DMAs (weights + arithmetic + stores)
+// =2 no epilogue stores, =3 no pixel-row DMAs (weights + arithmetic + stores), =4 no bias loads at the head of the epilogue
 #ifndef SRGD_C1S_DIAG
 #define SRGD_C1S_DIAG 0
 #endif
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
   // all bias vectors (and, per pixel block, all residual vectors) are loaded AHEAD of the first store: stores count in vmcnt too, so
   // a load issued behind a store would be waited for together with that store's completion
   f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0, bs2 = bs0, bs3 = bs0, bs4 = bs0, bs5 = bs0, bs6 = bs0, bs7 = bs0;
-  if (p.bias) {
+  if (p.bias && SRGD_C1S_DIAG != 4) {
     const float* bp = p.bias + n0 + q16 * 32;
     bs0 = *reinterpret_cast<const f32x4*>(bp); bs1 = *reinterpret_cast<const f32x4*>(bp + 4);
     bs2 = *reinterpret_cast<const f32x4*>(bp + 8); bs3 = *reinterpret_cast<const f32x4*>(bp + 12);
