@@ -53,6 +53,11 @@ typedef struct srgd_engine srgd_engine;
                                 * per layer: 2^-22 per product instead of fp32's 2^-24 (plain bf16: 2^-9).  Meets the 1e-3 parity
                                 * bar like SRGD_PRECISION_FP32 at three 16-bit MFMAs per product instead of the 1/16-rate fp32
                                 * MFMA.  Layers whose input channels are not a multiple of 32 stay on the exact-fp32 kernel. */
+#define SRGD_PRECISION_F16MX2 6 /* PROTOTYPE: SRGD_PRECISION_F16X3 with the 3x3 convolutions' two cross terms (x_lo.w_hi, x_hi.w_lo) on MX-fp8
+                                 * operands - v_mfma_scale_f32_16x16x128_f8f6f4, two taps per instruction - next to the exact f16
+                                 * leading term (conv3x3_mx2.hip): two MFMAs' worth of matrix work per product instead of three,
+                                 * ~2^-15 of a product instead of 2^-22 (1.3e-4 on the reference's configs[0] fixture in CPU emulation;
+                                 * bar 1e-3).  Everything else as SRGD_PRECISION_F16X3 (no GroupNorm-in-staging for these layers). */
 
 /* Constructor arguments of ConditionalSRUnet (model.py:537-556) as get_model passes them
  * (model.py:3504-3514).  Unsupported combinations are rejected by srgd_create. */

@@ -59,6 +59,8 @@ def mixed_split_conv2d(x, w, b=None, stride=1, padding=0, mode="f16x2_w1"):
     s = weight_scale(w, "f16")
     wh, wl = halves(w * s, "f16")
     xh, xl = halves(x, "f16")
+    if mode == "f16mx2":
+        xl = x.clamp(-65504.0, 65504.0) - xh     # the prototype kernel (conv3x3_mx2.hip) quantises x - x_hi itself, not its f16 rounding
     y = F.conv2d(xh, wh, None, stride=stride, padding=padding)
     if mode == "f16x2_w1":
         y = y + F.conv2d(xl, wh, None, stride=stride, padding=padding)

@@ -17,6 +17,7 @@ PRECISION_BF16 = 1
 PRECISION_BF16_W8 = 2    # bf16 kernels, conv weights rounded through fp8 e4m3 (per-output-channel scale)
 PRECISION_FP8 = 3        # 3x3 convolutions on the block-scaled MX-fp8 matrix cores (e4m3 + E8M0 per 32 channels), rest bf16
 PRECISION_F16X3 = 5      # fp32 tensors, convolutions as three f16 MFMAs per product on (hi, lo) operand pairs: <= 1e-3 parity like fp32
+PRECISION_F16MX2 = 6     # prototype: F16X3 with the 3x3 convolutions' cross terms on MX-fp8 operands (conv3x3_mx2.hip)
 PRECISION_FP8_MIXED = 4  # the same below the top resolution; the 256x256-resolution zones keep bf16 3x3 convolutions
 
 

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrgd_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
-SOURCES = ["conv_igemm.hip", "conv3x3_bf16.hip", "conv3x3_split.hip", "conv1x1_split.hip", "conv1x1_bf16.hip", "conv3x3_mxfp8.hip", "conv1x1_mxfp8.hip", "quant_mxfp8.hip", "norm_act.hip", "attention.hip", "linattn_fused.hip", "linattn_fused256.hip", "cond.hip", "sampler.hip", "imageio.hip", "engine.hip", "kernel_api.hip"]
+SOURCES = ["conv_igemm.hip", "conv3x3_bf16.hip", "conv3x3_split.hip", "conv3x3_mx2.hip", "conv1x1_split.hip", "conv1x1_bf16.hip", "conv3x3_mxfp8.hip", "conv1x1_mxfp8.hip", "quant_mxfp8.hip", "norm_act.hip", "attention.hip", "linattn_fused.hip", "linattn_fused256.hip", "cond.hip", "sampler.hip", "imageio.hip", "engine.hip", "kernel_api.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value",
          "-fno-gpu-rdc", "-DNDEBUG", "-fvisibility=hidden"]
 

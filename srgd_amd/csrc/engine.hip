@@ -115,6 +115,7 @@ struct ConvW {
   void* wq = nullptr;         // conv3x3_mxfp8 packing (fp8 mode: e4m3 weights + E8M0 block scales)
   void* wq1 = nullptr;        // conv1x1_mxfp8 packing (fp8 mode: the pointwise layers whose inputs have MX-fp8 twins)
   void* ws3 = nullptr;        // conv3x3_split packing (f16x3 mode: (hi, lo) f16 tiles of the scaled weights)
+  void* wm3 = nullptr;        // conv3x3_mx2 packing (f16mx2 prototype mode: f16 hi tile + MX-e4m3 planes of w_hi and w_lo)
   void* ws = nullptr;         // conv_igemm_split packing (f16x3 mode: every other layer with Cin % 32 == 0)
   void* ws1 = nullptr;        // conv1x1_split packing (f16x3 mode: 1x1 / pixel-shuffle / space-to-depth layers with Cout % 128 == 0)
   float ws_inv = 1.f;         // 1 / the layer's power-of-two weight scale (f16x3 mode)
@@ -263,6 +264,7 @@ struct srgd_engine {
   // 1.2931 HR tiles/s, and with gn_apply's hoisted coefficient loads 1.3657 / 1.3677 and 1.3660 / 1.3676 on a faster box: two
   // tiles is ahead by 0.1 % and takes the GroupNorm share from 6.0 to 5.0 % (one HBM pass less over every 256-channel tensor),
   // so the limit is two now.
+  bool mx2 = false;           // SRGD_PRECISION_F16MX2 (prototype): split mode whose 3x3 convolutions run conv3x3_mx2.hip
   bool split = false;         // SRGD_PRECISION_F16X3: fp32 tensors, convolutions as three f16 MFMAs per product (conv3x3_split.hip)
   bool fp8 = false;           // SRGD_PRECISION_FP8: 3x3 convolutions on the block-scaled MX-fp8 matrix cores, the rest as bf16
   bool w8 = false;            // SRGD_PRECISION_BF16_W8: conv weights rounded through fp8 e4m3 (per-output-channel scale)
@@ -407,8 +409,9 @@ int build_topology(srgd_engine* e) {
   if (c.sinus_dim < 2 || c.sinus_dim % 2) SRGD_FAIL("learned_sinusoidal_dim must be even");
   if (c.dim % 16 != 0) SRGD_FAIL("unet_dim must be a multiple of 16");
   if (c.groups < 1 || c.dim % c.groups != 0) SRGD_FAIL("unet_dim must be divisible by resnet_block_groups");
-  if (c.precision < SRGD_PRECISION_FP32 || c.precision > SRGD_PRECISION_F16X3) SRGD_FAIL("unknown precision mode");
-  e->split = c.precision == SRGD_PRECISION_F16X3;
+  if (c.precision < SRGD_PRECISION_FP32 || c.precision > SRGD_PRECISION_F16MX2) SRGD_FAIL("unknown precision mode");
+  e->mx2 = c.precision == SRGD_PRECISION_F16MX2;
+  e->split = c.precision == SRGD_PRECISION_F16X3 || e->mx2;
   e->bf16 = c.precision != SRGD_PRECISION_FP32 && !e->split;
   e->w8 = c.precision == SRGD_PRECISION_BF16_W8;
   e->fp8 = c.precision == SRGD_PRECISION_FP8 || c.precision == SRGD_PRECISION_FP8_MIXED;
@@ -495,7 +498,11 @@ int pack_conv(srgd_engine* e, ConvW& c) {
     const float scale = split_weight_scale(e->wt[c.wi].data.data(), e->wt[c.wi].numel(), true);
     c.ws_inv = 1.0f / scale;
     std::vector<unsigned short> ps;
-    if (c.kind == CK_NORMAL && c.KS == 3 && c.Cout % 128 == 0) {
+    if (c.kind == CK_NORMAL && c.KS == 3 && c.Cout % 128 == 0 && e->mx2) {
+      std::vector<unsigned char> pm;
+      pack_conv3x3_mx2(e->wt[c.wi].data.data(), c.Cin, c.Cout, scale, pm);
+      SRGD_TRY(upload(e, pm.data(), pm.size(), &c.wm3));
+    } else if (c.kind == CK_NORMAL && c.KS == 3 && c.Cout % 128 == 0) {
       pack_conv3x3_split(e->wt[c.wi].data.data(), c.Cin, c.Cout, true, scale, ps);
       SRGD_TRY(upload(e, ps.data(), ps.size() * 2, &c.ws3));
     }
@@ -687,7 +694,7 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
     SRGD_TRY(q_twin(x, in0, C0, Hin * Win, &mq0));
     if (in1) SRGD_TRY(q_twin(x, in1, C1, Hin * Win, &mq1));
   }
-  const bool split3 = e->split && c.ws3 && !e->force_generic_conv && conv3x3_split_eligible(a);
+  const bool split3 = e->split && (c.ws3 || c.wm3) && !e->force_generic_conv && conv3x3_split_eligible(a);
   const bool split1 = e->split && !split3 && c.ws1 && !stats && !e->force_generic_conv && !e->no_conv1x1 && conv1x1_split_eligible(a);
   const bool splitg = e->split && !split3 && !split1 && c.ws && conv_igemm_split_eligible(a);
   const int fam = split3 ? KC_CONV3S : split1 ? KC_CONV1S : splitg ? KC_CONVS : fast ? KC_CONV3 : fastq1 ? KC_CONV1Q : fast1 ? KC_CONV1 : KC_CONV;
@@ -724,6 +731,10 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
   }
   if (split3) {
     if (stats) e->stats_slots = conv3x3_bf16_stats_slots(a);
+    if (c.wm3) {
+      if (gn_in) SRGD_FAIL("internal: fused input GroupNorm requested on conv3x3_mx2");
+      return conv3x3_mx2(a, c.wm3, c.ws_inv, x.st);
+    }
     return conv3x3_split(a, c.ws3, c.ws_inv, true, x.st, gn_in ? e->coefA : nullptr, gn_in ? e->coefB : nullptr);
   }
   if (gn_in) SRGD_FAIL("internal: fused input GroupNorm requested on the generic conv path");

@@ -123,8 +123,21 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
     SRGD_TRY(dws.alloc(ps.size() * 2));
     SRGD_HIP(hipMemcpy(dws.p, ps.data(), ps.size() * 2, hipMemcpyHostToDevice));
   }
-  if (stats_slots) *stats_slots = (fast || split3) ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
+  // impl 14: the two-MFMA split arithmetic prototype (conv3x3_mx2.hip: f16 leading term + both cross terms on MX-fp8 operands)
+  const bool mx2 = impl == 14;
+  DevBuf dwm;
+  if (mx2) {
+    if (is_bf16 || kind != 0 || !conv3x3_split_eligible(a)) SRGD_FAIL("srgd_k_conv2d: impl 14 takes fp32 tensors and conv3x3_split's shapes");
+    const float scale = split_weight_scale(weight_oihw_host, (size_t)Cout * Cin * KS * KS, true);
+    ws_inv = 1.0f / scale;
+    std::vector<unsigned char> pm;
+    pack_conv3x3_mx2(weight_oihw_host, Cin, Cout, scale, pm);
+    SRGD_TRY(dwm.alloc(pm.size()));
+    SRGD_HIP(hipMemcpy(dwm.p, pm.data(), pm.size(), hipMemcpyHostToDevice));
+  }
+  if (stats_slots) *stats_slots = (fast || split3 || mx2) ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
   auto run = [&]() -> int {
+    if (mx2) return conv3x3_mx2(a, dwm.p, ws_inv, st);
     if (split3) return conv3x3_split(a, dws.p, ws_inv, split_f16, st, split_gnin ? gn_tail_a : nullptr, split_gnin ? gn_tail_b : nullptr, split_form2 ? 2 : 0);
     if (split1) return conv1x1_split(a, dws.p, ws_inv, st);
     if (splitg) return conv_igemm_split(a, dws.p, ws_inv, split_f16, st);

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import SamplerGeometry, StepScalars, UnetConfig, check
 
 _PRECISIONS = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16, "bf16_w8": _lib.PRECISION_BF16_W8,
-               "fp8": _lib.PRECISION_FP8, "fp8_mixed": _lib.PRECISION_FP8_MIXED, "f16x3": _lib.PRECISION_F16X3}
+               "fp8": _lib.PRECISION_FP8, "fp8_mixed": _lib.PRECISION_FP8_MIXED, "f16x3": _lib.PRECISION_F16X3, "f16mx2": _lib.PRECISION_F16MX2}
 
 
 def _stream_ptr(device: torch.device) -> C.c_void_p:

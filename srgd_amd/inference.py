@@ -49,7 +49,7 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=71)
     p.add_argument("--backend", type=str, default="ddp")
     # engine-only switches (absent upstream)
-    p.add_argument("--precision", choices=["fp32", "f16x3", "bf16", "bf16_w8", "fp8", "fp8_mixed"], default="f16x3",
+    p.add_argument("--precision", choices=["fp32", "f16x3", "f16mx2", "bf16", "bf16_w8", "fp8", "fp8_mixed"], default="f16x3",
                    help="f16x3 (default since round 6): fp32 tensors, every convolution product as three f16 MFMAs on (hi, lo) operand "
                         "pairs - within 1e-5 of the reference's CPU path on its fixtures (bar: 1e-3), 3x the speed of fp32; "
                         "fp32: exact-fp32 MFMA (the reference's arithmetic up to summation order); bf16 / bf16_w8 / fp8 / fp8_mixed: "
@@ -249,7 +249,7 @@ def main(argv=None):
     sr_model.noise_source = "device" if args.device_noise else "host"
     sr_model.precision = args.precision
     print(f"engine precision: {args.precision} (noise: {sr_model.noise_source})")
-    if args.amp and args.precision in ("fp32", "f16x3"):
+    if args.amp and args.precision in ("fp32", "f16x3", "f16mx2"):
         # callers of earlier builds got bf16 from amp=True; upstream's sampler ignores amp and so does this one
         print("note: amp is accepted and ignored as upstream (the sampler computes at fp32 accuracy: f16x3 ~3.4x, fp32 ~10x slower "
               "than the bf16 engine); pass --precision bf16 for the throughput mode")

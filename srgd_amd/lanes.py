@@ -23,11 +23,11 @@ MAX_SAMPLES_FOR_TWO_LANES = 100     # tiles x guidance passes of one launch (bf1
 MAX_LANES = 2                       # three and four lanes measured 4 % SLOWER than one (25 tiles per step)
 # Automatic two-lane mode only where it was A/B-measured (profiles/r5/step_lanes_ab.txt: bf16 and fp8; round 6: f16x3).  fp32 (parity mode, 10x the kernel time per launch: the partial last wave is a rounding error there) keeps one lane
 # unless forced: a second engine is a second copy of the packed weights, scratch and graphs (memory note).
-AUTO_LANE_PRECISIONS = ("bf16", "bf16_w8", "fp8", "fp8_mixed", "f16x3")
+AUTO_LANE_PRECISIONS = ("bf16", "bf16_w8", "fp8", "fp8_mixed", "f16x3", "f16mx2")
 # f16x3 (profiles/r6/images_sweep_and_f16x3_lanes.txt, same box): one HR tile per step 0.3806 -> 0.4011 (+5.4 %), five in lock-step
 # (125 tiles per launch) 0.4035 -> 0.4096 (+1.5 %): its 512-thread, one-workgroup-per-CU convolution kernels leave a longer partial
 # last wave than the bf16 kernels, so every one-launch step runs as two lanes
-MAX_SAMPLES_BY_PRECISION = {"f16x3": 125}
+MAX_SAMPLES_BY_PRECISION = {"f16x3": 125, "f16mx2": 125}
 
 
 def lanes_wanted(n_tiles: int, passes: int, sub_batch: int, setting: Optional[int], precision: str = "bf16") -> int:

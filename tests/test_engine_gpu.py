@@ -1208,3 +1208,36 @@ def test_fp8_fused_twins_equal_separate_quantisation_passes_bitwise():
         sampler.noise_source = "host"
     assert torch.isfinite(outs["1"]).all()
     assert torch.equal(outs["1"], outs["0"])
+
+
+def test_f16mx2_prototype_mode_meets_the_bar_on_the_reference_fixtures():
+    # SRGD_PRECISION_F16MX2 (prototype, conv3x3_mx2.hip): f16x3 with the 3x3 convolutions' cross terms on MX-fp8 operands.  Against the
+    # REFERENCE's own outputs: configs[0] (10 steps), configs[1]'s geometry (2 steps) and, when the fixture is in the tree, configs[1]
+    # at full length (50 steps, 1,025 tile-forwards) - the north-star bar 1e-3 on the finished images; CPU emulation predicted 1.3e-4 on configs[0]
+    rows = {}
+    for case in (next(c for c in C.SAMPLER_CASES if c["name"] == "dim128_config1"), C.WIDE_CASES[0], C.FULL_CASES[0]):
+        path = os.path.join(G, f"sample_{case['name']}.npz")
+        if not os.path.exists(path):
+            continue
+        z = np.load(path)
+        want = torch.from_numpy(z["image"] if "image" in z else z["image_u16"].astype(np.float32) / 65535.0)
+        sampler = build_sampler(case["dim"], weight_seed=case["weight_seed"])
+        cond = C.sampler_condition(case).cuda()
+        label = torch.tensor([case["label"]]).cuda()
+        sampler.noise_source = "host"
+        errs = {}
+        for prec in ("f16mx2", "f16x3"):
+            torch.manual_seed(case["seed"])
+            out = sampler.tiled_sample(batch_size=case["batch_size"], condition_x=cond, class_label=label, num_sample_steps=case["steps"],
+                                       cond_scale=case["cond_scale"], class_cond_scale=case["class_cond_scale"], precision=prec,
+                                       **C.extra_kwargs(case)).cpu()
+            errs[prec] = float((out - want).abs().max())
+        rows[case["name"]] = errs
+        # the 2-step run stops while the canvas is still mostly noise: x_start = (x - sigma eps) / alpha amplifies eps differences by
+        # up to 148x there - f16x3 itself is 25x further from the reference on it than on a finished image.  The
+        # prototype does NOT meet the bar on that fixture (measured 2.4e-3), which is one reason it is not the CLI's parity mode.
+        bar = 5e-3 if case["steps"] == 2 else 1e-3
+        assert errs["f16mx2"] <= bar, (case["name"], errs)
+        assert errs["f16mx2"] > errs["f16x3"]                    # it IS the cheaper arithmetic
+    _report(test="f16mx2_prototype_vs_reference", max_abs=rows)
+    assert len(rows) >= 2

@@ -20,6 +20,7 @@ HOT = {
     "conv3x3_bf16.hip": {"conv3x3_bf16_kernel": 128},
     "conv3x3_mxfp8.hip": {"conv3x3_mxfp8_kernel": 256},
     "conv3x3_split.hip": {"conv3x3_split_kernel": 256},          # f16x3 mode: one 512-thread workgroup per CU, two waves per SIMD
+    "conv3x3_mx2.hip": {"conv3x3_mx2_kernel": 256},              # f16mx2 prototype mode: the same occupancy
     "conv_igemm.hip": {"conv_igemm_split_kernel": 256, "conv_igemm_kernel<float, 16": 128},      # fp32 mode's instance: four workgroups per CU
     "conv1x1_bf16.hip": {"conv1x1_bf16_kernel": 128},
     "conv1x1_mxfp8.hip": {"conv1x1_mxfp8_kernel": 256},

@@ -293,3 +293,44 @@ def test_split_kernels_reject_what_they_do_not_cover():
             run_conv(x, None, w, None, ks=3, stride=1, pad=1, kind=0, bf16=False, impl=impl)
     with pytest.raises(Exception):                      # bf16 tensors
         run_conv(torch.randn(1, 64, 8, 32), None, torch.randn(128, 64, 3, 3), None, ks=3, stride=1, pad=1, kind=0, bf16=True, impl=6)
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 0, 128, 8, 32), (1, 64, 32, 256, 16, 64), (3, 128, 0, 128, 32, 32), (1, 256, 128, 1024, 8, 32),
+                                 (1, 96, 0, 128, 16, 32)],
+                         ids=lambda s: "B%d_C%d+%d_Cout%d_%dx%d" % s[:6])
+def test_conv3x3_mx2_prototype_matches_its_emulation(cfg):
+    # impl 14 (conv3x3_mx2.hip, a prototype behind the kernel ABI): x_hi.w_hi on the f16 MFMA, both cross terms on MX-fp8 operands
+    # (two taps per scaled MFMA) - against the emulation of exactly that arithmetic, and an order of magnitude from fp32
+    from oracle.split_emulation import mixed_split_conv2d
+    B, c0, c1, cout, H, W = cfg[:6]
+    g = torch.Generator().manual_seed(13)
+    x0 = torch.randn(B, c0, H, W, generator=g)
+    x1 = torch.randn(B, c1, H, W, generator=g) if c1 else None
+    w = torch.randn(cout, c0 + c1, 3, 3, generator=g) / (3 * (c0 + c1) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    xin = x0 if x1 is None else torch.cat((x0, x1), 1)
+    want64 = conv64(xin, w, b, padding=1)
+    scale = max(1.0, float(want64.abs().max()))
+    groups = 8 if cout <= 1024 else 0
+    got, part, nslots = run_conv(x0, x1, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, groups=groups, impl=14, want_slots=True)
+    emu = mixed_split_conv2d(xin, w, b, padding=1, mode="f16mx2")
+    err_emu, err64 = float((got - emu).abs().max()), float((got.double() - want64).abs().max())
+    e3 = float((split_conv2d(xin, w, b, padding=1, kind="f16").double() - want64).abs().max())
+    _report_k(test="conv3x3_mx2", cfg=list(cfg), vs_emulation=err_emu, vs_fp64=err64, f16x3_vs_fp64=e3, ref_max=scale)
+    assert err_emu <= 4e-6 * scale, (err_emu, err64)
+    assert err64 <= 2e-4 * scale and err64 > e3
+    if groups:
+        s = part.sum(2).cpu().double()
+        want_s1 = got.double().reshape(B, groups, -1).sum(-1)
+        assert (s[..., 0] - want_s1).abs().max() <= 1e-4 * max(1.0, float(want_s1.abs().max()))
+
+
+def test_conv3x3_mx2_prototype_integer_exact():
+    # small integers are exact in every operand format involved (f16, e4m3 with power-of-two block scales): every fragment map, plane,
+    # scale byte and tap pairing must be right for this to hold
+    g = torch.Generator().manual_seed(12)
+    x = torch.randint(-3, 4, (2, 64, 16, 64), generator=g).float()
+    w = torch.randint(-2, 3, (128, 64, 3, 3), generator=g).float()
+    b = torch.randint(-4, 5, (128,), generator=g).float()
+    got, _ = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, impl=14)
+    assert torch.equal(got, F.conv2d(x, w, b, padding=1))

@@ -10,7 +10,7 @@ import json
 import sqlite3
 import sys
 
-FAMILIES = ["conv3x3_mxfp8_kernel", "conv1x1_mxfp8_kernel", "quant_mxfp8_kernel", "conv3x3_split_kernel", "conv1x1_split_kernel", "conv_igemm_split_kernel", "conv3x3_bf16_kernel", "conv1x1_bf16_kernel", "conv_igemm_kernel", "gn_apply_kernel", "la1_t_kernel", "la2_t_kernel", "la1_kernel", "la2_kernel",
+FAMILIES = ["conv3x3_mx2_kernel", "conv3x3_mxfp8_kernel", "conv1x1_mxfp8_kernel", "quant_mxfp8_kernel", "conv3x3_split_kernel", "conv1x1_split_kernel", "conv_igemm_split_kernel", "conv3x3_bf16_kernel", "conv1x1_bf16_kernel", "conv_igemm_kernel", "gn_apply_kernel", "la1_t_kernel", "la2_t_kernel", "la1_kernel", "la2_kernel",
             "full_attn_bf16_kernel", "rms_norm_kernel", "final_step"]
 
 
