@@ -51,6 +51,7 @@ constexpr int B_Q = B_HI;                      // four planes [p][h]
 constexpr int B_SC = B_HI + 4 * B_PLANE;       // 16,384: 512 scale bytes [p][wn][r16][J]
 constexpr int B_UNIT = B_SC + 512;             // 16,896
 constexpr int LDS_BYTES = 2 * A_BUF + 3 * B_UNIT;   // 151,040
+constexpr int COEF_BYTES = 2 * 256;            // GNIN: 32 scales | 32 shifts (fp32) of a channel chunk, double-buffered
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -66,6 +67,8 @@ struct Mx2Args {
   int Cout;
   float* out;
   float* gn_partial; int groups;
+  const float* gn_in_a;   // GNIN: y = silu(a[b][c] * x + b[b][c]) applied to the input while it is staged ([B][Cin] fp32)
+  int gn_in_b_off;        // byte offset of the shift array from gn_in_a (one allocation)
 };
 
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
@@ -115,7 +118,7 @@ __device__ __forceinline__ uint2 mx_quant8_finite(const float (&y)[8], int* scal
   return make_uint2(w0, w1);
 }
 
-template <bool STATS>
+template <bool STATS, bool GNIN>
 __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -190,10 +193,37 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
     load_piece(cc, a_pix1, ra10, ra11);
     load_piece(cc, a_pix2, ra20, ra21);
   };
+  // GNIN instances (conv3x3_split.hip): the PRODUCER's GroupNorm-apply + SiLU (reference Block.forward model.py:250-259 between two
+  // convolutions) on the fp32 halo pieces ahead of the split; out-of-image pixels stay zero.  The chunk's 64 coefficients come in
+  // through ONE 4-byte-per-lane LDS-DMA per wave (every wave issues it: identical bytes, identical vmcnt counts), as in
+  // conv3x3_bf16.hip - registers for them do not exist here.
+  char* const sCoef = smem + LDS_BYTES;
+  const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(GNIN ? p.gn_in_a + (size_t)b * Cin : p.in0), 0, GNIN ? p.gn_in_b_off + Cin * 4 : 0, 0x00020000);
+  auto coef_dma = [&](int cc) {
+    const int l4 = lane * 4;
+    const int voff = l4 < 128 ? l4 : p.gn_in_b_off + l4 - 128;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc, (lds_ptr)(sCoef + (cc & 1) * 256), 4, voff, cc * KC * 4, 0, 0);
+  };
+  auto act8 = [&](int cc, u32x4& r0, u32x4& r1) {
+    const char* sc = sCoef + (cc & 1) * 256 + a_sub * 32;
+    const f32x4 ga0 = *reinterpret_cast<const f32x4*>(sc), ga1 = *reinterpret_cast<const f32x4*>(sc + 16);
+    const f32x4 gb0 = *reinterpret_cast<const f32x4*>(sc + 128), gb1 = *reinterpret_cast<const f32x4*>(sc + 144);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned u0 = r0[k], u1 = r1[k];       // (element copied out first: conv3x3_split.hip)
+      const float t0 = __builtin_fmaf(ga0[k], __uint_as_float(u0), gb0[k]), t1 = __builtin_fmaf(ga1[k], __uint_as_float(u1), gb1[k]);
+      r0[k] = __float_as_uint(t0 * __builtin_amdgcn_rcpf(1.0f + __expf(-t0)));
+      r1[k] = __float_as_uint(t1 * __builtin_amdgcn_rcpf(1.0f + __expf(-t1)));
+    }
+  };
   // split, quantise, write: hi image piece; e4m3 of x_lo -> plane (0, h), of x_hi -> plane (1, h), h = octet >> 1, 8 bytes at
   // (octet & 1) * 8 of the pixel's 16; the quad's lane 0 writes the two scale bytes
   const int q_off = (a_sub >> 1) * A_PLANE + (a_sub & 1) * 8;
-  auto store_piece = [&](int cc, int j, const u32x4& r0, const u32x4& r1) {
+  auto store_piece = [&](int cc, int j, u32x4 r0, u32x4 r1) {
+    if constexpr (GNIN) {
+      if ((j == 0 ? a_pix0 : (j == 1 ? a_pix1 : a_pix2)) >= 0) act8(cc, r0, r1);
+    }
     u32x4 hi;
     float yh[8], yl[8];
     split8f(r0, r1, hi, yh, yl);
@@ -317,9 +347,17 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
 #undef K_ROWQ
   };
 
-  // ---- prologue: B[0], A(0) through registers
-  issue_b(0, 0);
-  load_a(0);
+  // ---- prologue: [coefficients of chunk 0,] B[0], A(0) through registers
+  if constexpr (GNIN) {
+    coef_dma(0);
+    issue_b(0, 0);
+    load_a(0);
+    WAIT_VM(6);                                  // the coefficient slot and B[0] have landed (the six fp32 loads may still fly) ...
+    BARRIER();                                   // ... in every wave: the slot is complete
+  } else {
+    issue_b(0, 0);
+    load_a(0);
+  }
   store_piece(0, 0, ra00, ra01);
   store_piece(0, 1, ra10, ra11);
   store_piece(0, 2, ra20, ra21);
@@ -335,6 +373,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
     const bool more = cc + 1 < CC;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
+      if (GNIN && tap == 0 && more) coef_dma(cc + 1);            // oldest request of the step: the counted wait below covers it
       if (tap < 8 || more) issue_b(cc, tap + 1);
       if (tap == 0 && more) {
         __builtin_amdgcn_sched_barrier(0);
@@ -489,7 +528,7 @@ void pack_conv3x3_mx2(const float* src_oihw, int Cin, int Cout, float scale, std
       }
 }
 
-int conv3x3_mx2(const ConvArgs& a, const void* packed_w, float w_inv_scale, hipStream_t st) {
+int conv3x3_mx2(const ConvArgs& a, const void* packed_w, float w_inv_scale, hipStream_t st, const float* gn_in_a, const float* gn_in_b) {
   if (!conv3x3_split_eligible(a)) SRGD_FAIL("conv3x3_mx2: shape not eligible");
   if (a.bias && ((size_t)a.bias & 15)) SRGD_FAIL("conv3x3_mx2: the bias array must be 16-byte aligned");
   if ((size_t)9 * ((a.C0 + a.C1) / KC) * (a.Cout / BN3) * B_UNIT >= (1ull << 31)) SRGD_FAIL("conv3x3_mx2: packed weights beyond 2 GiB");
@@ -497,15 +536,23 @@ int conv3x3_mx2(const ConvArgs& a, const void* packed_w, float w_inv_scale, hipS
   p.in0 = (const float*)a.in0; p.in1 = (const float*)a.in1; p.C0 = a.C0; p.C1 = a.C1;
   p.B = a.B; p.H = a.Hin; p.W = a.Win; p.w = packed_w; p.bias = a.bias; p.w_inv_scale = w_inv_scale; p.Cout = a.Cout;
   p.out = (float*)a.out; p.gn_partial = a.gn_partial; p.groups = a.groups;
+  const bool gnin = gn_in_a != nullptr;
+  if (gnin && (a.C1 != 0 || !gn_in_b || gn_in_b < gn_in_a || (size_t)((const char*)gn_in_b - (const char*)gn_in_a) > (1u << 30)))
+    SRGD_FAIL("conv3x3_mx2: fused input GroupNorm needs one source and scale / shift arrays in one allocation");
+  p.gn_in_a = gn_in_a;
+  p.gn_in_b_off = gnin ? (int)((const char*)gn_in_b - (const char*)gn_in_a) : 0;
   const int grid = a.B * (a.Hin / PH) * (a.Win / PW) * (a.Cout / BN3);
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mx2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mx2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+#define K_SET(S_, G_) SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mx2_kernel<S_, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + COEF_BYTES));
+    K_SET(true, false) K_SET(false, false) K_SET(true, true) K_SET(false, true)
+#undef K_SET
     once.done();
   }
-  if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mx2_kernel<true>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);
-  else hipLaunchKernelGGL((conv3x3_mx2_kernel<false>), dim3(grid), dim3(NT3), LDS_BYTES, st, p);
+  const bool stats = a.gn_partial != nullptr;
+#define K_GO(S_, G_) hipLaunchKernelGGL((conv3x3_mx2_kernel<S_, G_>), dim3(grid), dim3(NT3), LDS_BYTES + COEF_BYTES, st, p)
+  if (stats && gnin) K_GO(true, true); else if (stats) K_GO(true, false); else if (gnin) K_GO(false, true); else K_GO(false, false);
+#undef K_GO
   SRGD_HIP(hipGetLastError());
   return 0;
 }

@@ -628,7 +628,7 @@ bool final_fusion_possible(const srgd_engine* e) {
 // staging; *gn_in_done tells the caller whether that happened (otherwise it must run gn_apply first).
 bool conv_can_fuse_gn_in(srgd_engine* e, const ConvW& c, int nb, int H, int W) {
   if (e->split) {       // f16x3 mode: conv3x3_split applies it to the fp32 halo pieces in registers, ahead of the split
-    if (!c.ws3 || e->force_generic_conv || e->no_gn_fusion || c.Cout / 128 > e->split_gn_fusion_max_ntiles) return false;
+    if ((!c.ws3 && !c.wm3) || e->force_generic_conv || e->no_gn_fusion || c.Cout / 128 > e->split_gn_fusion_max_ntiles) return false;
     ConvArgs a{};
     a.C0 = c.Cin; a.C1 = 0; a.ps0 = c.Cin; a.B = nb; a.Hin = H; a.Win = W; a.Hout = H; a.Wout = W;
     a.KH = a.KW = c.KS; a.stride = c.stride; a.pad = c.pad; a.Cout = c.Cout; a.CoutPad = c.CoutPad; a.mode = c.mode;
@@ -731,10 +731,7 @@ int run_conv(Ctx& x, const ConvW& c, const void* in0, int C0, const void* in1, i
   }
   if (split3) {
     if (stats) e->stats_slots = conv3x3_bf16_stats_slots(a);
-    if (c.wm3) {
-      if (gn_in) SRGD_FAIL("internal: fused input GroupNorm requested on conv3x3_mx2");
-      return conv3x3_mx2(a, c.wm3, c.ws_inv, x.st);
-    }
+    if (c.wm3) return conv3x3_mx2(a, c.wm3, c.ws_inv, x.st, gn_in ? e->coefA : nullptr, gn_in ? e->coefB : nullptr);
     return conv3x3_split(a, c.ws3, c.ws_inv, true, x.st, gn_in ? e->coefA : nullptr, gn_in ? e->coefB : nullptr);
   }
   if (gn_in) SRGD_FAIL("internal: fused input GroupNorm requested on the generic conv path");

@@ -124,7 +124,9 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
     SRGD_HIP(hipMemcpy(dws.p, ps.data(), ps.size() * 2, hipMemcpyHostToDevice));
   }
   // impl 14: the two-MFMA split arithmetic prototype (conv3x3_mx2.hip: f16 leading term + both cross terms on MX-fp8 operands)
-  const bool mx2 = impl == 14;
+  const bool mx2 = impl == 14 || impl == 15;      // 15: with the producer's GroupNorm + SiLU applied while the input is staged (as impl 11)
+  if (impl == 15 && (!gn_tail_a || !gn_tail_b || C1)) SRGD_FAIL("srgd_k_conv2d: impl 15 (GroupNorm-in-staging) needs one source and gn_tail_a / gn_tail_b");
+  if (impl == 15) { a.gn_res_src = nullptr; a.gn_res_a = nullptr; a.gn_res_b = nullptr; }
   DevBuf dwm;
   if (mx2) {
     if (is_bf16 || kind != 0 || !conv3x3_split_eligible(a)) SRGD_FAIL("srgd_k_conv2d: impl 14 takes fp32 tensors and conv3x3_split's shapes");
@@ -137,7 +139,7 @@ int srgd_k_conv2d_timed(const void* in0, const void* in1, int C0, int C1, int B,
   }
   if (stats_slots) *stats_slots = (fast || split3 || mx2) ? conv3x3_bf16_stats_slots(a) : (a.Hout * a.Wout) / conv_tile_m();
   auto run = [&]() -> int {
-    if (mx2) return conv3x3_mx2(a, dwm.p, ws_inv, st);
+    if (mx2) return conv3x3_mx2(a, dwm.p, ws_inv, st, impl == 15 ? gn_tail_a : nullptr, impl == 15 ? gn_tail_b : nullptr);
     if (split3) return conv3x3_split(a, dws.p, ws_inv, split_f16, st, split_gnin ? gn_tail_a : nullptr, split_gnin ? gn_tail_b : nullptr, split_form2 ? 2 : 0);
     if (split1) return conv1x1_split(a, dws.p, ws_inv, st);
     if (splitg) return conv_igemm_split(a, dws.p, ws_inv, split_f16, st);

@@ -95,7 +95,8 @@ int conv3x3_split(const ConvArgs& a, const void* packed_w, float w_inv_scale, bo
                   const float* gn_in_a = nullptr, const float* gn_in_b = nullptr, int form = 0);
 // conv3x3_mx2.hip: prototype of a TWO-MFMA split arithmetic (f16 leading term, both cross terms on MX-fp8 operands); conv3x3_split's shapes
 void pack_conv3x3_mx2(const float* src_oihw, int Cin, int Cout, float scale, std::vector<unsigned char>& out);
-int conv3x3_mx2(const ConvArgs& a, const void* packed_w, float w_inv_scale, hipStream_t st);
+int conv3x3_mx2(const ConvArgs& a, const void* packed_w, float w_inv_scale, hipStream_t st, const float* gn_in_a = nullptr,
+                const float* gn_in_b = nullptr);     // gn_in_*: [B][C0] fp32, one allocation (shift behind scale), one source
 // generic implicit GEMM of that mode (a.w ignored; every epilogue of the fp32 conv_igemm); weights from pack_conv_weights_split,
 // which takes pack_conv_weights' fp32 [tap][CoutPad][Cin] order
 bool conv_igemm_split_eligible(const ConvArgs& a);

@@ -334,3 +334,30 @@ def test_conv3x3_mx2_prototype_integer_exact():
     b = torch.randint(-4, 5, (128,), generator=g).float()
     got, _ = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, impl=14)
     assert torch.equal(got, F.conv2d(x, w, b, padding=1))
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 128, 16, 32), (1, 128, 256, 16, 64), (3, 32, 128, 8, 32)], ids=lambda s: "B%d_C%d_Cout%d_%dx%d" % s)
+def test_conv3x3_mx2_prototype_groupnorm_in_staging(cfg):
+    # impl 15: conv3x3_mx2 with the producer's GroupNorm + SiLU applied to the fp32 halo pieces ahead of the split (coefficients through
+    # an LDS slot); against the emulation of the same arithmetic on the activated tensor (v_exp / v_rcp: ~3e-7 relative before the split)
+    from oracle.split_emulation import mixed_split_conv2d
+    B, cin, cout, H, W = cfg
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, cin, H, W, generator=g) * 2
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cout, generator=g)
+    ca = 1 + 0.3 * torch.randn(B, cin, generator=g)
+    cb = 0.5 * torch.randn(B, cin, generator=g)
+    coef = torch.stack([ca, cb]).contiguous().to(DEV)
+    act = F.silu(ca[:, :, None, None] * x + cb[:, :, None, None])
+    want64 = F.conv2d(act.double(), w.double(), b.double(), padding=1)
+    scale = max(1.0, float(want64.abs().max()))
+    got, part, nslots = run_conv(x, None, w, b, ks=3, stride=1, pad=1, kind=0, bf16=False, groups=8, impl=15, want_slots=True,
+                                 gn_tail=(None, coef[0], coef[1]))
+    emu = mixed_split_conv2d(act, w, b, padding=1, mode="f16mx2")
+    err_emu, err64 = float((got - emu).abs().max()), float((got.double() - want64).abs().max())
+    _report_k(test="conv3x3_mx2_gnin", cfg=list(cfg), vs_emulation=err_emu, vs_fp64=err64, ref_max=scale)
+    # an activation that differs by an ulp can land on the other side of an e4m3 rounding boundary of a cross-term operand: 2^-15 of a product
+    assert err_emu <= 2e-5 * scale and err64 <= 2e-4 * scale, (err_emu, err64)
+    s = part.sum(2).cpu().double()
+    assert (s[..., 0] - got.double().reshape(B, 8, -1).sum(-1)).abs().max() <= 1e-4 * max(1.0, float(want64.abs().sum(1).max()))
