@@ -49,6 +49,9 @@ int srgd_k_conv2d(const void* in0, const void* in1, int C0, int C1, int B, int H
  * C0, C1 % 32 == 0, Cout % 128 == 0, Hout * Wout % 256 == 0); 11 = impl 6 with the producer's GroupNorm + SiLU applied while the input
  * is staged, as impl 5 (gn_tail_a / gn_tail_b = device fp32 [B][C0], 16-byte aligned; one source; gn_tail_src NULL); 12 / 13 = impl
  * 6 / 11 on the 256-thread form of that kernel (two workgroups per CU) instead of the engine's default (512 threads, one per CU).
+ * 14 / 15 = the two-MFMA prototype of SRGD_PRECISION_F16MX2 (conv3x3_mx2.hip: f16 leading term, both cross terms on MX-fp8 operands;
+ * conv3x3_split's shapes), 15 with the producer's GroupNorm + SiLU applied while the input is staged (as impl 5: gn_tail_a / gn_tail_b in
+ * ONE allocation, one source).
  * gn_tail_src (nullable, NHWC like out): out = silu(gn_tail_a[b][c] * gn_tail_src + gn_tail_b[b][c]) + conv(in) -
  * the second GroupNorm+SiLU of a ResnetBlock and its residual add folded into the 1x1 res_conv (model.py:250-259,:285);
  * gn_tail_a / gn_tail_b: device fp32 [B][Cout].  May alias out.

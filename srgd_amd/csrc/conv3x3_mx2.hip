@@ -274,6 +274,9 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   const bool second_tap = (q16 >> 1) != 0;
 
   typedef u32x4 frag;
+#ifndef SRGD_MX2_DIAG                      // pricing builds (wrong results): bit 0 = no f16 pixel-fragment reads, bit 1 = no e4m3 pixel-fragment reads
+#define SRGD_MX2_DIAG 0
+#endif
 #ifndef SRGD_MX2_NOSB
 #define K_SB __builtin_amdgcn_sched_barrier(0)
 #else
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
     if (!pair && !single) {
 #define K_ROWF(I, C0_, C1_, C2_, C3_)                                                         \
   {                                                                                            \
-    const frag ah = *reinterpret_cast<const frag*>(A + a_addr(tap, I));                        \
+    const frag ah = (SRGD_MX2_DIAG & 1) ? bh0 : *reinterpret_cast<const frag*>(A + a_addr(tap, I)); \
     K_F16MM(C0_, bh0, ah); K_F16MM(C1_, bh1, ah); K_F16MM(C2_, bh2, ah); K_F16MM(C3_, bh3, ah); \
   }
       K_ROWF(0, c00, c01, c02, c03)
@@ -327,11 +330,11 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
     const int sbw = *reinterpret_cast<const int*>((second_tap && !single ? Bt1 : Bt0) + bsc_base);
 #define K_ROWQ(I, C0_, C1_, C2_, C3_)                                                         \
   {                                                                                            \
-    const frag ah = *reinterpret_cast<const frag*>(A + a_addr(tap, I));                        \
+    const frag ah = (SRGD_MX2_DIAG & 1) ? bh0 : *reinterpret_cast<const frag*>(A + a_addr(tap, I)); \
     const int Pc0 = pc_of(t0, I), Pc1 = single ? Pc0 : pc_of(tap, I);                          \
     const v4i f0 = *reinterpret_cast<const v4i*>(A + a8_base + Pc0 * 16);                      \
     const v4i f1 = single ? v4i{0, 0, 0, 0} : *reinterpret_cast<const v4i*>(A + a8_base + Pc1 * 16); \
-    const v8i px = v8i{f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};                \
+    const v8i px = (SRGD_MX2_DIAG & 2) ? w0 : v8i{f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]}; \
     const int sp = *reinterpret_cast<const unsigned char*>(A + asc_base + (second_tap ? Pc1 : Pc0) * 2); \
     K_F16MM(C0_, bh0, ah); K_F16MM(C1_, bh1, ah); K_F16MM(C2_, bh2, ah); K_F16MM(C3_, bh3, ah); \
     K_QMM(C0_, w0, sbw, px, sp, 0); K_QMM(C1_, w1, sbw, px, sp, 1);                            \
