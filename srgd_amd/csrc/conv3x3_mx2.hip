@@ -32,6 +32,12 @@
 
 #include "kernels.hpp"
 
+// pricing builds (tools/build_variant.py only; wrong results): bit 0 = no f16 pixel-fragment reads, bit 1 = no e4m3 pixel-fragment
+// reads, bit 2 = no weight DMAs
+#ifndef SRGD_MX2_DIAG
+#define SRGD_MX2_DIAG 0
+#endif
+
 namespace srgd {
 namespace {
 
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   const int w_tap_stride = (int)(CC * w_tile_stride);
   const int tid16 = tid * 16;
   auto issue_b = [&](int cc, int tap) {
+    if (SRGD_MX2_DIAG & 4) return;               // (pricing build: no weight DMAs at all)
     if (tap >= 9) { tap -= 9; cc += 1; }
     char* dst = sB0 + (tap % 3) * B_UNIT;
     const int so = tap * w_tap_stride + cc * (int)w_tile_stride;
@@ -274,9 +281,6 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   const bool second_tap = (q16 >> 1) != 0;
 
   typedef u32x4 frag;
-#ifndef SRGD_MX2_DIAG                      // pricing builds (wrong results): bit 0 = no f16 pixel-fragment reads, bit 1 = no e4m3 pixel-fragment reads
-#define SRGD_MX2_DIAG 0
-#endif
 #ifndef SRGD_MX2_NOSB
 #define K_SB __builtin_amdgcn_sched_barrier(0)
 #else
