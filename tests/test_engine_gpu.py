@@ -785,8 +785,9 @@ def test_config2_full_length_against_the_reference():
     _full_length_check(C.FULL_CASES[0], CONFIG2_FULL_GATES_DB, "config2_full_vs_reference")
 
 
-# configs[4] at its full geometry against the reference: gates to be set 3 dB under the first measurement
-CONFIG5_FULL_GATES_DB = {"bf16": 52.0, "fp8_mixed": 46.0, "fp8": 30.0}
+# configs[4] at its full geometry against the reference (measured on MI355X: fp32 1.10e-5, f16x3 1.03e-5 max-abs; bf16 57.51 dB,
+# fp8_mixed 52.23 dB, fp8 36.32 dB): gates 3 dB under the measurement
+CONFIG5_FULL_GATES_DB = {"bf16": 54.5, "fp8_mixed": 49.2, "fp8": 33.3}
 
 
 def test_config5_full_geometry_against_the_reference():
@@ -1213,9 +1214,9 @@ def test_fp8_fused_twins_equal_separate_quantisation_passes_bitwise():
 def test_f16mx2_prototype_mode_meets_the_bar_on_the_reference_fixtures():
     # SRGD_PRECISION_F16MX2 (prototype, conv3x3_mx2.hip): f16x3 with the 3x3 convolutions' cross terms on MX-fp8 operands.  Against the
     # REFERENCE's own outputs: configs[0] (10 steps), configs[1]'s geometry (2 steps) and, when the fixture is in the tree, configs[1]
-    # at full length (50 steps, 1,025 tile-forwards) - the north-star bar 1e-3 on the finished images; CPU emulation predicted 1.3e-4 on configs[0]
+    # and configs[4] at full length (50 steps / 100 steps with class guidance) - the north-star bar 1e-3 on the finished images; CPU emulation predicted 1.3e-4 on configs[0]
     rows = {}
-    for case in (next(c for c in C.SAMPLER_CASES if c["name"] == "dim128_config1"), C.WIDE_CASES[0], C.FULL_CASES[0]):
+    for case in (next(c for c in C.SAMPLER_CASES if c["name"] == "dim128_config1"), C.WIDE_CASES[0], C.FULL_CASES[0], C.FULL5_CASES[0]):
         path = os.path.join(G, f"sample_{case['name']}.npz")
         if not os.path.exists(path):
             continue
