@@ -9,6 +9,7 @@ for P in bf16 fp8 fp8_mixed; do
 done
 python bench.py --no_cpu_baseline --precision fp32 --steps 2 --warmup 1 --images 2 > $O/bench_${T}_fp32.json 2>$O/err_fp32.txt || { tail $O/err_fp32.txt; exit 1; }
 python bench.py --no_cpu_baseline --precision f16x3 > $O/bench_${T}_f16x3.json 2>$O/err_f16x3.txt || { tail $O/err_f16x3.txt; exit 1; }
+python bench.py --no_cpu_baseline --precision f16mx2 > $O/bench_${T}_f16mx2.json 2>$O/err_f16mx2.txt || { tail $O/err_f16mx2.txt; exit 1; }
 python bench.py --no_cpu_baseline --precision f16x3 --images 1 > $O/bench_${T}_f16x3_images1.json 2>$O/err_f16x3_1.txt || { tail $O/err_f16x3_1.txt; exit 1; }
 SRGD_FORCE_DIST=1 python bench.py --gpus 1 --no_cpu_baseline --no_profile > $O/bench_${T}_forced_dist_nccl_world1_tiles.json 2>$O/err_fd1.txt || { tail $O/err_fd1.txt; exit 1; }
 python bench.py --no_cpu_baseline --no_profile --workload canvas --lr_size 2048 --steps 1 --warmup 0 > $O/bench_${T}_config4_canvas8192_1gpu.json 2>$O/err_c4.txt || { tail $O/err_c4.txt; exit 1; }
