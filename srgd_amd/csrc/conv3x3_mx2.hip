@@ -22,10 +22,12 @@
 //     offset apart), and the scale of (tap t + (g >> 1), product g & 1).  Taps pair as (0,1) (2,3) (4,5) (6,7) (8,-): five scaled MFMAs
 //     per chunk and accumulator block where 4.5 would do;
 //   * weight unit per (tap, chunk, n-tile) = 16.5 KB: f16 hi tile (8 KB, conv3x3_split's image) | four e4m3 planes (2 KB each:
-//     [p][h], p = 0: Q(w_hi), p = 1: Q(w_lo)) | 512 scale bytes [p][wn][r16][J]; 3-slot LDS-DMA ring holding taps t-1, t, t+1 (the
-//     unit of tap t+1 is fetched during step t: one step of lead, as in conv3x3_mxfp8.hip);
+//     [p][h], p = 0: Q(w_hi), p = 1: Q(w_lo)) | 512 scale bytes [p][wn][r16][J]; a 4-slot LDS-DMA ring = the tap pair being consumed
+//     + the pair in flight; the K loop advances in PAIR steps (one barrier per pair: ~1,000 MFMA cycles per wave between barriers,
+//     one pair-step of DMA lead);
 //   * both MFMA kinds accumulate into the same 16 x 16 fp32 blocks (same D layout), issued as inline asm with the accumulator tied.
-// LDS: 2 x (24 KB + 24 KB + 1 KB) of A + 3 x 16.5 KB of B = 147.5 KB - one workgroup per CU.
+// LDS: 2 x 46 KB of A (24 KB hi image + four 5.3 KB planes + scales) + 4 x 16.5 KB of B + 0.5 KB of GNIN coefficients = 158.5 KB - one
+// workgroup per CU.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -47,16 +49,17 @@ constexpr int KC = 32;
 constexpr int BN3 = 128;
 constexpr int NT3 = 512;
 constexpr int A_IMG = 24 * 1024;               // f16 hi halo image (1,536 16-byte pieces, 1,360 used)
-constexpr int A_PLANE = 384 * 16;              // one e4m3 plane: 16 B per halo pixel (pieces of pixels 340..383 land here too)
+constexpr int A_PLANE = HP * WP * 16;          // one e4m3 plane: 16 B per halo pixel (5,440)
 constexpr int A_Q = A_IMG;                     // the four planes [p][h]
 constexpr int A_SC = A_IMG + 4 * A_PLANE;      // pixel scales [P][p]
-constexpr int A_BUF = A_SC + 1024;             // 50,176
+constexpr int A_BUF = A_SC + 768;              // 47,104
 constexpr int B_HI = BN3 * KC * 2;             // 8 KiB f16 tile
 constexpr int B_PLANE = BN3 * 16;              // 2 KiB
 constexpr int B_Q = B_HI;                      // four planes [p][h]
 constexpr int B_SC = B_HI + 4 * B_PLANE;       // 16,384: 512 scale bytes [p][wn][r16][J]
 constexpr int B_UNIT = B_SC + 512;             // 16,896
-constexpr int LDS_BYTES = 2 * A_BUF + 3 * B_UNIT;   // 151,040
+constexpr int B_RING = 4;                      // two tap pairs: the one being consumed and the one in flight
+constexpr int LDS_BYTES = 2 * A_BUF + B_RING * B_UNIT;   // 161,792
 constexpr int COEF_BYTES = 2 * 256;            // GNIN: 32 scales | 32 shifts (fp32) of a channel chunk, double-buffered
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
 
   char* const sA0 = smem;
   char* const sB0 = smem + 2 * A_BUF;
+  const int tid16 = tid * 16;                      // the weight DMAs' per-lane offset; lane * 4 and (after the loop) the lane id are derived from it
 
   u32x4 ra00, ra01, ra10, ra11, ra20, ra21;
   auto load_piece = [&](int cc, int a_pix, u32x4& lo16, u32x4& hi16) {
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(GNIN ? p.gn_in_a + (size_t)b * Cin : p.in0), 0, GNIN ? p.gn_in_b_off + Cin * 4 : 0, 0x00020000);
   auto coef_dma = [&](int cc) {
-    const int l4 = lane * 4;
+    const int l4 = (tid16 >> 2) & 255;          // lane * 4, rebuilt from the DMA offset register: `lane` itself is not kept through the K loop
     const int voff = l4 < 128 ? l4 : p.gn_in_b_off + l4 - 128;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsc, (lds_ptr)(sCoef + (cc & 1) * 256), 4, voff, cc * KC * 4, 0, 0);
   };
@@ -239,22 +243,26 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
     char* A = sA0 + (cc & 1) * A_BUF;
     *reinterpret_cast<u32x4*>(A + (tid + NT3 * j) * 16) = hi;
     const int P = (tid >> 2) + (NT3 / 4) * j;
-    *reinterpret_cast<uint2*>(A + A_Q + q_off + P * 16) = ql;
-    *reinterpret_cast<uint2*>(A + A_Q + 2 * A_PLANE + q_off + P * 16) = qh;
-    if ((tid & 3) == 0) *reinterpret_cast<unsigned short*>(A + A_SC + P * 2) = (unsigned short)(sl | (sh << 8));
+    if (j < 2 || P < HP * WP) {                   // (pieces 1,360 .. 1,535 of the hi image are padding; the planes have none)
+      *reinterpret_cast<uint2*>(A + A_Q + q_off + P * 16) = ql;
+      *reinterpret_cast<uint2*>(A + A_Q + 2 * A_PLANE + q_off + P * 16) = qh;
+      if ((tid & 3) == 0) *reinterpret_cast<unsigned short*>(A + A_SC + P * 2) = (unsigned short)(sl | (sh << 8));
+    }
   };
-  // weight unit (tap, cc) -> ring slot tap % 3: 16 KB as two 1 KB pieces per wave + 512 scale bytes (waves of equal parity
+  // weight unit (tap, cc) -> its ring slot: 16 KB as two 1 KB pieces per wave + 512 scale bytes (waves of equal parity
   // copy the same 256: every wave issues the same three instructions)
   const int w_tap_stride = (int)(CC * w_tile_stride);
-  const int tid16 = tid * 16;
+  // ring slot of tap t of a chunk of parity par: pair k = t >> 1 sits in slots 2 ((k ^ par) & 1) + (t & 1) - five pairs per chunk, so
+  // the parity of the pair count carries over the chunk boundary (tap 8 of this chunk and taps 0, 1 of the next never share slots)
+  auto slot_off = [&](int par, int tap) { return ((((tap >> 1) & 1) ^ par) * 2 + (tap & 1)) * B_UNIT; };
   auto issue_b = [&](int cc, int tap) {
     if (SRGD_MX2_DIAG & 4) return;               // (pricing build: no weight DMAs at all)
     if (tap >= 9) { tap -= 9; cc += 1; }
-    char* dst = sB0 + (tap % 3) * B_UNIT;
+    char* dst = sB0 + slot_off(cc & 1, tap);
     const int so = tap * w_tap_stride + cc * (int)w_tile_stride;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(dst + wave * 1024), 16, tid16, so, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(dst + 8192 + wave * 1024), 16, tid16, so + 8192, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(dst + B_SC + (wave & 1) * 256), 4, lane * 4, so + B_SC + (wave & 1) * 256, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(dst + B_SC + (wave & 1) * 256), 4, (tid16 >> 2) & 255, so + B_SC + (wave & 1) * 256, 0, 0);
   };
 
   f32x4 c00 = 0, c01 = 0, c02 = 0, c03 = 0, c10 = 0, c11 = 0, c12 = 0, c13 = 0,
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   // MFMA covers taps (tap - 1, tap), 2 = tap 8 alone (K blocks 2 and 3 are zero).
   auto compute = [&](int cc, int tap) {
     const char* A = sA0 + (cc & 1) * A_BUF;
-    const char* Bt = sB0 + (tap % 3) * B_UNIT;
+    const char* Bt = sB0 + slot_off(cc & 1, tap);
     const frag bh0 = *reinterpret_cast<const frag*>(Bt + b_base), bh1 = *reinterpret_cast<const frag*>(Bt + b_base + 1024),
                bh2 = *reinterpret_cast<const frag*>(Bt + b_base + 2048), bh3 = *reinterpret_cast<const frag*>(Bt + b_base + 3072);
     const bool pair = (tap & 1) != 0, single = tap == 8;
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
     }
     // scaled MFMA of taps (t0, t1) = (tap - 1, tap), or (8, -)
     const int t0 = single ? 8 : tap - 1;
-    const char* Bt0 = sB0 + (t0 % 3) * B_UNIT;                     // unit of tap t0
+    const char* Bt0 = sB0 + slot_off(cc & 1, t0);                  // unit of tap t0
     const char* Bt1 = Bt;                                          // unit of tap t1 = tap (single: unused)
     v8i w0, w1, w2, w3;
 #define K_LOADW(J)                                                                            \
@@ -358,11 +366,13 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   if constexpr (GNIN) {
     coef_dma(0);
     issue_b(0, 0);
+    issue_b(0, 1);
     load_a(0);
     WAIT_VM(6);                                  // the coefficient slot and B[0] have landed (the six fp32 loads may still fly) ...
     BARRIER();                                   // ... in every wave: the slot is complete
   } else {
     issue_b(0, 0);
+    issue_b(0, 1);
     load_a(0);
   }
   store_piece(0, 0, ra00, ra01);
@@ -372,30 +382,33 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   BARRIER();
 
-  // ---- main loop.  Per K-step s = (cc, tap): issue B[s+1] into the slot last read two steps ago (its readers - the f16 MFMAs of
-  // step s-2 and the scaled MFMAs of step s-1 - are behind the barrier that ended step s-1); tap 0 also issues the six fp32 loads of
-  // chunk cc+1 behind it (the counted wait lets them fly); compute(s); taps 3..5 split one piece each into the other A buffer; wait
-  // for B[s+1]; barrier.
+  // ---- main loop, in steps of a TAP PAIR (0,1) (2,3) (4,5) (6,7) (8): issue the weight units of the next pair into the two slots
+  // the previous pair left (its readers are behind the barrier that ended the last step); pair 0 also issues the six fp32 loads of
+  // chunk cc+1 behind them (the counted wait lets them fly); the pair's MFMAs; pairs 1..3 split one piece each into the other A
+  // buffer; wait for the next pair's units; barrier.  One barrier per ~1,000 MFMA cycles and wave, one pair-step of DMA lead.
   for (int cc = 0; cc < CC; ++cc) {
     const bool more = cc + 1 < CC;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      if (GNIN && tap == 0 && more) coef_dma(cc + 1);            // oldest request of the step: the counted wait below covers it
-      if (tap < 8 || more) issue_b(cc, tap + 1);
-      if (tap == 0 && more) {
+    for (int k = 0; k < 5; ++k) {
+      if (GNIN && k == 0 && more) coef_dma(cc + 1);              // oldest request of the step: the counted wait below covers it
+      if (k < 3) { issue_b(cc, 2 * k + 2); issue_b(cc, 2 * k + 3); }
+      else if (k == 3) issue_b(cc, 8);
+      else if (more) { issue_b(cc, 9); issue_b(cc, 10); }
+      if (k == 0 && more) {
         __builtin_amdgcn_sched_barrier(0);
         load_a(cc + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      compute(cc, tap);
+      compute(cc, 2 * k);
+      if (k < 4) compute(cc, 2 * k + 1);
       if (more) {
-        if (tap == 3) store_piece(cc + 1, 0, ra00, ra01);
-        if (tap == 4) store_piece(cc + 1, 1, ra10, ra11);
-        if (tap == 5) store_piece(cc + 1, 2, ra20, ra21);
+        if (k == 1) store_piece(cc + 1, 0, ra00, ra01);
+        if (k == 2) store_piece(cc + 1, 1, ra10, ra11);
+        if (k == 3) store_piece(cc + 1, 2, ra20, ra21);
       }
-      if (tap == 0 && more) WAIT_VM(6); else WAIT_VM(0);
-      if (tap == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (tap < 8 || more) BARRIER();
+      if (k == 0 && more) WAIT_VM(6); else WAIT_VM(0);
+      if (k == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (k < 4 || more) BARRIER();
     }
   }
 #undef K_QMM
@@ -409,8 +422,11 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   asm volatile("" : "+v"(c20), "+v"(c21), "+v"(c22), "+v"(c23), "+v"(c30), "+v"(c31), "+v"(c32), "+v"(c33));
 
   // ------------------------------- epilogue (conv3x3_split.hip: register-direct, fp32, full-line stores) --------------------------
+  int tidE = tid16;                                     // per-lane epilogue addresses from an opaque copy: not carried through the K loop
+  asm volatile("" : "+v"(tidE));
+  const int laneE = (tidE >> 4) & 63, r16E = laneE & 15, q16E = laneE >> 4;
   const int chw = nt * BN3 + wn * 64;
-  const int chl = q16 * 16;
+  const int chl = q16E * 16;
   f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0, bs2 = bs0, bs3 = bs0;
   if (p.bias) {
     const float* bp = p.bias + chw + chl;
@@ -423,9 +439,9 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   constexpr int STG_ROW = 272;
   static_assert(8 * 16 * STG_ROW <= A_BUF, "store staging fits the idle A buffer");
   char* const stg = smem + (CC & 1) * A_BUF + wave * (16 * STG_ROW);
-  const int stg_w = r16 * STG_ROW + q16 * 64;
-  const int stg_r = (lane >> 4) * STG_ROW + (lane & 15) * 16;
-  const int line_off = (lane >> 4) * p.Cout * 4 + (lane & 15) * 16;
+  const int stg_w = r16E * STG_ROW + q16E * 64;
+  const int stg_r = (laneE >> 4) * STG_ROW + (laneE & 15) * 16;
+  const int line_off = (laneE >> 4) * p.Cout * 4 + (laneE & 15) * 16;
   const float ws = p.w_inv_scale;
   f32x4 s1v = {0.f, 0.f, 0.f, 0.f}, s2v = s1v;
   asm volatile("" : "+v"(bs0), "+v"(bs1), "+v"(bs2), "+v"(bs3));
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
     if (cpg >= 32) { a1 = xor16_sum(a1); a2 = xor16_sum(a2); }
     if (cpg >= 64) { a1 = xor32_sum(a1); a2 = xor32_sum(a2); }
     const int rows_per_group = cpg >= 64 ? 4 : cpg >> 4;
-    if (r16 == 0 && (q16 & (rows_per_group - 1)) == 0) {
+    if (r16E == 0 && (q16E & (rows_per_group - 1)) == 0) {
       const int tpg = cpg >= BN3 ? cpg / BN3 : 1;
       const int wpt = cpg >= BN3 ? 8 : 4;
       const int nslots = tiles_y * tiles_x * tpg * wpt;
