@@ -512,7 +512,7 @@ float f16_bits_to_f32_mx2(unsigned short h) {
 
 }  // namespace
 
-size_t conv3x3_mx2_packed_bytes(int Cin, int Cout) { return (size_t)9 * (Cin / KC) * (Cout / BN3) * B_UNIT; }
+static size_t conv3x3_mx2_packed_bytes(int Cin, int Cout) { return (size_t)9 * (Cin / KC) * (Cout / BN3) * B_UNIT; }
 
 // OIHW fp32 -> [tap][cc][ntile][unit]; unit = f16 hi tile (conv3x3_split's image and row order) | e4m3 planes [p][h] of Q(w_hi) (p = 0)
 // and Q(w_lo) (p = 1), 16 bytes per row and plane | scale bytes [p][wn][r16][J] (row n = 64 wn + 16 J + r16); blocks = the 32 input
