@@ -57,7 +57,9 @@ typedef struct srgd_engine srgd_engine;
                                  * operands - v_mfma_scale_f32_16x16x128_f8f6f4, two taps per instruction - next to the exact f16
                                  * leading term (conv3x3_mx2.hip): two MFMAs' worth of matrix work per product instead of three,
                                  * ~2^-15 of a product instead of 2^-22 (1.3e-4 on the reference's configs[0] fixture in CPU emulation;
-                                 * bar 1e-3).  Everything else as SRGD_PRECISION_F16X3 (no GroupNorm-in-staging for these layers). */
+                                 * bar 1e-3).  The blocks at the tile's own resolution (final block, last up stage, first down stage) keep
+                                 * the three-MFMA arithmetic - that is where the error is made: within 1.4-1.8x of SRGD_PRECISION_F16X3
+                                 * on every reference fixture, +7 % throughput.  Everything else as SRGD_PRECISION_F16X3. */
 
 /* Constructor arguments of ConditionalSRUnet (model.py:537-556) as get_model passes them
  * (model.py:3504-3514).  Unsupported combinations are rejected by srgd_create. */

@@ -265,6 +265,11 @@ struct srgd_engine {
   // tiles is ahead by 0.1 % and takes the GroupNorm share from 6.0 to 5.0 % (one HBM pass less over every 256-channel tensor),
   // so the limit is two now.
   bool mx2 = false;           // SRGD_PRECISION_F16MX2 (prototype): split mode whose 3x3 convolutions run conv3x3_mx2.hip
+  bool mx2_pack = true;       // (while packing) this block's 3x3 convolutions take the two-MFMA arithmetic; false: they stay on conv3x3_split
+  // blocks nearest the output / input kept on the three-MFMA arithmetic (SRGD_MX2_EXACT_TAIL / _HEAD override).  Default: everything at
+  // the tile's own resolution - final block + last up stage (tail 2), first down stage (head 1) - because that is where the error is
+  // made (tools/mx2_tail_study.py, profiles/r6/conv3x3_mx2_prototype.txt: configs[1] after 2 steps 2.3e-3 -> 2.3e-4 for 4 % of speed)
+  int mx2_exact_tail = 2, mx2_exact_head = 1;
   bool split = false;         // SRGD_PRECISION_F16X3: fp32 tensors, convolutions as three f16 MFMAs per product (conv3x3_split.hip)
   bool fp8 = false;           // SRGD_PRECISION_FP8: 3x3 convolutions on the block-scaled MX-fp8 matrix cores, the rest as bf16
   bool w8 = false;            // SRGD_PRECISION_BF16_W8: conv weights rounded through fp8 e4m3 (per-output-channel scale)
@@ -498,7 +503,7 @@ int pack_conv(srgd_engine* e, ConvW& c) {
     const float scale = split_weight_scale(e->wt[c.wi].data.data(), e->wt[c.wi].numel(), true);
     c.ws_inv = 1.0f / scale;
     std::vector<unsigned short> ps;
-    if (c.kind == CK_NORMAL && c.KS == 3 && c.Cout % 128 == 0 && e->mx2) {
+    if (c.kind == CK_NORMAL && c.KS == 3 && c.Cout % 128 == 0 && e->mx2 && e->mx2_pack) {
       std::vector<unsigned char> pm;
       pack_conv3x3_mx2(e->wt[c.wi].data.data(), c.Cin, c.Cout, scale, pm);
       SRGD_TRY(upload(e, pm.data(), pm.size(), &c.wm3));
@@ -1216,6 +1221,8 @@ int srgd_create(const srgd_unet_config* cfg, srgd_engine** out) {
   e->cfg = *cfg;
   SRGD_TRY(build_topology(e.get()));
   if (const char* v = getenv("SRGD_GN_FUSION")) e->no_gn_fusion = atoi(v) == 0;   // experiment switch (see no_gn_fusion)
+  e->mx2_exact_tail = env_int("SRGD_MX2_EXACT_TAIL", e->mx2_exact_tail);
+  e->mx2_exact_head = env_int("SRGD_MX2_EXACT_HEAD", e->mx2_exact_head);
   if (const char* v = getenv("SRGD_GN_FUSION_NTILES")) e->gn_fusion_max_ntiles = e->split_gn_fusion_max_ntiles = atoi(v);
   if (const char* v = getenv("SRGD_GRAPHS")) e->use_graphs = atoi(v) != 0;
   if (const char* v = getenv("SRGD_CONV1X1")) e->no_conv1x1 = atoi(v) == 0;
@@ -1396,16 +1403,26 @@ int srgd_finalize_weights(srgd_engine* e) {
     SRGD_TRY(pack_lin(e, e->cls1));
     SRGD_TRY(pack_lin(e, e->cls3));
   }
-  for (auto& s : e->downs) {
+  // f16mx2 prototype: the blocks nearest the output (final block = 1, + last up stage = 2, ...) / the input (first down stage = 1, ...)
+  // can stay on the three-MFMA arithmetic - an error made there reaches x_start undamped
+  const int n_st = (int)e->downs.size();
+  for (int i = 0; i < n_st; ++i) {
+    auto& s = e->downs[i];
+    e->mx2_pack = i >= e->mx2_exact_head;
     SRGD_TRY(pack_res(e, s.rb[0])); SRGD_TRY(pack_res(e, s.rb[1]));
     SRGD_TRY(pack_attn(e, s.attn)); SRGD_TRY(pack_conv(e, s.resample));
   }
+  e->mx2_pack = true;
   SRGD_TRY(pack_res(e, e->mid1)); SRGD_TRY(pack_attn(e, e->mid_attn)); SRGD_TRY(pack_res(e, e->mid2));
-  for (auto& s : e->ups) {
+  for (int i = 0; i < n_st; ++i) {
+    auto& s = e->ups[i];
+    e->mx2_pack = (n_st - 1 - i) + 2 > e->mx2_exact_tail;      // last up stage = tail level 2
     SRGD_TRY(pack_res(e, s.rb[0])); SRGD_TRY(pack_res(e, s.rb[1]));
     SRGD_TRY(pack_attn(e, s.attn)); SRGD_TRY(pack_conv(e, s.resample));
   }
+  e->mx2_pack = e->mx2_exact_tail < 1;
   SRGD_TRY(pack_res(e, e->final_rb));
+  e->mx2_pack = true;
   for (auto& t : e->wt) { std::vector<float>().swap(t.data); }
   e->finalized = true;
   return 0;

@@ -1234,11 +1234,10 @@ def test_f16mx2_prototype_mode_meets_the_bar_on_the_reference_fixtures():
                                        **C.extra_kwargs(case)).cpu()
             errs[prec] = float((out - want).abs().max())
         rows[case["name"]] = errs
-        # the 2-step run stops while the canvas is still mostly noise: x_start = (x - sigma eps) / alpha amplifies eps differences by
-        # up to 148x there - f16x3 itself is 25x further from the reference on it than on a finished image.  The
-        # prototype does NOT meet the bar on that fixture (measured 2.4e-3), which is one reason it is not the CLI's parity mode.
-        bar = 5e-3 if case["steps"] == 2 else 1e-3
-        assert errs["f16mx2"] <= bar, (case["name"], errs)
-        assert errs["f16mx2"] > errs["f16x3"]                    # it IS the cheaper arithmetic
+        # with the engine's default placement (two-MFMA arithmetic below the tile's resolution, three-MFMA at 256^2: final block, last
+        # up stage, first down stage) the mode meets the bar AND fp32's regression guard on the 2-step stress fixture too (measured
+        # 9.4e-6 / 2.3e-4 / 1.3e-5; with the two-MFMA arithmetic everywhere 1.4e-4 / 2.3e-3 / 6.5e-5: tools/mx2_tail_study.py)
+        assert errs["f16mx2"] <= (3e-4 if case["steps"] == 2 else 1e-4), (case["name"], errs)
+        assert errs["f16mx2"] != errs["f16x3"]                   # it IS a different arithmetic
     _report(test="f16mx2_prototype_vs_reference", max_abs=rows)
     assert len(rows) >= 2
