@@ -32,12 +32,6 @@
 
 #include "kernels.hpp"
 
-// Diagnostic builds (tools/build_variant.py only; results are wrong on purpose): -DSRGD_C1S_DIAG=1 issues no MFMAs (data movement only),
-// =2 no epilogue stores, =3 no pixel-row DMAs (weights + arithmetic + stores), =4 no bias loads at the head of the epilogue
-#ifndef SRGD_C1S_DIAG
-#define SRGD_C1S_DIAG 0
-#endif
-
 namespace srgd {
 namespace {
 
@@ -179,12 +173,8 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
     char* sa = st + wave * 4096;
     // (per-lane offsets selected with v_cndmask, the descriptors by two branches: see conv1x1_bf16.hip)
     const int v0 = first ? a_b00 : a_b10, v1 = first ? a_b01 : a_b11, v2 = first ? a_b02 : a_b12, v3 = first ? a_b03 : a_b13;
-#if SRGD_C1S_DIAG == 3
-    dma(rsw, sa, tid16, i_w); dma(rsw, sa + 1024, tid16, i_w); dma(rsw, sa + 2048, tid16, i_w); dma(rsw, sa + 3072, tid16, i_w);   // (same request count, L2-resident source)
-#else
     if (first) { dma(rs0, sa, v0, soff); dma(rs0, sa + 1024, v1, soff); dma(rs0, sa + 2048, v2, soff); dma(rs0, sa + 3072, v3, soff); }
     else { dma(rs1, sa, v0, soff); dma(rs1, sa + 1024, v1, soff); dma(rs1, sa + 2048, v2, soff); dma(rs1, sa + 3072, v3, soff); }
-#endif
     dma(rsw, st + A_BYTES + wave * 1024, tid16, i_w);                       // hi tile: 8 waves x 1 KiB
     dma(rsw, st + A_BYTES + B_TILE + wave * 1024, tid16, i_w + B_TILE);     // lo tile
     i_w += (int)w_tile_stride;
@@ -220,11 +210,7 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
     return acc;
   };
   auto mma = [&](f32x4& c, const u32x4& wt, const u32x4& px) {
-#if SRGD_C1S_DIAG == 1
-    c[0] += __uint_as_float(wt[0] ^ px[0]);            // keeps the operand reads alive
-#else
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wt), __builtin_bit_cast(f16x8, px), c, 0, 0, 0);
-#endif
   };
   auto compute = [&]() __attribute__((always_inline)) {
     const char* st = smem + c_slot * STAGE;
@@ -282,7 +268,7 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
   // all bias vectors (and, per pixel block, all residual vectors) are loaded AHEAD of the first store: stores count in vmcnt too, so
   // a load issued behind a store would be waited for together with that store's completion
   f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0, bs2 = bs0, bs3 = bs0, bs4 = bs0, bs5 = bs0, bs6 = bs0, bs7 = bs0;
-  if (p.bias && SRGD_C1S_DIAG != 4) {
+  if (p.bias) {
     const float* bp = p.bias + n0 + q16 * 32;
     bs0 = *reinterpret_cast<const f32x4*>(bp); bs1 = *reinterpret_cast<const f32x4*>(bp + 4);
     bs2 = *reinterpret_cast<const f32x4*>(bp + 8); bs3 = *reinterpret_cast<const f32x4*>(bp + 12);
@@ -388,14 +374,11 @@ __global__ __launch_bounds__(NT, 2) void conv1x1_split_kernel(Split1Args p) {
       for (int e = 0; e < 4; ++e) { v0_[J][e] = silu<true>(v0_[J][e]); v1_[J][e] = silu<true>(v1_[J][e]); }
     }
   }
-#if SRGD_C1S_DIAG == 2
-  if (v0_[0][0] == 123.456f && v1_[7][3] == 654.321f)           // (never true: the values stay live, nothing is stored)
-#endif
   {
     // Stores go through a 2 KB per-wave LDS staging area so that every store instruction writes FULL 128-byte lines.  Straight from
     // the accumulators a lane owns one 128-byte segment (32 channels of one pixel) and needs eight 16-byte stores for it: every
     // instruction touches 64 different lines, 16 bytes each - and the stores, not the loads or the MFMAs, were what bounded this
-    // kernel (diagnostic builds, profiles/r6/conv1x1_split_phase_diagnostics.txt: 128 -> 128 @256x256 0.390 ms, without the stores
+    // kernel (diagnostic builds - knobs in profiles/r6/pricing_and_ab_knobs.patch -, profiles/r6/conv1x1_split_phase_diagnostics.txt: 128 -> 128 @256x256 0.390 ms, without the stores
     // 0.206 ms, without the MFMAs 0.362 ms, without the pixel-row DMAs 0.353 ms).  Per pixel block, in four rounds: the 16 lanes
     // holding channel quarter g' write their 16 pixels x 128 B into the staging area, all 64 lanes read it back 16 bytes at a time
     // in memory order (8 lanes per pixel line) and store.  Wave-private: LDS executes a wave's instructions in order, no barrier.

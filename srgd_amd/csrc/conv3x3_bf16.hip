@@ -54,13 +54,7 @@ constexpr int B_BYTES = BN3 * KC * 2;          // 8 KiB
 constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 73,728: two workgroups per CU
 constexpr int COEF_BYTES = 2 * 256;            // GNIN: 32 scales | 32 shifts (fp32) per channel chunk, double-buffered
 constexpr bool STAMPS = SRGD_CONV3_STAMPS != 0;
-#ifndef SRGD_CONV3_DIRECT_STORES           // A/B builds: 1 = the 16-byte stores straight from the accumulators (round 5)
-#define SRGD_CONV3_DIRECT_STORES 0
-#endif
 static_assert(8 * 16 * 144 <= A_BYTES, "store staging fits the idle A buffer");
-#ifndef SRGD_CONV3_DIAG_LDS_PAD            // pricing builds: extra dynamic LDS per workgroup (16 KiB -> ONE workgroup per CU)
-#define SRGD_CONV3_DIAG_LDS_PAD 0
-#endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -442,10 +436,7 @@ __global__ __launch_bounds__(NT3, 4) void conv3x3_bf16_kernel(Conv3Args p) {
     }                                                                                              \
     const u32x4 lo_ = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])}; \
     const u32x4 hi_ = {pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]), pack_bf16x2(v3[0], v3[1]), pack_bf16x2(v3[2], v3[3])}; \
-    if (SRGD_CONV3_DIRECT_STORES) {                                                                \
-      buffer_store16(lo_, rso, o_voff, so_);                                                       \
-      buffer_store16(hi_, rso, o_voff, so_ + 16);                                                  \
-    } else {                                                                                       \
+    {                                                                                              \
       *reinterpret_cast<u32x4*>(stg + stg_w) = lo_;                                                \
       *reinterpret_cast<u32x4*>(stg + stg_w + 16) = hi_;                                           \
       asm volatile("" ::: "memory");                                                               \
@@ -561,14 +552,14 @@ int conv3x3_bf16(const ConvArgs& a, const void* packed_w, const float* gn_in_a, 
   if (DeviceSetup once(attr_set); once.need) {
 #define K_SET(S_, G_)                                                                                  \
   SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<S_, G_>),               \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (G_ ? COEF_BYTES : 0) + SRGD_CONV3_DIAG_LDS_PAD));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + (G_ ? COEF_BYTES : 0)));
     K_SET(true, false) K_SET(false, false) K_SET(true, true) K_SET(false, true)
 #undef K_SET
     once.done();
   }
   const bool stats = a.gn_partial != nullptr;
 #define K_GO(S_, G_) \
-  hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_>), dim3(grid), dim3(NT3), LDS_BYTES + (G_ ? COEF_BYTES : 0) + SRGD_CONV3_DIAG_LDS_PAD, st, p)
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<S_, G_>), dim3(grid), dim3(NT3), LDS_BYTES + (G_ ? COEF_BYTES : 0), st, p)
   if (stats && gnin) K_GO(true, true); else if (stats) K_GO(true, false);
   else if (gnin) K_GO(false, true); else K_GO(false, false);
 #undef K_GO

@@ -34,12 +34,6 @@
 
 #include "kernels.hpp"
 
-// pricing builds (tools/build_variant.py only; wrong results): bit 0 = no f16 pixel-fragment reads, bit 1 = no e4m3 pixel-fragment
-// reads, bit 2 = no weight DMAs
-#ifndef SRGD_MX2_DIAG
-#define SRGD_MX2_DIAG 0
-#endif
-
 namespace srgd {
 namespace {
 
@@ -256,7 +250,6 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   // the parity of the pair count carries over the chunk boundary (tap 8 of this chunk and taps 0, 1 of the next never share slots)
   auto slot_off = [&](int par, int tap) { return ((((tap >> 1) & 1) ^ par) * 2 + (tap & 1)) * B_UNIT; };
   auto issue_b = [&](int cc, int tap) {
-    if (SRGD_MX2_DIAG & 4) return;               // (pricing build: no weight DMAs at all)
     if (tap >= 9) { tap -= 9; cc += 1; }
     char* dst = sB0 + slot_off(cc & 1, tap);
     const int so = tap * w_tap_stride + cc * (int)w_tile_stride;
@@ -289,11 +282,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
   const bool second_tap = (q16 >> 1) != 0;
 
   typedef u32x4 frag;
-#ifndef SRGD_MX2_NOSB
 #define K_SB __builtin_amdgcn_sched_barrier(0)
-#else
-#define K_SB
-#endif
 #define K_F16MM(C_, WT_, PX_) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(C_) : "v"(WT_), "v"(PX_))
 #define K_QMM_OPSEL_0 "op_sel_hi:[0,0,0]"
 #define K_QMM_OPSEL_1 "op_sel:[1,0,0] op_sel_hi:[0,0,0]"
@@ -314,7 +303,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
     if (!pair && !single) {
 #define K_ROWF(I, C0_, C1_, C2_, C3_)                                                         \
   {                                                                                            \
-    const frag ah = (SRGD_MX2_DIAG & 1) ? bh0 : *reinterpret_cast<const frag*>(A + a_addr(tap, I)); \
+    const frag ah = *reinterpret_cast<const frag*>(A + a_addr(tap, I));                        \
     K_F16MM(C0_, bh0, ah); K_F16MM(C1_, bh1, ah); K_F16MM(C2_, bh2, ah); K_F16MM(C3_, bh3, ah); \
   }
       K_ROWF(0, c00, c01, c02, c03)
@@ -342,11 +331,11 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_mx2_kernel(Mx2Args p) {
     const int sbw = *reinterpret_cast<const int*>((second_tap && !single ? Bt1 : Bt0) + bsc_base);
 #define K_ROWQ(I, C0_, C1_, C2_, C3_)                                                         \
   {                                                                                            \
-    const frag ah = (SRGD_MX2_DIAG & 1) ? bh0 : *reinterpret_cast<const frag*>(A + a_addr(tap, I)); \
+    const frag ah = *reinterpret_cast<const frag*>(A + a_addr(tap, I));                        \
     const int Pc0 = pc_of(t0, I), Pc1 = single ? Pc0 : pc_of(tap, I);                          \
     const v4i f0 = *reinterpret_cast<const v4i*>(A + a8_base + Pc0 * 16);                      \
     const v4i f1 = single ? v4i{0, 0, 0, 0} : *reinterpret_cast<const v4i*>(A + a8_base + Pc1 * 16); \
-    const v8i px = (SRGD_MX2_DIAG & 2) ? w0 : v8i{f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]}; \
+    const v8i px = v8i{f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};                \
     const int sp = *reinterpret_cast<const unsigned char*>(A + asc_base + (second_tap ? Pc1 : Pc0) * 2); \
     K_F16MM(C0_, bh0, ah); K_F16MM(C1_, bh1, ah); K_F16MM(C2_, bh2, ah); K_F16MM(C3_, bh3, ah); \
     K_QMM(C0_, w0, sbw, px, sp, 0); K_QMM(C1_, w1, sbw, px, sp, 1);                            \

@@ -48,18 +48,6 @@ namespace {
 #ifndef SRGD_MXFP8_DIAG_GNVALU
 #define SRGD_MXFP8_DIAG_GNVALU 0
 #endif
-// Pricing builds of a persistent form (tools/build_variant.py only; results are wrong on purpose): bit 0 = the prologue does not wait
-// for the first halo patch (what prefetching it under the previous tile's epilogue could hide at most), bit 1 = no epilogue stores,
-// bit 2 = every tile stores into one L2-resident window (the store instructions without the HBM write stream)
-#ifndef SRGD_MXFP8_DIAG
-#define SRGD_MXFP8_DIAG 0
-#endif
-#ifndef SRGD_MXFP8_DIAG_LDS_PAD             // pricing builds: extra dynamic LDS per workgroup (16 KiB -> ONE workgroup per CU)
-#define SRGD_MXFP8_DIAG_LDS_PAD 0
-#endif
-#ifndef SRGD_MXFP8_DIRECT_STORES          // A/B builds: 1 = the 16-byte stores straight from the accumulators (rounds 4-5)
-#define SRGD_MXFP8_DIRECT_STORES 0
-#endif
 constexpr bool QSTAMPS = SRGD_MXFP8_STAMPS != 0;
 constexpr int QPH = 8, QPW = 32;                 // output patch
 constexpr int QHP = QPH + 2, QWP = QPW + 2;      // halo patch: 10 x 34 = 340 pixels
@@ -356,9 +344,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
   // ---- prologue: A(0), B[0]
   issue_a(0);
   issue_b(0, 0, 0);
-#if !(SRGD_MXFP8_DIAG & 1)
   QWAIT_VM(0);
-#endif
   QBARRIER();
 
   if constexpr (QSTAMPS) t1 = __builtin_amdgcn_s_memtime();
@@ -410,17 +396,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
     bs3 = *reinterpret_cast<const f32x4*>(bp + 12);
   }
   const size_t pix_base = (size_t)(b * p.H + y0 + RPW * wm) * p.W + x0;      // the wave's first pixel
-#if SRGD_MXFP8_DIAG & 4
-  // (every tile's stores land in the same 1,024-pixel window of the first image: same requests, L2-resident lines, no HBM write stream)
-  const u32x4 rso = make_raw_rsrc(p.out + (((size_t)(y0 + RPW * wm) * p.W + x0) & 1023) * p.Cout + chw, (unsigned)(RPW * p.W * p.Cout * 2));
-#else
   const u32x4 rso = make_raw_rsrc(p.out + pix_base * p.Cout + chw, (unsigned)(RPW * p.W * p.Cout * 2));
-#endif
   const u32x4 rsq = make_raw_rsrc(p.oq ? p.oq + pix_base * p.Cout + chw : (unsigned char*)p.out, p.oq ? (unsigned)(RPW * p.W * p.Cout) : 0u);
   const int lane_elem = r16E * p.Cout + chl;              // element offset of the lane's run from the wave's base
   // bf16 stores leave as FULL 128-byte lines (the wave's 64 channels of a pixel): straight from the accumulators a lane owns 32 bytes
   // of a pixel and a store instruction touches 64 scattered 16-byte pieces - the vector memory path takes them one piece at a time,
-  // and the pricing builds (-DSRGD_MXFP8_DIAG=2, profiles/r6/conv3x3_mxfp8_persistent_pricing.txt) showed the stores costing
+  // and the pricing builds (profiles/r6/conv3x3_mxfp8_persistent_pricing.txt, knobs in profiles/r6/pricing_and_ab_knobs.patch) showed the stores costing
   // out_bytes / ~6 TB/s ON TOP of the arithmetic in every shape (128 -> 128 @256^2: 1,864 -> 2,627 TF without them).  Each 16-pixel
   // block goes through 16 staging rows of the wave (144-byte pitch: conflict-free 16-byte writes) in the halo-patch area, which
   // is dead behind the K loop's last barrier; LDS executes a wave's instructions in order, so no barrier - only compiler fences
@@ -445,10 +426,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
     }                                                                                              \
     const u32x4 lo_ = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])}; \
     const u32x4 hi_ = {pack_bf16x2(v2[0], v2[1]), pack_bf16x2(v2[2], v2[3]), pack_bf16x2(v3[0], v3[1]), pack_bf16x2(v3[2], v3[3])}; \
-    if (SRGD_MXFP8_DIRECT_STORES) {                                                                \
-      buffer_store16(lo_, rso, lane_elem * 2, eo_ * 2);                                            \
-      buffer_store16(hi_, rso, lane_elem * 2, eo_ * 2 + 16);                                       \
-    } else {                                                                                       \
+    {                                                                                              \
       /* through the wave's staging rows: 16 pixels x 128 B in, 8 full 128-byte lines per store instruction out */ \
       *reinterpret_cast<u32x4*>(stg + stg_w) = lo_;                                                \
       *reinterpret_cast<u32x4*>(stg + stg_w + 16) = hi_;                                           \
@@ -472,9 +450,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void conv3x3_mxfp8_kernel(ConvQArg
       if ((gE & 1) == 0) p.os[((pix_base * p.Cout + chw) >> 5) + ((size_t)(eo_ + lane_elem) >> 5)] = (unsigned char)sb_; \
     }                                                                                              \
   } while (0)
-#if SRGD_MXFP8_DIAG & 2
-  if (c00[0] == 123.456f && c73[3] == 654.321f)           // (never true: the accumulators stay live, nothing is stored)
-#endif
   { K_QEMIT(0); K_QEMIT(1); K_QEMIT(2); K_QEMIT(3); K_QEMIT(4); K_QEMIT(5); K_QEMIT(6); K_QEMIT(7); }
 #undef K_QEMIT
   if (STATS) {
@@ -601,12 +576,12 @@ int conv3x3_mxfp8(const ConvArgs& a, const void* q0, const void* s0, const void*
   if (a.bias && ((size_t)a.bias & 15)) SRGD_FAIL("conv3x3_mxfp8: the bias array must be 16-byte aligned");
   static bool attr_set[64] = {};
   if (DeviceSetup once(attr_set); once.need) {
-    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS + SRGD_MXFP8_DIAG_LDS_PAD));
-    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS + SRGD_MXFP8_DIAG_LDS_PAD));
+    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
+    SRGD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mxfp8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, QLDS));
     once.done();
   }
-  if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true>), dim3(grid), dim3(NW * 64), QLDS + SRGD_MXFP8_DIAG_LDS_PAD, st, p);
-  else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false>), dim3(grid), dim3(NW * 64), QLDS + SRGD_MXFP8_DIAG_LDS_PAD, st, p);
+  if (a.gn_partial) hipLaunchKernelGGL((conv3x3_mxfp8_kernel<true>), dim3(grid), dim3(NW * 64), QLDS, st, p);
+  else hipLaunchKernelGGL((conv3x3_mxfp8_kernel<false>), dim3(grid), dim3(NW * 64), QLDS, st, p);
   SRGD_HIP(hipGetLastError());
 #if SRGD_MXFP8_STAMPS
   {                                                     // stamp build: synchronous, prints the phase means and the slot timeline

@@ -42,9 +42,6 @@ constexpr int A_BUF = 2 * A_IMG;               // hi | lo
 constexpr int B_TILE = BN3 * KC * 2;           // 8 KiB: one 16-bit weight tile
 constexpr int B_SLOT = 2 * B_TILE;             // hi | lo
 constexpr int LDS_BYTES = 2 * A_BUF + 3 * B_SLOT;   // 147,456: one workgroup per CU
-#ifndef SRGD_CONV3S_DIRECT_STORES          // A/B builds: 1 = four 16-byte stores per block straight from the accumulators
-#define SRGD_CONV3S_DIRECT_STORES 0
-#endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -343,12 +340,7 @@ __global__ __launch_bounds__(NT3, 2) void conv3x3_split_kernel(Split3Args p) {
       s2v = __builtin_elementwise_fma(v2, v2, s2v);                                                \
       s2v = __builtin_elementwise_fma(v3, v3, s2v);                                                \
     }                                                                                              \
-    if (SRGD_CONV3S_DIRECT_STORES) {                                                               \
-      buffer_store16(__builtin_bit_cast(u32x4, v0), rso, o_voff, so_);                             \
-      buffer_store16(__builtin_bit_cast(u32x4, v1), rso, o_voff, so_ + 16);                        \
-      buffer_store16(__builtin_bit_cast(u32x4, v2), rso, o_voff, so_ + 32);                        \
-      buffer_store16(__builtin_bit_cast(u32x4, v3), rso, o_voff, so_ + 48);                        \
-    } else {                                                                                       \
+    {                                                                                              \
       *reinterpret_cast<f32x4*>(stg + stg_w) = v0;                                                 \
       *reinterpret_cast<f32x4*>(stg + stg_w + 16) = v1;                                            \
       *reinterpret_cast<f32x4*>(stg + stg_w + 32) = v2;                                            \
