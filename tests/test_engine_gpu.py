@@ -197,10 +197,12 @@ def test_two_step_lanes_are_bitwise_identical_to_one():
         edm.noise_source = "host"
 
 
-def test_f16x3_lanes_graphs_and_lockstep_are_bitwise_neutral_at_dim128():
+@pytest.mark.parametrize("precision", ["f16x3", "f16mx2"])
+def test_f16x3_lanes_graphs_and_lockstep_are_bitwise_neutral_at_dim128(precision):
     # the split-operand kernels (persistent conv1x1_split, conv3x3_split with GroupNorm-in-staging, the RMSNorm / GroupNorm-tail
     # epilogues) under everything the sampler does around them, at the production width: two concurrent step lanes (automatic for
-    # f16x3), hipGraph replay vs eager launches, two images in lock-step vs their solo runs - all bit-identical
+    # f16x3), hipGraph replay vs eager launches, two images in lock-step vs their solo runs - all bit-identical; the same for the
+    # f16mx2 prototype (conv3x3_mx2 below the tile's resolution)
     import os
     sampler = build_sampler(128)
     conds = torch.cat([C.synthetic_lr_condition(i, 64, 64) for i in range(2)]).cuda()        # 256^2 images: one tile per step each
@@ -213,21 +215,21 @@ def test_f16x3_lanes_graphs_and_lockstep_are_bitwise_neutral_at_dim128():
         outs = []
         for lanes in (1, 2, None):
             sampler.step_lanes = lanes
-            outs.append(sampler.tiled_sample(batch_size=25, condition_x=big, class_label=label, num_sample_steps=5, precision="f16x3").cpu())
+            outs.append(sampler.tiled_sample(batch_size=25, condition_x=big, class_label=label, num_sample_steps=5, precision=precision).cpu())
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
         sampler.step_lanes = None
         for mode in ("0",):
             os.environ["SRGD_GRAPHS"] = mode
             sampler.model._invalidate_engines()
-            eager = sampler.tiled_sample(batch_size=25, condition_x=big, class_label=label, num_sample_steps=5, precision="f16x3").cpu()
+            eager = sampler.tiled_sample(batch_size=25, condition_x=big, class_label=label, num_sample_steps=5, precision=precision).cpu()
         assert torch.equal(eager, outs[0])
         os.environ.pop("SRGD_GRAPHS", None)
         sampler.model._invalidate_engines()
         both = sampler.tiled_sample(batch_size=8, condition_x=conds, class_label=label, num_sample_steps=4, class_cond_scale=1.5,
-                                    precision="f16x3").cpu()
+                                    precision=precision).cpu()
         for i in range(2):
             solo = sampler.tiled_sample(batch_size=8, condition_x=conds[i:i + 1], class_label=label, num_sample_steps=4,
-                                        class_cond_scale=1.5, precision="f16x3").cpu()
+                                        class_cond_scale=1.5, precision=precision).cpu()
             assert torch.equal(both[i:i + 1], solo), i
         assert torch.isfinite(both).all()
     finally:
