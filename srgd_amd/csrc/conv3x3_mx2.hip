@@ -1,20 +1,23 @@
-// 3x3 / stride 1 / pad 1 convolution in a TWO-MFMA split-operand arithmetic for gfx950 (MI355X) - a prototype behind the kernel ABI
-// (include/srgd_hip_kernels.h, impl 14), not wired into a precision mode.  The op: Block.proj, reference model.py:246.
+// 3x3 / stride 1 / pad 1 convolution in a TWO-MFMA split-operand arithmetic for gfx950 (MI355X) - a prototype: kernel ABI impl 14 / 15
+// (include/srgd_hip_kernels.h) and the 3x3 layers below the tile's resolution of SRGD_PRECISION_F16MX2 (engine.hip: the blocks at
+// the tile's own resolution stay on conv3x3_split.hip).  The op: Block.proj, reference model.py:246.
 //
-// Arithmetic (DESIGN.md section 10; emulation: oracle/split_emulation.py mixed_split_conv2d(mode="f16mx2")):
+// Arithmetic (DESIGN.md section 4.2; emulation: oracle/split_emulation.py mixed_split_conv2d(mode="f16mx2")):
 //     x = x_hi + x_lo,  w * s = w_hi + w_lo                      (x_hi, w_hi, w_lo f16 as in conv3x3_split.hip; x_lo = x - x_hi in fp32;
 //                                                                 s = the layer's power of two)
 //     conv(x, w) ~= [ x_hi . w_hi  +  Q(x_lo) . Q(w_hi)  +  Q(x_hi) . Q(w_lo) ] / s
 // where Q is OCP MX-fp8 (e4m3 elements, one E8M0 scale per 32 input channels - the engine's scale rule, common.hpp mx_quant8).  The
 // leading term runs on v_mfma_f32_16x16x32_f16 (exact products); the two cross terms are 2^-11 of it and need only the ~2^-4 an
 // e4m3 pair carries, so they run on v_mfma_scale_f32_16x16x128_f8f6f4 at twice the f16 rate: three products for the matrix time
-// of two.  Measured on the CPU (profiles/r6/split_numerics_cheaper_variants.jsonl, reference configs[0] fixture): 1.3e-4 max-abs at
-// the final pixel (f16x3 5.2e-6, bar 1e-3).
+// of two.  Priced on the CPU first (profiles/r6/split_numerics_cheaper_variants.jsonl, reference configs[0] fixture: 1.3e-4 max-abs at
+// the final pixel, f16x3 5.2e-6, bar 1e-3); measured on the GPU against the reference's fixtures and per shape in
+// profiles/r6/conv3x3_mx2_prototype.txt (384-438 TF algorithmic where conv3x3_split runs 332-378; matrix pipe 47 % busy - the kernel is
+// bound by its LDS operand reads, not by the MFMAs it saved).
 //
 // Kernel = conv3x3_split.hip's (8 x 32 pixel patch x 128 channels per 512-thread workgroup, K walked in 32-channel chunks, the halo
 // patch of a chunk staged once for all nine taps, fp32 input through VGPRs, weights by LDS-DMA, register-direct epilogue) with:
 //   * staging: a thread's 8 channels are split into f16 hi / lo; hi goes to the 16-bit halo image as before; lo AND hi are
-//     quantised to e4m3 over the pixel's 32-channel block (the four lanes of a quad hold it: mx_quant8) and written to four
+//     quantised to e4m3 over the pixel's 32-channel block (the four lanes of a quad hold it: mx_quant8_finite below) and written to four
 //     16-byte-per-pixel planes [product p][half h] (p = 0: x_lo, p = 1: x_hi), scale bytes [pixel][p];
 //   * one scaled MFMA covers TWO taps: its four 32-wide K blocks are (tap t, x_lo.w_hi), (tap t, x_hi.w_lo), (tap t+1, x_lo.w_hi),
 //     (tap t+1, x_hi.w_lo).  With the operand map decoded for conv3x3_mxfp8.hip - lane (r, g) supplies K bytes [16g, 16g+16) and
@@ -25,7 +28,8 @@
 //     [p][h], p = 0: Q(w_hi), p = 1: Q(w_lo)) | 512 scale bytes [p][wn][r16][J]; a 4-slot LDS-DMA ring = the tap pair being consumed
 //     + the pair in flight; the K loop advances in PAIR steps (one barrier per pair: ~1,000 MFMA cycles per wave between barriers,
 //     one pair-step of DMA lead);
-//   * both MFMA kinds accumulate into the same 16 x 16 fp32 blocks (same D layout), issued as inline asm with the accumulator tied.
+//   * both MFMA kinds accumulate into the same 16 x 16 fp32 blocks (same D layout), issued as inline asm with the accumulator tied;
+//   * GNIN instances apply the producer's GroupNorm + SiLU to the fp32 pieces ahead of the split (coefficients through an LDS slot).
 // LDS: 2 x 46 KB of A (24 KB hi image + four 5.3 KB planes + scales) + 4 x 16.5 KB of B + 0.5 KB of GNIN coefficients = 158.5 KB - one
 // workgroup per CU.
 #include <cmath>
